@@ -1,0 +1,347 @@
+"""Shared test helpers (TEST INFRASTRUCTURE).
+
+* ``Oracle``      -- ctypes binding of oracle/libstmmqr_oracle.so, the CPU restatement of
+                     STMMQR/src/qr/SparseQR_factorize.c (see oracle/stmmqr_oracle.h).
+* ``load_golden`` -- committed fixtures tests/golden/*.npz, produced from the REAL reference by
+                     tests/golden/make_golden.py (oracle/_ref/refdump).
+* sketches / comparison helpers shared by the CPU and GPU parity tests.
+
+Nothing here reads /root/reference at run time.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+from pathlib import Path
+
+import numpy as np
+
+ROOT = Path(__file__).resolve().parent.parent
+GOLDEN = ROOT / "tests" / "golden"
+ORACLE_DIR = ROOT / "oracle"
+
+I64 = np.int64
+c_long_p = C.POINTER(C.c_long)
+c_double_p = C.POINTER(C.c_double)
+
+
+def _ip(a):
+    return None if a is None else a.ctypes.data_as(c_long_p)
+
+
+def _dp(a):
+    return None if a is None else a.ctypes.data_as(c_double_p)
+
+
+# --------------------------------------------------------------------------------------
+# fixtures
+# --------------------------------------------------------------------------------------
+SYM_ARRAYS = ["Sp", "Sj", "Qfill", "PLinv", "Sleft", "Parent", "Child", "Childp", "Super", "Rp", "Rj",
+              "Post", "Hip", "Fm", "Cm"]
+SYM_SCALARS = ["m", "n", "anz", "nf", "maxfn", "rjsize", "do_rank_detection", "maxstack", "hisize", "keepH",
+               "ntasks", "ns"]
+
+
+def golden_names():
+    return sorted(p.stem for p in GOLDEN.glob("*.npz"))
+
+
+def load_golden(name: str) -> dict:
+    """Return a dict of numpy arrays; integer arrays are widened to int64."""
+    z = np.load(GOLDEN / f"{name}.npz")
+    out = {}
+    for k in z.files:
+        a = z[k]
+        if a.dtype.kind in "iu" and a.dtype != np.int8:
+            a = a.astype(I64)
+        out[k] = np.ascontiguousarray(a)
+    return out
+
+
+def scalar(g: dict, key: str):
+    return g[key].reshape(-1)[0].item()
+
+
+def sketch_weights(n: int):
+    i = np.arange(n, dtype=np.float64)
+    return np.sin(0.7 * i + 0.3), np.cos(1.3 * i + 0.1)
+
+
+def block_sketch(v: np.ndarray) -> np.ndarray:
+    """(||v||_2, <v,w1>, <v,w2>) -- order-sensitive fingerprint of one packed block."""
+    if v.size == 0:
+        return np.zeros(3)
+    w1, w2 = sketch_weights(v.size)
+    return np.array([np.linalg.norm(v), float(v @ w1), float(v @ w2)])
+
+
+def determined_mask(Stair, fp: int, fn: int, fm: int) -> np.ndarray:
+    """Boolean mask over one packed R+H block (qr_rhpack layout, SparseQR_factorize.c:1691-1784) selecting
+    the entries that are uniquely determined by A: everything in the pivotal columns (R and H) and the R rows
+    of the non-pivotal columns.  The Householder vectors of NON-pivotal columns only rotate the contribution
+    block; where the symbolic structure over-estimates the numerical rank they are built from rounding noise
+    and legitimately differ between two correct implementations, so they are checked functionally
+    (A = QR, Q'Q = I) instead of element by element."""
+    parts = []
+    rm = 0
+    for k in range(fp):
+        t = int(Stair[k])
+        if t == 0:
+            parts.append(np.ones(rm, bool))
+        else:
+            if rm < fm:
+                rm += 1
+            parts.append(np.ones(t, bool))
+    h = rm
+    for k in range(fp, fn):
+        t = int(Stair[k])
+        h = min(h + 1, fm)
+        parts.append(np.ones(rm, bool))
+        parts.append(np.zeros(max(t - h, 0), bool))
+    return np.concatenate(parts) if parts else np.zeros(0, bool)
+
+
+def front_R(block, Stair, fp: int, fn: int, fm: int) -> np.ndarray:
+    """Dense rm-by-fn R part of one packed R+H block (rows = live pivots of the front)."""
+    cols = []
+    rm = 0
+    p = 0
+    for k in range(fp):
+        t = int(Stair[k])
+        if t == 0:
+            cols.append((p, rm)); p += rm
+        else:
+            if rm < fm:
+                rm += 1
+            cols.append((p, rm)); p += t
+    h = rm
+    for k in range(fp, fn):
+        t = int(Stair[k])
+        h = min(h + 1, fm)
+        cols.append((p, rm)); p += rm + max(t - h, 0)
+    assert p == block.size, (p, block.size)
+    R = np.zeros((rm, fn))
+    for k, (a, r) in enumerate(cols):
+        R[:r, k] = block[a:a + r]
+    return R
+
+
+def rrow_signature(R: np.ndarray) -> np.ndarray:
+    """Per R row: (|first nonzero-position entry| i.e. |diagonal|, ||row||, |<row, w>|).  Invariant under the
+    row sign flips that are the only freedom of R = chol(A'A) (sign of R_kk = -sign(alpha), and alpha depends
+    on how the rounding-noise rows of a child's contribution block happened to be rotated)."""
+    rm, fn = R.shape
+    if rm == 0:
+        return np.zeros((0, 3))
+    w1, _ = sketch_weights(fn)
+    # the diagonal of row i is its first structurally stored entry = largest-|.| leading entry position:
+    lead = np.array([np.flatnonzero(R[i])[0] if np.any(R[i]) else 0 for i in range(rm)])
+    return np.stack([np.abs(R[np.arange(rm), lead]), np.linalg.norm(R, axis=1), np.abs(R @ w1)], axis=1)
+
+
+def determined_part(block, Stair, fp, fn, fm):
+    mk = determined_mask(Stair, fp, fn, fm)
+    assert mk.size == block.size, (mk.size, block.size)
+    return block[mk]
+
+
+# --------------------------------------------------------------------------------------
+# oracle binding
+# --------------------------------------------------------------------------------------
+class OrcSymbolic(C.Structure):
+    _fields_ = [(k, C.c_long) for k in
+                ["m", "n", "anz", "nf", "maxfn", "rjsize", "hisize", "maxstack", "do_rank_detection"]] + \
+               [(k, c_long_p) for k in
+                ["Sp", "Sj", "Qfill", "PLinv", "Sleft", "Child", "Childp", "Super", "Rp", "Rj", "Post", "Hip"]]
+
+
+class OrcNumeric(C.Structure):
+    _fields_ = [("Stack", c_double_p), ("Rblock_off", c_long_p), ("Rdead", C.c_char_p),
+                ("HStair", c_long_p), ("HTau", c_double_p), ("Hii", c_long_p), ("HPinv", c_long_p),
+                ("Hm", c_long_p), ("Hr", c_long_p), ("Cm", c_long_p),
+                ("rank", C.c_long), ("rank1", C.c_long), ("maxfrank", C.c_long), ("maxfm", C.c_long),
+                ("rh_total", C.c_long), ("flopcount", C.c_double),
+                ("Csave", c_double_p), ("Csave_off", c_long_p),
+                ("t_assemble", C.c_double), ("t_front", C.c_double), ("t_pack", C.c_double)]
+
+
+class OrcChunk(C.Structure):
+    _fields_ = [("fchunk", C.c_long), ("small", C.c_long), ("minchunk", C.c_long), ("minchunk_ratio", C.c_long)]
+
+
+def build_oracle(force: bool = False) -> Path:
+    so = ORACLE_DIR / "libstmmqr_oracle.so"
+    src = ORACLE_DIR / "stmmqr_oracle.c"
+    if force or not so.exists() or so.stat().st_mtime < src.stat().st_mtime:
+        subprocess.check_call(["make", "-C", str(ORACLE_DIR), "port"], stdout=subprocess.DEVNULL)
+    return so
+
+
+class Symbolic:
+    """Owns the numpy arrays behind an OrcSymbolic."""
+
+    def __init__(self, g: dict, prefix: str = "sym_"):
+        self.arr = {k: np.ascontiguousarray(g[prefix + k], dtype=I64) for k in SYM_ARRAYS if prefix + k in g}
+        self.sc = {k: int(scalar(g, prefix + k)) for k in SYM_SCALARS if prefix + k in g}
+        if self.arr.get("Qfill") is not None and self.arr["Qfill"].size == 0:
+            self.arr["Qfill"] = None
+        s = OrcSymbolic()
+        for k in ["m", "n", "anz", "nf", "maxfn", "rjsize", "hisize", "maxstack", "do_rank_detection"]:
+            setattr(s, k, self.sc[k])
+        for k in ["Sp", "Sj", "Qfill", "PLinv", "Sleft", "Child", "Childp", "Super", "Rp", "Rj", "Post", "Hip"]:
+            setattr(s, k, _ip(self.arr.get(k)))
+        self.c = s
+
+    def __getattr__(self, k):
+        if k in ("arr", "sc", "c"):
+            raise AttributeError(k)
+        if k in self.sc:
+            return self.sc[k]
+        if k in self.arr:
+            return self.arr[k]
+        raise AttributeError(k)
+
+
+class Numeric:
+    """Caller-allocated outputs of orc_factorize."""
+
+    def __init__(self, S: Symbolic, save_c: bool = False):
+        nf, n, m = S.nf, S.n, S.m
+        self.Stack = np.zeros(max(S.maxstack, 1))
+        self.Rblock_off = np.zeros(max(nf, 1), I64)
+        self.Rdead = np.zeros(max(n, 1), np.int8)
+        self.HStair = np.zeros(max(S.rjsize, 1), I64)
+        self.HTau = np.zeros(max(S.rjsize, 1))
+        self.Hii = np.zeros(max(S.hisize, 1), I64)
+        self.HPinv = np.zeros(max(m, 1), I64)
+        self.Hm = np.zeros(max(nf, 1), I64)
+        self.Hr = np.zeros(max(nf, 1), I64)
+        self.Cm = np.zeros(max(nf, 1), I64)
+        self.Csave = np.zeros(max(S.maxstack, 1)) if save_c else None
+        self.Csave_off = np.zeros(max(nf, 1), I64) if save_c else None
+        c = OrcNumeric()
+        c.Stack = _dp(self.Stack); c.Rblock_off = _ip(self.Rblock_off)
+        c.Rdead = C.cast(self.Rdead.ctypes.data, C.c_char_p)
+        c.HStair = _ip(self.HStair); c.HTau = _dp(self.HTau); c.Hii = _ip(self.Hii)
+        c.HPinv = _ip(self.HPinv); c.Hm = _ip(self.Hm); c.Hr = _ip(self.Hr); c.Cm = _ip(self.Cm)
+        c.Csave = _dp(self.Csave); c.Csave_off = _ip(self.Csave_off)
+        self.c = c
+
+    # packed R+H block of front f (needs rsize: distance to the next block in postorder)
+    def rh_blocks(self, S: Symbolic):
+        order = S.Post[: S.nf]
+        offs = self.Rblock_off[order]
+        ends = np.append(offs[1:], self.c.rh_total)
+        out = {}
+        for f, a, b in zip(order, offs, ends):
+            out[int(f)] = self.Stack[a:b]
+        return out
+
+
+class Oracle:
+    def __init__(self):
+        self.lib = C.CDLL(str(build_oracle()))
+        L = self.lib
+        L.orc_factorize.restype = C.c_int
+        L.orc_factorize.argtypes = [C.POINTER(OrcSymbolic), c_long_p, c_long_p, c_double_p, C.c_double, C.c_long,
+                                    C.POINTER(OrcChunk), C.POINTER(OrcNumeric)]
+        L.orc_front.restype = C.c_long
+        L.orc_front.argtypes = [C.c_long, C.c_long, C.c_long, C.c_double, C.c_long, C.POINTER(OrcChunk),
+                                c_double_p, c_long_p, C.c_char_p, c_double_p, c_double_p, c_double_p]
+        L.orc_larfg.restype = C.c_double
+        L.orc_larfg.argtypes = [C.c_long, c_double_p, c_double_p]
+        L.orc_larftb.restype = None
+        L.orc_larftb.argtypes = [C.c_int, C.c_long, C.c_long, C.c_long, C.c_long, C.c_long, c_double_p, c_double_p,
+                                 c_double_p, c_double_p]
+        L.orc_cpack.restype = C.c_long
+        L.orc_cpack.argtypes = [C.c_long] * 4 + [c_double_p, c_double_p]
+        L.orc_rhpack.restype = C.c_long
+        L.orc_rhpack.argtypes = [C.c_long] * 3 + [c_long_p, c_double_p, c_double_p, c_long_p]
+        L.orc_fcsize.restype = C.c_long
+        L.orc_fcsize.argtypes = [C.c_long] * 4
+        L.orc_qmult.restype = None
+        L.orc_qmult.argtypes = [C.c_int, C.POINTER(OrcSymbolic), C.POINTER(OrcNumeric), c_double_p, c_double_p]
+        L.orc_rmult.restype = None
+        L.orc_rmult.argtypes = [C.POINTER(OrcSymbolic), C.POINTER(OrcNumeric), c_double_p, c_double_p]
+        L.orc_rsolve.restype = C.c_int
+        L.orc_rsolve.argtypes = [C.POINTER(OrcSymbolic), C.POINTER(OrcNumeric), c_double_p, c_double_p]
+        L.orc_stranspose2.restype = None
+        L.orc_stranspose2.argtypes = [C.c_long, C.c_long, c_long_p, c_long_p, c_double_p, c_long_p, c_long_p,
+                                      c_long_p, c_double_p, c_long_p]
+
+    @staticmethod
+    def chunk(fchunk=32, small=5000, minchunk=4, ratio=4):
+        return OrcChunk(fchunk, small, minchunk, ratio)
+
+    def factorize(self, S: Symbolic, Ap, Ai, Ax, tol, ntol, chunk=None, save_c=False) -> Numeric:
+        N = Numeric(S, save_c)
+        ch = chunk or self.chunk()
+        Ap = np.ascontiguousarray(Ap, I64); Ai = np.ascontiguousarray(Ai, I64)
+        Ax = np.ascontiguousarray(Ax, np.float64)
+        rc = self.lib.orc_factorize(C.byref(S.c), _ip(Ap), _ip(Ai), _dp(Ax), float(tol), int(ntol), C.byref(ch),
+                                    C.byref(N.c))
+        if rc != 0:
+            raise RuntimeError(f"orc_factorize failed: {rc}")
+        return N
+
+    def front(self, F, Stair, npiv, tol, ntol, chunk=None):
+        """F: (m,n) Fortran-ordered float64, modified in place. Returns (rank, Tau, Rdead, flops)."""
+        m, n = F.shape
+        assert F.flags.f_contiguous
+        ch = chunk or self.chunk()
+        Tau = np.zeros(max(n, 1)); Rdead = np.zeros(max(npiv, 1), np.int8)
+        W = np.zeros(max(ch.fchunk, 1) * max(n, 1) + 64)
+        fl = C.c_double(0)
+        r = self.lib.orc_front(m, n, npiv, float(tol), int(ntol), C.byref(ch), _dp(F), _ip(Stair),
+                               C.cast(Rdead.ctypes.data, C.c_char_p), _dp(Tau), _dp(W), C.byref(fl))
+        return int(r), Tau[:n], Rdead[:npiv], fl.value
+
+    # ---- checkers ----
+    def qmult(self, method, S: Symbolic, N: Numeric, x):
+        x = np.array(x, dtype=np.float64, copy=True)
+        w = np.zeros(S.m)
+        self.lib.orc_qmult(method, C.byref(S.c), C.byref(N.c), _dp(x), _dp(w))
+        return x
+
+    def rmult(self, S: Symbolic, N: Numeric, x):
+        x = np.ascontiguousarray(x, np.float64)
+        y = np.zeros(S.m)
+        self.lib.orc_rmult(C.byref(S.c), C.byref(N.c), _dp(x), _dp(y))
+        return y
+
+    def rsolve(self, S: Symbolic, N: Numeric, y):
+        y = np.ascontiguousarray(y, np.float64)
+        x = np.zeros(S.n)
+        rc = self.lib.orc_rsolve(C.byref(S.c), C.byref(N.c), _dp(y), _dp(x))
+        if rc != 0:
+            raise RuntimeError("rank deficient")
+        return x
+
+
+# --------------------------------------------------------------------------------------
+# residual checks on a factorization held as (Symbolic, Numeric-like)
+# --------------------------------------------------------------------------------------
+def csc_matvec(m, Ap, Ai, Ax, x):
+    y = np.zeros(m)
+    n = len(Ap) - 1
+    cols = np.repeat(np.arange(n), np.diff(Ap))
+    np.add.at(y, Ai, Ax * x[cols])
+    return y
+
+
+def aqr_probe_error(orc: Oracle, S: Symbolic, N: Numeric, Ap, Ai, Ax, nprobe=4, seed=7):
+    """max over random x of ||A*E*x - Q*(R*x)|| / (||A||_F ||x||)   (SURVEY.md 8d parity metric)."""
+    rng = np.random.default_rng(seed)
+    m, n = S.m, S.n
+    q = S.Qfill if S.Qfill is not None else np.arange(n)
+    anorm = np.linalg.norm(Ax) or 1.0
+    worst = 0.0
+    for _ in range(nprobe):
+        x = rng.standard_normal(n)
+        xa = np.zeros(n)
+        xa[q] = x                      # (A E) x = A (E x)
+        y1 = csc_matvec(m, Ap, Ai, Ax, xa)
+        y2 = orc.qmult(1, S, N, orc.rmult(S, N, x))
+        worst = max(worst, np.linalg.norm(y1 - y2) / (anorm * np.linalg.norm(x)))
+    return worst
