@@ -1,0 +1,211 @@
+/* include/stmmqr_hip.h -- C ABI of libstmmqr_hip.so, the MI355X-native numerical-factorization path
+ * for STM-Multifrontal-QR.
+ *
+ * Drop-in scope: the hot path of the reference, STMMQR/src/qr/SparseQR_factorize.c +
+ * SparseQR_multithreads.c (qr_factorize -> qr_kernel -> {qr_fsize, qr_assemble, qr_front, qr_cpack,
+ * qr_rhpack} + qr_stranspose2 + qr_hpinv), executed on one gfx950 device.  All entry points are plain
+ * C (extern "C", pointers and sizes only).  "Long" below is the reference's Sparse_long = C long
+ * (STMMQR/include/SparseBase_config.h:29); all numerics are fp64 (Makefile.option:62).
+ *
+ * Three groups of symbols:
+ *   1. the drop-in seam with the reference's own names and signatures (a maintainer links this library
+ *      instead of compiling SparseQR_factorize.c / SparseQR_multithreads.c);
+ *   2. the same path on plain arrays (stmmqr_*), used by the Python host side, the tests and bench.py;
+ *   3. configuration / introspection.
+ *
+ * Error convention (reference: SparseQR_factorize.c:329-333,378-383,540-545): nothing throws across
+ * this boundary; failures free partial state, return NULL / a negative code and leave
+ * cc->status < SPARSE_OK.  A missing or unusable GPU is an error (STMMQR_ERR_DEVICE), never a CPU
+ * fallback.
+ */
+#ifndef STMMQR_HIP_H
+#define STMMQR_HIP_H
+
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef long stm_long;
+
+/* ---- status codes (values of cc->status in the reference: SparseCore.h "SPARSE_OK" family) ---- */
+#define STMMQR_OK                0
+#define STMMQR_ERR_OUT_OF_MEMORY (-2)   /* SPARSE_OUT_OF_MEMORY */
+#define STMMQR_ERR_TOO_LARGE     (-3)   /* SPARSE_TOO_LARGE     */
+#define STMMQR_ERR_INVALID       (-4)   /* SPARSE_INVALID       */
+#define STMMQR_ERR_DEVICE        (-5)   /* SPARSE_GPU_PROBLEM: no gfx950 device / HIP runtime error */
+
+/* ================================================================================================
+ * Layout-compatible mirrors of the structs that cross the seam
+ * ================================================================================================ */
+
+/* sparse_csc  (STMMQR/include/SparseCore.h:514-556) */
+typedef struct stm_sparse_csc {
+    size_t nrow, ncol, nzmax;
+    void *p, *i, *nz, *x, *z;
+    int stype, itype, xtype, dtype, sorted, packed;
+} stm_sparse_csc;
+
+/* qr_symbolic (STMMQR/include/SparseQR_struct.h:26-137): produced by qr_analyze, borrowed, never modified */
+typedef struct stm_qr_symbolic {
+    stm_long m, n, anz;
+    stm_long *Sp, *Sj, *Qfill, *PLinv, *Sleft;
+    stm_long nf, maxfn;
+    stm_long *Parent, *Child, *Childp, *Super, *Rp, *Rj, *Post;
+    stm_long rjsize, do_rank_detection, maxstack, hisize, keepH;
+    stm_long *Hip;
+    stm_long ntasks, ns;
+    stm_long *TaskChildp, *TaskChild, *TaskStack, *TaskFront, *TaskFrontp, *On_stack, *Stack_maxstack;
+    stm_long *Fm, *Cm;
+} stm_qr_symbolic;
+
+/* qr_numeric (STMMQR/include/SparseQR_struct.h:145-209): returned, owned by the caller, released by the
+ * reference's qr_freenum (SparseQR.c:1225-1272), hence every array is malloc'ed with the sizes stored here
+ * and accounted in cc->malloc_count / memory_inuse exactly like SparseCore_malloc does. */
+typedef struct stm_qr_numeric {
+    double **Rblock;
+    double **Stacks;
+    stm_long *Stack_size;
+    stm_long hisize, n, m, nf, ntasks, ns, maxstack;
+    char *Rdead;
+    stm_long rank, rank1, maxfrank;
+    double norm_E_fro;
+    stm_long keepH, rjsize;
+    stm_long *HStair;
+    double *HTau;
+    stm_long *Hii, *HPinv, *Hm, *Hr;
+    stm_long maxfm;
+} stm_qr_numeric;
+
+/* sparse_common is opaque here: the few fields the path touches are reached through byte offsets.
+ * The defaults are the offsets of the stock reference build (LP64); a host that compiles the reference
+ * with a different layout passes its own offsetof() values once (INTEGRATION.md shows the stub). */
+typedef struct sparse_common_struct stm_sparse_common;
+typedef struct stm_common_layout {
+    size_t status, malloc_count, memory_usage, memory_inuse, blas_ok;
+    size_t SPQR_grain, SPQR_small, SPQR_shrink, SPQR_flopcount, SPQR_flopcount_bound;
+} stm_common_layout;
+void stmmqr_set_common_layout(const stm_common_layout *layout);
+void stmmqr_get_common_layout(stm_common_layout *layout);
+
+/* ================================================================================================
+ * 1. Drop-in seam (reference names; prototypes STMMQR/include/SparseQR.h:127-268)
+ * ================================================================================================ */
+
+/* SparseQR.h:127-135; call sites SparseQR.c:349 (&A,FALSE,tol,n) and :371 (&Y,TRUE,tol,n2) */
+stm_qr_numeric *qr_factorize(stm_sparse_csc **Ahandle, stm_long freeA, double tol, stm_long ntol,
+                             stm_qr_symbolic *QRsym, stm_sparse_common *cc);
+
+/* SparseQR.h:137-143 ; globals FCHUNK/SMALL/MINCHUNK/MINCHUNK_RATIO (SparseQR.h:16-19) become library state */
+int chunk_getSettings(size_t fchunk, size_t small_, size_t minchunk, size_t minchunk_ratio);
+
+/* Inner seams on HOST buffers (device copies are made inside; used for unit parity).
+ * cc may be NULL.  SparseQR.h:145-268. */
+void qr_stranspose2(stm_sparse_csc *A, stm_long *Qfill, stm_long *Sp, stm_long *PLinv, double *Sx, stm_long *W);
+void qr_hpinv(stm_qr_symbolic *QRsym, stm_qr_numeric *QRnum, stm_long *W);
+stm_long qr_fsize(stm_long f, stm_long *Super, stm_long *Rp, stm_long *Rj, stm_long *Sleft, stm_long *Child,
+                  stm_long *Childp, stm_long *Cm, stm_long *Fmap, stm_long *Stair);
+void qr_assemble(stm_long f, stm_long fm, int keepH, stm_long *Super, stm_long *Rp, stm_long *Rj, stm_long *Sp,
+                 stm_long *Sj, stm_long *Sleft, stm_long *Child, stm_long *Childp, double *Sx, stm_long *Fmap,
+                 stm_long *Cm, double **Cblock, stm_long *Hr, stm_long *Stair, stm_long *Hii, stm_long *Hip,
+                 double *F, stm_long *Cmap);
+stm_long qr_csize(stm_long c, stm_long *Rp, stm_long *Cm, stm_long *Super);
+stm_long qr_front(stm_long m, stm_long n, stm_long npiv, double tol, stm_long ntol, stm_long fchunk, double *F,
+                  stm_long *Stair, char *Rdead, double *Tau, double *W, double *wscale, double *wssq,
+                  stm_sparse_common *cc);
+stm_long qr_fcsize(stm_long m, stm_long n, stm_long npiv, stm_long g);
+stm_long qr_cpack(stm_long m, stm_long n, stm_long npiv, stm_long g, double *F, double *C);
+stm_long qr_rhpack(int keepH, stm_long m, stm_long n, stm_long npiv, stm_long *Stair, double *F, double *R,
+                   stm_long *p_rm);
+void qr_larftb(int method, stm_long m, stm_long n, stm_long k, stm_long ldc, stm_long ldv, double *V,
+               double *Tau, double *C, double *W, stm_sparse_common *cc);
+
+/* ================================================================================================
+ * 2. The same path on plain arrays
+ * ================================================================================================ */
+
+/* symbolic inputs as plain arrays (same meaning as the qr_symbolic fields of the same name) */
+typedef struct stmmqr_symbolic_view {
+    stm_long m, n, anz, nf, maxfn, rjsize, hisize, do_rank_detection;
+    const stm_long *Sp, *Sj, *Qfill, *PLinv, *Sleft;
+    const stm_long *Child, *Childp, *Super, *Rp, *Rj, *Post, *Hip, *Fm;
+} stmmqr_symbolic_view;
+
+/* per-call measurements (all times in milliseconds, HIP events on the library's own stream) */
+typedef struct stmmqr_stats {
+    double flops;              /* the reference's FLOP_COUNT formula (SparseQR_factorize.c:1571)          */
+    double ms_total;           /* upload-excluded device time: gather S .. pack R+H                        */
+    double ms_assemble;        /* front_setup + assemble kernels                                            */
+    double ms_front;           /* panel + trailing-update kernels                                           */
+    double ms_pack;            /* R+H count / scan / copy kernels                                           */
+    double ms_h2d, ms_d2h;     /* PCIe transfers of A values in, packed factors out                         */
+    double ms_host;            /* host-side planning + hpinv                                                */
+    double bytes_assemble;     /* algorithmic bytes of the assembly kernels, SURVEY.md 8(d) formula        */
+    double bytes_pack;
+    double flops_update;       /* flops executed by the MFMA trailing-update kernel (4*m*n*k per block)    */
+    double ms_update;          /* time of the MFMA trailing-update launches only                            */
+    stm_long nlaunch;          /* kernel launches in the timed region                                       */
+    stm_long nlevels;
+} stmmqr_stats;
+
+typedef struct stmmqr_plan stmmqr_plan;     /* device-resident symbolic plan + arenas; reusable across calls */
+
+/* Build the device plan from the symbolic analysis (host work + one upload).  Returns NULL on error
+ * (*status gets the code).  device < 0 selects the current HIP device. */
+stmmqr_plan *stmmqr_plan_create(const stmmqr_symbolic_view *sym, int device, int *status);
+void stmmqr_plan_destroy(stmmqr_plan *plan);
+
+/* Give the plan the pattern of A (column pointers / row indices): builds the qr_stranspose2 gather map
+ * (SparseQR_factorize.c:755-785) once.  stmmqr_factorize_device does this itself when Ap/Ai are non-NULL. */
+int stmmqr_plan_set_pattern(stmmqr_plan *plan, const stm_long *Ap, const stm_long *Ai);
+
+/* Numeric factorization of A (CSC, Long indices) with a plan.  Results stay resident in HBM inside the plan;
+ * stmmqr_plan_download copies them out.  Ax may be a host pointer (uploaded, timed as ms_h2d) or, when
+ * ax_on_device != 0, a device pointer. */
+int stmmqr_factorize_device(stmmqr_plan *plan, const stm_long *Ap, const stm_long *Ai, const double *Ax,
+                            int ax_on_device, double tol, stm_long ntol, stmmqr_stats *stats);
+
+/* sizes needed by the caller to allocate the outputs of stmmqr_plan_download */
+int stmmqr_plan_result_sizes(const stmmqr_plan *plan, stm_long *rh_total, stm_long *rank);
+
+/* Copy the results of the last stmmqr_factorize_device to host arrays laid out like qr_numeric:
+ * Stack[rh_total] holds the packed R+H blocks in Post order (= the single shrunk stack of the reference's
+ * serial run), Rblock_off[nf] the offset of each front's block in it.  Any pointer may be NULL. */
+int stmmqr_plan_download(stmmqr_plan *plan, double *Stack, stm_long *Rblock_off, char *Rdead, stm_long *HStair,
+                         double *HTau, stm_long *Hii, stm_long *HPinv, stm_long *Hm, stm_long *Hr,
+                         stm_long *scalars /* [rank, rank1, maxfrank, maxfm] */, stmmqr_stats *stats);
+
+/* one-shot convenience: plan + factorize + download (what qr_factorize does internally) */
+int stmmqr_factorize_arrays(const stmmqr_symbolic_view *sym, const stm_long *Ap, const stm_long *Ai,
+                            const double *Ax, double tol, stm_long ntol, double *Stack, stm_long stack_cap,
+                            stm_long *Rblock_off, char *Rdead, stm_long *HStair, double *HTau, stm_long *Hii,
+                            stm_long *HPinv, stm_long *Hm, stm_long *Hr, stm_long *scalars, stmmqr_stats *stats);
+
+/* dense single-front kernels on host buffers (inner seams without the cc argument) */
+stm_long stmmqr_front(stm_long m, stm_long n, stm_long npiv, double tol, stm_long ntol, double *F,
+                      stm_long *Stair, char *Rdead, double *Tau, double *flops);
+int stmmqr_larftb_qtx(stm_long m, stm_long n, stm_long k, stm_long ldc, stm_long ldv, const double *V,
+                      const double *Tau, double *C);
+
+/* ================================================================================================
+ * 3. Configuration / introspection
+ * ================================================================================================ */
+typedef struct stmmqr_options {
+    int panel_width;        /* Householder panel width on device (<= 32); reference FCHUNK = 32          */
+    int big_front_cols;     /* fronts with fn >= this use the multi-workgroup panel/update path           */
+    int verbose;
+    int use_graph;          /* capture the level schedule into a hipGraph                                 */
+} stmmqr_options;
+void stmmqr_get_options(stmmqr_options *opt);
+void stmmqr_set_options(const stmmqr_options *opt);
+
+int stmmqr_device_count(void);                        /* number of visible HIP devices (0 = none)          */
+const char *stmmqr_device_name(int device);           /* gcnArchName, e.g. "gfx950:sramecc+:xnack-"        */
+const char *stmmqr_last_error(void);                  /* thread-local message of the last failure          */
+const char *stmmqr_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* STMMQR_HIP_H */

@@ -1,0 +1,9 @@
+"""MI355X-native numerical-factorization path for STM-Multifrontal-QR.
+
+The product is the C-ABI shared library ``libstmmqr_hip.so`` (sources in ``csrc/``, interface in
+``include/stmmqr_hip.h``).  This package is the thin host-side mirror of the reference's interface for that
+path (same names and argument meaning as STMMQR/include/SparseQR.h) on numpy arrays; it contains no numeric
+code and no CPU fallback: importing :mod:`capi` raises if the HIP library has not been built.
+"""
+from .capi import (HipQR, QRNumeric, StmmqrError, device_count, device_name, get_options, lib, lib_path,  # noqa: F401
+                   qr_assemble, qr_cpack, qr_factorize, qr_fcsize, qr_front, qr_larftb, qr_rhpack, set_options)

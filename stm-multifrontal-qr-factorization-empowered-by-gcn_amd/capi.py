@@ -1,0 +1,281 @@
+"""ctypes binding of libstmmqr_hip.so (include/stmmqr_hip.h).
+
+Mirrors the reference's operator interface for the hot path (STMMQR/include/SparseQR.h:127-268):
+``qr_factorize``, ``qr_front``, ``qr_larftb``, ``qr_cpack``, ``qr_rhpack``, ``qr_assemble`` keep their names and
+argument meaning; array arguments are numpy arrays (int64 = the reference's Long, float64).
+"""
+from __future__ import annotations
+
+import ctypes as C
+from pathlib import Path
+
+import numpy as np
+
+_HERE = Path(__file__).resolve().parent
+lib_path = _HERE / "libstmmqr_hip.so"
+
+c_long_p = C.POINTER(C.c_long)
+c_double_p = C.POINTER(C.c_double)
+I64 = np.int64
+
+
+class StmmqrError(RuntimeError):
+    pass
+
+
+if not lib_path.exists():
+    raise ImportError(
+        f"{lib_path} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+        "(hipcc --offload-arch=gfx950).  There is no CPU fallback for this path.")
+lib = C.CDLL(str(lib_path))
+
+
+class SymbolicView(C.Structure):
+    _fields_ = [(k, C.c_long) for k in ["m", "n", "anz", "nf", "maxfn", "rjsize", "hisize", "do_rank_detection"]] + \
+               [(k, c_long_p) for k in ["Sp", "Sj", "Qfill", "PLinv", "Sleft", "Child", "Childp", "Super", "Rp", "Rj",
+                                        "Post", "Hip", "Fm"]]
+
+
+class Stats(C.Structure):
+    _fields_ = [(k, C.c_double) for k in ["flops", "ms_total", "ms_assemble", "ms_front", "ms_pack", "ms_h2d", "ms_d2h",
+                                          "ms_host", "bytes_assemble", "bytes_pack", "flops_update", "ms_update"]] + \
+               [("nlaunch", C.c_long), ("nlevels", C.c_long)]
+
+    def as_dict(self):
+        return {k: getattr(self, k) for k, _ in self._fields_}
+
+
+class Options(C.Structure):
+    _fields_ = [("panel_width", C.c_int), ("big_front_cols", C.c_int), ("verbose", C.c_int), ("use_graph", C.c_int)]
+
+
+def _ip(a):
+    return None if a is None else a.ctypes.data_as(c_long_p)
+
+
+def _dp(a):
+    return None if a is None else a.ctypes.data_as(c_double_p)
+
+
+lib.stmmqr_last_error.restype = C.c_char_p
+lib.stmmqr_version.restype = C.c_char_p
+lib.stmmqr_device_name.restype = C.c_char_p
+lib.stmmqr_device_name.argtypes = [C.c_int]
+lib.stmmqr_plan_create.restype = C.c_void_p
+lib.stmmqr_plan_create.argtypes = [C.POINTER(SymbolicView), C.c_int, C.POINTER(C.c_int)]
+lib.stmmqr_plan_destroy.argtypes = [C.c_void_p]
+lib.stmmqr_plan_destroy.restype = None
+lib.stmmqr_plan_set_pattern.argtypes = [C.c_void_p, c_long_p, c_long_p]
+lib.stmmqr_factorize_device.argtypes = [C.c_void_p, c_long_p, c_long_p, C.c_void_p, C.c_int, C.c_double, C.c_long,
+                                        C.POINTER(Stats)]
+lib.stmmqr_plan_result_sizes.argtypes = [C.c_void_p, c_long_p, c_long_p]
+lib.stmmqr_plan_download.argtypes = [C.c_void_p, c_double_p, c_long_p, C.c_char_p, c_long_p, c_double_p, c_long_p,
+                                     c_long_p, c_long_p, c_long_p, c_long_p, C.POINTER(Stats)]
+lib.stmmqr_front.restype = C.c_long
+lib.stmmqr_front.argtypes = [C.c_long, C.c_long, C.c_long, C.c_double, C.c_long, c_double_p, c_long_p, C.c_char_p,
+                             c_double_p, c_double_p]
+lib.stmmqr_larftb_qtx.argtypes = [C.c_long] * 5 + [c_double_p, c_double_p, c_double_p]
+lib.qr_cpack.restype = C.c_long
+lib.qr_cpack.argtypes = [C.c_long] * 4 + [c_double_p, c_double_p]
+lib.qr_rhpack.restype = C.c_long
+lib.qr_rhpack.argtypes = [C.c_int, C.c_long, C.c_long, C.c_long, c_long_p, c_double_p, c_double_p, c_long_p]
+lib.qr_fcsize.restype = C.c_long
+lib.qr_fcsize.argtypes = [C.c_long] * 4
+lib.qr_assemble.restype = None
+lib.qr_assemble.argtypes = [C.c_long, C.c_long, C.c_int] + [c_long_p] * 8 + [c_double_p, c_long_p, c_long_p,
+                                                                             C.POINTER(c_double_p), c_long_p, c_long_p,
+                                                                             c_long_p, c_long_p, c_double_p, c_long_p]
+lib.stmmqr_get_options.argtypes = [C.POINTER(Options)]
+lib.stmmqr_set_options.argtypes = [C.POINTER(Options)]
+
+
+def last_error() -> str:
+    return lib.stmmqr_last_error().decode()
+
+
+def device_count() -> int:
+    return int(lib.stmmqr_device_count())
+
+
+def device_name(i: int = 0) -> str:
+    return lib.stmmqr_device_name(i).decode()
+
+
+def get_options() -> dict:
+    o = Options()
+    lib.stmmqr_get_options(C.byref(o))
+    return {k: getattr(o, k) for k, _ in o._fields_}
+
+
+def set_options(**kw):
+    o = Options()
+    lib.stmmqr_get_options(C.byref(o))
+    for k, v in kw.items():
+        setattr(o, k, v)
+    lib.stmmqr_set_options(C.byref(o))
+
+
+def _check(rc: int, what: str):
+    if rc != 0:
+        raise StmmqrError(f"{what} failed ({rc}): {last_error()}")
+
+
+class QRNumeric:
+    """Host copy of the reference's qr_numeric (STMMQR/include/SparseQR_struct.h:145-209), one stack."""
+
+    def __init__(self, nf, n, m, rjsize, hisize, rh_total):
+        self.Stack = np.zeros(max(rh_total, 1))
+        self.Rblock_off = np.zeros(max(nf, 1), I64)
+        self.Rdead = np.zeros(max(n, 1), np.int8)
+        self.HStair = np.zeros(max(rjsize, 1), I64)
+        self.HTau = np.zeros(max(rjsize, 1))
+        self.Hii = np.zeros(max(hisize, 1), I64)
+        self.HPinv = np.zeros(max(m, 1), I64)
+        self.Hm = np.zeros(max(nf, 1), I64)
+        self.Hr = np.zeros(max(nf, 1), I64)
+        self.rh_total = rh_total
+        self.rank = self.rank1 = self.maxfrank = self.maxfm = 0
+        self.stats = {}
+
+
+class HipQR:
+    """A device plan for one symbolic analysis (reusable across numeric factorizations).
+
+    ``sym`` is a dict with the qr_symbolic arrays/scalars of the same names (int64 numpy arrays).
+    """
+
+    def __init__(self, sym: dict, device: int = -1):
+        self._keep = {}
+        v = SymbolicView()
+        for k in ["m", "n", "anz", "nf", "maxfn", "rjsize", "hisize", "do_rank_detection"]:
+            setattr(v, k, int(sym[k]))
+        for k in ["Sp", "Sj", "Qfill", "PLinv", "Sleft", "Child", "Childp", "Super", "Rp", "Rj", "Post", "Hip", "Fm"]:
+            a = sym.get(k)
+            if a is not None and np.size(a) == 0 and k == "Qfill":
+                a = None
+            if a is not None:
+                a = np.ascontiguousarray(a, dtype=I64)
+                self._keep[k] = a
+            setattr(v, k, _ip(a))
+        self.sym = {k: int(sym[k]) for k in ["m", "n", "anz", "nf", "maxfn", "rjsize", "hisize"]}
+        st = C.c_int(0)
+        self._h = lib.stmmqr_plan_create(C.byref(v), device, C.byref(st))
+        if not self._h:
+            raise StmmqrError(f"stmmqr_plan_create failed ({st.value}): {last_error()}")
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib.stmmqr_plan_destroy(self._h)
+            self._h = None
+
+    __del__ = close
+
+    def set_pattern(self, Ap, Ai):
+        Ap = np.ascontiguousarray(Ap, I64); Ai = np.ascontiguousarray(Ai, I64)
+        _check(lib.stmmqr_plan_set_pattern(self._h, _ip(Ap), _ip(Ai)), "stmmqr_plan_set_pattern")
+
+    def factorize(self, Ax, tol, ntol, Ap=None, Ai=None, device_ptr: int | None = None, detail=False) -> dict:
+        """Numeric factorization; results stay in HBM.  Ax: numpy array, or device_ptr (int) of a device buffer."""
+        st = Stats()
+        if detail:
+            st.nlaunch = -1
+        if Ap is not None:
+            Ap = np.ascontiguousarray(Ap, I64); Ai = np.ascontiguousarray(Ai, I64)
+        if device_ptr is not None:
+            rc = lib.stmmqr_factorize_device(self._h, _ip(Ap), _ip(Ai), C.c_void_p(device_ptr), 1, float(tol), int(ntol),
+                                             C.byref(st))
+        else:
+            Ax = np.ascontiguousarray(Ax, np.float64)
+            rc = lib.stmmqr_factorize_device(self._h, _ip(Ap), _ip(Ai), Ax.ctypes.data_as(C.c_void_p), 0, float(tol),
+                                             int(ntol), C.byref(st))
+        _check(rc, "stmmqr_factorize_device")
+        return st.as_dict()
+
+    def download(self) -> QRNumeric:
+        rh = C.c_long(0); rk = C.c_long(0)
+        _check(lib.stmmqr_plan_result_sizes(self._h, C.byref(rh), C.byref(rk)), "stmmqr_plan_result_sizes")
+        s = self.sym
+        N = QRNumeric(s["nf"], s["n"], s["m"], s["rjsize"], s["hisize"], rh.value)
+        sc = np.zeros(4, I64)
+        st = Stats()
+        _check(lib.stmmqr_plan_download(self._h, _dp(N.Stack), _ip(N.Rblock_off),
+                                        C.cast(N.Rdead.ctypes.data, C.c_char_p), _ip(N.HStair), _dp(N.HTau), _ip(N.Hii),
+                                        _ip(N.HPinv), _ip(N.Hm), _ip(N.Hr), _ip(sc), C.byref(st)),
+               "stmmqr_plan_download")
+        N.rank, N.rank1, N.maxfrank, N.maxfm = (int(x) for x in sc)
+        N.stats = st.as_dict()
+        return N
+
+
+def qr_factorize(sym: dict, Ap, Ai, Ax, tol, ntol) -> QRNumeric:
+    """qr_factorize(&A, freeA, tol, ntol, QRsym, cc) on arrays (SparseQR.h:127-135)."""
+    plan = HipQR(sym)
+    try:
+        stats = plan.factorize(Ax, tol, ntol, Ap, Ai)
+        N = plan.download()
+        N.stats = {**stats, **{k: v for k, v in N.stats.items() if k in ("ms_d2h", "ms_host")}}
+        return N
+    finally:
+        plan.close()
+
+
+def qr_front(m, n, npiv, tol, ntol, F, Stair):
+    """qr_front (SparseQR.h:209-226).  F: (m,n) Fortran-ordered, modified in place; Stair int64, in/out.
+    Returns (rank, Tau, Rdead, flops)."""
+    assert F.flags.f_contiguous and F.dtype == np.float64 and F.shape == (m, n)
+    assert Stair.dtype == I64
+    Tau = np.zeros(max(n, 1)); Rdead = np.zeros(max(n, 1), np.int8); fl = C.c_double(0)
+    r = lib.stmmqr_front(m, n, npiv, float(tol), int(ntol), _dp(F), _ip(Stair), C.cast(Rdead.ctypes.data, C.c_char_p),
+                         _dp(Tau), C.byref(fl))
+    if r < 0:
+        raise StmmqrError(f"stmmqr_front failed: {last_error()}")
+    return int(r), Tau[:n], Rdead[:min(n, max(npiv, 0))], fl.value
+
+
+def qr_larftb(method, m, n, k, ldc, ldv, V, Tau, Cmat):
+    """qr_larftb, method QR_QTX = 0 (SparseQR.h:255-268): C <- (I - V T V')' C in place."""
+    if method != 0:
+        raise StmmqrError("only QR_QTX is on the factorization path")
+    _check(lib.stmmqr_larftb_qtx(m, n, k, ldc, ldv, _dp(V), _dp(Tau), _dp(Cmat)), "stmmqr_larftb_qtx")
+
+
+def qr_fcsize(m, n, npiv, g):
+    return int(lib.qr_fcsize(m, n, npiv, g))
+
+
+def qr_cpack(m, n, npiv, g, F):
+    """qr_cpack (SparseQR.h:235-242): returns (cm, packed C)."""
+    Cp = np.zeros(max(qr_fcsize(m, n, npiv, g), 1))
+    cm = lib.qr_cpack(m, n, npiv, g, _dp(F), _dp(Cp))
+    if cm < 0:
+        raise StmmqrError("qr_cpack failed")
+    return int(cm), Cp[:qr_fcsize(m, n, npiv, g)]
+
+
+def qr_rhpack(m, n, npiv, Stair, F):
+    """qr_rhpack with keepH (SparseQR.h:244-253): returns (rsize, rm, packed R+H)."""
+    R = np.zeros(max(m * n, 1)); rm = C.c_long(0)
+    rs = lib.qr_rhpack(1, m, n, npiv, _ip(Stair), _dp(F), _dp(R), C.byref(rm))
+    if rs < 0:
+        raise StmmqrError("qr_rhpack failed")
+    return int(rs), int(rm.value), R[:rs]
+
+
+def qr_assemble(f, fm, Super, Rp, Rj, Sp, Sj, Sleft, Child, Childp, Sx, Fmap, Cm, Cblocks: dict, Hr, Stair, Hii, Hip):
+    """qr_assemble (SparseQR.h:178-200).  Cblocks: {child: packed C array}.  Returns (F, Cmap); Stair/Hii in place."""
+    nf = len(Rp) - 1
+    fn = int(Rp[f + 1] - Rp[f])
+    F = np.zeros((fm, fn), order="F")
+    Cmap = np.zeros(max(fn, 1), I64)
+    ptrs = (c_double_p * (nf + 1))()
+    keep = {}
+    for c, a in Cblocks.items():
+        keep[c] = np.ascontiguousarray(a, np.float64)
+        ptrs[c] = _dp(keep[c])
+    arrs = [np.ascontiguousarray(a, I64) for a in (Super, Rp, Rj, Sp, Sj, Sleft, Child, Childp)]
+    Sx = np.ascontiguousarray(Sx, np.float64)
+    Fmap = np.ascontiguousarray(Fmap, I64); Cm = np.ascontiguousarray(Cm, I64); Hr = np.ascontiguousarray(Hr, I64)
+    Hip = np.ascontiguousarray(Hip, I64)
+    lib.qr_assemble(f, fm, 1, *[_ip(a) for a in arrs], _dp(Sx), _ip(Fmap), _ip(Cm), ptrs, _ip(Hr), _ip(Stair), _ip(Hii),
+                    _ip(Hip), _dp(F), _ip(Cmap))
+    return F, Cmap

@@ -1,0 +1,43 @@
+// stmmqr_device.h -- structures shared by the host planner and the gfx950 kernels.
+//
+// Device-side view of one front of the multifrontal QR (reference: qr_kernel's per-front loop,
+// STMMQR/src/qr/SparseQR_factorize.c:886-974).  All indices are 32-bit on the device (rjsize, hisize,
+// anz < 2^31 is checked by the planner); arena offsets are 64-bit.
+#pragma once
+#include <stdint.h>
+
+#define STM_NB 32            // Householder panel width (reference FCHUNK = 32, qrtest.c:152)
+#define STM_BIGROW 0x3fffffff
+
+// symbolic, immutable after planning
+struct FrontSym {
+    long long foff;          // offset (doubles) of F in the front arena; F is column-major, ld rows
+    long long coff;          // offset (doubles) of the packed contribution block in the C arena
+    int ld;                  // leading dimension of F (>= fm upper bound, even)
+    int fn, fp;              // columns, pivotal columns            (Rp[f+1]-Rp[f], Super[f+1]-Super[f])
+    int col1;                // first pivotal column                (Super[f])
+    int rp;                  // Rp[f]: slot of this front in Rj / HStair / HTau / Rjrel / Cmap
+    int hip;                 // Hip[f]: slot in Hii
+    int child0, child1;      // children = Child[child0 .. child1)
+    int srow0, srow1;        // rows of S assembled here = [Sleft[col1], Sleft[col1+fp])
+    int fm_ub;               // symbolic upper bound on the number of rows
+    int npanels;             // ceil(fn / STM_NB)
+    int parent;              // parent front or -1
+    int pad0;
+};
+
+// numeric, written by the kernels
+struct FrontNum {
+    int fm;                  // rows of F                           (qr_fsize)
+    int g;                   // rows eliminated so far = next diagonal row
+    int rank;                // live pivotal columns                (qr_front's return value)
+    int done;                // 1 once g reached fm and the tail columns were finalised
+    int pg1, pt;             // pending block reflector: rows [pg1, pt)
+    int pk1, pnb;            // ... built from columns [pk1, pk1+pnb)
+    int pc0;                 // ... to be applied to columns [pc0, fn)
+    int pad1;
+    int cm;                  // rows of the contribution block      (qr_cpack's return value)
+    int rsize;               // entries of the packed R+H block     (qr_rhpack's return value)
+    double flops;            // reference flop count of this front  (FLOP_COUNT, :1571)
+    int pdiag[STM_NB];       // row of the unit diagonal of each reflector of the pending block (BIGROW: none)
+};

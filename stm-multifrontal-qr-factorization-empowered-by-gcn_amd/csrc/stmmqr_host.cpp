@@ -1,0 +1,894 @@
+// stmmqr_host.cpp -- host side of libstmmqr_hip.so: symbolic planner, level scheduler, C ABI.
+//
+// Reference counterparts (paths relative to /root/reference/STMMQR):
+//   stmmqr_plan_create      the allocation / setup half of qr_factorize   src/qr/SparseQR_factorize.c:222-498
+//   run_schedule            qr_kernel's per-front loop + qr_multithreads   :791-985, SparseQR_multithreads.c:14-115
+//                           (tree parallelism re-cast as level-batched launches on a HIP stream: every front
+//                            of one tree level is independent, so a level = a few batched kernel launches;
+//                            no blocking waits inside workers, cf. SURVEY.md 3.3 deadlock note)
+//   stmmqr_plan_download    the wrap-up half of qr_factorize (:554-742) incl. qr_hpinv (:991-1060)
+//   qr_factorize            the drop-in seam                                include/SparseQR.h:127-135
+//
+// There is NO CPU fallback in this file: every numeric operation is a kernel in stmmqr_kernels.hip.  If no
+// gfx950 device is usable the entry points fail with STMMQR_ERR_DEVICE.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/stmmqr_hip.h"
+#include "stmmqr_device.h"
+#include "stmmqr_kernels.h"
+
+namespace {
+
+thread_local std::string g_err;
+stmmqr_options g_opt = {STM_NB, 128, 0, 0};
+size_t g_chunk[4] = {32, 5000, 4, 4};     // FCHUNK, SMALL, MINCHUNK, MINCHUNK_RATIO (SparseQR.h:16-19)
+
+// offsets inside the reference's sparse_common for the stock LP64 build; verified against the real header
+// by tests/test_abi_layout.py where /root/reference is present.
+stm_common_layout g_layout = {
+    /* status */ 1004, /* malloc_count */ 1032, /* memory_usage */ 1040, /* memory_inuse */ 1048,
+    /* blas_ok */ 1100, /* SPQR_grain */ 1104, /* SPQR_small */ 1112, /* SPQR_shrink */ 1120,
+    /* SPQR_flopcount */ 1128, /* SPQR_flopcount_bound */ 1136};
+
+int fail(int code, const std::string &msg)
+{
+    g_err = msg;
+    if (g_opt.verbose) fprintf(stderr, "[stmmqr_hip] error %d: %s\n", code, msg.c_str());
+    return code;
+}
+
+#define HIPCHK(expr)                                                                                      \
+    do {                                                                                                  \
+        hipError_t e_ = (expr);                                                                           \
+        if (e_ != hipSuccess)                                                                             \
+            return fail(e_ == hipErrorOutOfMemory ? STMMQR_ERR_OUT_OF_MEMORY : STMMQR_ERR_DEVICE,        \
+                        std::string(#expr) + ": " + hipGetErrorString(e_));                              \
+    } while (0)
+#define LCHK(expr)                                                                                        \
+    do {                                                                                                  \
+        int e_ = (expr);                                                                                  \
+        if (e_ != 0) return fail(STMMQR_ERR_DEVICE, std::string(#expr) + ": " + hipGetErrorString((hipError_t)e_)); \
+    } while (0)
+
+double now_ms()
+{
+    using namespace std::chrono;
+    return duration<double, std::milli>(steady_clock::now().time_since_epoch()).count();
+}
+
+template <class T> struct DevBuf {
+    T *p = nullptr;
+    size_t n = 0;
+    int alloc(size_t count)
+    {
+        release();
+        n = count;
+        if (count == 0) count = 1;
+        hipError_t e = hipMalloc((void **)&p, count * sizeof(T));
+        if (e != hipSuccess) { p = nullptr; n = 0; return (int)e; }
+        return 0;
+    }
+    int upload(const std::vector<T> &h, hipStream_t st)
+    {
+        int e = alloc(h.size());
+        if (e) return e;
+        if (!h.empty()) return (int)hipMemcpyAsync(p, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice, st);
+        return 0;
+    }
+    void release()
+    {
+        if (p) (void)hipFree(p);
+        p = nullptr; n = 0;
+    }
+    ~DevBuf() { release(); }
+};
+
+struct Level {
+    int all_off = 0, n_all = 0;          // every front of the level (small first, then big by npanels desc)
+    int n_small = 0, n_big = 0;
+    int asm_parts_off = 0, asm_maxparts = 1;
+    int cpk_parts_off = 0, cpk_maxparts = 1;
+    int lds_small = 0, lds_big = 0;      // dynamic LDS (doubles) for the panel staging
+    std::vector<int> nbig_at;            // big fronts with npanels > p
+    std::vector<int> maxcb_at;           // max trailing column blocks at panel p
+};
+
+}  // namespace
+
+struct stmmqr_plan {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev[8] = {};
+    long m = 0, n = 0, anz = 0, nf = 0, maxfn = 0, rjsize = 0, hisize = 0;
+    int do_rank = 1;
+    std::vector<long> Sp, Sj, Qfill, PLinv, Sleft, Child, Childp, Super, Rp, Rj, Post, Hip, Fm;
+    bool has_qfill = false;
+    std::vector<FrontSym> fs;
+    std::vector<Level> levels;
+    std::vector<int> lists;              // host copy of d_lists
+    int post_off = 0, rh_parts_off = 0, rh_maxparts = 1;
+    long long farena = 0, carena = 0;
+    int tslots = 1;
+    bool pattern_set = false;
+    double bytes_assemble_idx = 0;       // index bytes of the assembly (symbolic part of SURVEY 8d formula)
+
+    DevBuf<FrontSym> d_fs;
+    DevBuf<FrontNum> d_fnum;
+    DevBuf<double> d_F, d_C, d_T, d_Sx, d_Ax, d_Tau, d_RH;
+    DevBuf<int> d_tslot, d_Sp, d_Sjrel, d_Sj0, d_Sleft, d_Child, d_Rjrel, d_Stair, d_Hii, d_Cmap, d_Cursor,
+        d_Rhoff, d_lists, d_smap;
+    DevBuf<long long> d_Rboff, d_total;
+    DevBuf<char> d_Rdead;
+
+    // results of the last factorization
+    bool factored = false;
+    long long rh_total = 0;
+    long rank = 0;
+    std::vector<FrontNum> h_fnum;
+    double last_tol = 0;
+    long last_ntol = 0;
+    stmmqr_stats stats = {};
+
+    DevCtx ctx() const
+    {
+        DevCtx c;
+        c.fs = d_fs.p; c.fnum = d_fnum.p; c.Farena = d_F.p; c.Carena = d_C.p; c.Tws = d_T.p; c.tslot = d_tslot.p;
+        c.Sx = d_Sx.p; c.Sp = d_Sp.p; c.Sjrel = d_Sjrel.p; c.Sj0 = d_Sj0.p; c.Sleft = d_Sleft.p;
+        c.Child = d_Child.p; c.Rjrel = d_Rjrel.p; c.Stair = d_Stair.p; c.Tau = d_Tau.p; c.Hii = d_Hii.p;
+        c.Rdead = d_Rdead.p; c.Cmap = d_Cmap.p; c.Cursor = d_Cursor.p; c.Rhoff = d_Rhoff.p; c.Rboff = d_Rboff.p;
+        c.tol = last_tol; c.ntol = (int)last_ntol;
+        return c;
+    }
+    ~stmmqr_plan()
+    {
+        for (auto &e : ev)
+            if (e) (void)hipEventDestroy(e);
+        if (stream) (void)hipStreamDestroy(stream);
+    }
+};
+
+namespace {
+
+const int LDS_CAP_DOUBLES = 16384;        // 128 KiB of dynamic LDS for the staged panel
+
+int ensure_device(int device)
+{
+    int cnt = 0;
+    hipError_t e = hipGetDeviceCount(&cnt);
+    if (e != hipSuccess || cnt <= 0)
+        return fail(STMMQR_ERR_DEVICE, "no HIP device visible: the MI355X path has no CPU fallback");
+    if (device >= cnt) return fail(STMMQR_ERR_DEVICE, "device index out of range");
+    if (device >= 0) HIPCHK(hipSetDevice(device));
+    static bool configured = false;
+    if (!configured) {
+        LCHK(stm_configure_kernels());
+        configured = true;
+    }
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// planner: everything that depends only on the symbolic analysis
+// ------------------------------------------------------------------------------------------------
+int build_plan(stmmqr_plan &P, const stmmqr_symbolic_view &v)
+{
+    P.m = v.m; P.n = v.n; P.anz = v.anz; P.nf = v.nf; P.maxfn = v.maxfn; P.rjsize = v.rjsize;
+    P.hisize = v.hisize; P.do_rank = v.do_rank_detection ? 1 : 0;
+    const long m = v.m, n = v.n, nf = v.nf;
+    if (m < 0 || n < 0 || nf < 0) return fail(STMMQR_ERR_INVALID, "negative dimension");
+    if (v.anz >= (1L << 31) - 1 || v.rjsize >= (1L << 31) - 1 || v.hisize >= (1L << 31) - 1 || m >= (1L << 30) ||
+        n >= (1L << 30))
+        return fail(STMMQR_ERR_TOO_LARGE, "problem exceeds the 32-bit device index range");
+    auto cp = [](std::vector<long> &dst, const stm_long *src, long cnt) {
+        dst.assign(src, src + (cnt > 0 ? cnt : 0));
+    };
+    cp(P.Sp, v.Sp, m + 1); cp(P.Sj, v.Sj, v.anz); cp(P.PLinv, v.PLinv, m); cp(P.Sleft, v.Sleft, n + 2);
+    cp(P.Child, v.Child, nf + 1); cp(P.Childp, v.Childp, nf + 2); cp(P.Super, v.Super, nf + 1);
+    cp(P.Rp, v.Rp, nf + 1); cp(P.Rj, v.Rj, v.rjsize); cp(P.Post, v.Post, nf); cp(P.Hip, v.Hip, nf + 1);
+    P.has_qfill = v.Qfill != nullptr;
+    if (P.has_qfill) cp(P.Qfill, v.Qfill, n);
+
+    // ---- per-front symbolic sizes -----------------------------------------------------------
+    std::vector<long> parent(nf, -1);
+    for (long f = 0; f < nf; f++)
+        for (long q = P.Childp[f]; q < P.Childp[f + 1]; q++) parent[P.Child[q]] = f;
+
+    // upper bound on the rows of every front: taken from the analysis when given (QRsym->Fm, worst case when
+    // rank detection is on: SparseQR_analyze.c:461-471), otherwise recomputed with the same recurrence
+    P.Fm.assign(nf, 0);
+    if (v.Fm) {
+        for (long f = 0; f < nf; f++) P.Fm[f] = v.Fm[f];
+    } else {
+        std::vector<long> cmub(nf, 0);
+        for (long kf = 0; kf < nf; kf++) {
+            const long f = P.Post[kf];
+            const long fp = P.Super[f + 1] - P.Super[f], fn = P.Rp[f + 1] - P.Rp[f];
+            long fm = P.Sleft[P.Super[f + 1]] - P.Sleft[P.Super[f]];
+            for (long q = P.Childp[f]; q < P.Childp[f + 1]; q++) fm += cmub[P.Child[q]];
+            P.Fm[f] = fm;
+            const long cn = fn - fp;
+            cmub[f] = P.do_rank ? std::min(fm, cn) : std::min(std::max(fm - std::min(fm, fp), 0L), cn);
+        }
+    }
+
+    P.fs.assign(nf, FrontSym());
+    long long foff = 0, coff = 0;
+    for (long kf = 0; kf < nf; kf++) {
+        const long f = P.Post[kf];
+        FrontSym &s = P.fs[f];
+        const long fp = P.Super[f + 1] - P.Super[f], fn = P.Rp[f + 1] - P.Rp[f];
+        const long fm = P.Fm[f];
+        if (fm * fn >= (1L << 31)) return fail(STMMQR_ERR_TOO_LARGE, "a single front exceeds 2^31 entries");
+        s.fn = (int)fn; s.fp = (int)fp; s.col1 = (int)P.Super[f]; s.rp = (int)P.Rp[f]; s.hip = (int)P.Hip[f];
+        s.child0 = (int)P.Childp[f]; s.child1 = (int)P.Childp[f + 1];
+        s.srow0 = (int)P.Sleft[P.Super[f]]; s.srow1 = (int)P.Sleft[P.Super[f + 1]];
+        s.fm_ub = (int)fm;
+        s.ld = (int)std::max(2L, (fm + 1) & ~1L);
+        s.npanels = (int)((fn + STM_NB - 1) / STM_NB);
+        s.parent = (int)parent[f];
+        s.foff = foff;
+        foff += (long long)s.ld * fn;
+        const long cn = fn - fp;
+        const long cm = P.do_rank ? std::min(fm, cn) : std::min(std::max(fm - std::min(fm, fp), 0L), cn);
+        s.coff = coff;
+        coff += (long long)cm * (cm + 1) / 2 + (long long)cm * (cn - cm);
+        coff = (coff + 1) & ~1LL;
+    }
+    P.farena = foff; P.carena = coff;
+
+    // ---- relative indices (value independent): child column -> parent column, S entry -> front column ----
+    std::vector<int> Rjrel(std::max(1L, v.rjsize), 0), Sjrel(std::max(1L, v.anz), 0), Sj0(std::max(1L, m), -1);
+    {
+        std::vector<int> Fmap(std::max(1L, n), -1);
+        for (long f = 0; f < nf; f++) {
+            const long p1 = P.Rp[f], fn = P.Rp[f + 1] - p1;
+            for (long j = 0; j < fn; j++) Fmap[P.Rj[p1 + j]] = (int)j;
+            for (long r = P.fs[f].srow0; r < P.fs[f].srow1; r++)
+                for (long p = P.Sp[r]; p < P.Sp[r + 1]; p++) Sjrel[p] = Fmap[P.Sj[p]];
+            for (long q = P.Childp[f]; q < P.Childp[f + 1]; q++) {
+                const long c = P.Child[q];
+                const long fpc = P.Super[c + 1] - P.Super[c], pc = P.Rp[c] + fpc, cn = P.Rp[c + 1] - pc;
+                for (long cj = 0; cj < cn; cj++) Rjrel[pc + cj] = Fmap[P.Rj[pc + cj]];
+                P.bytes_assemble_idx += 4.0 * (double)(2 * cn);
+            }
+        }
+        for (long r = 0; r < m; r++)
+            if (P.Sp[r + 1] > P.Sp[r]) Sj0[r] = (int)P.Sj[P.Sp[r]];
+        P.bytes_assemble_idx += 4.0 * (double)v.anz;
+    }
+
+    // ---- level schedule ---------------------------------------------------------------------------
+    std::vector<int> level(nf, 0);
+    int nlev = 0;
+    for (long kf = 0; kf < nf; kf++) {
+        const long f = P.Post[kf];
+        int lv = 0;
+        for (long q = P.Childp[f]; q < P.Childp[f + 1]; q++) lv = std::max(lv, level[P.Child[q]] + 1);
+        level[f] = lv;
+        nlev = std::max(nlev, lv + 1);
+    }
+    std::vector<std::vector<int>> byl(nlev);
+    for (long kf = 0; kf < nf; kf++) byl[level[P.Post[kf]]].push_back((int)P.Post[kf]);
+
+    auto is_big = [&](int f) {
+        const FrontSym &s = P.fs[f];
+        return s.fn >= g_opt.big_front_cols && s.fm_ub >= 64;
+    };
+    std::vector<int> tslot(std::max(1L, nf), 0);
+    P.levels.assign(nlev, Level());
+    P.lists.clear();
+    P.tslots = 1;
+    for (int lv = 0; lv < nlev; lv++) {
+        Level &L = P.levels[lv];
+        std::vector<int> small, big;
+        for (int f : byl[lv]) (is_big(f) ? big : small).push_back(f);
+        std::stable_sort(big.begin(), big.end(), [&](int a, int b) { return P.fs[a].npanels > P.fs[b].npanels; });
+        L.all_off = (int)P.lists.size();
+        L.n_small = (int)small.size(); L.n_big = (int)big.size(); L.n_all = L.n_small + L.n_big;
+        P.lists.insert(P.lists.end(), small.begin(), small.end());
+        P.lists.insert(P.lists.end(), big.begin(), big.end());
+        // assembly parts (all fronts, list order)
+        L.asm_parts_off = (int)P.lists.size();
+        L.asm_maxparts = 1;
+        for (int i = 0; i < L.n_all; i++) {
+            const FrontSym &s = P.fs[P.lists[L.all_off + i]];
+            long work = (long)s.fm_ub * s.fn;
+            int parts = (int)std::min(128L, std::max(1L, (work + 16383) / 16384));
+            P.lists.push_back(parts);
+            L.asm_maxparts = std::max(L.asm_maxparts, parts);
+        }
+        // C-pack parts (big fronts only; small ones pack inside k_front_wg)
+        L.cpk_parts_off = (int)P.lists.size();
+        L.cpk_maxparts = 1;
+        for (int i = 0; i < L.n_big; i++) {
+            const FrontSym &s = P.fs[big[i]];
+            long cn = s.fn - s.fp;
+            long work = cn * std::min((long)s.fm_ub, cn);
+            int parts = (int)std::min(64L, std::max(1L, (work + 16383) / 16384));
+            P.lists.push_back(parts);
+            L.cpk_maxparts = std::max(L.cpk_maxparts, parts);
+        }
+        int maxp = 0;
+        long maxfm_small = 0, maxfm_big = 0;
+        for (int f : small) maxfm_small = std::max(maxfm_small, (long)P.fs[f].fm_ub);
+        for (size_t i = 0; i < big.size(); i++) {
+            maxp = std::max(maxp, P.fs[big[i]].npanels);
+            maxfm_big = std::max(maxfm_big, (long)P.fs[big[i]].fm_ub);
+            tslot[big[i]] = (int)i;
+        }
+        P.tslots = std::max(P.tslots, (int)big.size());
+        L.lds_small = (int)std::min((long)LDS_CAP_DOUBLES, (maxfm_small | 1) * STM_NB);
+        L.lds_big = (int)std::min((long)LDS_CAP_DOUBLES, (maxfm_big | 1) * STM_NB);
+        L.nbig_at.assign(maxp, 0);
+        L.maxcb_at.assign(maxp, 0);
+        for (int p = 0; p < maxp; p++) {
+            int cnt = 0, mcb = 0;
+            for (int f : big) {
+                const FrontSym &s = P.fs[f];
+                if (s.npanels > p) {
+                    cnt++;
+                    const int k2 = std::min(s.fn, (p + 1) * STM_NB);
+                    mcb = std::max(mcb, (s.fn - k2 + 31) / 32);
+                }
+            }
+            L.nbig_at[p] = cnt;
+            L.maxcb_at[p] = mcb;
+        }
+    }
+    // all fronts in Post order + R+H copy parts
+    P.post_off = (int)P.lists.size();
+    for (long kf = 0; kf < nf; kf++) P.lists.push_back((int)P.Post[kf]);
+    P.rh_parts_off = (int)P.lists.size();
+    P.rh_maxparts = 1;
+    for (long kf = 0; kf < nf; kf++) {
+        const FrontSym &s = P.fs[P.Post[kf]];
+        int parts = std::min(64, std::max(1, s.fn / 16));
+        P.lists.push_back(parts);
+        P.rh_maxparts = std::max(P.rh_maxparts, parts);
+    }
+    if (P.lists.empty()) P.lists.push_back(0);
+
+    // ---- device memory ----------------------------------------------------------------------------
+    size_t freeb = 0, totalb = 0;
+    HIPCHK(hipMemGetInfo(&freeb, &totalb));
+    const double need = 8.0 * ((double)P.farena + (double)P.carena) * 1.05 + 64.0 * (double)(v.rjsize + v.anz);
+    if (need > 0.92 * (double)freeb)
+        return fail(STMMQR_ERR_OUT_OF_MEMORY, "front arena does not fit in free HBM");
+    hipStream_t st = P.stream;
+    auto up32 = [&](DevBuf<int> &d, const std::vector<long> &h) {
+        std::vector<int> t(h.begin(), h.end());
+        return d.upload(t, st);
+    };
+    LCHK(P.d_fs.upload(P.fs, st));
+    LCHK(P.d_fnum.alloc(std::max(1L, nf)));
+    HIPCHK(hipMemsetAsync(P.d_fnum.p, 0, std::max(1L, nf) * sizeof(FrontNum), st));
+    LCHK(P.d_F.alloc((size_t)P.farena));
+    LCHK(P.d_C.alloc((size_t)P.carena));
+    LCHK(P.d_T.alloc((size_t)P.tslots * STM_NB * STM_NB));
+    LCHK(P.d_tslot.upload(tslot, st));
+    LCHK(P.d_Sx.alloc((size_t)v.anz));
+    LCHK(P.d_Ax.alloc((size_t)v.anz));
+    LCHK(P.d_smap.alloc((size_t)v.anz));
+    LCHK(up32(P.d_Sp, P.Sp));
+    LCHK(P.d_Sjrel.upload(Sjrel, st));
+    LCHK(P.d_Sj0.upload(Sj0, st));
+    LCHK(up32(P.d_Sleft, P.Sleft));
+    LCHK(up32(P.d_Child, P.Child));
+    LCHK(P.d_Rjrel.upload(Rjrel, st));
+    LCHK(P.d_Stair.alloc((size_t)v.rjsize));
+    LCHK(P.d_Tau.alloc((size_t)v.rjsize));
+    LCHK(P.d_Hii.alloc((size_t)v.hisize));
+    LCHK(P.d_Cmap.alloc((size_t)v.rjsize));
+    LCHK(P.d_Cursor.alloc((size_t)v.rjsize));
+    LCHK(P.d_Rhoff.alloc((size_t)v.rjsize));
+    LCHK(P.d_Rboff.alloc((size_t)std::max(1L, nf)));
+    LCHK(P.d_total.alloc(1));
+    LCHK(P.d_Rdead.alloc((size_t)std::max(1L, n)));
+    LCHK(P.d_lists.upload(P.lists, st));
+    HIPCHK(hipStreamSynchronize(st));
+    return 0;
+}
+
+// qr_stranspose2 as a symbolic map: smap[s] = p such that Sx[s] = Ax[p]  (SparseQR_factorize.c:755-785)
+int set_pattern(stmmqr_plan &P, const stm_long *Ap, const stm_long *Ai)
+{
+    const long m = P.m, n = P.n;
+    if (!Ap || !Ai) return fail(STMMQR_ERR_INVALID, "Ap/Ai are required");
+    if (Ap[n] != P.anz) return fail(STMMQR_ERR_INVALID, "nnz(A) differs from the symbolic analysis");
+    std::vector<long> W(P.Sp.begin(), P.Sp.begin() + m);
+    std::vector<int> smap(std::max(1L, P.anz), 0);
+    for (long col = 0; col < n; col++) {
+        const long j = P.has_qfill ? P.Qfill[col] : col;
+        for (long p = Ap[j]; p < Ap[j + 1]; p++) {
+            const long i = Ai[p];
+            if (i < 0 || i >= m) return fail(STMMQR_ERR_INVALID, "row index out of range");
+            smap[W[P.PLinv[i]]++] = (int)p;
+        }
+    }
+    if (P.anz > 0)
+        HIPCHK(hipMemcpyAsync(P.d_smap.p, smap.data(), (size_t)P.anz * sizeof(int), hipMemcpyHostToDevice, P.stream));
+    HIPCHK(hipStreamSynchronize(P.stream));
+    P.pattern_set = true;
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// the level-batched schedule (device resident inputs -> device resident factors)
+// ------------------------------------------------------------------------------------------------
+int run_schedule(stmmqr_plan &P, bool detail)
+{
+    hipStream_t st = P.stream;
+    const DevCtx c = P.ctx();
+    const int *L0 = P.d_lists.p;
+    long nlaunch = 0;
+    float t_asm = 0, t_front = 0, t_upd = 0;
+    // detail timing: bracket each category with events and accumulate (forces one sync per level)
+    auto timed = [&](float &acc, auto &&fn) -> int {
+        if (!detail) return fn();
+        HIPCHK(hipEventRecord(P.ev[2], st));
+        int e = fn();
+        if (e) return e;
+        HIPCHK(hipEventRecord(P.ev[3], st));
+        HIPCHK(hipEventSynchronize(P.ev[3]));
+        float ms = 0;
+        HIPCHK(hipEventElapsedTime(&ms, P.ev[2], P.ev[3]));
+        acc += ms;
+        return 0;
+    };
+
+    HIPCHK(hipMemsetAsync(P.d_F.p, 0, (size_t)P.farena * sizeof(double), st));
+    HIPCHK(hipMemsetAsync(P.d_Rdead.p, 0, (size_t)std::max(1L, P.n), st));
+    LCHK(stm_launch_gather_sx(P.d_Ax.p, P.d_smap.p, P.d_Sx.p, (int)P.anz, st));
+    nlaunch += 3;
+    for (const Level &L : P.levels) {
+        const int *all = L0 + L.all_off;
+        int e = timed(t_asm, [&]() -> int {
+            LCHK(stm_launch_setup(c, all, L.n_all, st));
+            LCHK(stm_launch_assemble(c, all, L0 + L.asm_parts_off, L.n_all, L.asm_maxparts, st));
+            return 0;
+        });
+        if (e) return e;
+        nlaunch += 2;
+        e = timed(t_front, [&]() -> int {
+            if (L.n_small > 0) { LCHK(stm_launch_front_wg(c, all, L.n_small, L.lds_small, st)); nlaunch++; }
+            return 0;
+        });
+        if (e) return e;
+        const int *big = all + L.n_small;
+        for (size_t p = 0; p < L.nbig_at.size(); p++) {
+            e = timed(t_front, [&]() -> int {
+                LCHK(stm_launch_panel(c, big, L.nbig_at[p], (int)p, L.lds_big, st));
+                return 0;
+            });
+            if (e) return e;
+            e = timed(t_upd, [&]() -> int {
+                LCHK(stm_launch_update(c, big, L.nbig_at[p], (int)p, L.maxcb_at[p], st));
+                return 0;
+            });
+            if (e) return e;
+            nlaunch += 2;
+        }
+        if (L.n_big > 0) {
+            e = timed(t_front, [&]() -> int {
+                LCHK(stm_launch_cpack(c, big, L0 + L.cpk_parts_off, L.n_big, L.cpk_maxparts, st));
+                return 0;
+            });
+            if (e) return e;
+            nlaunch++;
+        }
+    }
+    P.stats.ms_assemble = t_asm;
+    P.stats.ms_front = t_front + t_upd;
+    P.stats.ms_update = t_upd;
+    P.stats.nlaunch = nlaunch;
+    P.stats.nlevels = (long)P.levels.size();
+    return 0;
+}
+
+int run_pack(stmmqr_plan &P)
+{
+    hipStream_t st = P.stream;
+    const DevCtx c = P.ctx();
+    const int *L0 = P.d_lists.p;
+    LCHK(stm_launch_rh_count(c, L0 + P.post_off, (int)P.nf, st));
+    LCHK(stm_launch_rh_scan(c, L0 + P.post_off, (int)P.nf, P.d_total.p, st));
+    long long total = 0;
+    HIPCHK(hipMemcpyAsync(&total, P.d_total.p, sizeof(long long), hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    P.rh_total = total;
+    if ((size_t)total > P.d_RH.n) LCHK(P.d_RH.alloc((size_t)(total + total / 8 + 1024)));
+    LCHK(stm_launch_rh_copy(c, L0 + P.post_off, L0 + P.rh_parts_off, (int)P.nf, P.rh_maxparts, P.d_RH.p, st));
+    P.stats.nlaunch += 3;
+    return 0;
+}
+
+}  // namespace
+
+// =================================================================================================
+// C ABI
+// =================================================================================================
+extern "C" {
+
+const char *stmmqr_version(void) { return "stmmqr_hip 0.1 (gfx950)"; }
+const char *stmmqr_last_error(void) { return g_err.c_str(); }
+void stmmqr_get_options(stmmqr_options *o) { if (o) *o = g_opt; }
+void stmmqr_set_options(const stmmqr_options *o)
+{
+    if (!o) return;
+    g_opt = *o;
+    if (g_opt.big_front_cols < 1) g_opt.big_front_cols = 1;
+}
+void stmmqr_set_common_layout(const stm_common_layout *l) { if (l) g_layout = *l; }
+void stmmqr_get_common_layout(stm_common_layout *l) { if (l) *l = g_layout; }
+
+int stmmqr_device_count(void)
+{
+    int cnt = 0;
+    if (hipGetDeviceCount(&cnt) != hipSuccess) return 0;
+    return cnt;
+}
+const char *stmmqr_device_name(int device)
+{
+    static thread_local char name[256];
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) != hipSuccess) return "";
+    snprintf(name, sizeof name, "%s", prop.gcnArchName);
+    return name;
+}
+
+int chunk_getSettings(size_t a, size_t b, size_t c, size_t d)
+{
+    g_chunk[0] = a; g_chunk[1] = b; g_chunk[2] = c; g_chunk[3] = d;
+    return 0;
+}
+
+stmmqr_plan *stmmqr_plan_create(const stmmqr_symbolic_view *sym, int device, int *status)
+{
+    int st = 0;
+    stmmqr_plan *P = nullptr;
+    if (!sym) st = fail(STMMQR_ERR_INVALID, "null symbolic view");
+    if (!st) st = ensure_device(device);
+    if (!st) {
+        P = new (std::nothrow) stmmqr_plan();
+        if (!P) st = fail(STMMQR_ERR_OUT_OF_MEMORY, "host allocation failed");
+    }
+    if (!st) {
+        (void)hipGetDevice(&P->device);
+        if (hipStreamCreateWithFlags(&P->stream, hipStreamNonBlocking) != hipSuccess)
+            st = fail(STMMQR_ERR_DEVICE, "hipStreamCreate failed");
+        for (auto &e : P->ev)
+            if (!st && hipEventCreate(&e) != hipSuccess) st = fail(STMMQR_ERR_DEVICE, "hipEventCreate failed");
+    }
+    if (!st) {
+        const double t0 = now_ms();
+        st = build_plan(*P, *sym);
+        if (!st) P->stats.ms_host = now_ms() - t0;
+    }
+    if (st && P) { delete P; P = nullptr; }
+    if (status) *status = st;
+    return P;
+}
+
+void stmmqr_plan_destroy(stmmqr_plan *plan) { delete plan; }
+
+int stmmqr_plan_set_pattern(stmmqr_plan *plan, const stm_long *Ap, const stm_long *Ai)
+{
+    if (!plan) return fail(STMMQR_ERR_INVALID, "null plan");
+    HIPCHK(hipSetDevice(plan->device));
+    return set_pattern(*plan, Ap, Ai);
+}
+
+int stmmqr_factorize_device(stmmqr_plan *plan, const stm_long *Ap, const stm_long *Ai, const double *Ax,
+                            int ax_on_device, double tol, stm_long ntol, stmmqr_stats *stats)
+{
+    if (!plan || !Ax) return fail(STMMQR_ERR_INVALID, "null plan / values");
+    stmmqr_plan &P = *plan;
+    HIPCHK(hipSetDevice(P.device));
+    if (Ap && Ai) {
+        int e = set_pattern(P, Ap, Ai);
+        if (e) return e;
+    }
+    if (!P.pattern_set) return fail(STMMQR_ERR_INVALID, "pattern of A was never given");
+    const double host_ms_plan = P.stats.ms_host;
+    P.stats = stmmqr_stats();
+    P.stats.ms_host = host_ms_plan;
+    P.factored = false;
+    if (!P.do_rank) tol = -1;                                  // SparseQR_factorize.c:285-289
+    P.last_tol = tol; P.last_ntol = ntol;
+    hipStream_t st = P.stream;
+    const bool detail = g_opt.verbose >= 2 || (stats && stats->nlaunch == -1);
+
+    HIPCHK(hipEventRecord(P.ev[0], st));
+    if (P.anz > 0) {
+        HIPCHK(hipMemcpyAsync(P.d_Ax.p, Ax, (size_t)P.anz * sizeof(double),
+                              ax_on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, st));
+    }
+    HIPCHK(hipEventRecord(P.ev[1], st));
+    int e = run_schedule(P, detail);
+    if (e) return e;
+    HIPCHK(hipEventRecord(P.ev[4], st));
+    e = run_pack(P);
+    if (e) return e;
+    HIPCHK(hipEventRecord(P.ev[5], st));
+    HIPCHK(hipStreamSynchronize(st));
+    float ms = 0;
+    HIPCHK(hipEventElapsedTime(&ms, P.ev[0], P.ev[1])); P.stats.ms_h2d = ms;
+    HIPCHK(hipEventElapsedTime(&ms, P.ev[1], P.ev[5])); P.stats.ms_total = ms;
+    HIPCHK(hipEventElapsedTime(&ms, P.ev[4], P.ev[5])); P.stats.ms_pack = ms;
+
+    // per-front numeric summary (small): flops, ranks
+    P.h_fnum.resize((size_t)std::max(1L, P.nf));
+    if (P.nf > 0)
+        HIPCHK(hipMemcpy(P.h_fnum.data(), P.d_fnum.p, (size_t)P.nf * sizeof(FrontNum), hipMemcpyDeviceToHost));
+    double flops = 0, bytes_asm = P.bytes_assemble_idx, bytes_pack = 0, fl_upd = 0;
+    long rank = 0;
+    for (long f = 0; f < P.nf; f++) {
+        const FrontNum &nm = P.h_fnum[f];
+        const FrontSym &s = P.fs[f];
+        flops += nm.flops;
+        rank += nm.rank;
+        const double cn = s.fn - s.fp, cm = nm.cm;
+        const double csize = cm * (cm + 1) / 2 + cm * (cn - cm);
+        bytes_asm += 8.0 * ((double)nm.fm * s.fn) + 8.0 * csize;   // F first write + child C read (as a child)
+        bytes_pack += 16.0 * (csize + (double)nm.rsize);
+    }
+    bytes_asm += 8.0 * (double)P.anz;
+    (void)fl_upd;
+    P.rank = rank;
+    P.stats.flops = flops;
+    P.stats.bytes_assemble = bytes_asm;
+    P.stats.bytes_pack = bytes_pack;
+    P.factored = true;
+    if (stats) *stats = P.stats;
+    return 0;
+}
+
+int stmmqr_plan_result_sizes(const stmmqr_plan *plan, stm_long *rh_total, stm_long *rank)
+{
+    if (!plan || !plan->factored) return fail(STMMQR_ERR_INVALID, "no factorization held by the plan");
+    if (rh_total) *rh_total = (stm_long)plan->rh_total;
+    if (rank) *rank = plan->rank;
+    return 0;
+}
+
+int stmmqr_plan_download(stmmqr_plan *plan, double *Stack, stm_long *Rblock_off, char *Rdead, stm_long *HStair,
+                         double *HTau, stm_long *Hii, stm_long *HPinv, stm_long *Hm, stm_long *Hr,
+                         stm_long *scalars, stmmqr_stats *stats)
+{
+    if (!plan || !plan->factored) return fail(STMMQR_ERR_INVALID, "no factorization held by the plan");
+    stmmqr_plan &P = *plan;
+    HIPCHK(hipSetDevice(P.device));
+    hipStream_t st = P.stream;
+    const long nf = P.nf, m = P.m, n = P.n;
+    HIPCHK(hipEventRecord(P.ev[6], st));
+    if (Stack && P.rh_total > 0)
+        HIPCHK(hipMemcpyAsync(Stack, P.d_RH.p, (size_t)P.rh_total * sizeof(double), hipMemcpyDeviceToHost, st));
+    std::vector<int> stair32((size_t)std::max(1L, P.rjsize)), hii32((size_t)std::max(1L, P.hisize));
+    std::vector<long long> rboff((size_t)std::max(1L, nf));
+    if (P.rjsize > 0)
+        HIPCHK(hipMemcpyAsync(stair32.data(), P.d_Stair.p, (size_t)P.rjsize * sizeof(int), hipMemcpyDeviceToHost, st));
+    if (P.hisize > 0)
+        HIPCHK(hipMemcpyAsync(hii32.data(), P.d_Hii.p, (size_t)P.hisize * sizeof(int), hipMemcpyDeviceToHost, st));
+    if (HTau && P.rjsize > 0)
+        HIPCHK(hipMemcpyAsync(HTau, P.d_Tau.p, (size_t)P.rjsize * sizeof(double), hipMemcpyDeviceToHost, st));
+    if (Rdead && n > 0) HIPCHK(hipMemcpyAsync(Rdead, P.d_Rdead.p, (size_t)n, hipMemcpyDeviceToHost, st));
+    if (nf > 0)
+        HIPCHK(hipMemcpyAsync(rboff.data(), P.d_Rboff.p, (size_t)nf * sizeof(long long), hipMemcpyDeviceToHost, st));
+    HIPCHK(hipEventRecord(P.ev[7], st));
+    HIPCHK(hipStreamSynchronize(st));
+    float ms = 0;
+    HIPCHK(hipEventElapsedTime(&ms, P.ev[6], P.ev[7]));
+    P.stats.ms_d2h = ms;
+
+    const double t0 = now_ms();
+    if (HStair) for (long i = 0; i < P.rjsize; i++) HStair[i] = stair32[i];
+    if (Rblock_off) for (long f = 0; f < nf; f++) Rblock_off[f] = (stm_long)rboff[f];
+    long maxfrank = 1, maxfm = 0, rank = 0;
+    for (long f = 0; f < nf; f++) {
+        const FrontNum &nm = P.h_fnum[f];
+        if (Hm) Hm[f] = nm.fm;
+        if (Hr) Hr[f] = nm.rank;
+        maxfrank = std::max(maxfrank, (long)nm.rank);
+        maxfm = std::max(maxfm, (long)nm.fm);
+        rank += nm.rank;
+    }
+    // qr_hpinv (SparseQR_factorize.c:991-1060): global row permutation, Hii rewritten in place
+    if (Hii || HPinv) {
+        std::vector<long> W((size_t)std::max(1L, m), 0);
+        long row1 = 0, row2 = m;
+        for (long i = P.Sleft[n]; i < m; i++) W[i] = --row2;
+        for (long f = 0; f < nf; f++) {
+            const int *Hi = hii32.data() + P.Hip[f];
+            const FrontNum &nm = P.h_fnum[f];
+            const long rm = nm.rank, fm = nm.fm;
+            for (long i = 0; i < rm; i++) W[Hi[i]] = row1++;
+            const long cn = P.fs[f].fn - P.fs[f].fp;
+            const long cm = std::min(fm - rm, cn);
+            for (long i = fm - 1; i >= rm + cm; i--) W[Hi[i]] = --row2;
+        }
+        if (HPinv) for (long i = 0; i < m; i++) HPinv[i] = W[P.PLinv[i]];
+        if (Hii) {
+            for (long f = 0; f < nf; f++) {
+                const int *Hi = hii32.data() + P.Hip[f];
+                stm_long *Ho = Hii + P.Hip[f];
+                const long fm = P.h_fnum[f].fm;
+                for (long i = 0; i < fm; i++) Ho[i] = W[Hi[i]];
+            }
+        }
+    }
+    if (scalars) {
+        scalars[0] = rank;
+        long rank1 = rank;
+        if (P.last_ntol < n) {
+            std::vector<char> rd((size_t)std::max(1L, n));
+            if (Rdead) memcpy(rd.data(), Rdead, (size_t)n);
+            else HIPCHK(hipMemcpy(rd.data(), P.d_Rdead.p, (size_t)n, hipMemcpyDeviceToHost));
+            rank1 = 0;
+            for (long j = 0; j < P.last_ntol; j++) rank1 += !rd[j];
+        }
+        scalars[1] = rank1; scalars[2] = maxfrank; scalars[3] = maxfm;
+    }
+    P.stats.ms_host += now_ms() - t0;
+    if (stats) *stats = P.stats;
+    return 0;
+}
+
+int stmmqr_factorize_arrays(const stmmqr_symbolic_view *sym, const stm_long *Ap, const stm_long *Ai,
+                            const double *Ax, double tol, stm_long ntol, double *Stack, stm_long stack_cap,
+                            stm_long *Rblock_off, char *Rdead, stm_long *HStair, double *HTau, stm_long *Hii,
+                            stm_long *HPinv, stm_long *Hm, stm_long *Hr, stm_long *scalars, stmmqr_stats *stats)
+{
+    int st = 0;
+    stmmqr_plan *P = stmmqr_plan_create(sym, -1, &st);
+    if (!P) return st;
+    st = stmmqr_factorize_device(P, Ap, Ai, Ax, 0, tol, ntol, stats);
+    if (!st && Stack && P->rh_total > stack_cap) st = fail(STMMQR_ERR_INVALID, "Stack buffer too small");
+    if (!st) st = stmmqr_plan_download(P, Stack, Rblock_off, Rdead, HStair, HTau, Hii, HPinv, Hm, Hr, scalars, stats);
+    stmmqr_plan_destroy(P);
+    return st;
+}
+
+// -------------------------------------------------------------------------------------------------
+// drop-in seam: qr_factorize with the reference's structs
+// -------------------------------------------------------------------------------------------------
+static inline int &cc_int(stm_sparse_common *cc, size_t off) { return *(int *)((char *)cc + off); }
+static inline size_t &cc_size(stm_sparse_common *cc, size_t off) { return *(size_t *)((char *)cc + off); }
+static inline double &cc_dbl(stm_sparse_common *cc, size_t off) { return *(double *)((char *)cc + off); }
+
+// SparseCore_malloc semantics (src/core/SparseCore_common.c:603-655): malloc(max(1,n)*size) + counters
+static void *cc_malloc(size_t n, size_t size, stm_sparse_common *cc, bool zero = false)
+{
+    void *p = zero ? calloc(std::max<size_t>(1, n), size) : malloc(std::max<size_t>(1, n) * size);
+    if (!p) {
+        if (cc) cc_int(cc, g_layout.status) = STMMQR_ERR_OUT_OF_MEMORY;
+        return nullptr;
+    }
+    if (cc) {
+        cc_size(cc, g_layout.malloc_count)++;
+        cc_size(cc, g_layout.memory_inuse) += n * size;
+        cc_size(cc, g_layout.memory_usage) =
+            std::max(cc_size(cc, g_layout.memory_usage), cc_size(cc, g_layout.memory_inuse));
+    }
+    return p;
+}
+static void cc_free(size_t n, size_t size, void *p, stm_sparse_common *cc)
+{
+    if (!p) return;
+    free(p);
+    if (cc) {
+        cc_size(cc, g_layout.malloc_count)--;
+        cc_size(cc, g_layout.memory_inuse) -= n * size;
+    }
+}
+// SparseCore_free_sparse (src/core/SparseCore_matrix_type.c:146-180)
+static void cc_free_sparse(stm_sparse_csc **Ah, stm_sparse_common *cc)
+{
+    if (!Ah || !*Ah) return;
+    stm_sparse_csc *A = *Ah;
+    cc_free(A->ncol + 1, sizeof(stm_long), A->p, cc);
+    cc_free(A->nzmax, sizeof(stm_long), A->i, cc);
+    cc_free(A->ncol, sizeof(stm_long), A->nz, cc);
+    cc_free(A->nzmax, sizeof(double), A->x, cc);
+    cc_free(1, sizeof(stm_sparse_csc), A, cc);
+    *Ah = nullptr;
+}
+static void free_numeric(stm_qr_numeric *N, stm_sparse_common *cc)
+{
+    if (!N) return;
+    cc_free(N->nf, sizeof(double *), N->Rblock, cc);
+    cc_free(N->n, 1, N->Rdead, cc);
+    cc_free(N->rjsize, sizeof(stm_long), N->HStair, cc);
+    cc_free(N->rjsize, sizeof(double), N->HTau, cc);
+    cc_free(N->nf, sizeof(stm_long), N->Hm, cc);
+    cc_free(N->nf, sizeof(stm_long), N->Hr, cc);
+    cc_free(N->hisize, sizeof(stm_long), N->Hii, cc);
+    cc_free(N->m, sizeof(stm_long), N->HPinv, cc);
+    if (N->Stacks)
+        for (stm_long s = 0; s < N->ns; s++)
+            cc_free(N->Stack_size ? N->Stack_size[s] : N->maxstack, sizeof(double), N->Stacks[s], cc);
+    cc_free(N->ns, sizeof(double *), N->Stacks, cc);
+    cc_free(N->ns, sizeof(stm_long), N->Stack_size, cc);
+    cc_free(1, sizeof(stm_qr_numeric), N, cc);
+}
+
+stm_qr_numeric *qr_factorize(stm_sparse_csc **Ahandle, stm_long freeA, double tol, stm_long ntol,
+                             stm_qr_symbolic *S, stm_sparse_common *cc)
+{
+    if (!S) {                                                  // SparseQR_factorize.c:247-254
+        if (freeA) cc_free_sparse(Ahandle, cc);
+        return nullptr;
+    }
+    auto set_status = [&](int st) { if (cc) cc_int(cc, g_layout.status) = st; };
+    stm_sparse_csc *A = Ahandle ? *Ahandle : nullptr;
+    if (!A) { set_status(STMMQR_ERR_INVALID); return nullptr; }
+
+    stmmqr_symbolic_view v;
+    v.m = S->m; v.n = S->n; v.anz = S->anz; v.nf = S->nf; v.maxfn = S->maxfn; v.rjsize = S->rjsize;
+    v.hisize = S->hisize; v.do_rank_detection = S->do_rank_detection;
+    v.Sp = S->Sp; v.Sj = S->Sj; v.Qfill = S->Qfill; v.PLinv = S->PLinv; v.Sleft = S->Sleft;
+    v.Child = S->Child; v.Childp = S->Childp; v.Super = S->Super; v.Rp = S->Rp; v.Rj = S->Rj; v.Post = S->Post;
+    v.Hip = S->Hip; v.Fm = S->Fm;
+
+    int st = 0;
+    stmmqr_plan *P = stmmqr_plan_create(&v, -1, &st);
+    stmmqr_stats stats;
+    if (!st) st = stmmqr_factorize_device(P, (const stm_long *)A->p, (const stm_long *)A->i, (const double *)A->x, 0,
+                                          tol, ntol, &stats);
+    if (freeA) cc_free_sparse(Ahandle, cc);                    // :324-327
+    if (st) {
+        if (P) stmmqr_plan_destroy(P);
+        set_status(st);
+        return nullptr;
+    }
+    const stm_long nf = S->nf, n = S->n, m = S->m;
+    stm_qr_numeric *N = (stm_qr_numeric *)cc_malloc(1, sizeof(stm_qr_numeric), cc, true);
+    if (!N) { stmmqr_plan_destroy(P); return nullptr; }
+    N->n = n; N->m = m; N->nf = nf; N->rjsize = S->rjsize; N->hisize = S->hisize; N->keepH = S->keepH;
+    N->maxstack = S->maxstack; N->ns = 1; N->ntasks = 1; N->maxfm = -1; N->norm_E_fro = 0;
+    N->Rblock = (double **)cc_malloc(nf, sizeof(double *), cc);
+    N->Rdead = (char *)cc_malloc(n, 1, cc, true);
+    N->Stacks = (double **)cc_malloc(1, sizeof(double *), cc, true);
+    N->Stack_size = (stm_long *)cc_malloc(1, sizeof(stm_long), cc, true);
+    N->HStair = (stm_long *)cc_malloc(S->rjsize, sizeof(stm_long), cc);
+    N->HTau = (double *)cc_malloc(S->rjsize, sizeof(double), cc);
+    N->Hii = (stm_long *)cc_malloc(S->hisize, sizeof(stm_long), cc);
+    N->Hm = (stm_long *)cc_malloc(nf, sizeof(stm_long), cc);
+    N->Hr = (stm_long *)cc_malloc(nf, sizeof(stm_long), cc);
+    N->HPinv = (stm_long *)cc_malloc(m, sizeof(stm_long), cc);
+    std::vector<stm_long> roff((size_t)std::max<stm_long>(1, nf));
+    stm_long scal[4] = {0, 0, 0, 0};
+    bool ok = N->Rblock && N->Rdead && N->Stacks && N->Stack_size && N->HStair && N->HTau && N->Hii && N->Hm &&
+              N->Hr && N->HPinv;
+    if (ok) {
+        // the reference shrinks its stack to exactly the packed R+H (:597-663): allocate that size directly
+        N->Stack_size[0] = (stm_long)P->rh_total;
+        N->Stacks[0] = (double *)cc_malloc((size_t)P->rh_total, sizeof(double), cc);
+        ok = N->Stacks[0] != nullptr;
+    }
+    if (ok) {
+        st = stmmqr_plan_download(P, N->Stacks[0], roff.data(), N->Rdead, N->HStair, N->HTau, N->Hii, N->HPinv, N->Hm,
+                                  N->Hr, scal, &stats);
+        ok = st == 0;
+    }
+    stmmqr_plan_destroy(P);
+    if (!ok) {
+        free_numeric(N, cc);
+        set_status(st ? st : STMMQR_ERR_OUT_OF_MEMORY);
+        return nullptr;
+    }
+    for (stm_long f = 0; f < nf; f++) N->Rblock[f] = N->Stacks[0] + roff[f];
+    N->rank = scal[0]; N->rank1 = scal[1]; N->maxfrank = scal[2]; N->maxfm = scal[3];
+    if (cc) cc_dbl(cc, g_layout.SPQR_flopcount) = stats.flops;
+    return N;
+}
+
+}  // extern "C"

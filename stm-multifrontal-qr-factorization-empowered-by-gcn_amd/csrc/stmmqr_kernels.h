@@ -1,0 +1,46 @@
+// stmmqr_kernels.h -- kernel argument block and launcher prototypes (host <-> stmmqr_kernels.hip)
+#pragma once
+#include <hip/hip_runtime_api.h>
+#include "stmmqr_device.h"
+
+// Everything a kernel needs, passed by value.  Pointers are device pointers.
+struct DevCtx {
+    const FrontSym *fs;        // [nf]
+    FrontNum *fnum;            // [nf]
+    double *Farena;            // fronts
+    double *Carena;            // packed contribution blocks
+    double *Tws;               // T factors of the large fronts in flight, [slots][NB*NB]
+    const int *tslot;          // [nf] slot in Tws (large fronts only)
+    const double *Sx;          // [anz] values of S = A(P,Q), row form
+    const int *Sp;             // [m+1]
+    const int *Sjrel;          // [anz] column of each S entry inside its front
+    const int *Sj0;            // [m]   leftmost column of each S row
+    const int *Sleft;          // [n+2]
+    const int *Child;          // [nf+1]
+    const int *Rjrel;          // [rjsize] for child c, slot Rp[c]+fp+cj: column of the parent
+    int *Stair;                // [rjsize] HStair
+    double *Tau;               // [rjsize] HTau
+    int *Hii;                  // [hisize]
+    char *Rdead;               // [n]
+    int *Cmap;                 // [rjsize] for child c, slot Rp[c]+fp+ci: row of the parent
+    int *Cursor;               // [rjsize] scratch of k_setup
+    int *Rhoff;                // [rjsize] column offsets inside a packed R+H block
+    long long *Rboff;          // [nf] offset of each packed R+H block
+    double tol;
+    int ntol;
+};
+
+int stm_configure_kernels(void);
+int stm_update_lds_bytes(void);
+int stm_launch_gather_sx(const double *Ax, const int *smap, double *Sx, int anz, hipStream_t st);
+int stm_launch_setup(const DevCtx &c, const int *flist, int nfr, hipStream_t st);
+int stm_launch_assemble(const DevCtx &c, const int *flist, const int *nparts, int nfr, int maxparts, hipStream_t st);
+int stm_launch_front_wg(const DevCtx &c, const int *flist, int nfr, int lds_doubles, hipStream_t st);
+int stm_launch_panel(const DevCtx &c, const int *flist, int nfr, int p, int lds_doubles, hipStream_t st);
+int stm_launch_update(const DevCtx &c, const int *flist, int nfr, int p, int maxcb, hipStream_t st);
+int stm_launch_larft(const DevCtx &c, int f, hipStream_t st);
+int stm_launch_cpack(const DevCtx &c, const int *flist, const int *nparts, int nfr, int maxparts, hipStream_t st);
+int stm_launch_rh_count(const DevCtx &c, const int *flist, int nfr, hipStream_t st);
+int stm_launch_rh_scan(const DevCtx &c, const int *post, int nf, long long *rh_total, hipStream_t st);
+int stm_launch_rh_copy(const DevCtx &c, const int *flist, const int *nparts, int nfr, int maxparts, double *RH,
+                       hipStream_t st);

@@ -345,3 +345,28 @@ def aqr_probe_error(orc: Oracle, S: Symbolic, N: Numeric, Ap, Ai, Ax, nprobe=4, 
         y2 = orc.qmult(1, S, N, orc.rmult(S, N, x))
         worst = max(worst, np.linalg.norm(y1 - y2) / (anorm * np.linalg.norm(x)))
     return worst
+
+
+def numeric_from_gpu(S: Symbolic, G) -> Numeric:
+    """Wrap the arrays of a package QRNumeric (GPU result) in the oracle's Numeric so the oracle's checkers
+    (qmult / rmult / rsolve, rh_blocks) can read them."""
+    N = Numeric.__new__(Numeric)
+    N.Stack = np.ascontiguousarray(G.Stack, np.float64)
+    N.Rblock_off = np.ascontiguousarray(G.Rblock_off, I64)
+    N.Rdead = np.ascontiguousarray(G.Rdead, np.int8)
+    N.HStair = np.ascontiguousarray(G.HStair, I64)
+    N.HTau = np.ascontiguousarray(G.HTau, np.float64)
+    N.Hii = np.ascontiguousarray(G.Hii, I64)
+    N.HPinv = np.ascontiguousarray(G.HPinv, I64)
+    N.Hm = np.ascontiguousarray(G.Hm, I64)
+    N.Hr = np.ascontiguousarray(G.Hr, I64)
+    N.Cm = np.zeros(max(S.nf, 1), I64)
+    N.Csave = None; N.Csave_off = None
+    c = OrcNumeric()
+    c.Stack = _dp(N.Stack); c.Rblock_off = _ip(N.Rblock_off)
+    c.Rdead = C.cast(N.Rdead.ctypes.data, C.c_char_p)
+    c.HStair = _ip(N.HStair); c.HTau = _dp(N.HTau); c.Hii = _ip(N.Hii)
+    c.HPinv = _ip(N.HPinv); c.Hm = _ip(N.Hm); c.Hr = _ip(N.Hr); c.Cm = _ip(N.Cm)
+    c.rank = G.rank; c.rank1 = G.rank1; c.maxfrank = G.maxfrank; c.maxfm = G.maxfm; c.rh_total = G.rh_total
+    N.c = c
+    return N
