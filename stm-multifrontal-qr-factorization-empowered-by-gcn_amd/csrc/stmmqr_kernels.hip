@@ -343,6 +343,7 @@ __device__ void dev_panel(const FrontSym &s, FrontNum *num, double *F, int *St, 
             // zero the column from the diagonal down, no reflector, g does not advance (:1495-1544)
             for (int i = tid; i < tmax - g; i += NT) col[i] = 0;
             if (tid == 0) { St[k] = 0; Tau[k] = 0; Rdead[k] = 1; s_diag[j] = STM_BIGROW; s_tau[j] = 0; }
+            if (k == npiv - 1) rank = g;                // (:1604-1608) also taken on a dead last pivot
             __syncthreads();
             continue;
         }
@@ -808,8 +809,8 @@ int stm_launch_rh_copy(const DevCtx &c, const int *flist, const int *nparts, int
 int stm_configure_kernels(void)
 {
     // allow the panel kernels to ask for up to 144 KiB of dynamic LDS (160 KiB per CU on gfx950)
-    CK(hipFuncSetAttribute((const void *)k_front_wg, hipFuncAttributeMaxDynamicSharedMemorySize, 147456));
-    CK(hipFuncSetAttribute((const void *)k_panel, hipFuncAttributeMaxDynamicSharedMemorySize, 147456));
+    CK(hipFuncSetAttribute((const void *)k_front_wg, hipFuncAttributeMaxDynamicSharedMemorySize, 131072));
+    CK(hipFuncSetAttribute((const void *)k_panel, hipFuncAttributeMaxDynamicSharedMemorySize, 131072));
     CK(hipFuncSetAttribute((const void *)k_update, hipFuncAttributeMaxDynamicSharedMemorySize, 65536));
     return 0;
 }

@@ -95,10 +95,8 @@ def test_qr_larftb(pkg, oracle, m, n, k):
     W = np.zeros(32 * 32 + 32 * n + 64)
     for k1 in range(0, kk, 32):
         nb = min(32, kk - k1)
-        Vs = V[k1:, k1:k1 + nb]
-        oracle.lib.orc_larftb(0, m - k1, n, nb, m, m, _dp(V[k1:, k1:]) if False else C.cast(V.ctypes.data + 8 * (k1 + k1 * m), C.POINTER(C.c_double)),
-                              C.cast(Tau.ctypes.data + 8 * k1, C.POINTER(C.c_double)),
-                              C.cast(Co.ctypes.data + 8 * k1, C.POINTER(C.c_double)), _dp(W))
+        dptr = lambda a, off: C.cast(a.ctypes.data + 8 * off, C.POINTER(C.c_double))
+        oracle.lib.orc_larftb(0, m - k1, n, nb, m, m, dptr(V, k1 + k1 * m), dptr(Tau, k1), dptr(Co, k1), _dp(W))
     assert np.linalg.norm(Cg - Co) <= 1e-12 * np.linalg.norm(Co)
 
 
