@@ -39,5 +39,6 @@ struct FrontNum {
     int cm;                  // rows of the contribution block      (qr_cpack's return value)
     int rsize;               // entries of the packed R+H block     (qr_rhpack's return value)
     double flops;            // reference flop count of this front  (FLOP_COUNT, :1571)
+    double flops_upd;        // dlarfb flops handed to the MFMA update: 4 * rows * cols * reflectors
     int pdiag[STM_NB];       // row of the unit diagonal of each reflector of the pending block (BIGROW: none)
 };

@@ -430,7 +430,7 @@ int run_schedule(stmmqr_plan &P, bool detail)
     const DevCtx c = P.ctx();
     const int *L0 = P.d_lists.p;
     long nlaunch = 0;
-    float t_asm = 0, t_front = 0, t_upd = 0;
+    float t_asm = 0, t_front = 0, t_upd = 0, t_cpk = 0;
     // detail timing: bracket each category with events and accumulate (forces one sync per level)
     auto timed = [&](float &acc, auto &&fn) -> int {
         if (!detail) return fn();
@@ -478,7 +478,7 @@ int run_schedule(stmmqr_plan &P, bool detail)
             nlaunch += 2;
         }
         if (L.n_big > 0) {
-            e = timed(t_front, [&]() -> int {
+            e = timed(t_cpk, [&]() -> int {
                 LCHK(stm_launch_cpack(c, big, L0 + L.cpk_parts_off, L.n_big, L.cpk_maxparts, st));
                 return 0;
             });
@@ -489,6 +489,7 @@ int run_schedule(stmmqr_plan &P, bool detail)
     P.stats.ms_assemble = t_asm;
     P.stats.ms_front = t_front + t_upd;
     P.stats.ms_update = t_upd;
+    P.stats.ms_pack = t_cpk;
     P.stats.nlaunch = nlaunch;
     P.stats.nlevels = (long)P.levels.size();
     return 0;
@@ -623,7 +624,7 @@ int stmmqr_factorize_device(stmmqr_plan *plan, const stm_long *Ap, const stm_lon
     float ms = 0;
     HIPCHK(hipEventElapsedTime(&ms, P.ev[0], P.ev[1])); P.stats.ms_h2d = ms;
     HIPCHK(hipEventElapsedTime(&ms, P.ev[1], P.ev[5])); P.stats.ms_total = ms;
-    HIPCHK(hipEventElapsedTime(&ms, P.ev[4], P.ev[5])); P.stats.ms_pack = ms;
+    HIPCHK(hipEventElapsedTime(&ms, P.ev[4], P.ev[5])); P.stats.ms_pack += ms;
 
     // per-front numeric summary (small): flops, ranks
     P.h_fnum.resize((size_t)std::max(1L, P.nf));
@@ -635,6 +636,7 @@ int stmmqr_factorize_device(stmmqr_plan *plan, const stm_long *Ap, const stm_lon
         const FrontNum &nm = P.h_fnum[f];
         const FrontSym &s = P.fs[f];
         flops += nm.flops;
+        fl_upd += nm.flops_upd;
         rank += nm.rank;
         const double cn = s.fn - s.fp, cm = nm.cm;
         const double csize = cm * (cm + 1) / 2 + cm * (cn - cm);
@@ -642,7 +644,7 @@ int stmmqr_factorize_device(stmmqr_plan *plan, const stm_long *Ap, const stm_lon
         bytes_pack += 16.0 * (csize + (double)nm.rsize);
     }
     bytes_asm += 8.0 * (double)P.anz;
-    (void)fl_upd;
+    P.stats.flops_update = fl_upd;
     P.rank = rank;
     P.stats.flops = flops;
     P.stats.bytes_assemble = bytes_asm;

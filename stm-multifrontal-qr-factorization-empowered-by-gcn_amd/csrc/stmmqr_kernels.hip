@@ -150,7 +150,7 @@ __global__ __launch_bounds__(NT) void k_setup(DevCtx c, const int *__restrict__ 
     if (tid == 0) {
         FrontNum *nm = &c.fnum[f];
         nm->fm = fm; nm->g = 0; nm->rank = min(fm, s.fp); nm->done = 0;
-        nm->pg1 = 0; nm->pt = 0; nm->pk1 = 0; nm->pnb = 0; nm->pc0 = 0; nm->cm = 0; nm->rsize = 0; nm->flops = 0;
+        nm->pg1 = 0; nm->pt = 0; nm->pk1 = 0; nm->pnb = 0; nm->pc0 = 0; nm->cm = 0; nm->rsize = 0; nm->flops = 0; nm->flops_upd = 0;
     }
 }
 
@@ -382,6 +382,11 @@ __device__ void dev_panel(const FrontSym &s, FrontNum *num, double *F, int *St, 
         num->g = g; num->rank = rank; num->done = done;
         num->pg1 = g1; num->pt = tlast; num->pk1 = k1; num->pnb = nbp; num->pc0 = k2;
         num->flops += flops;
+        {
+            int nlive = 0;
+            for (int j = 0; j < nbp; j++) nlive += (s_tau[j] != 0.0);
+            num->flops_upd += 4.0 * (double)(tlast - g1) * (double)(n - k2) * (double)nlive;
+        }
     }
     __syncthreads();
 }

@@ -1,0 +1,47 @@
+"""Deterministic 3-D grid stand-ins for the SuiteSparse matrices that are absent from the reference checkout
+(/root/reference/.MISSING_LARGE_BLOBS: xenon1, sme3Dc, 3D_51448_3D).  SURVEY.md 8(d) fixes the generators:
+
+  xenon1 stand-in  : gen3d(36, 36, 38, stencil 27pt, dof 1, values U(-1,1), diag += 27, seed 0x58454E31)  n = 49 248
+
+Every report that uses them says "stand-in".  Pure numpy; used by make_golden.py (build container) and by bench.py /
+tests on the GPU box to regenerate the VALUES (the symbolic analysis of the pattern is a committed fixture).
+"""
+import numpy as np
+
+
+def gen3d(nx, ny, nz, seed, stencil27=True):
+    """CSC (Ap, Ai, Ax) of an unsymmetric-valued 7/27-point operator on an nx*ny*nz grid."""
+    rng = np.random.default_rng(seed)
+    idx = np.arange(nx * ny * nz).reshape(nx, ny, nz)
+    rows, cols = [], []
+    for dx in (-1, 0, 1):
+        for dy in (-1, 0, 1):
+            for dz in (-1, 0, 1):
+                if not stencil27 and abs(dx) + abs(dy) + abs(dz) > 1:
+                    continue
+                xs = slice(max(0, -dx), nx - max(0, dx)); xt = slice(max(0, dx), nx - max(0, -dx))
+                ys = slice(max(0, -dy), ny - max(0, dy)); yt = slice(max(0, dy), ny - max(0, -dy))
+                zs = slice(max(0, -dz), nz - max(0, dz)); zt = slice(max(0, dz), nz - max(0, -dz))
+                rows.append(idx[xs, ys, zs].ravel()); cols.append(idx[xt, yt, zt].ravel())
+    r = np.concatenate(rows); c = np.concatenate(cols)
+    v = rng.uniform(-1, 1, r.size)
+    v[r == c] += 27 if stencil27 else 7
+    n = idx.size
+    o = np.lexsort((r, c))
+    r, c, v = r[o], c[o], v[o]
+    Ap = np.zeros(n + 1, np.int64)
+    np.add.at(Ap, c + 1, 1)
+    Ap = np.cumsum(Ap)
+    return n, n, Ap, r.astype(np.int64), v
+
+
+STANDINS = {
+    # name: (nx, ny, nz, seed, 27-point?, ordering for the reference run: 2 = METIS)
+    "xenon1_standin": (36, 36, 38, 0x58454E31, True, 2),
+    "grid20_standin": (20, 20, 20, 0x58454E31, True, 2),
+}
+
+
+def standin_matrix(name):
+    nx, ny, nz, seed, s27, _ = STANDINS[name]
+    return gen3d(nx, ny, nz, seed, s27)

@@ -43,8 +43,11 @@ SYM_SCALARS = ["m", "n", "anz", "nf", "maxfn", "rjsize", "do_rank_detection", "m
                "ntasks", "ns"]
 
 
-def golden_names():
-    return sorted(p.stem for p in GOLDEN.glob("*.npz"))
+BIG_FIXTURES = ("xenon1_standin",)      # full BASELINE size: too slow for the scalar CPU oracle, GPU tests only
+
+
+def golden_names(include_big: bool = False):
+    return sorted(p.stem for p in GOLDEN.glob("*.npz") if include_big or p.stem not in BIG_FIXTURES)
 
 
 def load_golden(name: str) -> dict:
@@ -56,6 +59,14 @@ def load_golden(name: str) -> dict:
         if a.dtype.kind in "iu" and a.dtype != np.int8:
             a = a.astype(I64)
         out[k] = np.ascontiguousarray(a)
+    if "in_Ax" not in out:
+        # large stand-in: pattern and values come from the seeded generator (tests/golden/gen3d.py)
+        import sys
+        sys.path.insert(0, str(GOLDEN))
+        from gen3d import standin_matrix
+        m, n, Ap, Ai, Ax = standin_matrix(name)
+        assert m == scalar(out, "in_m") and n == scalar(out, "in_n") and Ax.size == scalar(out, "sym_anz")
+        out["in_Ap"], out["in_Ai"], out["in_Ax"] = Ap, Ai, Ax
     return out
 
 

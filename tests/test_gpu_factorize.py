@@ -84,3 +84,20 @@ def test_no_rank_detection_tol_negative(pkg, oracle):
     from parity import numeric_as_ref
     # with tol < 0 nothing is declared dead unless a pivot is exactly zero: structure must agree with the oracle
     compare_integers(S, N, numeric_as_ref(S, No))
+
+
+def test_full_size_standin(pkg, oracle):
+    """BASELINE configs[2] size (xenon1 stand-in, n = 49 248, 1.5e11 flops): integer outputs and R rows against the
+    reference's golden vectors, backward error through the packed factors, Q orthogonality on probes."""
+    g = load_golden("xenon1_standin")
+    S, G = gpu_run(pkg, g)
+    N = numeric_from_gpu(S, G)
+    compare_integers(S, N, g)
+    assert G.stats["flops"] == scalar(g, "flopcount")
+    got, ref = rrow_sig_all(S, N), g["num_rrow_sig"]
+    assert np.max(np.abs(got - ref) / np.maximum(ref[:, 1:2], 1e-300), initial=0.0) <= 1e-9
+    from stmmqr_testlib import aqr_probe_error
+    assert aqr_probe_error(oracle, S, N, g["in_Ap"], g["in_Ai"], g["in_Ax"], nprobe=2) < 1e-13
+    x = np.random.default_rng(3).standard_normal(S.m)
+    y = oracle.qmult(1, S, N, oracle.qmult(0, S, N, x))          # Q Q' x = x
+    assert np.linalg.norm(y - x) <= 1e-12 * np.linalg.norm(x)
