@@ -18,6 +18,8 @@
  *   grain   : cc->SPQR_grain; 1 = serial qr_kernel(0) (STMMQR/README.md:71-72)
  *   tolmode : d = driver default tol = 20(m+n)eps*maxcolnorm (qrtest.c:135-142), n = no rank detection (tol=-1)
  *   threads : env REFDUMP_POOL (pool size for TPSM_init when grain>1; default 64)
+ *   env REFDUMP_HIPLIB=<path to libstmmqr_hip.so>: the interposed seam calls THAT library's qr_factorize
+ *   (drop-in check: the reference's SparseQR / QR_qmult / QR_solve / SparseQR_free run on its result)
  */
 #define _GNU_SOURCE
 #include <dlfcn.h>
@@ -70,6 +72,14 @@ qr_numeric *qr_factorize(sparse_csc **Ahandle, Long freeA, double tol, Long ntol
                          qr_symbolic *QRsym, sparse_common *cc)
 {
     static factorize_fn real = NULL;
+    if (!real && getenv("REFDUMP_HIPLIB")) {
+        /* drop-in check: route the seam to libstmmqr_hip.so's qr_factorize; everything around it
+         * (SparseQR, QR_qmult, QR_solve, SparseQR_free) stays the compiled reference */
+        void *h = dlopen(getenv("REFDUMP_HIPLIB"), RTLD_NOW | RTLD_LOCAL);
+        if (!h) { fprintf(stderr, "refdump: cannot load %s: %s\n", getenv("REFDUMP_HIPLIB"), dlerror()); exit(2); }
+        real = (factorize_fn)dlsym(h, "qr_factorize");
+        printf("seam routed to %s\n", getenv("REFDUMP_HIPLIB"));
+    }
     if (!real) real = (factorize_fn)dlsym(RTLD_NEXT, "qr_factorize");
     if (!real) { fprintf(stderr, "refdump: cannot find the reference qr_factorize\n"); exit(2); }
 
