@@ -158,7 +158,8 @@ struct stmmqr_plan {
 
 namespace {
 
-const int LDS_CAP_DOUBLES = 16384;        // 128 KiB of dynamic LDS for the staged panel
+const int LDS_CAP_DOUBLES = 16384;        // 128 KiB of dynamic LDS for the staged (sub-)panel, k_panel
+const int LDS_CAP_SMALL = 15360;          // 120 KiB in k_front_wg (it carries 8 KiB more static LDS)
 
 int ensure_device(int device)
 {
@@ -326,7 +327,7 @@ int build_plan(stmmqr_plan &P, const stmmqr_symbolic_view &v)
             tslot[big[i]] = (int)i;
         }
         P.tslots = std::max(P.tslots, (int)big.size());
-        L.lds_small = (int)std::min((long)LDS_CAP_DOUBLES, (maxfm_small | 1) * STM_NB);
+        L.lds_small = (int)std::min((long)LDS_CAP_SMALL, (maxfm_small | 1) * STM_NB);
         L.lds_big = (int)std::min((long)LDS_CAP_DOUBLES, (maxfm_big | 1) * STM_NB);
         L.nbig_at.assign(maxp, 0);
         L.maxcb_at.assign(maxp, 0);

@@ -41,7 +41,8 @@ __device__ __forceinline__ double wave_sum(double v)
     return v;
 }
 
-// sum over the whole workgroup; every thread gets the result.  s_red: NW doubles of LDS.
+// sum over the whole workgroup of NTH threads; every thread gets the result.  s_red: NTH/64 doubles of LDS.
+template <int NTH>
 __device__ __forceinline__ double block_sum(double v, double *s_red)
 {
     v = wave_sum(v);
@@ -50,7 +51,7 @@ __device__ __forceinline__ double block_sum(double v, double *s_red)
     __syncthreads();
     double r = 0;
 #pragma unroll
-    for (int w = 0; w < NW; w++) r += s_red[w];
+    for (int w = 0; w < NTH / 64; w++) r += s_red[w];
     return r;
 }
 
@@ -210,203 +211,17 @@ __global__ __launch_bounds__(NT) void k_assemble(DevCtx c, const int *__restrict
 }
 
 // ------------------------------------------------------------------------------------------------
-// dlarft('F','C'): T (NB x NB upper triangular, column-major, zero padded) of the reflectors stored in the
-// nbp columns of P (column stride pst, row 0 of P = front row g1).  s_diag[j] = front row of the unit
-// diagonal of reflector j (BIGROW / tau 0: no reflector); rows >= tlast are structurally zero.
-// T(0:b-1,b) = -tau_b T(0:b-1,0:b-1) (V(:,0:b-1)' v_b)   
-// ------------------------------------------------------------------------------------------------
-__device__ void dev_larft(const double *P, long long pst, int g1, int tlast, int nbp, const int *s_diag,
-                          const double *s_tau, double (*s_G)[STM_NB + 1], double (*s_T)[STM_NB + 1], double *Tout)
-{
-    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    const int npairs = nbp * (nbp - 1) / 2;
-    for (int idx = wid; idx < npairs; idx += NW) {
-        int b = (int)((1.0 + sqrt(1.0 + 8.0 * idx)) * 0.5);
-        while (b * (b - 1) / 2 > idx) b--;
-        while ((b + 1) * b / 2 <= idx) b++;
-        const int a = idx - b * (b - 1) / 2;
-        double sum = 0;
-        if (s_tau[a] != 0.0 && s_tau[b] != 0.0) {
-            const int db = s_diag[b];                   // > s_diag[a]
-            const double *va = P + a * pst - g1, *vb = P + b * pst - g1;
-            sum = (lane == 0) ? va[db] : 0.0;           // v_b(db) = 1
-            for (int i = db + 1 + lane; i < tlast; i += 64) sum += va[i] * vb[i];
-            sum = wave_sum(sum);
-        }
-        if (lane == 0) s_G[a][b] = sum;
-    }
-    __syncthreads();
-    if (wid == 0) {
-        // lane a owns row a of T
-        const int a = lane;
-        for (int b = 0; b < nbp; b++) {
-            if (a < STM_NB) {
-                double v = 0;
-                const double tb = s_tau[b];
-                if (a < b && tb != 0.0) {
-                    for (int l = a; l < b; l++) v += s_T[a][l] * s_G[l][b];
-                    v *= -tb;
-                } else if (a == b) v = tb;
-                s_T[a][b] = v;
-            }
-        }
-    }
-    __syncthreads();
-    for (int e = tid; e < STM_NB * STM_NB; e += NT) {
-        const int a = e % STM_NB, b = e / STM_NB;
-        Tout[e] = (a < nbp && b < nbp) ? s_T[a][b] : 0.0;
-    }
-}
-
-// ------------------------------------------------------------------------------------------------
-// qr_front, one panel of <= STM_NB columns (reference: the column loop :1434-1609 with the panel policy
-// fixed to k1 = p*NB, which changes rounding only, SURVEY.md A.4).  Executed by one whole workgroup.
-// The panel F(g1:tmax, k1:k2) is staged in LDS when it fits; otherwise it is worked on in place (L2).
-// Produces: R and V in F, Tau, Stair, Rdead, the T factor (Tout, NB x NB, column-major) and the pending
-// block-reflector description in FrontNum (pg1, pt, pk1, pnb, pdiag).
-// ------------------------------------------------------------------------------------------------
-__device__ void dev_panel(const FrontSym &s, FrontNum *num, double *F, int *St, double *Tau, char *Rdead,
-                          int p, double tol, int ntol_global, double *Tout, double *lds, int lds_doubles)
-{
-    __shared__ double s_red[NW];
-    __shared__ int s_diag[STM_NB];
-    __shared__ double s_tau[STM_NB];
-    __shared__ double s_G[STM_NB][STM_NB + 1];
-    __shared__ double s_T[STM_NB][STM_NB + 1];
-
-    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    const int m = num->fm, n = s.fn, npiv = s.fp;
-    const long long ld = s.ld;
-    const int k1 = p * STM_NB;
-    const int k2 = min(n, k1 + STM_NB);
-    const int nbp = k2 - k1;
-    const int was_done = num->done;
-    int g = num->g, rank = num->rank;
-    __syncthreads();                                   // everyone has read FrontNum before anyone writes it
-    if (was_done) {
-        if (tid == 0) num->pnb = 0;
-        return;
-    }
-    const int ntol = min(ntol_global - s.col1, npiv);
-    const int g1 = g;
-    int tmax = min(m, max(St[k2 - 1], g1 + nbp));
-    const int mp = tmax - g1;
-    double flops = 0;
-    int done = 0, tlast = g1;
-
-    double *P;
-    long long pst;
-    const bool in_lds = (mp > 0) && ((long long)(mp | 1) * nbp <= (long long)lds_doubles);
-    if (in_lds) {
-        pst = mp | 1;
-        P = lds;
-        for (int j = wid; j < nbp; j += NW) {
-            const double *src = F + g1 + (k1 + j) * ld;
-            for (int i = lane; i < mp; i += 64) P[i + j * pst] = src[i];
-        }
-    } else {
-        pst = ld;
-        P = F + g1 + k1 * ld;
-    }
-    __syncthreads();
-
-    for (int j = 0; j < nbp; j++) {
-        const int k = k1 + j;
-        if (g >= m) {
-            // no rows left: remaining pivotal columns are dead, remaining columns are empty (:1444-1458)
-            for (int kk = k + tid; kk < n; kk += NT) {
-                if (kk < npiv) { Rdead[kk] = 1; St[kk] = 0; }
-                else St[kk] = m;
-                Tau[kk] = 0;
-            }
-            for (int jj = j + tid; jj < nbp; jj += NT) { s_diag[jj] = STM_BIGROW; s_tau[jj] = 0; }
-            done = 1;
-            break;
-        }
-        const int t = max(g + 1, St[k]);
-        double *col = P + (g - g1) + j * pst;          // col[0] = F(g,k)
-        const int len = t - g;                          // >= 1
-        // ---- dlarfg ----
-        double ss = 0;
-        for (int i = 1 + tid; i < len; i += NT) { const double x = col[i]; ss += x * x; }
-        ss = block_sum(ss, s_red);
-        const double alpha = col[0];
-        double tau = 0, beta = alpha, scal = 0;
-        if (len > 1 && ss != 0.0) {
-            const double xnorm = sqrt(ss);
-            beta = -copysign(hypot(alpha, xnorm), alpha);
-            tau = (beta - alpha) / beta;
-            scal = 1.0 / (alpha - beta);
-        }
-        const bool dead = (k < ntol) && (fabs(beta) <= tol);
-        if (dead) {
-            // zero the column from the diagonal down, no reflector, g does not advance (:1495-1544)
-            for (int i = tid; i < tmax - g; i += NT) col[i] = 0;
-            if (tid == 0) { St[k] = 0; Tau[k] = 0; Rdead[k] = 1; s_diag[j] = STM_BIGROW; s_tau[j] = 0; }
-            if (k == npiv - 1) rank = g;                // (:1604-1608) also taken on a dead last pivot
-            __syncthreads();
-            continue;
-        }
-        if (tid == 0) { St[k] = t; Tau[k] = tau; col[0] = beta; s_diag[j] = g; s_tau[j] = tau; }
-        if (tau != 0.0)
-            for (int i = 1 + tid; i < len; i += NT) col[i] *= scal;
-        flops += (double)len * (3.0 + 4.0 * (double)(n - k - 1));
-        __syncthreads();
-        // ---- dlarf on the rest of the panel: one wave per column, shuffles for v'c ----
-        if (tau != 0.0) {
-            for (int jj = j + 1 + wid; jj < nbp; jj += NW) {
-                double *cc = P + (g - g1) + jj * pst;
-                double w = (lane == 0) ? cc[0] : 0.0;
-                for (int i = 1 + lane; i < len; i += 64) w += col[i] * cc[i];
-                w = wave_sum(w) * tau;
-                if (lane == 0) cc[0] -= w;
-                for (int i = 1 + lane; i < len; i += 64) cc[i] -= w * col[i];
-            }
-        }
-        tlast = t;
-        g++;
-        if (k == npiv - 1) rank = g;
-        __syncthreads();
-    }
-    __syncthreads();
-
-    dev_larft(P, pst, g1, tlast, nbp, s_diag, s_tau, s_G, s_T, Tout);
-    if (in_lds) {
-        for (int j = wid; j < nbp; j += NW) {
-            double *dst = F + g1 + (k1 + j) * ld;
-            for (int i = lane; i < mp; i += 64) dst[i] = P[i + j * pst];
-        }
-    }
-    if (tid < STM_NB) num->pdiag[tid] = (tid < nbp) ? s_diag[tid] : STM_BIGROW;
-    if (tid == 0) {
-        num->g = g; num->rank = rank; num->done = done;
-        num->pg1 = g1; num->pt = tlast; num->pk1 = k1; num->pnb = nbp; num->pc0 = k2;
-        num->flops += flops;
-        {
-            int nlive = 0;
-            for (int j = 0; j < nbp; j++) nlive += (s_tau[j] != 0.0);
-            num->flops_upd += 4.0 * (double)(tlast - g1) * (double)(n - k2) * (double)nlive;
-        }
-    }
-    __syncthreads();
-}
-
-// ------------------------------------------------------------------------------------------------
-// qr_larftb(QR_QTX): C <- (I - V T V')' C for one BN-column block of the trailing matrix, on fp64 MFMA.
-//   C = F(pg1:pt, c0:c0+BN), V = F(pg1:pt, pk1:pk1+pnb) (unit diagonal at pdiag[], zero above),
-//   T = NB x NB upper triangular.  lds: >= 2*BN*VS + STM_NB*WS doubles.
+// qr_larftb(QR_QTX): C <- (I - V T V')' C for one block of <= BN columns, on fp64 MFMA.
+//   C = F(g1:g1+mp, c0:c0+nc), V = F(g1:g1+mp, k1:k1+nbp) with the unit diagonal of reflector j at absolute row
+//   diag[j] (STM_BIGROW: no reflector) and zeros above it, T = NB x NB upper triangular (column-major, ld NB).
+//   lds: >= 2*BN*VS + STM_NB*WS doubles.  diag / T may live in LDS or global memory.
 // v_mfma_f64_16x16x4_f64 operand maps (cdna_hip_programming.md 3): A[i=l&15][k=l>>4], B[k=l>>4][j=l&15],
 // D[i=(l>>4)+4r][j=l&15].
 // ------------------------------------------------------------------------------------------------
-__device__ void dev_update_block(const FrontSym &s, const FrontNum *num, double *F, const double *T, int cb,
-                                 double *lds)
+__device__ void dev_update_block(double *F, long long ld, int g1, int mp, int k1, int nbp, const int *diag,
+                                 const double *T, int c0, int nc, double *lds)
 {
-    const int g1 = num->pg1, mp = num->pt - num->pg1, k1 = num->pk1, nbp = num->pnb;
-    if (nbp <= 0 || mp <= 0) return;
-    const int c0 = num->pc0 + cb * BN;
-    if (c0 >= s.fn) return;
-    const int nc = min(BN, s.fn - c0);
-    const long long ld = s.ld;
+    if (nbp <= 0 || mp <= 0 || nc <= 0) return;
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int l15 = lane & 15, l4 = lane >> 4;
 
@@ -416,7 +231,7 @@ __device__ void dev_update_block(const FrontSym &s, const FrontNum *num, double 
     __shared__ int s_pd[STM_NB];
 
     __syncthreads();                        // previous users of lds are done
-    if (tid < STM_NB) s_pd[tid] = num->pdiag[tid];
+    if (tid < STM_NB) s_pd[tid] = (tid < nbp) ? diag[tid] : STM_BIGROW;
     __syncthreads();
 
     const int lrow = tid & 63, lcg = tid >> 6;          // loader mapping: 64 rows x 4 column groups of 8
@@ -516,6 +331,313 @@ __device__ void dev_update_block(const FrontSym &s, const FrontNum *num, double 
 }
 
 // ------------------------------------------------------------------------------------------------
+// dlarft('F','C'): T (NB x NB upper triangular, column-major, zero padded) of nc <= NB reflectors stored in the
+// columns of Vg (= &F(0, first column), absolute row indexing, leading dimension ld), rows [r0, r1).
+// diag[j] = absolute row of the unit diagonal of reflector j (BIGROW: none), tau[j] its coefficient.
+//   G = V'V by fp64 MFMA (each wave sweeps every NW-th group of 4 rows; the same register is the A and the B
+//   operand of the diagonal tiles), cross-wave sum through LDS scratch, then
+//   T(0:b-1,b) = -tau_b T(0:b-1,0:b-1) G(0:b-1,b)   (SURVEY.md A.4).   scratch: >= NW*3*256 doubles.
+// ------------------------------------------------------------------------------------------------
+template <int NTH>
+__device__ void dev_gram_T(const double *Vg, long long ld, int r0, int r1, int nc, const int *diag, const double *tau,
+                           double (*s_G)[STM_NB + 1], double (*s_T)[STM_NB + 1], double *Tout, double *scratch)
+{
+    constexpr int NWV = NTH / 64;
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int l15 = lane & 15, l4 = lane >> 4;
+    const bool two = nc > 16;
+    const int d0 = (l15 < nc) ? diag[l15] : STM_BIGROW;
+    const int d1 = (16 + l15 < nc) ? diag[16 + l15] : STM_BIGROW;
+    const double *V0 = Vg + (long long)l15 * ld, *V1 = Vg + (long long)(16 + l15) * ld;
+    d4 g00 = {0, 0, 0, 0}, g01 = {0, 0, 0, 0}, g11 = {0, 0, 0, 0};
+    const int nk = (r1 - r0 + 3) / 4;
+    for (int kk = wid; kk < nk; kk += NWV) {
+        const int i = r0 + 4 * kk + l4;
+        double a0 = 0, a1 = 0;
+        if (i < r1) {
+            if (i >= d0) a0 = (i == d0) ? 1.0 : V0[i];
+            if (two && i >= d1) a1 = (i == d1) ? 1.0 : V1[i];
+        }
+        g00 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, a0, g00, 0, 0, 0);
+        if (two) {
+            g01 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, a1, g01, 0, 0, 0);
+            g11 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, a1, g11, 0, 0, 0);
+        }
+    }
+    __syncthreads();                                    // scratch is free
+    // cross-wave sum in groups of 4 waves (scratch: 4 * 768 doubles)
+    for (int grp = 0; grp < NWV / 4; grp++) {
+        if ((wid >> 2) == grp) {
+            double *sc = scratch + (wid & 3) * 768;
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const int o = (l4 + 4 * r) * 16 + l15;
+                if (grp == 0) { sc[o] = g00[r]; sc[256 + o] = g01[r]; sc[512 + o] = g11[r]; }
+                else { sc[o] += g00[r]; sc[256 + o] += g01[r]; sc[512 + o] += g11[r]; }
+            }
+        }
+        __syncthreads();
+    }
+    for (int e = tid; e < 768; e += NTH) {
+        const double v = scratch[e] + scratch[768 + e] + scratch[1536 + e] + scratch[2304 + e];
+        const int tile = e >> 8, a = (e >> 4) & 15, b = e & 15;
+        s_G[a + (tile == 2 ? 16 : 0)][b + (tile >= 1 ? 16 : 0)] = v;
+    }
+    __syncthreads();
+    if (wid == 0 && lane < STM_NB) {
+        const int a = lane;                             // lane a owns row a of T
+        for (int b = 0; b < nc; b++) {
+            double v = 0;
+            const double tb = tau[b];
+            if (a < b && tb != 0.0) {
+                for (int l = a; l < b; l++) v += s_T[a][l] * s_G[l][b];
+                v *= -tb;
+            } else if (a == b) v = tb;
+            s_T[a][b] = v;
+        }
+    }
+    __syncthreads();
+    for (int e = tid; e < STM_NB * STM_NB; e += NTH) {
+        const int a = e % STM_NB, b = e / STM_NB;
+        Tout[e] = (a < nc && b < nc && a <= b) ? s_T[a][b] : 0.0;
+    }
+    __syncthreads();
+}
+
+// ------------------------------------------------------------------------------------------------
+// Apply the reflectors of an LDS-resident sub-panel to the remaining columns of the panel (qr_private_apply1 /
+// dlarf semantics, :1359-1381, reflector after reflector).  One wave owns one column: the column's active rows
+// [gs, r1) live in that wave's registers (<= 64 per lane, i.e. 4096 rows), V is read from LDS with the
+// unit-diagonal / zero mask, each v'c is a wave64 shuffle reduction.  Columns taller than 4096 active rows use
+// the slower two-pass form on the column in global memory.
+//   Vl[(i - gs) + j*pst] = F(i, k1 + j0 + j) for the sub-panel columns j < sw.
+// ------------------------------------------------------------------------------------------------
+template <int NTH>
+__device__ void dev_apply_subpanel(const double *Vl, long long pst, int gs, int r1, int sw, const int *diag,
+                                   const double *tau, double *Fc /* = &F(0, first remaining column) */, long long ld,
+                                   int ncols)
+{
+    constexpr int NWV = NTH / 64;
+    constexpr int MAXQ = 64;
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const int rows = r1 - gs;
+    if (rows <= 0) return;
+    const int nq = (rows + 63) >> 6;
+    for (int jc = wid; jc < ncols; jc += NWV) {
+        double *cg = Fc + jc * ld + gs;                 // cg[r] = F(gs + r, column)
+        if (nq <= MAXQ && NTH >= 512) {
+            double creg[MAXQ];
+#pragma unroll
+            for (int q = 0; q < MAXQ; q++) {
+                const int r = lane + 64 * q;
+                creg[q] = (q < nq && r < rows) ? cg[r] : 0.0;
+            }
+            for (int i = 0; i < sw; i++) {
+                const double ti = tau[i];
+                if (ti == 0.0) continue;
+                const double *v = Vl + i * pst + lane;  // explicit unit-lower-trapezoidal image: no masks
+                double z = 0;
+#pragma unroll
+                for (int q = 0; q < MAXQ; q++)
+                    if (q < nq) z += v[64 * q] * creg[q];
+                z = wave_sum(z) * ti;
+#pragma unroll
+                for (int q = 0; q < MAXQ; q++)
+                    if (q < nq) creg[q] -= z * v[64 * q];
+            }
+#pragma unroll
+            for (int q = 0; q < MAXQ; q++) {
+                const int r = lane + 64 * q;
+                if (q < nq && r < rows) cg[r] = creg[q];
+            }
+        } else {
+            for (int i = 0; i < sw; i++) {
+                const double ti = tau[i];
+                if (ti == 0.0) continue;
+                const double *v = Vl + i * pst;
+                double z = 0;
+                for (int r = lane; r < rows; r += 64) z += v[r] * cg[r];
+                z = wave_sum(z) * ti;
+                for (int r = lane; r < rows; r += 64) cg[r] -= z * v[r];
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// qr_front, one panel of <= STM_NB columns (reference: the column loop :1434-1609 with the panel policy
+// fixed to k1 = p*NB, which changes rounding only, SURVEY.md A.4).  Executed by one whole workgroup.
+//
+// The panel F(g:tmax, k1:k2) is processed in sub-panels of `sw` columns that fit the LDS budget (a 4000-row panel
+// gets 4-column sub-panels, a 500-row panel is one sub-panel): each sub-panel is staged in LDS, reduced column
+// by column there (norms: wave64 shuffles + one LDS step; dlarf: one wave per remaining sub-panel column),
+// written back, and its block reflector is applied to the remaining columns of the panel with the fp64-MFMA
+// routine above -- a blocked QR inside the panel, so the tall panel streams through the CU once per sub-panel
+// instead of once per column.  Panels taller than the LDS budget for one column fall back to in-place work.
+// Produces: R and V in F, Tau, Stair, Rdead, the T factor of the whole panel (Tout, NB x NB) and the pending
+// block-reflector description in FrontNum (pg1, pt, pk1, pnb, pc0, pdiag).
+// ------------------------------------------------------------------------------------------------
+template <int NTH>
+__device__ void dev_panel(const FrontSym &s, FrontNum *num, double *F, int *St, double *Tau, char *Rdead,
+                          int p, double tol, int ntol_global, double *Tout, double *lds, int lds_doubles)
+{
+    constexpr int NWV = NTH / 64;
+    __shared__ double s_red[NWV];
+    __shared__ int s_diag[STM_NB];
+    __shared__ double s_tau[STM_NB];
+    __shared__ double s_G[STM_NB][STM_NB + 1];
+    __shared__ double s_T[STM_NB][STM_NB + 1];
+
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int m = num->fm, n = s.fn, npiv = s.fp;
+    const long long ld = s.ld;
+    const int k1 = p * STM_NB;
+    const int k2 = min(n, k1 + STM_NB);
+    const int nbp = k2 - k1;
+    const int was_done = num->done;
+    int g = num->g, rank = num->rank;
+    __syncthreads();                                   // everyone has read FrontNum before anyone writes it
+    if (was_done) {
+        if (tid == 0) num->pnb = 0;
+        return;
+    }
+    const int ntol = min(ntol_global - s.col1, npiv);
+    const int g1 = g;
+    const int tmax = min(m, max(St[k2 - 1], g1 + nbp));
+    const int mp = tmax - g1;
+    double flops = 0;
+    int done = 0, tlast = g1;
+
+    // sub-panel width: as many columns as fit in LDS with the rows of the first sub-panel
+    int SW = 0;
+    if (mp > 0) SW = min(nbp, lds_doubles / (((mp + 63) & ~63) | 1));   // columns padded to whole 64-row slots
+    const bool in_place = (SW == 0);
+    if (in_place) SW = nbp;
+
+    for (int j0 = 0; j0 < nbp && !done; j0 += SW) {
+        const int sw = min(SW, nbp - j0);
+        const int gs = g;                               // first active row of this sub-panel
+        const int ms = tmax - gs;
+        long long pst;
+        double *Pb;                                     // Pb[(i-roff) + (j-coff)*pst] = F(i, k1+j)
+        int roff = 0, coff = 0;                         // (never form a pointer outside the LDS object)
+        if (!in_place && ms > 0) {
+            const int msp = (ms + 63) & ~63;            // zero-padded so that 64-row slots can be read unmasked
+            pst = msp | 1;
+            for (int j = wid; j < sw; j += NWV) {
+                const double *src = F + (k1 + j0 + j) * ld;
+                for (int i = lane; i < msp; i += 64) lds[i + j * pst] = (i < ms) ? src[gs + i] : 0.0;
+            }
+            Pb = lds; roff = gs; coff = j0;
+        } else {
+            pst = ld;
+            Pb = F + k1 * ld;
+        }
+        __syncthreads();
+        int nlive = 0;
+        for (int j = j0; j < j0 + sw; j++) {
+            const int k = k1 + j;
+            if (g >= m) {
+                // no rows left: remaining pivotal columns are dead, remaining columns are empty (:1444-1458)
+                for (int kk = k + tid; kk < n; kk += NTH) {
+                    if (kk < npiv) { Rdead[kk] = 1; St[kk] = 0; }
+                    else St[kk] = m;
+                    Tau[kk] = 0;
+                }
+                for (int jj = j + tid; jj < nbp; jj += NTH) { s_diag[jj] = STM_BIGROW; s_tau[jj] = 0; }
+                done = 1;
+                break;
+            }
+            const int t = max(g + 1, St[k]);
+            double *col = Pb + (g - roff) + (j - coff) * pst;   // col[0] = F(g,k)
+            const int len = t - g;                      // >= 1
+            // ---- dlarfg ----
+            const double alpha = col[0];                // read before the barriers below: thread 0 overwrites it
+            double ss = 0;
+            for (int i = 1 + tid; i < len; i += NTH) { const double x = col[i]; ss += x * x; }
+            ss = block_sum<NTH>(ss, s_red);
+            double tau = 0, beta = alpha, scal = 0;
+            if (len > 1 && ss != 0.0) {
+                const double xnorm = sqrt(ss);
+                beta = -copysign(hypot(alpha, xnorm), alpha);
+                tau = (beta - alpha) / beta;
+                scal = 1.0 / (alpha - beta);
+            }
+            const bool dead = (k < ntol) && (fabs(beta) <= tol);
+            if (dead) {
+                // zero the column from the diagonal down, no reflector, g does not advance (:1495-1544)
+                for (int i = tid; i < tmax - g; i += NTH) col[i] = 0;
+                if (tid == 0) { St[k] = 0; Tau[k] = 0; Rdead[k] = 1; s_diag[j] = STM_BIGROW; s_tau[j] = 0; }
+                if (k == npiv - 1) rank = g;            // (:1604-1608) also taken on a dead last pivot
+                __syncthreads();
+                continue;
+            }
+            if (tid == 0) { St[k] = t; Tau[k] = tau; col[0] = beta; s_diag[j] = g; s_tau[j] = tau; }
+            if (tau != 0.0)
+                for (int i = 1 + tid; i < len; i += NTH) col[i] *= scal;
+            flops += (double)len * (3.0 + 4.0 * (double)(n - k - 1));
+            __syncthreads();
+            // ---- dlarf on the rest of the SUB-panel: one wave per column, shuffles for v'c ----
+            if (tau != 0.0) {
+                nlive++;
+                for (int jj = j + 1 + wid; jj < j0 + sw; jj += NWV) {
+                    double *cc = Pb + (g - roff) + (jj - coff) * pst;
+                    double w = (lane == 0) ? cc[0] : 0.0;
+                    for (int i = 1 + lane; i < len; i += 64) w += col[i] * cc[i];
+                    w = wave_sum(w) * tau;
+                    if (lane == 0) cc[0] -= w;
+                    for (int i = 1 + lane; i < len; i += 64) cc[i] -= w * col[i];
+                }
+            }
+            tlast = t;
+            g++;
+            if (k == npiv - 1) rank = g;
+            __syncthreads();
+        }
+        __syncthreads();
+        if (!in_place && ms > 0) {
+            for (int j = wid; j < sw; j += NWV) {
+                double *dst = F + (k1 + j0 + j) * ld;
+                for (int i = gs + lane; i < tmax; i += 64) dst[i] = lds[(i - gs) + j * pst];
+            }
+        }
+        __syncthreads();
+        // ---- apply this sub-panel's reflectors to the remaining columns of the panel; V is still in LDS ----
+        if (!in_place && !done && j0 + sw < nbp && nlive > 0 && tlast > gs) {
+            // turn the LDS image into the explicit unit-lower-trapezoidal V (R entries above the diagonals were
+            // already written back): the apply loop then needs no masks
+            for (int e = tid; e < sw * sw; e += NTH) {
+                const int i = e % sw, j = e / sw;       // rows gs..gs+sw-1 are the only ones at or above a diagonal
+                const int d = s_diag[j0 + j] - gs;
+                if (i < ms) lds[i + j * pst] = (s_tau[j0 + j] == 0.0) ? 0.0 : ((i < d) ? 0.0 : ((i == d) ? 1.0 : lds[i + j * pst]));
+            }
+            if (nlive < sw)                              // dead / identity columns: whole column is not a reflector
+                for (int j = 0; j < sw; j++)
+                    if (s_tau[j0 + j] == 0.0)
+                        for (int i = tid; i < ms; i += NTH) lds[i + j * pst] = 0.0;
+            __syncthreads();
+            dev_apply_subpanel<NTH>(lds, pst, gs, tlast, sw, s_diag + j0, s_tau + j0, F + (long long)(k1 + j0 + sw) * ld,
+                                    ld, nbp - (j0 + sw));
+            __syncthreads();
+        }
+    }
+    // ---- T of the whole panel for the trailing update ----
+    dev_gram_T<NTH>(F + (long long)k1 * ld, ld, g1, tlast, nbp, s_diag, s_tau, s_G, s_T, Tout, lds);
+    if (tid < STM_NB) num->pdiag[tid] = (tid < nbp) ? s_diag[tid] : STM_BIGROW;
+    if (tid == 0) {
+        num->g = g; num->rank = rank; num->done = done;
+        num->pg1 = g1; num->pt = tlast; num->pk1 = k1; num->pnb = nbp; num->pc0 = k2;
+        num->flops += flops;
+        {
+            int nl = 0;
+            for (int j = 0; j < nbp; j++) nl += (s_tau[j] != 0.0);
+            num->flops_upd += 4.0 * (double)(tlast - g1) * (double)(n - k2) * (double)nl;
+        }
+    }
+    __syncthreads();
+}
+
+// ------------------------------------------------------------------------------------------------
 // qr_cpack: C = F(rank:, fp:) upper trapezoid -> packed column-major; coalesced on the
 // packed side.  part/nparts as in dev_assemble.
 // ------------------------------------------------------------------------------------------------
@@ -561,11 +683,13 @@ __global__ __launch_bounds__(NT) void k_front_wg(DevCtx c, const int *__restrict
     FrontNum *num = &c.fnum[f];
     double *F = c.Farena + s.foff;
     for (int p = 0; p < s.npanels; p++) {
-        dev_panel(s, num, F, c.Stair + s.rp, c.Tau + s.rp, c.Rdead + s.col1, p, c.tol, c.ntol, s_Tw, dyn_lds,
+        dev_panel<NT>(s, num, F, c.Stair + s.rp, c.Tau + s.rp, c.Rdead + s.col1, p, c.tol, c.ntol, s_Tw, dyn_lds,
                   lds_doubles);
         const int k2 = min(s.fn, (p + 1) * STM_NB);
         const int ncb = (s.fn - k2 + BN - 1) / BN;
-        for (int cb = 0; cb < ncb; cb++) dev_update_block(s, num, F, s_Tw, cb, dyn_lds);
+        for (int cb = 0; cb < ncb; cb++)
+            dev_update_block(F, s.ld, num->pg1, num->pt - num->pg1, num->pk1, num->pnb, num->pdiag, s_Tw, k2 + cb * BN,
+                             min(BN, s.fn - (k2 + cb * BN)), dyn_lds);
         __syncthreads();
     }
     dev_cpack(c, s, num, 0, 1);
@@ -574,13 +698,14 @@ __global__ __launch_bounds__(NT) void k_front_wg(DevCtx c, const int *__restrict
 // ------------------------------------------------------------------------------------------------
 // large fronts: panel and trailing update are separate launches (many workgroups per update)
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(NT) void k_panel(DevCtx c, const int *__restrict__ flist, int p, int lds_doubles)
+#define NTP 512               // threads of the large-front panel kernel (8 waves, <= 256 VGPRs each)
+__global__ __launch_bounds__(NTP) void k_panel(DevCtx c, const int *__restrict__ flist, int p, int lds_doubles)
 {
     extern __shared__ double dyn_lds[];
     const int f = flist[blockIdx.x];
     const FrontSym s = c.fs[f];
     if (p >= s.npanels) return;
-    dev_panel(s, &c.fnum[f], c.Farena + s.foff, c.Stair + s.rp, c.Tau + s.rp, c.Rdead + s.col1, p, c.tol, c.ntol,
+    dev_panel<NTP>(s, &c.fnum[f], c.Farena + s.foff, c.Stair + s.rp, c.Tau + s.rp, c.Rdead + s.col1, p, c.tol, c.ntol,
               c.Tws + (long long)c.tslot[f] * STM_NB * STM_NB, dyn_lds, lds_doubles);
 }
 
@@ -590,13 +715,17 @@ __global__ __launch_bounds__(NT) void k_update(DevCtx c, const int *__restrict__
     const int f = flist[blockIdx.y];
     const FrontSym s = c.fs[f];
     if (p >= s.npanels) return;
-    dev_update_block(s, &c.fnum[f], c.Farena + s.foff, c.Tws + (long long)c.tslot[f] * STM_NB * STM_NB, blockIdx.x,
-                     dyn_lds);
+    const FrontNum *num = &c.fnum[f];
+    const int c0 = num->pc0 + blockIdx.x * BN;
+    if (c0 >= s.fn) return;
+    dev_update_block(c.Farena + s.foff, s.ld, num->pg1, num->pt - num->pg1, num->pk1, num->pnb, num->pdiag,
+                     c.Tws + (long long)c.tslot[f] * STM_NB * STM_NB, c0, min(BN, s.fn - c0), dyn_lds);
 }
 
 // standalone T factor of the pending block reflector described by FrontNum (qr_larftb seam)
 __global__ __launch_bounds__(NT) void k_larft(DevCtx c, int f)
 {
+    extern __shared__ double dyn_lds[];
     __shared__ int s_diag[STM_NB];
     __shared__ double s_tau[STM_NB];
     __shared__ double s_G[STM_NB][STM_NB + 1];
@@ -609,9 +738,8 @@ __global__ __launch_bounds__(NT) void k_larft(DevCtx c, int f)
         s_tau[tid] = (tid < num->pnb && num->pdiag[tid] != STM_BIGROW) ? c.Tau[s.rp + num->pk1 + tid] : 0.0;
     }
     __syncthreads();
-    const double *P = c.Farena + s.foff + num->pg1 + (long long)num->pk1 * s.ld;
-    dev_larft(P, s.ld, num->pg1, num->pt, num->pnb, s_diag, s_tau, s_G, s_T,
-              c.Tws + (long long)c.tslot[f] * STM_NB * STM_NB);
+    dev_gram_T<NT>(c.Farena + s.foff + (long long)num->pk1 * s.ld, s.ld, num->pg1, num->pt, num->pnb, s_diag, s_tau, s_G,
+               s_T, c.Tws + (long long)c.tslot[f] * STM_NB * STM_NB, dyn_lds);
 }
 
 __global__ __launch_bounds__(NT) void k_cpack(DevCtx c, const int *__restrict__ flist,
@@ -772,8 +900,9 @@ int stm_launch_front_wg(const DevCtx &c, const int *flist, int nfr, int lds_doub
 int stm_launch_panel(const DevCtx &c, const int *flist, int nfr, int p, int lds_doubles, hipStream_t st)
 {
     if (nfr <= 0) return 0;
-    hipLaunchKernelGGL(k_panel, dim3(nfr), dim3(NT), (size_t)lds_doubles * sizeof(double), st, c, flist, p,
-                       lds_doubles);
+    size_t bytes = (size_t)lds_doubles * sizeof(double);
+    if (bytes < (size_t)stm_update_lds_bytes()) bytes = stm_update_lds_bytes();   // in-panel MFMA update + Gram scratch
+    hipLaunchKernelGGL(k_panel, dim3(nfr), dim3(NTP), bytes, st, c, flist, p, (int)(bytes / sizeof(double)));
     return (int)hipGetLastError();
 }
 int stm_launch_update(const DevCtx &c, const int *flist, int nfr, int p, int maxcb, hipStream_t st)
@@ -784,7 +913,7 @@ int stm_launch_update(const DevCtx &c, const int *flist, int nfr, int p, int max
 }
 int stm_launch_larft(const DevCtx &c, int f, hipStream_t st)
 {
-    hipLaunchKernelGGL(k_larft, dim3(1), dim3(NT), 0, st, c, f);
+    hipLaunchKernelGGL(k_larft, dim3(1), dim3(NT), (size_t)stm_update_lds_bytes(), st, c, f);
     return (int)hipGetLastError();
 }
 int stm_launch_cpack(const DevCtx &c, const int *flist, const int *nparts, int nfr, int maxparts, hipStream_t st)
@@ -814,7 +943,7 @@ int stm_launch_rh_copy(const DevCtx &c, const int *flist, const int *nparts, int
 int stm_configure_kernels(void)
 {
     // allow the panel kernels to ask for up to 144 KiB of dynamic LDS (160 KiB per CU on gfx950)
-    CK(hipFuncSetAttribute((const void *)k_front_wg, hipFuncAttributeMaxDynamicSharedMemorySize, 131072));
+    CK(hipFuncSetAttribute((const void *)k_front_wg, hipFuncAttributeMaxDynamicSharedMemorySize, 122880));
     CK(hipFuncSetAttribute((const void *)k_panel, hipFuncAttributeMaxDynamicSharedMemorySize, 131072));
     CK(hipFuncSetAttribute((const void *)k_update, hipFuncAttributeMaxDynamicSharedMemorySize, 65536));
     return 0;

@@ -95,7 +95,7 @@ struct OneFront {
     }
 };
 
-int lds_for(long m) { return (int)std::min(16384L, (m | 1) * STM_NB); }
+int lds_for(long m) { return (int)std::min(15360L, (m | 1) * STM_NB); }
 
 }  // namespace
 
