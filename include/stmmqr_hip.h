@@ -196,6 +196,7 @@ typedef struct stmmqr_options {
     int big_front_cols;     /* fronts with fn >= this use the multi-workgroup panel/update path           */
     int verbose;
     int use_graph;          /* capture the level schedule into a hipGraph                                 */
+    int lookahead;          /* overlap panel p+1 with the rest of the trailing update of panel p (2 streams) */
 } stmmqr_options;
 void stmmqr_get_options(stmmqr_options *opt);
 void stmmqr_set_options(const stmmqr_options *opt);

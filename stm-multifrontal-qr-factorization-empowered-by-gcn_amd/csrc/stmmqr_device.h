@@ -26,19 +26,26 @@ struct FrontSym {
     int pad0;
 };
 
+// one pending block reflector (written by the panel kernel, read by the update kernel)
+struct PanelDesc {
+    int pg1, pt;             // rows [pg1, pt)
+    int pk1, pnb;            // built from columns [pk1, pk1+pnb)
+    int pc0;                 // to be applied to columns [pc0, fn)
+    int pad;
+    int pdiag[STM_NB];       // row of the unit diagonal of each reflector (BIGROW: none)
+};
+
 // numeric, written by the kernels
 struct FrontNum {
     int fm;                  // rows of F                           (qr_fsize)
     int g;                   // rows eliminated so far = next diagonal row
     int rank;                // live pivotal columns                (qr_front's return value)
     int done;                // 1 once g reached fm and the tail columns were finalised
-    int pg1, pt;             // pending block reflector: rows [pg1, pt)
-    int pk1, pnb;            // ... built from columns [pk1, pk1+pnb)
-    int pc0;                 // ... to be applied to columns [pc0, fn)
-    int pad1;
     int cm;                  // rows of the contribution block      (qr_cpack's return value)
     int rsize;               // entries of the packed R+H block     (qr_rhpack's return value)
     double flops;            // reference flop count of this front  (FLOP_COUNT, :1571)
     double flops_upd;        // dlarfb flops handed to the MFMA update: 4 * rows * cols * reflectors
-    int pdiag[STM_NB];       // row of the unit diagonal of each reflector of the pending block (BIGROW: none)
+    // pending block reflectors, double buffered by panel parity so that the look-ahead schedule can factorize
+    // panel p+1 while the tail of update p is still reading the description of panel p
+    PanelDesc pd[2];
 };

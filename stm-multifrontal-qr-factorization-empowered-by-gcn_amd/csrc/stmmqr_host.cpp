@@ -29,7 +29,7 @@
 namespace {
 
 thread_local std::string g_err;
-stmmqr_options g_opt = {STM_NB, 128, 0, 0};
+stmmqr_options g_opt = {STM_NB, 128, 0, 0, 0};
 size_t g_chunk[4] = {32, 5000, 4, 4};     // FCHUNK, SMALL, MINCHUNK, MINCHUNK_RATIO (SparseQR.h:16-19)
 
 // offsets inside the reference's sparse_common for the stock LP64 build; verified against the real header
@@ -106,8 +106,9 @@ struct Level {
 
 struct stmmqr_plan {
     int device = 0;
-    hipStream_t stream = nullptr;
+    hipStream_t stream = nullptr, stream2 = nullptr;   // stream2: look-ahead (rest of the trailing update)
     hipEvent_t ev[8] = {};
+    std::vector<hipEvent_t> evpool;                    // ordering events of the look-ahead schedule
     long m = 0, n = 0, anz = 0, nf = 0, maxfn = 0, rjsize = 0, hisize = 0;
     int do_rank = 1;
     std::vector<long> Sp, Sj, Qfill, PLinv, Sleft, Child, Childp, Super, Rp, Rj, Post, Hip, Fm;
@@ -127,6 +128,7 @@ struct stmmqr_plan {
     DevBuf<int> d_tslot, d_Sp, d_Sjrel, d_Sj0, d_Sleft, d_Child, d_Rjrel, d_Stair, d_Hii, d_Cmap, d_Cursor,
         d_Rhoff, d_lists, d_smap;
     DevBuf<long long> d_Rboff, d_total;
+    DevBuf<unsigned long long> d_dbg;
     DevBuf<char> d_Rdead;
 
     // results of the last factorization
@@ -146,13 +148,18 @@ struct stmmqr_plan {
         c.Child = d_Child.p; c.Rjrel = d_Rjrel.p; c.Stair = d_Stair.p; c.Tau = d_Tau.p; c.Hii = d_Hii.p;
         c.Rdead = d_Rdead.p; c.Cmap = d_Cmap.p; c.Cursor = d_Cursor.p; c.Rhoff = d_Rhoff.p; c.Rboff = d_Rboff.p;
         c.tol = last_tol; c.ntol = (int)last_ntol;
+        c.dbg = getenv("STMMQR_DBG") ? atoi(getenv("STMMQR_DBG")) : 0;
+        c.dbgbuf = d_dbg.p;
         return c;
     }
     ~stmmqr_plan()
     {
         for (auto &e : ev)
             if (e) (void)hipEventDestroy(e);
+        for (auto &e : evpool)
+            if (e) (void)hipEventDestroy(e);
         if (stream) (void)hipStreamDestroy(stream);
+        if (stream2) (void)hipStreamDestroy(stream2);
     }
 };
 
@@ -374,7 +381,7 @@ int build_plan(stmmqr_plan &P, const stmmqr_symbolic_view &v)
     HIPCHK(hipMemsetAsync(P.d_fnum.p, 0, std::max(1L, nf) * sizeof(FrontNum), st));
     LCHK(P.d_F.alloc((size_t)P.farena));
     LCHK(P.d_C.alloc((size_t)P.carena));
-    LCHK(P.d_T.alloc((size_t)P.tslots * STM_NB * STM_NB));
+    LCHK(P.d_T.alloc((size_t)2 * P.tslots * STM_NB * STM_NB));
     LCHK(P.d_tslot.upload(tslot, st));
     LCHK(P.d_Sx.alloc((size_t)v.anz));
     LCHK(P.d_Ax.alloc((size_t)v.anz));
@@ -393,6 +400,8 @@ int build_plan(stmmqr_plan &P, const stmmqr_symbolic_view &v)
     LCHK(P.d_Rhoff.alloc((size_t)v.rjsize));
     LCHK(P.d_Rboff.alloc((size_t)std::max(1L, nf)));
     LCHK(P.d_total.alloc(1));
+    LCHK(P.d_dbg.alloc(8));
+    HIPCHK(hipMemsetAsync(P.d_dbg.p, 0, 8 * sizeof(unsigned long long), st));
     LCHK(P.d_Rdead.alloc((size_t)std::max(1L, n)));
     LCHK(P.d_lists.upload(P.lists, st));
     HIPCHK(hipStreamSynchronize(st));
@@ -432,6 +441,15 @@ int run_schedule(stmmqr_plan &P, bool detail)
     const int *L0 = P.d_lists.p;
     long nlaunch = 0;
     float t_asm = 0, t_front = 0, t_upd = 0, t_cpk = 0;
+    size_t evnext = 0;
+    auto next_event = [&]() -> hipEvent_t {
+        if (evnext == P.evpool.size()) {
+            hipEvent_t e = nullptr;
+            if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return nullptr;
+            P.evpool.push_back(e);
+        }
+        return P.evpool[evnext++];
+    };
     // detail timing: bracket each category with events and accumulate (forces one sync per level)
     auto timed = [&](float &acc, auto &&fn) -> int {
         if (!detail) return fn();
@@ -465,18 +483,42 @@ int run_schedule(stmmqr_plan &P, bool detail)
         });
         if (e) return e;
         const int *big = all + L.n_small;
-        for (size_t p = 0; p < L.nbig_at.size(); p++) {
-            e = timed(t_front, [&]() -> int {
+        if (detail || !g_opt.lookahead) {
+            for (size_t p = 0; p < L.nbig_at.size(); p++) {
+                e = timed(t_front, [&]() -> int {
+                    LCHK(stm_launch_panel(c, big, L.nbig_at[p], (int)p, L.lds_big, st));
+                    return 0;
+                });
+                if (e) return e;
+                e = timed(t_upd, [&]() -> int {
+                    LCHK(stm_launch_update(c, big, L.nbig_at[p], (int)p, 0, L.maxcb_at[p], st));
+                    return 0;
+                });
+                if (e) return e;
+                nlaunch += 2;
+            }
+        } else {
+            // look-ahead: the update of panel p is split into the column block the NEXT panel needs (stays on the
+            // main stream) and the rest, which runs on stream2 while panel p+1 is being factorized
+            hipStream_t s2 = P.stream2;
+            hipEvent_t prev_rest = nullptr;
+            for (size_t p = 0; p < L.nbig_at.size(); p++) {
                 LCHK(stm_launch_panel(c, big, L.nbig_at[p], (int)p, L.lds_big, st));
-                return 0;
-            });
-            if (e) return e;
-            e = timed(t_upd, [&]() -> int {
-                LCHK(stm_launch_update(c, big, L.nbig_at[p], (int)p, L.maxcb_at[p], st));
-                return 0;
-            });
-            if (e) return e;
-            nlaunch += 2;
+                hipEvent_t evp = next_event(), evr = next_event();
+                if (!evp || !evr) return fail(STMMQR_ERR_DEVICE, "hipEventCreate failed");
+                HIPCHK(hipEventRecord(evp, st));
+                if (prev_rest) HIPCHK(hipStreamWaitEvent(st, prev_rest, 0));      // same columns: keep the order
+                LCHK(stm_launch_update(c, big, L.nbig_at[p], (int)p, 0, std::min(1, L.maxcb_at[p]), st));
+                if (L.maxcb_at[p] > 1) {
+                    HIPCHK(hipStreamWaitEvent(s2, evp, 0));
+                    LCHK(stm_launch_update(c, big, L.nbig_at[p], (int)p, 1, L.maxcb_at[p] - 1, s2));
+                    HIPCHK(hipEventRecord(evr, s2));
+                    prev_rest = evr;
+                    nlaunch++;
+                }
+                nlaunch += 2;
+            }
+            if (prev_rest) HIPCHK(hipStreamWaitEvent(st, prev_rest, 0));
         }
         if (L.n_big > 0) {
             e = timed(t_cpk, [&]() -> int {
@@ -565,7 +607,8 @@ stmmqr_plan *stmmqr_plan_create(const stmmqr_symbolic_view *sym, int device, int
     }
     if (!st) {
         (void)hipGetDevice(&P->device);
-        if (hipStreamCreateWithFlags(&P->stream, hipStreamNonBlocking) != hipSuccess)
+        if (hipStreamCreateWithFlags(&P->stream, hipStreamNonBlocking) != hipSuccess ||
+            hipStreamCreateWithFlags(&P->stream2, hipStreamNonBlocking) != hipSuccess)
             st = fail(STMMQR_ERR_DEVICE, "hipStreamCreate failed");
         for (auto &e : P->ev)
             if (!st && hipEventCreate(&e) != hipSuccess) st = fail(STMMQR_ERR_DEVICE, "hipEventCreate failed");
@@ -646,6 +689,13 @@ int stmmqr_factorize_device(stmmqr_plan *plan, const stm_long *Ap, const stm_lon
     }
     bytes_asm += 8.0 * (double)P.anz;
     P.stats.flops_update = fl_upd;
+    if (getenv("STMMQR_DBG") && (atoi(getenv("STMMQR_DBG")) & 16)) {
+        unsigned long long hb[8];
+        HIPCHK(hipMemcpy(hb, P.d_dbg.p, sizeof hb, hipMemcpyDeviceToHost));
+        fprintf(stderr, "[panel cycles, summed over workgroups] stage-in %llu  columns %llu  write-back %llu  apply %llu  gram %llu\n",
+                hb[0], hb[1], hb[2], hb[3], hb[4]);
+        HIPCHK(hipMemset(P.d_dbg.p, 0, sizeof hb));
+    }
     P.rank = rank;
     P.stats.flops = flops;
     P.stats.bytes_assemble = bytes_asm;

@@ -28,6 +28,9 @@ struct DevCtx {
     long long *Rboff;          // [nf] offset of each packed R+H block
     double tol;
     int ntol;
+    unsigned long long *dbgbuf; // [8] phase cycle sums of the panel kernel (STMMQR_DBG bit 4), else unused
+    int dbg;                   // timing ablations only (bit0: no in-panel apply, bit1: no T, bit2: no dlarf in sub-panel,
+                               //  bit3: LDS sub-panel path for every tall panel)
 };
 
 int stm_configure_kernels(void);
@@ -37,7 +40,7 @@ int stm_launch_setup(const DevCtx &c, const int *flist, int nfr, hipStream_t st)
 int stm_launch_assemble(const DevCtx &c, const int *flist, const int *nparts, int nfr, int maxparts, hipStream_t st);
 int stm_launch_front_wg(const DevCtx &c, const int *flist, int nfr, int lds_doubles, hipStream_t st);
 int stm_launch_panel(const DevCtx &c, const int *flist, int nfr, int p, int lds_doubles, hipStream_t st);
-int stm_launch_update(const DevCtx &c, const int *flist, int nfr, int p, int maxcb, hipStream_t st);
+int stm_launch_update(const DevCtx &c, const int *flist, int nfr, int p, int cb0, int ncb, hipStream_t st);
 int stm_launch_larft(const DevCtx &c, int f, hipStream_t st);
 int stm_launch_cpack(const DevCtx &c, const int *flist, const int *nparts, int nfr, int maxparts, hipStream_t st);
 int stm_launch_rh_count(const DevCtx &c, const int *flist, int nfr, hipStream_t st);

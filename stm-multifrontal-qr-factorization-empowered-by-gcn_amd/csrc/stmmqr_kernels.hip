@@ -24,6 +24,22 @@
 
 typedef double d4 __attribute__((ext_vector_type(4)));
 
+// small LDS working set of the panel routines, declared once per kernel and shared by every code path
+struct PanelShared {
+    double red[16];
+    double nextss;             // |x|^2 of the next column, produced by the wave that just updated it
+    int nextss_col;            // ... valid for this panel column (-1: none)
+    int stair[STM_NB];
+    int diag[STM_NB];
+    double tau[STM_NB];
+    double G[STM_NB][STM_NB + 1];
+    double T[STM_NB][STM_NB + 1];
+    double part[8 * 32];
+    double top[2][8];
+    double Ts[8][9];
+    double gp[32];
+};
+
 #define NT 256
 #define NW (NT / 64)
 #define BN 32                 // trailing-update column block
@@ -34,11 +50,31 @@ typedef double d4 __attribute__((ext_vector_type(4)));
 // ------------------------------------------------------------------------------------------------
 // small helpers
 // ------------------------------------------------------------------------------------------------
+// one DPP step of an fp64 butterfly: v + (v moved by the DPP control), both 32-bit halves moved separately
+template <int CTRL>
+__device__ __forceinline__ double dpp_add(double v)
+{
+    const int lo = __double2loint(v), hi = __double2hiint(v);
+    const int lo2 = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xf, 0xf, true);
+    const int hi2 = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xf, 0xf, true);
+    return v + __hiloint2double(hi2, lo2);
+}
+
+// sum over the 64 lanes of a wave, result in every lane.  Four DPP steps (quad_perm [1,0,3,2], [2,3,0,1],
+// row_half_mirror, row_mirror) give every lane the total of its row of 16; the four row totals are combined
+// through v_readlane -- no LDS crossbar traffic (ds_bpermute), which dominated the shuffle version.
 __device__ __forceinline__ double wave_sum(double v)
 {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
+    v = dpp_add<0xB1>(v);
+    v = dpp_add<0x4E>(v);
+    v = dpp_add<0x141>(v);
+    v = dpp_add<0x140>(v);
+    const int lo = __double2loint(v), hi = __double2hiint(v);
+    double r = __hiloint2double(__builtin_amdgcn_readlane(hi, 0), __builtin_amdgcn_readlane(lo, 0));
+    r += __hiloint2double(__builtin_amdgcn_readlane(hi, 16), __builtin_amdgcn_readlane(lo, 16));
+    r += __hiloint2double(__builtin_amdgcn_readlane(hi, 32), __builtin_amdgcn_readlane(lo, 32));
+    r += __hiloint2double(__builtin_amdgcn_readlane(hi, 48), __builtin_amdgcn_readlane(lo, 48));
+    return r;
 }
 
 // sum over the whole workgroup of NTH threads; every thread gets the result.  s_red: NTH/64 doubles of LDS.
@@ -151,7 +187,7 @@ __global__ __launch_bounds__(NT) void k_setup(DevCtx c, const int *__restrict__ 
     if (tid == 0) {
         FrontNum *nm = &c.fnum[f];
         nm->fm = fm; nm->g = 0; nm->rank = min(fm, s.fp); nm->done = 0;
-        nm->pg1 = 0; nm->pt = 0; nm->pk1 = 0; nm->pnb = 0; nm->pc0 = 0; nm->cm = 0; nm->rsize = 0; nm->flops = 0; nm->flops_upd = 0;
+        nm->pd[0].pnb = 0; nm->pd[1].pnb = 0; nm->cm = 0; nm->rsize = 0; nm->flops = 0; nm->flops_upd = 0;
     }
 }
 
@@ -351,17 +387,25 @@ __device__ void dev_gram_T(const double *Vg, long long ld, int r0, int r1, int n
     const double *V0 = Vg + (long long)l15 * ld, *V1 = Vg + (long long)(16 + l15) * ld;
     d4 g00 = {0, 0, 0, 0}, g01 = {0, 0, 0, 0}, g11 = {0, 0, 0, 0};
     const int nk = (r1 - r0 + 3) / 4;
-    for (int kk = wid; kk < nk; kk += NWV) {
-        const int i = r0 + 4 * kk + l4;
-        double a0 = 0, a1 = 0;
-        if (i < r1) {
-            if (i >= d0) a0 = (i == d0) ? 1.0 : V0[i];
-            if (two && i >= d1) a1 = (i == d1) ? 1.0 : V1[i];
+    // four row groups per trip: the 8 loads are issued before the first MFMA needs one (latency-bound otherwise)
+    for (int kk = wid; kk < nk; kk += 4 * NWV) {
+        double a0[4], a1[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const int i = r0 + 4 * (kk + u * NWV) + l4;
+            a0[u] = 0; a1[u] = 0;
+            if (kk + u * NWV < nk && i < r1) {
+                if (i >= d0) a0[u] = (i == d0) ? 1.0 : V0[i];
+                if (two && i >= d1) a1[u] = (i == d1) ? 1.0 : V1[i];
+            }
         }
-        g00 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, a0, g00, 0, 0, 0);
-        if (two) {
-            g01 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, a1, g01, 0, 0, 0);
-            g11 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, a1, g11, 0, 0, 0);
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            g00 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[u], a0[u], g00, 0, 0, 0);
+            if (two) {
+                g01 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[u], a1[u], g01, 0, 0, 0);
+                g11 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1[u], a1[u], g11, 0, 0, 0);
+            }
         }
     }
     __syncthreads();                                    // scratch is free
@@ -385,14 +429,20 @@ __device__ void dev_gram_T(const double *Vg, long long ld, int r0, int r1, int n
     }
     __syncthreads();
     if (wid == 0 && lane < STM_NB) {
-        const int a = lane;                             // lane a owns row a of T
-        for (int b = 0; b < nc; b++) {
+        // lane a owns row a of T and keeps it in registers: T(a,b) = -tau_b sum_{l<b} T(a,l) G(l,b); T(a,l) = 0 for
+        // l < a, so no per-lane bounds are needed and G(l,b) is a broadcast LDS read
+        const int a = lane;
+        double trow[STM_NB];
+#pragma unroll
+        for (int b = 0; b < STM_NB; b++) {
             double v = 0;
-            const double tb = tau[b];
-            if (a < b && tb != 0.0) {
-                for (int l = a; l < b; l++) v += s_T[a][l] * s_G[l][b];
-                v *= -tb;
-            } else if (a == b) v = tb;
+            if (b < nc) {
+                const double tb = tau[b];
+#pragma unroll
+                for (int l = 0; l < b; l++) v += trow[l] * s_G[l][b];
+                v = (a < b && tb != 0.0) ? -tb * v : ((a == b) ? tb : 0.0);
+            }
+            trow[b] = v;
             s_T[a][b] = v;
         }
     }
@@ -413,7 +463,7 @@ __device__ void dev_gram_T(const double *Vg, long long ld, int r0, int r1, int n
 //   Vl[(i - gs) + j*pst] = F(i, k1 + j0 + j) for the sub-panel columns j < sw.
 // ------------------------------------------------------------------------------------------------
 template <int NTH>
-__device__ void dev_apply_subpanel(const double *Vl, long long pst, int gs, int r1, int sw, const int *diag,
+__device__ __forceinline__ void dev_apply_subpanel(const double *Vl, long long pst, int gs, int r1, int sw, const int *diag,
                                    const double *tau, double *Fc /* = &F(0, first remaining column) */, long long ld,
                                    int ncols)
 {
@@ -465,6 +515,31 @@ __device__ void dev_apply_subpanel(const double *Vl, long long pst, int gs, int 
 }
 
 // ------------------------------------------------------------------------------------------------
+// workgroup-wide sum of K values per thread; every thread gets all K sums.  s_part: (NTH/64)*K doubles.
+// ------------------------------------------------------------------------------------------------
+template <int NTH, int K>
+__device__ __forceinline__ void block_reduce_vec(double (&x)[K], double *s_part)
+{
+    constexpr int NWV = NTH / 64;
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+#pragma unroll
+    for (int i = 0; i < K; i++) x[i] = wave_sum(x[i]);
+    __syncthreads();
+    if (lane == 0) {
+#pragma unroll
+        for (int i = 0; i < K; i++) s_part[wid * K + i] = x[i];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < K; i++) {
+        double r = 0;
+#pragma unroll
+        for (int w = 0; w < NWV; w++) r += s_part[w * K + i];
+        x[i] = r;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // qr_front, one panel of <= STM_NB columns (reference: the column loop :1434-1609 with the panel policy
 // fixed to k1 = p*NB, which changes rounding only).  Executed by one whole workgroup.
 //
@@ -478,15 +553,16 @@ __device__ void dev_apply_subpanel(const double *Vl, long long pst, int gs, int 
 // block-reflector description in FrontNum (pg1, pt, pk1, pnb, pc0, pdiag).
 // ------------------------------------------------------------------------------------------------
 template <int NTH>
-__device__ void dev_panel(const FrontSym &s, FrontNum *num, double *F, int *St, double *Tau, char *Rdead,
-                          int p, double tol, int ntol_global, double *Tout, double *lds, int lds_doubles)
+__device__ __forceinline__ void dev_panel(PanelShared &ps, const FrontSym &s, FrontNum *num, double *F, int *St, double *Tau, char *Rdead,
+                          int p, double tol, int ntol_global, double *Tout, double *lds, int lds_doubles, int dbg = 0,
+                          unsigned long long *dbgbuf = nullptr)
 {
     constexpr int NWV = NTH / 64;
-    __shared__ double s_red[NWV];
-    __shared__ int s_diag[STM_NB];
-    __shared__ double s_tau[STM_NB];
-    __shared__ double s_G[STM_NB][STM_NB + 1];
-    __shared__ double s_T[STM_NB][STM_NB + 1];
+    double *s_red = ps.red;
+    int *s_diag = ps.diag;
+    double *s_tau = ps.tau;
+    double (*s_G)[STM_NB + 1] = ps.G;
+    double (*s_T)[STM_NB + 1] = ps.T;
 
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int m = num->fm, n = s.fn, npiv = s.fp;
@@ -498,12 +574,15 @@ __device__ void dev_panel(const FrontSym &s, FrontNum *num, double *F, int *St, 
     int g = num->g, rank = num->rank;
     __syncthreads();                                   // everyone has read FrontNum before anyone writes it
     if (was_done) {
-        if (tid == 0) num->pnb = 0;
+        if (tid == 0) num->pd[p & 1].pnb = 0;
         return;
     }
     const int ntol = min(ntol_global - s.col1, npiv);
     const int g1 = g;
-    const int tmax = min(m, max(St[k2 - 1], g1 + nbp));
+    if (tid == 0) ps.nextss_col = -1;
+    if (tid < nbp) ps.stair[tid] = St[k1 + tid];       // the panel's staircase, once (a global load per column
+    __syncthreads();                                   //  step would sit on the critical path)
+    const int tmax = min(m, max(ps.stair[nbp - 1], g1 + nbp));
     const int mp = tmax - g1;
     double flops = 0;
     int done = 0, tlast = g1;
@@ -513,7 +592,14 @@ __device__ void dev_panel(const FrontSym &s, FrontNum *num, double *F, int *St, 
     if (mp > 0) SW = min(nbp, lds_doubles / (((mp + 63) & ~63) | 1));   // columns padded to whole 64-row slots
     const bool in_place = (SW == 0);
     if (in_place) SW = nbp;
+    // tall sub-panels: all waves split the ROWS of every column step and one workgroup reduction delivers the
+    // column norm and all v'c dot products of the rest of the sub-panel (<= 7) at once
+    const bool tall = !in_place && mp > 768;
+    if (tall) SW = min(SW, 8);
 
+    unsigned long long tph[6] = {0, 0, 0, 0, 0, 0}, tc0 = 0;
+#define STAMP(idx) do { if (dbg & 16) { __syncthreads(); const unsigned long long t_ = clock64(); tph[idx] += t_ - tc0; tc0 = t_; } } while (0)
+    if (dbg & 16) tc0 = clock64();
     for (int j0 = 0; j0 < nbp && !done; j0 += SW) {
         const int sw = min(SW, nbp - j0);
         const int gs = g;                               // first active row of this sub-panel
@@ -534,6 +620,7 @@ __device__ void dev_panel(const FrontSym &s, FrontNum *num, double *F, int *St, 
             Pb = F + k1 * ld;
         }
         __syncthreads();
+        STAMP(0);
         int nlive = 0;
         for (int j = j0; j < j0 + sw; j++) {
             const int k = k1 + j;
@@ -548,18 +635,40 @@ __device__ void dev_panel(const FrontSym &s, FrontNum *num, double *F, int *St, 
                 done = 1;
                 break;
             }
-            const int t = max(g + 1, St[k]);
+            const int t = max(g + 1, ps.stair[j]);
             double *col = Pb + (g - roff) + (j - coff) * pst;   // col[0] = F(g,k)
             const int len = t - g;                      // >= 1
             // ---- dlarfg ----
             const double alpha = col[0];                // read before the barriers below: thread 0 overwrites it
-            double ss = 0;
-            for (int i = 1 + tid; i < len; i += NTH) { const double x = col[i]; ss += x * x; }
-            ss = block_sum<NTH>(ss, s_red);
+            const int nrest = tall ? (j0 + sw - 1 - j) : 0;     // remaining sub-panel columns (tall scheme, <= 7)
+            double part[8];
+            double top[8];
+#pragma unroll
+            for (int x = 0; x < 8; x++) { part[x] = 0; top[x] = 0; }
+            if (tall) {
+#pragma unroll
+                for (int x = 1; x < 8; x++)
+                    if (x <= nrest) top[x] = col[x * pst];      // F(g, k+x)
+                for (int i = 1 + tid; i < len; i += NTH) {
+                    const double xv = col[i];
+                    part[0] += xv * xv;
+#pragma unroll
+                    for (int x = 1; x < 8; x++)
+                        if (x <= nrest) part[x] += xv * col[i + x * pst];
+                }
+                block_reduce_vec<NTH, 8>(part, ps.part);
+            } else if (ps.nextss_col == j) {
+                part[0] = ps.nextss;                    // computed by the dlarf sweep of the previous column
+            } else {
+                double ss0 = 0;
+                for (int i = 1 + tid; i < len; i += NTH) { const double xv = col[i]; ss0 += xv * xv; }
+                part[0] = block_sum<NTH>(ss0, s_red);
+            }
+            const double ss = part[0];
             double tau = 0, beta = alpha, scal = 0;
             if (len > 1 && ss != 0.0) {
                 const double xnorm = sqrt(ss);
-                beta = -copysign(hypot(alpha, xnorm), alpha);
+                beta = -copysign(sqrt(alpha * alpha + ss), alpha);   // |x|^2 is unscaled anyway: no hypot
                 tau = (beta - alpha) / beta;
                 scal = 1.0 / (alpha - beta);
             }
@@ -573,20 +682,57 @@ __device__ void dev_panel(const FrontSym &s, FrontNum *num, double *F, int *St, 
                 continue;
             }
             if (tid == 0) { St[k] = t; Tau[k] = tau; col[0] = beta; s_diag[j] = g; s_tau[j] = tau; }
-            if (tau != 0.0)
-                for (int i = 1 + tid; i < len; i += NTH) col[i] *= scal;
             flops += (double)len * (3.0 + 4.0 * (double)(n - k - 1));
-            __syncthreads();
-            // ---- dlarf on the rest of the SUB-panel: one wave per column, shuffles for v'c ----
-            if (tau != 0.0) {
-                nlive++;
-                for (int jj = j + 1 + wid; jj < j0 + sw; jj += NWV) {
-                    double *cc = Pb + (g - roff) + (jj - coff) * pst;
-                    double w = (lane == 0) ? cc[0] : 0.0;
-                    for (int i = 1 + lane; i < len; i += 64) w += col[i] * cc[i];
-                    w = wave_sum(w) * tau;
-                    if (lane == 0) cc[0] -= w;
-                    for (int i = 1 + lane; i < len; i += 64) cc[i] -= w * col[i];
+            if (tall) {
+                // ---- scale x and apply H_k to the rest of the sub-panel in the same sweep over the rows ----
+                if (tau != 0.0) {
+                    nlive++;
+                    double w[8];
+#pragma unroll
+                    for (int x = 1; x < 8; x++) w[x] = tau * (top[x] + scal * part[x]);
+                    for (int i = 1 + tid; i < len; i += NTH) {
+                        const double v = col[i] * scal;
+                        col[i] = v;
+#pragma unroll
+                        for (int x = 1; x < 8; x++)
+                            if (x <= nrest) col[i + x * pst] -= w[x] * v;
+                    }
+                    if (tid == 0) {
+#pragma unroll
+                        for (int x = 1; x < 8; x++)
+                            if (x <= nrest) col[x * pst] -= w[x];
+                    }
+                }
+            } else {
+                if (tau != 0.0)
+                    for (int i = 1 + tid; i < len; i += NTH) col[i] *= scal;
+                __syncthreads();
+                // ---- dlarf on the rest of the SUB-panel: one wave per column, v'c by DPP reduction (A.3) ----
+                if (tau != 0.0) {
+                    nlive++;
+                    if (!(dbg & 4))
+                    for (int jj = j + 1 + wid; jj < j0 + sw; jj += NWV) {
+                        double *cc = Pb + (g - roff) + (jj - coff) * pst;
+                        double w = (lane == 0) ? cc[0] : 0.0;
+                        for (int i = 1 + lane; i < len; i += 64) w += col[i] * cc[i];
+                        w = wave_sum(w) * tau;
+                        if (lane == 0) cc[0] -= w;
+                        if (jj == j + 1) {
+                            // the next column: update it and accumulate its |x|^2 (rows below ITS diagonal g+1,
+                            // up to its own staircase) in the same sweep
+                            const int lenn = max(g + 2, ps.stair[jj]) - g;      // rows g .. g+lenn-1
+                            double sq = 0;
+                            for (int i = 1 + lane; i < max(len, lenn); i += 64) {
+                                double cv = cc[i];
+                                if (i < len) { cv -= w * col[i]; cc[i] = cv; }
+                                if (i >= 2 && i < lenn) sq += cv * cv;
+                            }
+                            sq = wave_sum(sq);
+                            if (lane == 0) { ps.nextss = sq; ps.nextss_col = jj; }
+                        } else {
+                            for (int i = 1 + lane; i < len; i += 64) cc[i] -= w * col[i];
+                        }
+                    }
                 }
             }
             tlast = t;
@@ -595,6 +741,7 @@ __device__ void dev_panel(const FrontSym &s, FrontNum *num, double *F, int *St, 
             __syncthreads();
         }
         __syncthreads();
+        STAMP(1);
         if (!in_place && ms > 0) {
             for (int j = wid; j < sw; j += NWV) {
                 double *dst = F + (k1 + j0 + j) * ld;
@@ -602,8 +749,9 @@ __device__ void dev_panel(const FrontSym &s, FrontNum *num, double *F, int *St, 
             }
         }
         __syncthreads();
+        STAMP(2);
         // ---- apply this sub-panel's reflectors to the remaining columns of the panel; V is still in LDS ----
-        if (!in_place && !done && j0 + sw < nbp && nlive > 0 && tlast > gs) {
+        if (!in_place && !done && j0 + sw < nbp && nlive > 0 && tlast > gs && !(dbg & 1)) {
             // turn the LDS image into the explicit unit-lower-trapezoidal V (R entries above the diagonals were
             // already written back): the apply loop then needs no masks
             for (int e = tid; e < sw * sw; e += NTH) {
@@ -621,12 +769,18 @@ __device__ void dev_panel(const FrontSym &s, FrontNum *num, double *F, int *St, 
             __syncthreads();
         }
     }
+    STAMP(3);
     // ---- T of the whole panel for the trailing update ----
-    dev_gram_T<NTH>(F + (long long)k1 * ld, ld, g1, tlast, nbp, s_diag, s_tau, s_G, s_T, Tout, lds);
-    if (tid < STM_NB) num->pdiag[tid] = (tid < nbp) ? s_diag[tid] : STM_BIGROW;
+    if (!(dbg & 2)) dev_gram_T<NTH>(F + (long long)k1 * ld, ld, g1, tlast, nbp, s_diag, s_tau, s_G, s_T, Tout, lds);
+    STAMP(4);
+    if ((dbg & 16) && tid == 0 && dbgbuf)
+        for (int e = 0; e < 5; e++) atomicAdd(&dbgbuf[e], tph[e]);
+#undef STAMP
+    PanelDesc *pd = &num->pd[p & 1];
+    if (tid < STM_NB) pd->pdiag[tid] = (tid < nbp) ? s_diag[tid] : STM_BIGROW;
     if (tid == 0) {
         num->g = g; num->rank = rank; num->done = done;
-        num->pg1 = g1; num->pt = tlast; num->pk1 = k1; num->pnb = nbp; num->pc0 = k2;
+        pd->pg1 = g1; pd->pt = tlast; pd->pk1 = k1; pd->pnb = nbp; pd->pc0 = k2;
         num->flops += flops;
         {
             int nl = 0;
@@ -678,17 +832,19 @@ __global__ __launch_bounds__(NT) void k_front_wg(DevCtx c, const int *__restrict
 {
     extern __shared__ double dyn_lds[];
     __shared__ double s_Tw[STM_NB * STM_NB];
+    __shared__ PanelShared ps;
     const int f = flist[blockIdx.x];
     const FrontSym s = c.fs[f];
     FrontNum *num = &c.fnum[f];
     double *F = c.Farena + s.foff;
     for (int p = 0; p < s.npanels; p++) {
-        dev_panel<NT>(s, num, F, c.Stair + s.rp, c.Tau + s.rp, c.Rdead + s.col1, p, c.tol, c.ntol, s_Tw, dyn_lds,
+        dev_panel<NT>(ps, s, num, F, c.Stair + s.rp, c.Tau + s.rp, c.Rdead + s.col1, p, c.tol, c.ntol, s_Tw, dyn_lds,
                   lds_doubles);
         const int k2 = min(s.fn, (p + 1) * STM_NB);
         const int ncb = (s.fn - k2 + BN - 1) / BN;
+        const PanelDesc *pd = &num->pd[p & 1];
         for (int cb = 0; cb < ncb; cb++)
-            dev_update_block(F, s.ld, num->pg1, num->pt - num->pg1, num->pk1, num->pnb, num->pdiag, s_Tw, k2 + cb * BN,
+            dev_update_block(F, s.ld, pd->pg1, pd->pt - pd->pg1, pd->pk1, pd->pnb, pd->pdiag, s_Tw, k2 + cb * BN,
                              min(BN, s.fn - (k2 + cb * BN)), dyn_lds);
         __syncthreads();
     }
@@ -702,36 +858,41 @@ __global__ __launch_bounds__(NT) void k_front_wg(DevCtx c, const int *__restrict
 __global__ __launch_bounds__(NTP) void k_panel(DevCtx c, const int *__restrict__ flist, int p, int lds_doubles)
 {
     extern __shared__ double dyn_lds[];
+    __shared__ PanelShared ps;
     const int f = flist[blockIdx.x];
     const FrontSym s = c.fs[f];
     if (p >= s.npanels) return;
-    dev_panel<NTP>(s, &c.fnum[f], c.Farena + s.foff, c.Stair + s.rp, c.Tau + s.rp, c.Rdead + s.col1, p, c.tol, c.ntol,
-              c.Tws + (long long)c.tslot[f] * STM_NB * STM_NB, dyn_lds, lds_doubles);
+    FrontNum *num = &c.fnum[f];
+    double *F = c.Farena + s.foff;
+    double *T = c.Tws + (long long)(2 * c.tslot[f] + (p & 1)) * STM_NB * STM_NB;
+    dev_panel<NTP>(ps, s, num, F, c.Stair + s.rp, c.Tau + s.rp, c.Rdead + s.col1, p, c.tol, c.ntol, T, dyn_lds,
+                       lds_doubles, c.dbg, c.dbgbuf);
 }
 
-__global__ __launch_bounds__(NT) void k_update(DevCtx c, const int *__restrict__ flist, int p)
+__global__ __launch_bounds__(NT) void k_update(DevCtx c, const int *__restrict__ flist, int p, int cb0)
 {
     extern __shared__ double dyn_lds[];
     const int f = flist[blockIdx.y];
     const FrontSym s = c.fs[f];
     if (p >= s.npanels) return;
-    const FrontNum *num = &c.fnum[f];
-    const int c0 = num->pc0 + blockIdx.x * BN;
+    const PanelDesc *pd = &c.fnum[f].pd[p & 1];
+    const int c0 = pd->pc0 + (cb0 + (int)blockIdx.x) * BN;
     if (c0 >= s.fn) return;
-    dev_update_block(c.Farena + s.foff, s.ld, num->pg1, num->pt - num->pg1, num->pk1, num->pnb, num->pdiag,
-                     c.Tws + (long long)c.tslot[f] * STM_NB * STM_NB, c0, min(BN, s.fn - c0), dyn_lds);
+    dev_update_block(c.Farena + s.foff, s.ld, pd->pg1, pd->pt - pd->pg1, pd->pk1, pd->pnb, pd->pdiag,
+                     c.Tws + (long long)(2 * c.tslot[f] + (p & 1)) * STM_NB * STM_NB, c0, min(BN, s.fn - c0), dyn_lds);
 }
 
 // standalone T factor of the pending block reflector described by FrontNum (qr_larftb seam)
 __global__ __launch_bounds__(NT) void k_larft(DevCtx c, int f)
 {
     extern __shared__ double dyn_lds[];
-    __shared__ int s_diag[STM_NB];
-    __shared__ double s_tau[STM_NB];
-    __shared__ double s_G[STM_NB][STM_NB + 1];
-    __shared__ double s_T[STM_NB][STM_NB + 1];
+    __shared__ PanelShared ps;
+    int *s_diag = ps.diag;
+    double *s_tau = ps.tau;
+    double (*s_G)[STM_NB + 1] = ps.G;
+    double (*s_T)[STM_NB + 1] = ps.T;
     const FrontSym s = c.fs[f];
-    const FrontNum *num = &c.fnum[f];
+    const PanelDesc *num = &c.fnum[f].pd[0];
     const int tid = threadIdx.x;
     if (tid < STM_NB) {
         s_diag[tid] = num->pdiag[tid];
@@ -739,7 +900,7 @@ __global__ __launch_bounds__(NT) void k_larft(DevCtx c, int f)
     }
     __syncthreads();
     dev_gram_T<NT>(c.Farena + s.foff + (long long)num->pk1 * s.ld, s.ld, num->pg1, num->pt, num->pnb, s_diag, s_tau, s_G,
-               s_T, c.Tws + (long long)c.tslot[f] * STM_NB * STM_NB, dyn_lds);
+               s_T, c.Tws + (long long)(2 * c.tslot[f]) * STM_NB * STM_NB, dyn_lds);
 }
 
 __global__ __launch_bounds__(NT) void k_cpack(DevCtx c, const int *__restrict__ flist,
@@ -905,10 +1066,10 @@ int stm_launch_panel(const DevCtx &c, const int *flist, int nfr, int p, int lds_
     hipLaunchKernelGGL(k_panel, dim3(nfr), dim3(NTP), bytes, st, c, flist, p, (int)(bytes / sizeof(double)));
     return (int)hipGetLastError();
 }
-int stm_launch_update(const DevCtx &c, const int *flist, int nfr, int p, int maxcb, hipStream_t st)
+int stm_launch_update(const DevCtx &c, const int *flist, int nfr, int p, int cb0, int ncb, hipStream_t st)
 {
-    if (nfr <= 0 || maxcb <= 0) return 0;
-    hipLaunchKernelGGL(k_update, dim3(maxcb, nfr), dim3(NT), (size_t)stm_update_lds_bytes(), st, c, flist, p);
+    if (nfr <= 0 || ncb <= 0) return 0;
+    hipLaunchKernelGGL(k_update, dim3(ncb, nfr), dim3(NT), (size_t)stm_update_lds_bytes(), st, c, flist, p, cb0);
     return (int)hipGetLastError();
 }
 int stm_launch_larft(const DevCtx &c, int f, hipStream_t st)

@@ -71,7 +71,7 @@ struct OneFront {
         const long cn = n - s.fp, cm = std::min(m, cn);
         std::vector<int> zero1(1, 0);
         bool ok = d_F.up(Fd) && d_St.up(st32) && d_fs.up(&s, 1) && d_nm.up(&nm, 1) &&
-                  d_C.alloc((size_t)std::max(1L, cm * (cm + 1) / 2 + cm * (cn - cm))) && d_T.alloc(STM_NB * STM_NB) &&
+                  d_C.alloc((size_t)std::max(1L, cm * (cm + 1) / 2 + cm * (cn - cm))) && d_T.alloc(2 * STM_NB * STM_NB) &&
                   d_Tau.alloc((size_t)std::max(1L, n)) && d_Rdead.alloc((size_t)std::max(1L, n)) && d_tslot.up(zero1) &&
                   d_flist.up(zero1) && d_Rhoff.alloc((size_t)std::max(1L, n)) && d_Rboff.alloc(1) &&
                   d_RH.alloc((size_t)std::max(1L, m * n));
@@ -124,7 +124,7 @@ stm_long stmmqr_front(stm_long m, stm_long n, stm_long npiv, double tol, stm_lon
         for (int p = 0; p < X.s.npanels && !e; p++) {
             e = stm_launch_panel(X.c, X.d_flist.p, 1, p, lds_for(m), nullptr);
             const int k2 = (int)std::min<long>(n, (long)(p + 1) * STM_NB);
-            if (!e) e = stm_launch_update(X.c, X.d_flist.p, 1, p, (int)((n - k2 + 31) / 32), nullptr);
+            if (!e) e = stm_launch_update(X.c, X.d_flist.p, 1, p, 0, (int)((n - k2 + 31) / 32), nullptr);
         }
     }
     if (e || hipDeviceSynchronize() != hipSuccess) return -1;
@@ -173,13 +173,14 @@ int stmmqr_larftb_qtx(stm_long m, stm_long n, stm_long k, stm_long ldc, stm_long
     // H_1..H_k applied block by block, first block first (Q' C = H_k ... H_1 C)
     for (stm_long k1 = 0; k1 < k; k1 += STM_NB) {
         const int nb = (int)std::min<stm_long>(STM_NB, k - k1);
-        X.nm.pg1 = (int)std::min(k1, m); X.nm.pt = (int)m; X.nm.pk1 = (int)k1; X.nm.pnb = nb; X.nm.pc0 = (int)k;
+        PanelDesc &pd = X.nm.pd[0];
+        pd.pg1 = (int)std::min(k1, m); pd.pt = (int)m; pd.pk1 = (int)k1; pd.pnb = nb; pd.pc0 = (int)k;
         for (int j = 0; j < STM_NB; j++)
-            X.nm.pdiag[j] = (j < nb && k1 + j < m && tau[k1 + j] != 0.0) ? (int)(k1 + j) : STM_BIGROW;
+            pd.pdiag[j] = (j < nb && k1 + j < m && tau[k1 + j] != 0.0) ? (int)(k1 + j) : STM_BIGROW;
         // a reflector with tau = 0 is the identity; one whose diagonal falls below m does not exist
         if (!X.push_num()) return STMMQR_ERR_DEVICE;
         if (stm_launch_larft(X.c, 0, nullptr)) return STMMQR_ERR_DEVICE;
-        if (stm_launch_update(X.c, X.d_flist.p, 1, 0, (int)((n + 31) / 32), nullptr)) return STMMQR_ERR_DEVICE;
+        if (stm_launch_update(X.c, X.d_flist.p, 1, 0, 0, (int)((n + 31) / 32), nullptr)) return STMMQR_ERR_DEVICE;
     }
     if (hipDeviceSynchronize() != hipSuccess) return STMMQR_ERR_DEVICE;
     if (!X.d_F.down(Fd.data(), Fd.size())) return STMMQR_ERR_DEVICE;
