@@ -166,6 +166,24 @@ int stmmqr_plan_set_pattern(stmmqr_plan *plan, const stm_long *Ap, const stm_lon
 int stmmqr_factorize_device(stmmqr_plan *plan, const stm_long *Ap, const stm_long *Ai, const double *Ax,
                             int ax_on_device, double tol, stm_long ntol, stmmqr_stats *stats);
 
+/* The same factorization in phases (multi-GPU): begin (upload values) -> factorize_group(g) for the groups of
+ * stmmqr_plan_set_groups in increasing order, with stmmqr_plan_import_front calls in between -> finish (pack). */
+int stmmqr_factorize_begin(stmmqr_plan *plan, const stm_long *Ap, const stm_long *Ai, const double *Ax,
+                           int ax_on_device, double tol, stm_long ntol);
+int stmmqr_factorize_group(stmmqr_plan *plan, int group, int detail);
+int stmmqr_factorize_finish(stmmqr_plan *plan, stmmqr_stats *stats);
+
+/* Subtree sharding.  group[f] >= 0: front f is factorized on this device in phase group[f];
+ * -1: on another device (its packed contribution block, row ids, fm/rank/cm arrive by import_front before the
+ * phase of its parent).  A child must never be in a later phase than its parent. */
+int stmmqr_plan_set_groups(stmmqr_plan *plan, const int *group /* [nf] */);
+/* info[0..5] = fm, rank, cm, csize, fn, fp of a factorized (or imported) front */
+int stmmqr_plan_front_info(stmmqr_plan *plan, stm_long f, stm_long *info);
+/* packed contribution block (csize doubles, qr_cpack layout) + cm row ids of front f; C may be a device pointer */
+int stmmqr_plan_export_front(stmmqr_plan *plan, stm_long f, double *C, stm_long *rows, int c_on_device);
+int stmmqr_plan_import_front(stmmqr_plan *plan, stm_long f, stm_long fm, stm_long rank, stm_long cm, const double *C,
+                             const stm_long *rows, int c_on_device);
+
 /* sizes needed by the caller to allocate the outputs of stmmqr_plan_download */
 int stmmqr_plan_result_sizes(const stmmqr_plan *plan, stm_long *rh_total, stm_long *rank);
 

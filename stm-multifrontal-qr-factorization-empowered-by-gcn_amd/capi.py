@@ -86,6 +86,13 @@ lib.qr_assemble.restype = None
 lib.qr_assemble.argtypes = [C.c_long, C.c_long, C.c_int] + [c_long_p] * 8 + [c_double_p, c_long_p, c_long_p,
                                                                              C.POINTER(c_double_p), c_long_p, c_long_p,
                                                                              c_long_p, c_long_p, c_double_p, c_long_p]
+lib.stmmqr_factorize_begin.argtypes = [C.c_void_p, c_long_p, c_long_p, C.c_void_p, C.c_int, C.c_double, C.c_long]
+lib.stmmqr_factorize_group.argtypes = [C.c_void_p, C.c_int, C.c_int]
+lib.stmmqr_factorize_finish.argtypes = [C.c_void_p, C.POINTER(Stats)]
+lib.stmmqr_plan_set_groups.argtypes = [C.c_void_p, C.POINTER(C.c_int)]
+lib.stmmqr_plan_front_info.argtypes = [C.c_void_p, C.c_long, c_long_p]
+lib.stmmqr_plan_export_front.argtypes = [C.c_void_p, C.c_long, C.c_void_p, c_long_p, C.c_int]
+lib.stmmqr_plan_import_front.argtypes = [C.c_void_p, C.c_long, C.c_long, C.c_long, C.c_long, C.c_void_p, c_long_p, C.c_int]
 lib.stmmqr_get_options.argtypes = [C.POINTER(Options)]
 lib.stmmqr_set_options.argtypes = [C.POINTER(Options)]
 
@@ -191,6 +198,48 @@ class HipQR:
                                              int(ntol), C.byref(st))
         _check(rc, "stmmqr_factorize_device")
         return st.as_dict()
+
+    # ---- phased interface / subtree sharding (include/stmmqr_hip.h, "Subtree sharding") ----
+    def set_groups(self, group):
+        g = np.ascontiguousarray(group, np.int32)
+        assert g.size == self.sym["nf"]
+        _check(lib.stmmqr_plan_set_groups(self._h, g.ctypes.data_as(C.POINTER(C.c_int))), "stmmqr_plan_set_groups")
+
+    def begin(self, Ax, tol, ntol, Ap=None, Ai=None, device_ptr=None):
+        if Ap is not None:
+            Ap = np.ascontiguousarray(Ap, I64); Ai = np.ascontiguousarray(Ai, I64)
+        if device_ptr is not None:
+            rc = lib.stmmqr_factorize_begin(self._h, _ip(Ap), _ip(Ai), C.c_void_p(device_ptr), 1, float(tol), int(ntol))
+        else:
+            Ax = np.ascontiguousarray(Ax, np.float64)
+            rc = lib.stmmqr_factorize_begin(self._h, _ip(Ap), _ip(Ai), Ax.ctypes.data_as(C.c_void_p), 0, float(tol), int(ntol))
+        _check(rc, "stmmqr_factorize_begin")
+
+    def run_group(self, g, detail=False):
+        _check(lib.stmmqr_factorize_group(self._h, int(g), int(detail)), "stmmqr_factorize_group")
+
+    def finish(self) -> dict:
+        st = Stats()
+        _check(lib.stmmqr_factorize_finish(self._h, C.byref(st)), "stmmqr_factorize_finish")
+        return st.as_dict()
+
+    def front_info(self, f) -> dict:
+        info = np.zeros(6, I64)
+        _check(lib.stmmqr_plan_front_info(self._h, int(f), _ip(info)), "stmmqr_plan_front_info")
+        return dict(zip(["fm", "rank", "cm", "csize", "fn", "fp"], (int(x) for x in info)))
+
+    def export_front(self, f):
+        """-> (info, packed C [csize], row ids [cm]) of a factorized front (host arrays)."""
+        info = self.front_info(f)
+        Cb = np.zeros(max(info["csize"], 1)); rows = np.zeros(max(info["cm"], 1), I64)
+        _check(lib.stmmqr_plan_export_front(self._h, int(f), Cb.ctypes.data_as(C.c_void_p), _ip(rows), 0),
+               "stmmqr_plan_export_front")
+        return info, Cb[:info["csize"]], rows[:info["cm"]]
+
+    def import_front(self, f, fm, rank, cm, Cb, rows):
+        Cb = np.ascontiguousarray(Cb, np.float64); rows = np.ascontiguousarray(rows, I64)
+        _check(lib.stmmqr_plan_import_front(self._h, int(f), int(fm), int(rank), int(cm), Cb.ctypes.data_as(C.c_void_p),
+                                            _ip(rows), 0), "stmmqr_plan_import_front")
 
     def download(self) -> QRNumeric:
         rh = C.c_long(0); rk = C.c_long(0)

@@ -114,7 +114,9 @@ struct stmmqr_plan {
     std::vector<long> Sp, Sj, Qfill, PLinv, Sleft, Child, Childp, Super, Rp, Rj, Post, Hip, Fm;
     bool has_qfill = false;
     std::vector<FrontSym> fs;
-    std::vector<Level> levels;
+    std::vector<std::vector<Level>> glevels;   // [group][level]
+    std::vector<int> group;                    // per front: phase on this device, -1 = elsewhere
+    int own_off = 0, n_own = 0;
     std::vector<int> lists;              // host copy of d_lists
     int post_off = 0, rh_parts_off = 0, rh_maxparts = 1;
     long long farena = 0, carena = 0;
@@ -132,7 +134,7 @@ struct stmmqr_plan {
     DevBuf<char> d_Rdead;
 
     // results of the last factorization
-    bool factored = false;
+    bool factored = false, begun = false, first_group = true;
     long long rh_total = 0;
     long rank = 0;
     std::vector<FrontNum> h_fnum;
@@ -182,6 +184,115 @@ int ensure_device(int device)
         configured = true;
     }
     return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// level schedule.  P.group[f] = g >= 0: front f is factorized here in phase g; -1: not on this device (its
+// contribution block is imported).  For every group the fronts are bucketed by tree level (leaves = 0, counted
+// inside the group), small ones first, large ones by decreasing panel count.  Everything is symbolic.
+// ------------------------------------------------------------------------------------------------
+void build_schedule(stmmqr_plan &P, std::vector<int> &tslot)
+{
+    const long nf = P.nf;
+    int ngroups = 1;
+    for (long f = 0; f < nf; f++) ngroups = std::max(ngroups, P.group[f] + 1);
+    auto is_big = [&](int f) {
+        const FrontSym &s = P.fs[f];
+        return s.fn >= g_opt.big_front_cols && s.fm_ub >= 64;
+    };
+    tslot.assign(std::max(1L, nf), 0);
+    P.glevels.assign(ngroups, std::vector<Level>());
+    P.lists.clear();
+    P.tslots = 1;
+    for (int grp = 0; grp < ngroups; grp++) {
+        std::vector<int> level(nf, -1);
+        int nlev = 0;
+        for (long kf = 0; kf < nf; kf++) {
+            const long f = P.Post[kf];
+            if (P.group[f] != grp) continue;
+            int lv = 0;
+            for (long q = P.Childp[f]; q < P.Childp[f + 1]; q++) lv = std::max(lv, level[P.Child[q]] + 1);
+            level[f] = lv;
+            nlev = std::max(nlev, lv + 1);
+        }
+        std::vector<std::vector<int>> byl(nlev);
+        for (long kf = 0; kf < nf; kf++)
+            if (P.group[P.Post[kf]] == grp) byl[level[P.Post[kf]]].push_back((int)P.Post[kf]);
+        std::vector<Level> &LV = P.glevels[grp];
+        LV.assign(nlev, Level());
+        for (int lv = 0; lv < nlev; lv++) {
+            Level &L = LV[lv];
+            std::vector<int> small, big;
+            for (int f : byl[lv]) (is_big(f) ? big : small).push_back(f);
+            std::stable_sort(big.begin(), big.end(), [&](int a, int b) { return P.fs[a].npanels > P.fs[b].npanels; });
+            L.all_off = (int)P.lists.size();
+            L.n_small = (int)small.size(); L.n_big = (int)big.size(); L.n_all = L.n_small + L.n_big;
+            P.lists.insert(P.lists.end(), small.begin(), small.end());
+            P.lists.insert(P.lists.end(), big.begin(), big.end());
+            L.asm_parts_off = (int)P.lists.size();
+            L.asm_maxparts = 1;
+            for (int i = 0; i < L.n_all; i++) {
+                const FrontSym &s = P.fs[P.lists[L.all_off + i]];
+                long work = (long)s.fm_ub * s.fn;
+                int parts = (int)std::min(128L, std::max(1L, (work + 16383) / 16384));
+                P.lists.push_back(parts);
+                L.asm_maxparts = std::max(L.asm_maxparts, parts);
+            }
+            L.cpk_parts_off = (int)P.lists.size();
+            L.cpk_maxparts = 1;
+            for (int i = 0; i < L.n_big; i++) {
+                const FrontSym &s = P.fs[big[i]];
+                long cn = s.fn - s.fp;
+                long work = cn * std::min((long)s.fm_ub, cn);
+                int parts = (int)std::min(64L, std::max(1L, (work + 16383) / 16384));
+                P.lists.push_back(parts);
+                L.cpk_maxparts = std::max(L.cpk_maxparts, parts);
+            }
+            int maxp = 0;
+            long maxfm_small = 0, maxfm_big = 0;
+            for (int f : small) maxfm_small = std::max(maxfm_small, (long)P.fs[f].fm_ub);
+            for (size_t i = 0; i < big.size(); i++) {
+                maxp = std::max(maxp, P.fs[big[i]].npanels);
+                maxfm_big = std::max(maxfm_big, (long)P.fs[big[i]].fm_ub);
+                tslot[big[i]] = (int)i;
+            }
+            P.tslots = std::max(P.tslots, (int)big.size());
+            L.lds_small = (int)std::min((long)LDS_CAP_SMALL, (maxfm_small | 1) * STM_NB);
+            L.lds_big = (int)std::min((long)LDS_CAP_DOUBLES, (maxfm_big | 1) * STM_NB);
+            L.nbig_at.assign(maxp, 0);
+            L.maxcb_at.assign(maxp, 0);
+            for (int p = 0; p < maxp; p++) {
+                int cnt = 0, mcb = 0;
+                for (int f : big) {
+                    const FrontSym &s = P.fs[f];
+                    if (s.npanels > p) {
+                        cnt++;
+                        const int k2 = std::min(s.fn, (p + 1) * STM_NB);
+                        mcb = std::max(mcb, (s.fn - k2 + 31) / 32);
+                    }
+                }
+                L.nbig_at[p] = cnt;
+                L.maxcb_at[p] = mcb;
+            }
+        }
+    }
+    // fronts factorized on this device, in Post order, + their R+H copy parts; then ALL fronts in Post order
+    P.own_off = (int)P.lists.size();
+    P.n_own = 0;
+    for (long kf = 0; kf < nf; kf++)
+        if (P.group[P.Post[kf]] >= 0) { P.lists.push_back((int)P.Post[kf]); P.n_own++; }
+    P.rh_parts_off = (int)P.lists.size();
+    P.rh_maxparts = 1;
+    for (long kf = 0; kf < nf; kf++) {
+        if (P.group[P.Post[kf]] < 0) continue;
+        const FrontSym &s = P.fs[P.Post[kf]];
+        int parts = std::min(64, std::max(1, s.fn / 16));
+        P.lists.push_back(parts);
+        P.rh_maxparts = std::max(P.rh_maxparts, parts);
+    }
+    P.post_off = (int)P.lists.size();
+    for (long kf = 0; kf < nf; kf++) P.lists.push_back((int)P.Post[kf]);
+    if (P.lists.empty()) P.lists.push_back(0);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -274,96 +385,10 @@ int build_plan(stmmqr_plan &P, const stmmqr_symbolic_view &v)
         P.bytes_assemble_idx += 4.0 * (double)v.anz;
     }
 
-    // ---- level schedule ---------------------------------------------------------------------------
-    std::vector<int> level(nf, 0);
-    int nlev = 0;
-    for (long kf = 0; kf < nf; kf++) {
-        const long f = P.Post[kf];
-        int lv = 0;
-        for (long q = P.Childp[f]; q < P.Childp[f + 1]; q++) lv = std::max(lv, level[P.Child[q]] + 1);
-        level[f] = lv;
-        nlev = std::max(nlev, lv + 1);
-    }
-    std::vector<std::vector<int>> byl(nlev);
-    for (long kf = 0; kf < nf; kf++) byl[level[P.Post[kf]]].push_back((int)P.Post[kf]);
-
-    auto is_big = [&](int f) {
-        const FrontSym &s = P.fs[f];
-        return s.fn >= g_opt.big_front_cols && s.fm_ub >= 64;
-    };
-    std::vector<int> tslot(std::max(1L, nf), 0);
-    P.levels.assign(nlev, Level());
-    P.lists.clear();
-    P.tslots = 1;
-    for (int lv = 0; lv < nlev; lv++) {
-        Level &L = P.levels[lv];
-        std::vector<int> small, big;
-        for (int f : byl[lv]) (is_big(f) ? big : small).push_back(f);
-        std::stable_sort(big.begin(), big.end(), [&](int a, int b) { return P.fs[a].npanels > P.fs[b].npanels; });
-        L.all_off = (int)P.lists.size();
-        L.n_small = (int)small.size(); L.n_big = (int)big.size(); L.n_all = L.n_small + L.n_big;
-        P.lists.insert(P.lists.end(), small.begin(), small.end());
-        P.lists.insert(P.lists.end(), big.begin(), big.end());
-        // assembly parts (all fronts, list order)
-        L.asm_parts_off = (int)P.lists.size();
-        L.asm_maxparts = 1;
-        for (int i = 0; i < L.n_all; i++) {
-            const FrontSym &s = P.fs[P.lists[L.all_off + i]];
-            long work = (long)s.fm_ub * s.fn;
-            int parts = (int)std::min(128L, std::max(1L, (work + 16383) / 16384));
-            P.lists.push_back(parts);
-            L.asm_maxparts = std::max(L.asm_maxparts, parts);
-        }
-        // C-pack parts (big fronts only; small ones pack inside k_front_wg)
-        L.cpk_parts_off = (int)P.lists.size();
-        L.cpk_maxparts = 1;
-        for (int i = 0; i < L.n_big; i++) {
-            const FrontSym &s = P.fs[big[i]];
-            long cn = s.fn - s.fp;
-            long work = cn * std::min((long)s.fm_ub, cn);
-            int parts = (int)std::min(64L, std::max(1L, (work + 16383) / 16384));
-            P.lists.push_back(parts);
-            L.cpk_maxparts = std::max(L.cpk_maxparts, parts);
-        }
-        int maxp = 0;
-        long maxfm_small = 0, maxfm_big = 0;
-        for (int f : small) maxfm_small = std::max(maxfm_small, (long)P.fs[f].fm_ub);
-        for (size_t i = 0; i < big.size(); i++) {
-            maxp = std::max(maxp, P.fs[big[i]].npanels);
-            maxfm_big = std::max(maxfm_big, (long)P.fs[big[i]].fm_ub);
-            tslot[big[i]] = (int)i;
-        }
-        P.tslots = std::max(P.tslots, (int)big.size());
-        L.lds_small = (int)std::min((long)LDS_CAP_SMALL, (maxfm_small | 1) * STM_NB);
-        L.lds_big = (int)std::min((long)LDS_CAP_DOUBLES, (maxfm_big | 1) * STM_NB);
-        L.nbig_at.assign(maxp, 0);
-        L.maxcb_at.assign(maxp, 0);
-        for (int p = 0; p < maxp; p++) {
-            int cnt = 0, mcb = 0;
-            for (int f : big) {
-                const FrontSym &s = P.fs[f];
-                if (s.npanels > p) {
-                    cnt++;
-                    const int k2 = std::min(s.fn, (p + 1) * STM_NB);
-                    mcb = std::max(mcb, (s.fn - k2 + 31) / 32);
-                }
-            }
-            L.nbig_at[p] = cnt;
-            L.maxcb_at[p] = mcb;
-        }
-    }
-    // all fronts in Post order + R+H copy parts
-    P.post_off = (int)P.lists.size();
-    for (long kf = 0; kf < nf; kf++) P.lists.push_back((int)P.Post[kf]);
-    P.rh_parts_off = (int)P.lists.size();
-    P.rh_maxparts = 1;
-    for (long kf = 0; kf < nf; kf++) {
-        const FrontSym &s = P.fs[P.Post[kf]];
-        int parts = std::min(64, std::max(1, s.fn / 16));
-        P.lists.push_back(parts);
-        P.rh_maxparts = std::max(P.rh_maxparts, parts);
-    }
-    if (P.lists.empty()) P.lists.push_back(0);
+    // ---- level schedule: one group holding every front (multi-GPU callers regroup with set_groups) ----
+    P.group.assign(nf, 0);
+    std::vector<int> tslot;
+    build_schedule(P, tslot);
 
     // ---- device memory ----------------------------------------------------------------------------
     size_t freeb = 0, totalb = 0;
@@ -434,7 +459,7 @@ int set_pattern(stmmqr_plan &P, const stm_long *Ap, const stm_long *Ai)
 // ------------------------------------------------------------------------------------------------
 // the level-batched schedule (device resident inputs -> device resident factors)
 // ------------------------------------------------------------------------------------------------
-int run_schedule(stmmqr_plan &P, bool detail)
+int run_schedule(stmmqr_plan &P, bool detail, int grp, bool first)
 {
     hipStream_t st = P.stream;
     const DevCtx c = P.ctx();
@@ -464,11 +489,15 @@ int run_schedule(stmmqr_plan &P, bool detail)
         return 0;
     };
 
-    HIPCHK(hipMemsetAsync(P.d_F.p, 0, (size_t)P.farena * sizeof(double), st));
-    HIPCHK(hipMemsetAsync(P.d_Rdead.p, 0, (size_t)std::max(1L, P.n), st));
-    LCHK(stm_launch_gather_sx(P.d_Ax.p, P.d_smap.p, P.d_Sx.p, (int)P.anz, st));
-    nlaunch += 3;
-    for (const Level &L : P.levels) {
+    if (first) {
+        HIPCHK(hipMemsetAsync(P.d_F.p, 0, (size_t)P.farena * sizeof(double), st));
+        HIPCHK(hipMemsetAsync(P.d_Rdead.p, 0, (size_t)std::max(1L, P.n), st));
+        HIPCHK(hipMemsetAsync(P.d_fnum.p, 0, (size_t)std::max(1L, P.nf) * sizeof(FrontNum), st));
+        LCHK(stm_launch_gather_sx(P.d_Ax.p, P.d_smap.p, P.d_Sx.p, (int)P.anz, st));
+        nlaunch += 4;
+    }
+    if (grp < 0 || grp >= (int)P.glevels.size()) return fail(STMMQR_ERR_INVALID, "no such front group");
+    for (const Level &L : P.glevels[grp]) {
         const int *all = L0 + L.all_off;
         int e = timed(t_asm, [&]() -> int {
             LCHK(stm_launch_setup(c, all, L.n_all, st));
@@ -529,12 +558,12 @@ int run_schedule(stmmqr_plan &P, bool detail)
             nlaunch++;
         }
     }
-    P.stats.ms_assemble = t_asm;
-    P.stats.ms_front = t_front + t_upd;
-    P.stats.ms_update = t_upd;
-    P.stats.ms_pack = t_cpk;
-    P.stats.nlaunch = nlaunch;
-    P.stats.nlevels = (long)P.levels.size();
+    P.stats.ms_assemble += t_asm;
+    P.stats.ms_front += t_front + t_upd;
+    P.stats.ms_update += t_upd;
+    P.stats.ms_pack += t_cpk;
+    P.stats.nlaunch += nlaunch;
+    P.stats.nlevels += (long)P.glevels[grp].size();
     return 0;
 }
 
@@ -543,14 +572,14 @@ int run_pack(stmmqr_plan &P)
     hipStream_t st = P.stream;
     const DevCtx c = P.ctx();
     const int *L0 = P.d_lists.p;
-    LCHK(stm_launch_rh_count(c, L0 + P.post_off, (int)P.nf, st));
+    LCHK(stm_launch_rh_count(c, L0 + P.own_off, P.n_own, st));
     LCHK(stm_launch_rh_scan(c, L0 + P.post_off, (int)P.nf, P.d_total.p, st));
     long long total = 0;
     HIPCHK(hipMemcpyAsync(&total, P.d_total.p, sizeof(long long), hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
     P.rh_total = total;
     if ((size_t)total > P.d_RH.n) LCHK(P.d_RH.alloc((size_t)(total + total / 8 + 1024)));
-    LCHK(stm_launch_rh_copy(c, L0 + P.post_off, L0 + P.rh_parts_off, (int)P.nf, P.rh_maxparts, P.d_RH.p, st));
+    LCHK(stm_launch_rh_copy(c, L0 + P.own_off, L0 + P.rh_parts_off, P.n_own, P.rh_maxparts, P.d_RH.p, st));
     P.stats.nlaunch += 3;
     return 0;
 }
@@ -632,8 +661,9 @@ int stmmqr_plan_set_pattern(stmmqr_plan *plan, const stm_long *Ap, const stm_lon
     return set_pattern(*plan, Ap, Ai);
 }
 
-int stmmqr_factorize_device(stmmqr_plan *plan, const stm_long *Ap, const stm_long *Ai, const double *Ax,
-                            int ax_on_device, double tol, stm_long ntol, stmmqr_stats *stats)
+// ---- phased interface: begin -> factorize_group(g) ... -> finish.  stmmqr_factorize_device = all of it ----
+int stmmqr_factorize_begin(stmmqr_plan *plan, const stm_long *Ap, const stm_long *Ai, const double *Ax,
+                           int ax_on_device, double tol, stm_long ntol)
 {
     if (!plan || !Ax) return fail(STMMQR_ERR_INVALID, "null plan / values");
     stmmqr_plan &P = *plan;
@@ -647,21 +677,38 @@ int stmmqr_factorize_device(stmmqr_plan *plan, const stm_long *Ap, const stm_lon
     P.stats = stmmqr_stats();
     P.stats.ms_host = host_ms_plan;
     P.factored = false;
+    P.begun = true;
+    P.first_group = true;
     if (!P.do_rank) tol = -1;                                  // SparseQR_factorize.c:285-289
     P.last_tol = tol; P.last_ntol = ntol;
     hipStream_t st = P.stream;
-    const bool detail = g_opt.verbose >= 2 || (stats && stats->nlaunch == -1);
-
     HIPCHK(hipEventRecord(P.ev[0], st));
     if (P.anz > 0) {
         HIPCHK(hipMemcpyAsync(P.d_Ax.p, Ax, (size_t)P.anz * sizeof(double),
                               ax_on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, st));
     }
     HIPCHK(hipEventRecord(P.ev[1], st));
-    int e = run_schedule(P, detail);
-    if (e) return e;
+    return 0;
+}
+
+int stmmqr_factorize_group(stmmqr_plan *plan, int group, int detail)
+{
+    if (!plan || !plan->begun) return fail(STMMQR_ERR_INVALID, "stmmqr_factorize_begin was not called");
+    stmmqr_plan &P = *plan;
+    HIPCHK(hipSetDevice(P.device));
+    int e = run_schedule(P, detail != 0, group, P.first_group);
+    P.first_group = false;
+    return e;
+}
+
+int stmmqr_factorize_finish(stmmqr_plan *plan, stmmqr_stats *stats)
+{
+    if (!plan || !plan->begun) return fail(STMMQR_ERR_INVALID, "stmmqr_factorize_begin was not called");
+    stmmqr_plan &P = *plan;
+    HIPCHK(hipSetDevice(P.device));
+    hipStream_t st = P.stream;
     HIPCHK(hipEventRecord(P.ev[4], st));
-    e = run_pack(P);
+    int e = run_pack(P);
     if (e) return e;
     HIPCHK(hipEventRecord(P.ev[5], st));
     HIPCHK(hipStreamSynchronize(st));
@@ -674,9 +721,10 @@ int stmmqr_factorize_device(stmmqr_plan *plan, const stm_long *Ap, const stm_lon
     P.h_fnum.resize((size_t)std::max(1L, P.nf));
     if (P.nf > 0)
         HIPCHK(hipMemcpy(P.h_fnum.data(), P.d_fnum.p, (size_t)P.nf * sizeof(FrontNum), hipMemcpyDeviceToHost));
-    double flops = 0, bytes_asm = P.bytes_assemble_idx, bytes_pack = 0, fl_upd = 0;
+    double flops = 0, bytes_asm = 0, bytes_pack = 0, fl_upd = 0;
     long rank = 0;
     for (long f = 0; f < P.nf; f++) {
+        if (P.group[f] < 0) continue;                  // factorized elsewhere
         const FrontNum &nm = P.h_fnum[f];
         const FrontSym &s = P.fs[f];
         flops += nm.flops;
@@ -687,21 +735,115 @@ int stmmqr_factorize_device(stmmqr_plan *plan, const stm_long *Ap, const stm_lon
         bytes_asm += 8.0 * ((double)nm.fm * s.fn) + 8.0 * csize;   // F first write + child C read (as a child)
         bytes_pack += 16.0 * (csize + (double)nm.rsize);
     }
-    bytes_asm += 8.0 * (double)P.anz;
-    P.stats.flops_update = fl_upd;
+    bytes_asm += 8.0 * (double)P.anz + P.bytes_assemble_idx;
     if (getenv("STMMQR_DBG") && (atoi(getenv("STMMQR_DBG")) & 16)) {
         unsigned long long hb[8];
         HIPCHK(hipMemcpy(hb, P.d_dbg.p, sizeof hb, hipMemcpyDeviceToHost));
-        fprintf(stderr, "[panel cycles, summed over workgroups] stage-in %llu  columns %llu  write-back %llu  apply %llu  gram %llu\n",
+        fprintf(stderr, "[panel cycles, summed over workgroups] stage-in+apply %llu  columns %llu  write-back %llu  - %llu  gram %llu\n",
                 hb[0], hb[1], hb[2], hb[3], hb[4]);
         HIPCHK(hipMemset(P.d_dbg.p, 0, sizeof hb));
     }
     P.rank = rank;
     P.stats.flops = flops;
+    P.stats.flops_update = fl_upd;
     P.stats.bytes_assemble = bytes_asm;
     P.stats.bytes_pack = bytes_pack;
     P.factored = true;
+    P.begun = false;
     if (stats) *stats = P.stats;
+    return 0;
+}
+
+int stmmqr_factorize_device(stmmqr_plan *plan, const stm_long *Ap, const stm_long *Ai, const double *Ax,
+                            int ax_on_device, double tol, stm_long ntol, stmmqr_stats *stats)
+{
+    int e = stmmqr_factorize_begin(plan, Ap, Ai, Ax, ax_on_device, tol, ntol);
+    if (e) return e;
+    const bool detail = g_opt.verbose >= 2 || (stats && stats->nlaunch == -1);
+    for (int g = 0; g < (int)plan->glevels.size() && !e; g++) e = stmmqr_factorize_group(plan, g, detail);
+    if (e) return e;
+    return stmmqr_factorize_finish(plan, stats);
+}
+
+// ---- multi-GPU support: regroup the fronts, move contribution blocks in and out of a plan --------------
+int stmmqr_plan_set_groups(stmmqr_plan *plan, const int *group)
+{
+    if (!plan || !group) return fail(STMMQR_ERR_INVALID, "null plan / groups");
+    stmmqr_plan &P = *plan;
+    HIPCHK(hipSetDevice(P.device));
+    for (long f = 0; f < P.nf; f++) {
+        P.group[f] = group[f];
+        // a front and the children it assembles must not be split inside one phase in the wrong order
+        for (long q = P.Childp[f]; q < P.Childp[f + 1]; q++)
+            if (group[f] >= 0 && group[P.Child[q]] > group[f])
+                return fail(STMMQR_ERR_INVALID, "a child is scheduled in a later phase than its parent");
+    }
+    std::vector<int> tslot;
+    build_schedule(P, tslot);
+    LCHK(P.d_T.alloc((size_t)2 * P.tslots * STM_NB * STM_NB));
+    LCHK(P.d_tslot.upload(tslot, P.stream));
+    LCHK(P.d_lists.upload(P.lists, P.stream));
+    HIPCHK(hipStreamSynchronize(P.stream));
+    return 0;
+}
+
+/* info[0..5] = fm, rank, cm, csize, fn, fp of front f after it has been factorized (or imported) here */
+int stmmqr_plan_front_info(stmmqr_plan *plan, stm_long f, stm_long *info)
+{
+    if (!plan || f < 0 || f >= plan->nf || !info) return fail(STMMQR_ERR_INVALID, "bad front");
+    stmmqr_plan &P = *plan;
+    HIPCHK(hipSetDevice(P.device));
+    HIPCHK(hipStreamSynchronize(P.stream));
+    FrontNum nm;
+    HIPCHK(hipMemcpy(&nm, P.d_fnum.p + f, sizeof nm, hipMemcpyDeviceToHost));
+    const long cn = P.fs[f].fn - P.fs[f].fp, cm = nm.cm;
+    info[0] = nm.fm; info[1] = nm.rank; info[2] = cm; info[3] = cm * (cm + 1) / 2 + cm * (cn - cm);
+    info[4] = P.fs[f].fn; info[5] = P.fs[f].fp;
+    return 0;
+}
+
+/* copy out the packed contribution block (csize doubles) and the cm row ids of front f */
+int stmmqr_plan_export_front(stmmqr_plan *plan, stm_long f, double *C, stm_long *rows, int c_on_device)
+{
+    stm_long info[6];
+    int e = stmmqr_plan_front_info(plan, f, info);
+    if (e) return e;
+    stmmqr_plan &P = *plan;
+    if (info[3] > 0 && C)
+        HIPCHK(hipMemcpy(C, P.d_C.p + P.fs[f].coff, (size_t)info[3] * sizeof(double),
+                         c_on_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost));
+    if (info[2] > 0 && rows) {
+        std::vector<int> r32((size_t)info[2]);
+        HIPCHK(hipMemcpy(r32.data(), P.d_Hii.p + P.fs[f].hip + info[1], (size_t)info[2] * sizeof(int), hipMemcpyDeviceToHost));
+        for (long i = 0; i < info[2]; i++) rows[i] = r32[i];
+    }
+    return 0;
+}
+
+/* install the contribution block of a front that was factorized on another device */
+int stmmqr_plan_import_front(stmmqr_plan *plan, stm_long f, stm_long fm, stm_long rank, stm_long cm, const double *C,
+                             const stm_long *rows, int c_on_device)
+{
+    if (!plan || f < 0 || f >= plan->nf) return fail(STMMQR_ERR_INVALID, "bad front");
+    stmmqr_plan &P = *plan;
+    HIPCHK(hipSetDevice(P.device));
+    const long cn = P.fs[f].fn - P.fs[f].fp;
+    if (cm < 0 || cm > cn || rank < 0 || rank + cm > P.fs[f].fm_ub)
+        return fail(STMMQR_ERR_INVALID, "imported front does not fit the symbolic bounds");
+    const long csize = cm * (cm + 1) / 2 + cm * (cn - cm);
+    HIPCHK(hipStreamSynchronize(P.stream));
+    FrontNum nm;
+    memset(&nm, 0, sizeof nm);
+    nm.fm = (int)fm; nm.rank = (int)rank; nm.cm = (int)cm; nm.done = 1; nm.g = (int)rank;
+    HIPCHK(hipMemcpy(P.d_fnum.p + f, &nm, sizeof nm, hipMemcpyHostToDevice));
+    if (csize > 0)
+        HIPCHK(hipMemcpy(P.d_C.p + P.fs[f].coff, C, (size_t)csize * sizeof(double),
+                         c_on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice));
+    if (cm > 0) {
+        std::vector<int> r32((size_t)cm);
+        for (long i = 0; i < cm; i++) r32[i] = (int)rows[i];
+        HIPCHK(hipMemcpy(P.d_Hii.p + P.fs[f].hip + rank, r32.data(), (size_t)cm * sizeof(int), hipMemcpyHostToDevice));
+    }
     return 0;
 }
 
@@ -746,13 +888,25 @@ int stmmqr_plan_download(stmmqr_plan *plan, double *Stack, stm_long *Rblock_off,
     if (HStair) for (long i = 0; i < P.rjsize; i++) HStair[i] = stair32[i];
     if (Rblock_off) for (long f = 0; f < nf; f++) Rblock_off[f] = (stm_long)rboff[f];
     long maxfrank = 1, maxfm = 0, rank = 0;
+    bool all_here = true;
     for (long f = 0; f < nf; f++) {
         const FrontNum &nm = P.h_fnum[f];
-        if (Hm) Hm[f] = nm.fm;
-        if (Hr) Hr[f] = nm.rank;
+        const bool own = P.group[f] >= 0;
+        all_here = all_here && own;
+        if (Hm) Hm[f] = own ? nm.fm : 0;
+        if (Hr) Hr[f] = own ? nm.rank : 0;
+        if (!own) continue;
         maxfrank = std::max(maxfrank, (long)nm.rank);
         maxfm = std::max(maxfm, (long)nm.fm);
         rank += nm.rank;
+    }
+    if (!all_here) {
+        // sharded run: the caller merges the shards and runs qr_hpinv on the union; Hii stays in S-row ids
+        if (Hii)
+            for (long f = 0; f < nf; f++)
+                if (P.group[f] >= 0)
+                    for (long i = 0; i < P.h_fnum[f].fm; i++) Hii[P.Hip[f] + i] = hii32[P.Hip[f] + i];
+        Hii = nullptr; HPinv = nullptr;
     }
     // qr_hpinv (SparseQR_factorize.c:991-1060): global row permutation, Hii rewritten in place
     if (Hii || HPinv) {

@@ -714,7 +714,19 @@ __device__ __forceinline__ void dev_panel(PanelShared &ps, const FrontSym &s, Fr
                     for (int jj = j + 1 + wid; jj < j0 + sw; jj += NWV) {
                         double *cc = Pb + (g - roff) + (jj - coff) * pst;
                         double w = (lane == 0) ? cc[0] : 0.0;
-                        for (int i = 1 + lane; i < len; i += 64) w += col[i] * cc[i];
+                        {
+                            // four independent partial sums: the LDS read latency overlaps instead of chaining
+                            double w1 = 0, w2 = 0, w3 = 0;
+                            int i = 1 + lane;
+                            for (; i + 192 < len; i += 256) {
+                                w += col[i] * cc[i];
+                                w1 += col[i + 64] * cc[i + 64];
+                                w2 += col[i + 128] * cc[i + 128];
+                                w3 += col[i + 192] * cc[i + 192];
+                            }
+                            for (; i < len; i += 64) w += col[i] * cc[i];
+                            w += w1 + w2 + w3;
+                        }
                         w = wave_sum(w) * tau;
                         if (lane == 0) cc[0] -= w;
                         if (jj == j + 1) {

@@ -1,0 +1,58 @@
+"""Subtree sharding on ONE GPU box: two plans play the two ranks of a 2-way partition (phase 0 on each, contribution
+blocks exported from "rank 1" and imported into "rank 0", phase 1 on rank 0); the merged result must be identical to
+the unsharded factorization -- same kernels on the same fronts, only placement and transport differ."""
+import importlib
+
+import numpy as np
+import pytest
+
+from stmmqr_testlib import Symbolic, load_golden, scalar
+
+pytestmark = pytest.mark.gpu
+PKG = "stm-multifrontal-qr-factorization-empowered-by-gcn_amd"
+
+
+@pytest.mark.parametrize("name", ["epb1", "grid20_standin", "syn_rankdef_grid", "lns_3937"])
+@pytest.mark.parametrize("nranks", [2, 4])
+def test_sharded_equals_unsharded(name, nranks):
+    pkg = importlib.import_module(PKG)
+    sh = importlib.import_module(PKG + ".sharded")
+    g = load_golden(name)
+    S = Symbolic(g)
+    sym = {**S.sc, **{k: v for k, v in S.arr.items() if v is not None}}
+    tol, ntol = scalar(g, "in_tol"), int(scalar(g, "in_ntol"))
+    ref = pkg.qr_factorize(sym, g["in_Ap"], g["in_Ai"], g["in_Ax"], tol, ntol)
+
+    owner, phase = sh.partition(sym, nranks)
+    plans, shards, flops = [], [], 0.0
+    for r in range(nranks):
+        p = pkg.HipQR(sym)
+        group = np.full(S.nf, -1, np.int32)
+        group[(owner == r) & (phase == 0)] = 0
+        if r == 0:
+            group[phase == 1] = 1
+        p.set_groups(group)
+        p.begin(g["in_Ax"], tol, ntol, g["in_Ap"], g["in_Ai"])
+        p.run_group(0)
+        plans.append(p)
+    nmoved = 0
+    for c, _par in sh.cross_edges(sym, owner, phase):
+        if owner[c] != 0:
+            info, Cb, rows = plans[owner[c]].export_front(c)
+            plans[0].import_front(c, info["fm"], info["rank"], info["cm"], Cb, rows)
+            nmoved += 1
+    assert nmoved >= 1 or not phase.any()      # a forest with enough roots needs no exchange at all
+    if phase.any():
+        plans[0].run_group(1)
+    for r, p in enumerate(plans):
+        st = p.finish()
+        flops += st["flops"]
+        shards.append(sh.shard_of(p.download(), sym, owner == r))
+        p.close()
+    G = sh.merge_shards(sym, shards)
+    assert flops == ref.stats["flops"]
+    nf = S.nf
+    assert (G.rank, G.maxfrank, G.maxfm, G.rh_total) == (ref.rank, ref.maxfrank, ref.maxfm, ref.rh_total)
+    for k in ("Hm", "Hr", "HStair", "HPinv", "Rdead", "Rblock_off", "Hii", "HTau"):
+        np.testing.assert_array_equal(getattr(G, k), getattr(ref, k), err_msg=k)
+    np.testing.assert_array_equal(G.Stack[:G.rh_total], ref.Stack[:ref.rh_total])
