@@ -215,6 +215,7 @@ typedef struct stmmqr_options {
     int verbose;
     int use_graph;          /* capture the level schedule into a hipGraph                                 */
     int lookahead;          /* overlap panel p+1 with the rest of the trailing update of panel p (2 streams) */
+    int split_update;       /* row-parallel (3-launch) trailing update for tall panels                      */
 } stmmqr_options;
 void stmmqr_get_options(stmmqr_options *opt);
 void stmmqr_set_options(const stmmqr_options *opt);

@@ -29,6 +29,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include <sys/time.h>
+#include <unistd.h>
 #include "SparseQR.h"
 #include "tpsm.h"
 #include "tpsm_sysinfo.h"
@@ -293,5 +294,11 @@ int main(int argc, char **argv)
     SparseQR_free(&QR, cc);
     SparseCore_free_sparse(&A, cc);
     SparseCore_finish(cc);
+    if (getenv("REFDUMP_HIPLIB")) {
+        /* the HIP runtime was pulled in through dlopen: skip its exit-time teardown (it can stall at process exit
+         * when the library is unloaded after main) */
+        fflush(stdout); fflush(stderr);
+        _exit(0);
+    }
     return 0;
 }

@@ -29,7 +29,7 @@
 namespace {
 
 thread_local std::string g_err;
-stmmqr_options g_opt = {STM_NB, 128, 0, 0, 0};
+stmmqr_options g_opt = {STM_NB, 128, 0, 0, 0, 1};
 size_t g_chunk[4] = {32, 5000, 4, 4};     // FCHUNK, SMALL, MINCHUNK, MINCHUNK_RATIO (SparseQR.h:16-19)
 
 // offsets inside the reference's sparse_common for the stock LP64 build; verified against the real header
@@ -100,6 +100,7 @@ struct Level {
     int lds_small = 0, lds_big = 0;      // dynamic LDS (doubles) for the panel staging
     std::vector<int> nbig_at;            // big fronts with npanels > p
     std::vector<int> maxcb_at;           // max trailing column blocks at panel p
+    std::vector<int> maxsl_at;           // max 256-row slabs of the fronts still active at panel p (0: small)
 };
 
 }  // namespace
@@ -121,12 +122,13 @@ struct stmmqr_plan {
     int post_off = 0, rh_parts_off = 0, rh_maxparts = 1;
     long long farena = 0, carena = 0;
     int tslots = 1;
+    long long wp_doubles = 0;            // workspace of the row-parallel update (partial W blocks)
     bool pattern_set = false;
     double bytes_assemble_idx = 0;       // index bytes of the assembly (symbolic part of SURVEY 8d formula)
 
     DevBuf<FrontSym> d_fs;
     DevBuf<FrontNum> d_fnum;
-    DevBuf<double> d_F, d_C, d_T, d_Sx, d_Ax, d_Tau, d_RH;
+    DevBuf<double> d_F, d_C, d_T, d_Sx, d_Ax, d_Tau, d_RH, d_Wp, d_Wp2;
     DevBuf<int> d_tslot, d_Sp, d_Sjrel, d_Sj0, d_Sleft, d_Child, d_Rjrel, d_Stair, d_Hii, d_Cmap, d_Cursor,
         d_Rhoff, d_lists, d_smap;
     DevBuf<long long> d_Rboff, d_total;
@@ -204,6 +206,7 @@ void build_schedule(stmmqr_plan &P, std::vector<int> &tslot)
     P.glevels.assign(ngroups, std::vector<Level>());
     P.lists.clear();
     P.tslots = 1;
+    P.wp_doubles = 0;
     for (int grp = 0; grp < ngroups; grp++) {
         std::vector<int> level(nf, -1);
         int nlev = 0;
@@ -261,18 +264,22 @@ void build_schedule(stmmqr_plan &P, std::vector<int> &tslot)
             L.lds_big = (int)std::min((long)LDS_CAP_DOUBLES, (maxfm_big | 1) * STM_NB);
             L.nbig_at.assign(maxp, 0);
             L.maxcb_at.assign(maxp, 0);
+            L.maxsl_at.assign(maxp, 0);
             for (int p = 0; p < maxp; p++) {
-                int cnt = 0, mcb = 0;
+                int cnt = 0, mcb = 0, msl = 0;
                 for (int f : big) {
                     const FrontSym &s = P.fs[f];
                     if (s.npanels > p) {
                         cnt++;
                         const int k2 = std::min(s.fn, (p + 1) * STM_NB);
                         mcb = std::max(mcb, (s.fn - k2 + 31) / 32);
+                        msl = std::max(msl, (s.fm_ub + 255) / 256);
                     }
                 }
                 L.nbig_at[p] = cnt;
                 L.maxcb_at[p] = mcb;
+                L.maxsl_at[p] = msl >= 3 ? msl : 0;          // row-parallel update only when it pays (>= 3 slabs)
+                P.wp_doubles = std::max(P.wp_doubles, (long long)cnt * mcb * msl * (STM_NB * 32));
             }
         }
     }
@@ -407,6 +414,8 @@ int build_plan(stmmqr_plan &P, const stmmqr_symbolic_view &v)
     LCHK(P.d_F.alloc((size_t)P.farena));
     LCHK(P.d_C.alloc((size_t)P.carena));
     LCHK(P.d_T.alloc((size_t)2 * P.tslots * STM_NB * STM_NB));
+    LCHK(P.d_Wp.alloc((size_t)P.wp_doubles));
+    LCHK(P.d_Wp2.alloc((size_t)P.wp_doubles));
     LCHK(P.d_tslot.upload(tslot, st));
     LCHK(P.d_Sx.alloc((size_t)v.anz));
     LCHK(P.d_Ax.alloc((size_t)v.anz));
@@ -425,8 +434,8 @@ int build_plan(stmmqr_plan &P, const stmmqr_symbolic_view &v)
     LCHK(P.d_Rhoff.alloc((size_t)v.rjsize));
     LCHK(P.d_Rboff.alloc((size_t)std::max(1L, nf)));
     LCHK(P.d_total.alloc(1));
-    LCHK(P.d_dbg.alloc(8));
-    HIPCHK(hipMemsetAsync(P.d_dbg.p, 0, 8 * sizeof(unsigned long long), st));
+    LCHK(P.d_dbg.alloc(16));
+    HIPCHK(hipMemsetAsync(P.d_dbg.p, 0, 16 * sizeof(unsigned long long), st));
     LCHK(P.d_Rdead.alloc((size_t)std::max(1L, n)));
     LCHK(P.d_lists.upload(P.lists, st));
     HIPCHK(hipStreamSynchronize(st));
@@ -520,7 +529,11 @@ int run_schedule(stmmqr_plan &P, bool detail, int grp, bool first)
                 });
                 if (e) return e;
                 e = timed(t_upd, [&]() -> int {
-                    LCHK(stm_launch_update(c, big, L.nbig_at[p], (int)p, 0, L.maxcb_at[p], st));
+                    if (L.maxsl_at[p] > 0 && g_opt.split_update) {
+                        LCHK(stm_launch_update_split(c, big, L.nbig_at[p], (int)p, 0, L.maxcb_at[p], L.maxsl_at[p], P.d_Wp.p, st));
+                        nlaunch += 2;
+                    } else
+                        LCHK(stm_launch_update(c, big, L.nbig_at[p], (int)p, 0, L.maxcb_at[p], st));
                     return 0;
                 });
                 if (e) return e;
@@ -537,10 +550,17 @@ int run_schedule(stmmqr_plan &P, bool detail, int grp, bool first)
                 if (!evp || !evr) return fail(STMMQR_ERR_DEVICE, "hipEventCreate failed");
                 HIPCHK(hipEventRecord(evp, st));
                 if (prev_rest) HIPCHK(hipStreamWaitEvent(st, prev_rest, 0));      // same columns: keep the order
-                LCHK(stm_launch_update(c, big, L.nbig_at[p], (int)p, 0, std::min(1, L.maxcb_at[p]), st));
+                const bool split = L.maxsl_at[p] > 0 && g_opt.split_update;
+                if (split)
+                    LCHK(stm_launch_update_split(c, big, L.nbig_at[p], (int)p, 0, std::min(1, L.maxcb_at[p]), L.maxsl_at[p], P.d_Wp.p, st));
+                else
+                    LCHK(stm_launch_update(c, big, L.nbig_at[p], (int)p, 0, std::min(1, L.maxcb_at[p]), st));
                 if (L.maxcb_at[p] > 1) {
                     HIPCHK(hipStreamWaitEvent(s2, evp, 0));
-                    LCHK(stm_launch_update(c, big, L.nbig_at[p], (int)p, 1, L.maxcb_at[p] - 1, s2));
+                    if (split)
+                        LCHK(stm_launch_update_split(c, big, L.nbig_at[p], (int)p, 1, L.maxcb_at[p] - 1, L.maxsl_at[p], P.d_Wp2.p, s2));
+                    else
+                        LCHK(stm_launch_update(c, big, L.nbig_at[p], (int)p, 1, L.maxcb_at[p] - 1, s2));
                     HIPCHK(hipEventRecord(evr, s2));
                     prev_rest = evr;
                     nlaunch++;
@@ -636,9 +656,20 @@ stmmqr_plan *stmmqr_plan_create(const stmmqr_symbolic_view *sym, int device, int
     }
     if (!st) {
         (void)hipGetDevice(&P->device);
-        if (hipStreamCreateWithFlags(&P->stream, hipStreamNonBlocking) != hipSuccess ||
-            hipStreamCreateWithFlags(&P->stream2, hipStreamNonBlocking) != hipSuccess)
+        if (hipStreamCreateWithFlags(&P->stream, hipStreamNonBlocking) != hipSuccess)
             st = fail(STMMQR_ERR_DEVICE, "hipStreamCreate failed");
+        if (!st) {
+            // look-ahead stream: keep a few CUs out of its mask so that the next panel's workgroup (one CU, ~150 KB
+            // of LDS) can start while the tail of the trailing update still fills the rest of the chip
+            uint32_t mask[8];
+            for (auto &w : mask) w = 0xffffffffu;
+            mask[0] &= ~0xffffu;
+            if (hipExtStreamCreateWithCUMask(&P->stream2, 8, mask) != hipSuccess) {
+                (void)hipGetLastError();
+                if (hipStreamCreateWithFlags(&P->stream2, hipStreamNonBlocking) != hipSuccess)
+                    st = fail(STMMQR_ERR_DEVICE, "hipStreamCreate failed");
+            }
+        }
         for (auto &e : P->ev)
             if (!st && hipEventCreate(&e) != hipSuccess) st = fail(STMMQR_ERR_DEVICE, "hipEventCreate failed");
     }
@@ -736,11 +767,13 @@ int stmmqr_factorize_finish(stmmqr_plan *plan, stmmqr_stats *stats)
         bytes_pack += 16.0 * (csize + (double)nm.rsize);
     }
     bytes_asm += 8.0 * (double)P.anz + P.bytes_assemble_idx;
-    if (getenv("STMMQR_DBG") && (atoi(getenv("STMMQR_DBG")) & 16)) {
-        unsigned long long hb[8];
+    if (getenv("STMMQR_DBG") && (atoi(getenv("STMMQR_DBG")) & 48)) {
+        unsigned long long hb[16];
         HIPCHK(hipMemcpy(hb, P.d_dbg.p, sizeof hb, hipMemcpyDeviceToHost));
         fprintf(stderr, "[panel cycles, summed over workgroups] stage-in+apply %llu  columns %llu  write-back %llu  - %llu  gram %llu\n",
                 hb[0], hb[1], hb[2], hb[3], hb[4]);
+        fprintf(stderr, "[tall column step cycles] pass1 %llu  reduce %llu  math+store %llu  update+barrier %llu\n", hb[5], hb[6],
+                hb[7], hb[8]);
         HIPCHK(hipMemset(P.d_dbg.p, 0, sizeof hb));
     }
     P.rank = rank;
@@ -781,6 +814,8 @@ int stmmqr_plan_set_groups(stmmqr_plan *plan, const int *group)
     std::vector<int> tslot;
     build_schedule(P, tslot);
     LCHK(P.d_T.alloc((size_t)2 * P.tslots * STM_NB * STM_NB));
+    LCHK(P.d_Wp.alloc((size_t)P.wp_doubles));
+    LCHK(P.d_Wp2.alloc((size_t)P.wp_doubles));
     LCHK(P.d_tslot.upload(tslot, P.stream));
     LCHK(P.d_lists.upload(P.lists, P.stream));
     HIPCHK(hipStreamSynchronize(P.stream));

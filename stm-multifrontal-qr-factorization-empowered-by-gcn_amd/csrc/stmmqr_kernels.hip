@@ -27,6 +27,8 @@ typedef double d4 __attribute__((ext_vector_type(4)));
 // small LDS working set of the panel routines, declared once per kernel and shared by every code path
 struct PanelShared {
     double red[16];
+    int st_out[STM_NB];        // Stair / dead flag of the panel columns, flushed to global once per panel (a global
+    int dead[STM_NB];          //  store inside the column loop makes every barrier wait for its completion)
     double nextss;             // |x|^2 of the next column, produced by the wave that just updated it
     int nextss_col;            // ... valid for this panel column (-1: none)
     int stair[STM_NB];
@@ -539,6 +541,15 @@ __device__ __forceinline__ void block_reduce_vec(double (&x)[K], double *s_part)
     }
 }
 
+// rows [g, tmax) a panel will touch (uniform over the workgroup; 0 when the front is already finished)
+__device__ __forceinline__ int panel_rows(const FrontSym &s, const FrontNum *num, const int *St, int p)
+{
+    if (num->done) return 0;
+    const int k1 = p * STM_NB, k2 = min(s.fn, k1 + STM_NB);
+    const int g = num->g;
+    return max(0, min(num->fm, max(St[k2 - 1], g + (k2 - k1))) - g);
+}
+
 // ------------------------------------------------------------------------------------------------
 // qr_front, one panel of <= STM_NB columns (reference: the column loop :1434-1609 with the panel policy
 // fixed to k1 = p*NB, which changes rounding only).  Executed by one whole workgroup.
@@ -552,7 +563,7 @@ __device__ __forceinline__ void block_reduce_vec(double (&x)[K], double *s_part)
 // Produces: R and V in F, Tau, Stair, Rdead, the T factor of the whole panel (Tout, NB x NB) and the pending
 // block-reflector description in FrontNum (pg1, pt, pk1, pnb, pc0, pdiag).
 // ------------------------------------------------------------------------------------------------
-template <int NTH>
+template <int NTH, bool INPLACE>
 __device__ __forceinline__ void dev_panel(PanelShared &ps, const FrontSym &s, FrontNum *num, double *F, int *St, double *Tau, char *Rdead,
                           int p, double tol, int ntol_global, double *Tout, double *lds, int lds_doubles, int dbg = 0,
                           unsigned long long *dbgbuf = nullptr)
@@ -585,19 +596,21 @@ __device__ __forceinline__ void dev_panel(PanelShared &ps, const FrontSym &s, Fr
     const int tmax = min(m, max(ps.stair[nbp - 1], g1 + nbp));
     const int mp = tmax - g1;
     double flops = 0;
-    int done = 0, tlast = g1;
+    int done = 0, tlast = g1, ncols_done = nbp;
 
     // sub-panel width: as many columns as fit in LDS with the rows of the first sub-panel
-    int SW = 0;
-    if (mp > 0) SW = min(nbp, lds_doubles / (((mp + 63) & ~63) | 1));   // columns padded to whole 64-row slots
-    const bool in_place = (SW == 0);
-    if (in_place) SW = nbp;
+    // INPLACE (rows too tall for even one LDS column, or nothing to do): work straight on F; otherwise sub-panels of
+    // SW columns in LDS.  The two cases are separate instantiations so that every access of the LDS case is a
+    // ds_* instruction (a pointer that may be either LDS or global compiles to slow FLAT accesses).
+    int SW = INPLACE ? nbp : max(1, min(nbp, lds_doubles / (((mp + 63) & ~63) | 1)));
+    constexpr bool in_place = INPLACE;
     // tall sub-panels: all waves split the ROWS of every column step and one workgroup reduction delivers the
     // column norm and all v'c dot products of the rest of the sub-panel (<= 7) at once
     const bool tall = !in_place && mp > 768;
     if (tall) SW = min(SW, 8);
 
-    unsigned long long tph[6] = {0, 0, 0, 0, 0, 0}, tc0 = 0;
+    unsigned long long tph[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, tc0 = 0, tc1 = 0;
+#define CSTAMP(idx) do { if (dbg & 32) { const unsigned long long t_ = clock64(); tph[idx] += t_ - tc1; tc1 = t_; } } while (0)
 #define STAMP(idx) do { if (dbg & 16) { __syncthreads(); const unsigned long long t_ = clock64(); tph[idx] += t_ - tc0; tc0 = t_; } } while (0)
     if (dbg & 16) tc0 = clock64();
     for (int j0 = 0; j0 < nbp && !done; j0 += SW) {
@@ -607,8 +620,8 @@ __device__ __forceinline__ void dev_panel(PanelShared &ps, const FrontSym &s, Fr
         long long pst;
         double *Pb;                                     // Pb[(i-roff) + (j-coff)*pst] = F(i, k1+j)
         int roff = 0, coff = 0;                         // (never form a pointer outside the LDS object)
-        if (!in_place && ms > 0) {
-            const int msp = (ms + 63) & ~63;            // zero-padded so that 64-row slots can be read unmasked
+        if constexpr (!INPLACE) {
+            const int msp = (max(ms, 0) + 63) & ~63;    // zero-padded so that 64-row slots can be read unmasked
             pst = msp | 1;
             for (int j = wid; j < sw; j += NWV) {
                 const double *src = F + (k1 + j0 + j) * ld;
@@ -633,12 +646,14 @@ __device__ __forceinline__ void dev_panel(PanelShared &ps, const FrontSym &s, Fr
                 }
                 for (int jj = j + tid; jj < nbp; jj += NTH) { s_diag[jj] = STM_BIGROW; s_tau[jj] = 0; }
                 done = 1;
+                ncols_done = j;                         // columns >= j were finalised above, straight in global memory
                 break;
             }
             const int t = max(g + 1, ps.stair[j]);
             double *col = Pb + (g - roff) + (j - coff) * pst;   // col[0] = F(g,k)
             const int len = t - g;                      // >= 1
             // ---- dlarfg ----
+            if (dbg & 32) tc1 = clock64();
             const double alpha = col[0];                // read before the barriers below: thread 0 overwrites it
             const int nrest = tall ? (j0 + sw - 1 - j) : 0;     // remaining sub-panel columns (tall scheme, <= 7)
             double part[8];
@@ -656,8 +671,10 @@ __device__ __forceinline__ void dev_panel(PanelShared &ps, const FrontSym &s, Fr
                     for (int x = 1; x < 8; x++)
                         if (x <= nrest) part[x] += xv * col[i + x * pst];
                 }
+                CSTAMP(5);
                 block_reduce_vec<NTH, 8>(part, ps.part);
-            } else if (ps.nextss_col == j) {
+                CSTAMP(6);
+            } else if (ps.nextss_col == j && !(dbg & 128)) {
                 part[0] = ps.nextss;                    // computed by the dlarf sweep of the previous column
             } else {
                 double ss0 = 0;
@@ -676,12 +693,14 @@ __device__ __forceinline__ void dev_panel(PanelShared &ps, const FrontSym &s, Fr
             if (dead) {
                 // zero the column from the diagonal down, no reflector, g does not advance (:1495-1544)
                 for (int i = tid; i < tmax - g; i += NTH) col[i] = 0;
-                if (tid == 0) { St[k] = 0; Tau[k] = 0; Rdead[k] = 1; s_diag[j] = STM_BIGROW; s_tau[j] = 0; }
+                if (tid == 0) { ps.st_out[j] = 0; ps.dead[j] = 1; s_diag[j] = STM_BIGROW; s_tau[j] = 0; }
                 if (k == npiv - 1) rank = g;            // (:1604-1608) also taken on a dead last pivot
                 __syncthreads();
                 continue;
             }
-            if (tid == 0) { St[k] = t; Tau[k] = tau; col[0] = beta; s_diag[j] = g; s_tau[j] = tau; }
+            // (col[0] = beta is stored only after a barrier that every reader of alpha = col[0] has passed)
+            if (tid == 0) { ps.st_out[j] = t; ps.dead[j] = 0; s_diag[j] = g; s_tau[j] = tau; if (tall) col[0] = beta; }
+            CSTAMP(7);
             flops += (double)len * (3.0 + 4.0 * (double)(n - k - 1));
             if (tall) {
                 // ---- scale x and apply H_k to the rest of the sub-panel in the same sweep over the rows ----
@@ -707,6 +726,7 @@ __device__ __forceinline__ void dev_panel(PanelShared &ps, const FrontSym &s, Fr
                 if (tau != 0.0)
                     for (int i = 1 + tid; i < len; i += NTH) col[i] *= scal;
                 __syncthreads();
+                if (tid == 0) col[0] = beta;            // no one reads F(g,k) any more in this step
                 // ---- dlarf on the rest of the SUB-panel: one wave per column, v'c by DPP reduction (A.3) ----
                 if (tau != 0.0) {
                     nlive++;
@@ -751,10 +771,11 @@ __device__ __forceinline__ void dev_panel(PanelShared &ps, const FrontSym &s, Fr
             g++;
             if (k == npiv - 1) rank = g;
             __syncthreads();
+            CSTAMP(8);
         }
         __syncthreads();
         STAMP(1);
-        if (!in_place && ms > 0) {
+        if (!in_place) {
             for (int j = wid; j < sw; j += NWV) {
                 double *dst = F + (k1 + j0 + j) * ld;
                 for (int i = gs + lane; i < tmax; i += 64) dst[i] = lds[(i - gs) + j * pst];
@@ -781,13 +802,20 @@ __device__ __forceinline__ void dev_panel(PanelShared &ps, const FrontSym &s, Fr
             __syncthreads();
         }
     }
+    __syncthreads();
+    if (tid < ncols_done) {                            // HStair / HTau / Rdead of this panel, one coalesced flush
+        St[k1 + tid] = ps.st_out[tid];
+        Tau[k1 + tid] = s_tau[tid];
+        if (ps.dead[tid]) Rdead[k1 + tid] = 1;
+    }
     STAMP(3);
     // ---- T of the whole panel for the trailing update ----
     if (!(dbg & 2)) dev_gram_T<NTH>(F + (long long)k1 * ld, ld, g1, tlast, nbp, s_diag, s_tau, s_G, s_T, Tout, lds);
     STAMP(4);
     if ((dbg & 16) && tid == 0 && dbgbuf)
-        for (int e = 0; e < 5; e++) atomicAdd(&dbgbuf[e], tph[e]);
+        for (int e = 0; e < 12; e++) atomicAdd(&dbgbuf[e], tph[e]);
 #undef STAMP
+#undef CSTAMP
     PanelDesc *pd = &num->pd[p & 1];
     if (tid < STM_NB) pd->pdiag[tid] = (tid < nbp) ? s_diag[tid] : STM_BIGROW;
     if (tid == 0) {
@@ -850,8 +878,12 @@ __global__ __launch_bounds__(NT) void k_front_wg(DevCtx c, const int *__restrict
     FrontNum *num = &c.fnum[f];
     double *F = c.Farena + s.foff;
     for (int p = 0; p < s.npanels; p++) {
-        dev_panel<NT>(ps, s, num, F, c.Stair + s.rp, c.Tau + s.rp, c.Rdead + s.col1, p, c.tol, c.ntol, s_Tw, dyn_lds,
-                  lds_doubles);
+        if ((c.dbg & 64) || panel_rows(s, num, c.Stair + s.rp, p) > lds_doubles - 65)
+            dev_panel<NT, true>(ps, s, num, F, c.Stair + s.rp, c.Tau + s.rp, c.Rdead + s.col1, p, c.tol, c.ntol, s_Tw,
+                                dyn_lds, lds_doubles, c.dbg);
+        else
+            dev_panel<NT, false>(ps, s, num, F, c.Stair + s.rp, c.Tau + s.rp, c.Rdead + s.col1, p, c.tol, c.ntol, s_Tw,
+                                 dyn_lds, lds_doubles, c.dbg);
         const int k2 = min(s.fn, (p + 1) * STM_NB);
         const int ncb = (s.fn - k2 + BN - 1) / BN;
         const PanelDesc *pd = &num->pd[p & 1];
@@ -877,8 +909,12 @@ __global__ __launch_bounds__(NTP) void k_panel(DevCtx c, const int *__restrict__
     FrontNum *num = &c.fnum[f];
     double *F = c.Farena + s.foff;
     double *T = c.Tws + (long long)(2 * c.tslot[f] + (p & 1)) * STM_NB * STM_NB;
-    dev_panel<NTP>(ps, s, num, F, c.Stair + s.rp, c.Tau + s.rp, c.Rdead + s.col1, p, c.tol, c.ntol, T, dyn_lds,
-                       lds_doubles, c.dbg, c.dbgbuf);
+    if ((c.dbg & 64) || panel_rows(s, num, c.Stair + s.rp, p) > lds_doubles - 65)
+        dev_panel<NTP, true>(ps, s, num, F, c.Stair + s.rp, c.Tau + s.rp, c.Rdead + s.col1, p, c.tol, c.ntol, T, dyn_lds,
+                             lds_doubles, c.dbg, c.dbgbuf);
+    else
+        dev_panel<NTP, false>(ps, s, num, F, c.Stair + s.rp, c.Tau + s.rp, c.Rdead + s.col1, p, c.tol, c.ntol, T, dyn_lds,
+                              lds_doubles, c.dbg, c.dbgbuf);
 }
 
 __global__ __launch_bounds__(NT) void k_update(DevCtx c, const int *__restrict__ flist, int p, int cb0)
@@ -913,6 +949,166 @@ __global__ __launch_bounds__(NT) void k_larft(DevCtx c, int f)
     __syncthreads();
     dev_gram_T<NT>(c.Farena + s.foff + (long long)num->pk1 * s.ld, s.ld, num->pg1, num->pt, num->pnb, s_diag, s_tau, s_G,
                s_T, c.Tws + (long long)(2 * c.tslot[f]) * STM_NB * STM_NB, dyn_lds);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Row-parallel trailing update for tall panels: the three phases of dev_update_block as three launches so that
+// the rows are split over workgroups too (a 4000-row update has 126 column blocks x 16 row slabs instead of
+// 126 workgroups that each walk 63 chunks):
+//   k_upd_w : partial W1 = V(slab)' C(slab, cb)            grid (cb, slab, front)   -> Wp[front][cb][slab]
+//   k_upd_t : W2 = T' sum_slabs W1                          grid (cb, front)         -> Wp[front][cb][0]
+//   k_upd_c : C(slab, cb) -= V(slab) W2                     grid (cb, slab, front)
+// SLAB rows per slab; the summation order over slabs is fixed (deterministic results).
+// ------------------------------------------------------------------------------------------------
+#define SLAB 256
+
+__device__ __forceinline__ void upd_load_chunk(const double *Vg, const double *Cg, long long ld, int i, int mp, int nbp,
+                                               int nc, const int *s_pd, int g1, int lrow, int lcg, double *Vs,
+                                               double *Cs, bool want_c)
+{
+#pragma unroll
+    for (int q = 0; q < 8; q++) {
+        const int col = lcg * 8 + q;
+        double v = 0, cv = 0;
+        if (i < mp) {
+            if (col < nbp) {
+                const int d = s_pd[col] - g1;
+                v = (i < d) ? 0.0 : ((i == d) ? 1.0 : Vg[i + col * ld]);
+            }
+            if (want_c && col < nc) cv = Cg[i + col * ld];
+        }
+        Vs[col * VS + lrow] = v;
+        if (want_c) Cs[col * VS + lrow] = cv;
+    }
+}
+
+__global__ __launch_bounds__(NT) void k_upd_w(DevCtx c, const int *__restrict__ flist, int p, int cb0, double *Wp,
+                                              int maxcb, int maxsl)
+{
+    extern __shared__ double dyn_lds[];
+    __shared__ int s_pd[STM_NB];
+    const int fi = blockIdx.z, f = flist[fi];
+    const FrontSym s = c.fs[f];
+    if (p >= s.npanels) return;
+    const PanelDesc *pd = &c.fnum[f].pd[p & 1];
+    const int g1 = pd->pg1, mp = pd->pt - pd->pg1, nbp = pd->pnb;
+    const int cb = blockIdx.x, sl = blockIdx.y;
+    const int c0 = pd->pc0 + (cb0 + cb) * BN;
+    if (nbp <= 0 || mp <= 0 || c0 >= s.fn || sl * SLAB >= mp) return;
+    const int nc = min(BN, s.fn - c0);
+    const long long ld = s.ld;
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, l15 = lane & 15, l4 = lane >> 4;
+    double *Vs = dyn_lds, *Cs = Vs + STM_NB * VS;
+    if (tid < STM_NB) s_pd[tid] = (tid < nbp) ? pd->pdiag[tid] : STM_BIGROW;
+    __syncthreads();
+    const double *Vg = c.Farena + s.foff + g1 + (long long)pd->pk1 * ld;
+    const double *Cg = c.Farena + s.foff + g1 + (long long)c0 * ld;
+    const int mi = wid >> 1, ni = wid & 1;
+    d4 acc = {0, 0, 0, 0};
+    const int rend = min(mp, (sl + 1) * SLAB);
+    for (int r0 = sl * SLAB; r0 < rend; r0 += RB) {
+        upd_load_chunk(Vg, Cg, ld, r0 + (tid & 63), mp, nbp, nc, s_pd, g1, tid & 63, tid >> 6, Vs, Cs, true);
+        __syncthreads();
+#pragma unroll
+        for (int kk = 0; kk < RB / 4; kk++) {
+            const double a = Vs[(16 * mi + l15) * VS + 4 * kk + l4];
+            const double b = Cs[(16 * ni + l15) * VS + 4 * kk + l4];
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
+        }
+        __syncthreads();
+    }
+    double *W = Wp + ((long long)(fi * maxcb + cb) * maxsl + sl) * (STM_NB * BN);
+#pragma unroll
+    for (int r = 0; r < 4; r++) W[(16 * mi + l4 + 4 * r) * BN + 16 * ni + l15] = acc[r];
+}
+
+__global__ __launch_bounds__(NT) void k_upd_t(DevCtx c, const int *__restrict__ flist, int p, int cb0, double *Wp,
+                                              int maxcb, int maxsl)
+{
+    __shared__ double s_W[STM_NB * WS];
+    const int fi = blockIdx.y, f = flist[fi];
+    const FrontSym s = c.fs[f];
+    if (p >= s.npanels) return;
+    const PanelDesc *pd = &c.fnum[f].pd[p & 1];
+    const int mp = pd->pt - pd->pg1, nbp = pd->pnb;
+    const int cb = blockIdx.x;
+    const int c0 = pd->pc0 + (cb0 + cb) * BN;
+    if (nbp <= 0 || mp <= 0 || c0 >= s.fn) return;
+    const int nsl = (mp + SLAB - 1) / SLAB;
+    const int tid = threadIdx.x;
+    double *W0 = Wp + ((long long)(fi * maxcb + cb) * maxsl) * (STM_NB * BN);
+    const double *T = c.Tws + (long long)(2 * c.tslot[f] + (p & 1)) * STM_NB * STM_NB;
+    for (int e = tid; e < STM_NB * BN; e += NT) {
+        double v = 0;
+        for (int sl = 0; sl < nsl; sl++) v += W0[(long long)sl * (STM_NB * BN) + e];
+        s_W[(e / BN) * WS + (e % BN)] = v;
+    }
+    __syncthreads();
+    const int l = tid & 31, cg = tid >> 5;
+    double w2[4] = {0, 0, 0, 0};
+    for (int q = 0; q <= l; q++) {
+        const double tq = T[q + l * STM_NB];
+#pragma unroll
+        for (int x = 0; x < 4; x++) w2[x] += tq * s_W[q * WS + cg * 4 + x];
+    }
+#pragma unroll
+    for (int x = 0; x < 4; x++) W0[l * BN + cg * 4 + x] = w2[x];      // slab 0 slot now holds W2
+}
+
+__global__ __launch_bounds__(NT) void k_upd_c(DevCtx c, const int *__restrict__ flist, int p, int cb0,
+                                              const double *Wp, int maxcb, int maxsl)
+{
+    extern __shared__ double dyn_lds[];
+    __shared__ int s_pd[STM_NB];
+    const int fi = blockIdx.z, f = flist[fi];
+    const FrontSym s = c.fs[f];
+    if (p >= s.npanels) return;
+    const PanelDesc *pd = &c.fnum[f].pd[p & 1];
+    const int g1 = pd->pg1, mp = pd->pt - pd->pg1, nbp = pd->pnb;
+    const int cb = blockIdx.x, sl = blockIdx.y;
+    const int c0 = pd->pc0 + (cb0 + cb) * BN;
+    if (nbp <= 0 || mp <= 0 || c0 >= s.fn || sl * SLAB >= mp) return;
+    const int nc = min(BN, s.fn - c0);
+    const long long ld = s.ld;
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, l15 = lane & 15, l4 = lane >> 4;
+    double *Vs = dyn_lds, *Cs = Vs + STM_NB * VS, *Ws = Cs + BN * VS;
+    if (tid < STM_NB) s_pd[tid] = (tid < nbp) ? pd->pdiag[tid] : STM_BIGROW;
+    const double *W2 = Wp + ((long long)(fi * maxcb + cb) * maxsl) * (STM_NB * BN);
+    for (int e = tid; e < STM_NB * BN; e += NT) Ws[(e / BN) * WS + (e % BN)] = W2[e];
+    __syncthreads();
+    const double *Vg = c.Farena + s.foff + g1 + (long long)pd->pk1 * ld;
+    double *Cg = c.Farena + s.foff + g1 + (long long)c0 * ld;
+    const int lrow = tid & 63, lcg = tid >> 6;
+    const int rend = min(mp, (sl + 1) * SLAB);
+    for (int r0 = sl * SLAB; r0 < rend; r0 += RB) {
+        const int i = r0 + lrow;
+        upd_load_chunk(Vg, Cg, ld, i, mp, nbp, nc, s_pd, g1, lrow, lcg, Vs, Cs, true);
+        __syncthreads();
+        d4 u0 = {0, 0, 0, 0}, u1 = {0, 0, 0, 0};
+#pragma unroll
+        for (int kk = 0; kk < STM_NB / 4; kk++) {
+            const double a = Vs[(4 * kk + l4) * VS + 16 * wid + l15];
+            const double b0 = Ws[(4 * kk + l4) * WS + l15];
+            const double b1 = Ws[(4 * kk + l4) * WS + 16 + l15];
+            u0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b0, u0, 0, 0, 0);
+            u1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b1, u1, 0, 0, 0);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const int row = 16 * wid + l4 + 4 * r;
+            Cs[l15 * VS + row] -= u0[r];
+            Cs[(16 + l15) * VS + row] -= u1[r];
+        }
+        __syncthreads();
+        if (i < mp) {
+#pragma unroll
+            for (int q = 0; q < 8; q++) {
+                const int col = lcg * 8 + q;
+                if (col < nc) Cg[i + col * ld] = Cs[col * VS + lrow];
+            }
+        }
+        __syncthreads();
+    }
 }
 
 __global__ __launch_bounds__(NT) void k_cpack(DevCtx c, const int *__restrict__ flist,
@@ -1082,6 +1278,16 @@ int stm_launch_update(const DevCtx &c, const int *flist, int nfr, int p, int cb0
 {
     if (nfr <= 0 || ncb <= 0) return 0;
     hipLaunchKernelGGL(k_update, dim3(ncb, nfr), dim3(NT), (size_t)stm_update_lds_bytes(), st, c, flist, p, cb0);
+    return (int)hipGetLastError();
+}
+int stm_launch_update_split(const DevCtx &c, const int *flist, int nfr, int p, int cb0, int ncb, int maxsl, double *Wp,
+                            hipStream_t st)
+{
+    if (nfr <= 0 || ncb <= 0 || maxsl <= 0) return 0;
+    const size_t lds = (size_t)stm_update_lds_bytes();
+    hipLaunchKernelGGL(k_upd_w, dim3(ncb, maxsl, nfr), dim3(NT), lds, st, c, flist, p, cb0, Wp, ncb, maxsl);
+    hipLaunchKernelGGL(k_upd_t, dim3(ncb, nfr), dim3(NT), 0, st, c, flist, p, cb0, Wp, ncb, maxsl);
+    hipLaunchKernelGGL(k_upd_c, dim3(ncb, maxsl, nfr), dim3(NT), lds, st, c, flist, p, cb0, (const double *)Wp, ncb, maxsl);
     return (int)hipGetLastError();
 }
 int stm_launch_larft(const DevCtx &c, int f, hipStream_t st)
