@@ -676,6 +676,7 @@ __device__ __forceinline__ void dev_panel(PanelShared &ps, const FrontSym &s, Fr
                 CSTAMP(6);
             } else if (ps.nextss_col == j && !(dbg & 128)) {
                 part[0] = ps.nextss;                    // computed by the dlarf sweep of the previous column
+                __syncthreads();                        // every wave has read alpha / nextss before anyone writes
             } else {
                 double ss0 = 0;
                 for (int i = 1 + tid; i < len; i += NTH) { const double xv = col[i]; ss0 += xv * xv; }

@@ -8,6 +8,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -82,6 +83,7 @@ struct OneFront {
         memset(&c, 0, sizeof c);
         c.fs = d_fs.p; c.fnum = d_nm.p; c.Farena = d_F.p; c.Carena = d_C.p; c.Tws = d_T.p; c.tslot = d_tslot.p;
         c.Stair = d_St.p; c.Tau = d_Tau.p; c.Rdead = d_Rdead.p; c.Rhoff = d_Rhoff.p; c.Rboff = d_Rboff.p;
+        c.dbg = getenv("STMMQR_DBG") ? atoi(getenv("STMMQR_DBG")) : 0;
         return true;
     }
     bool push_num() { return hipMemcpy(d_nm.p, &nm, sizeof nm, hipMemcpyHostToDevice) == hipSuccess; }
