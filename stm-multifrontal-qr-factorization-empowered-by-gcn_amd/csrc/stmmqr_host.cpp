@@ -29,7 +29,7 @@
 namespace {
 
 thread_local std::string g_err;
-stmmqr_options g_opt = {STM_NB, 128, 0, 0, 0, 1};
+stmmqr_options g_opt = {STM_NB, 64, 0, 0, 0, 1};
 size_t g_chunk[4] = {32, 5000, 4, 4};     // FCHUNK, SMALL, MINCHUNK, MINCHUNK_RATIO (SparseQR.h:16-19)
 
 // offsets inside the reference's sparse_common for the stock LP64 build; verified against the real header
@@ -542,6 +542,17 @@ int run_schedule(stmmqr_plan &P, bool detail, int grp, bool first)
         } else {
             // look-ahead: the update of panel p is split into the column block the NEXT panel needs (stays on the
             // main stream) and the rest, which runs on stream2 while panel p+1 is being factorized
+            if (!P.stream2) {
+                // look-ahead stream, created on first use: a few CUs are kept out of its mask so that the next panel's
+                // workgroup (one CU, ~150 KB of LDS) can start while the tail of the update fills the rest of the chip
+                uint32_t mask[8];
+                for (auto &w : mask) w = 0xffffffffu;
+                mask[0] &= ~0xffffu;
+                if (hipExtStreamCreateWithCUMask(&P.stream2, 8, mask) != hipSuccess) {
+                    (void)hipGetLastError();
+                    HIPCHK(hipStreamCreateWithFlags(&P.stream2, hipStreamNonBlocking));
+                }
+            }
             hipStream_t s2 = P.stream2;
             hipEvent_t prev_rest = nullptr;
             for (size_t p = 0; p < L.nbig_at.size(); p++) {
@@ -658,18 +669,6 @@ stmmqr_plan *stmmqr_plan_create(const stmmqr_symbolic_view *sym, int device, int
         (void)hipGetDevice(&P->device);
         if (hipStreamCreateWithFlags(&P->stream, hipStreamNonBlocking) != hipSuccess)
             st = fail(STMMQR_ERR_DEVICE, "hipStreamCreate failed");
-        if (!st) {
-            // look-ahead stream: keep a few CUs out of its mask so that the next panel's workgroup (one CU, ~150 KB
-            // of LDS) can start while the tail of the trailing update still fills the rest of the chip
-            uint32_t mask[8];
-            for (auto &w : mask) w = 0xffffffffu;
-            mask[0] &= ~0xffffu;
-            if (hipExtStreamCreateWithCUMask(&P->stream2, 8, mask) != hipSuccess) {
-                (void)hipGetLastError();
-                if (hipStreamCreateWithFlags(&P->stream2, hipStreamNonBlocking) != hipSuccess)
-                    st = fail(STMMQR_ERR_DEVICE, "hipStreamCreate failed");
-            }
-        }
         for (auto &e : P->ev)
             if (!st && hipEventCreate(&e) != hipSuccess) st = fail(STMMQR_ERR_DEVICE, "hipEventCreate failed");
     }

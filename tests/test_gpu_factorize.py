@@ -30,7 +30,7 @@ def gpu_run(pkg, g):
 
 
 @pytest.mark.parametrize("name", NAMES)
-@pytest.mark.parametrize("bigcols", [128, 16])
+@pytest.mark.parametrize("bigcols", [64, 16])
 def test_against_golden_and_oracle(pkg, oracle, name, bigcols):
     """bigcols=16 forces nearly every front through the multi-workgroup panel/update path."""
     g = load_golden(name)
@@ -38,7 +38,7 @@ def test_against_golden_and_oracle(pkg, oracle, name, bigcols):
     try:
         S, G = gpu_run(pkg, g)
     finally:
-        pkg.set_options(big_front_cols=128)
+        pkg.set_options(big_front_cols=64)
     N = numeric_from_gpu(S, G)
     # 1. integer outputs against the REAL reference's golden vectors
     compare_integers(S, N, g)

@@ -34,7 +34,7 @@ FRONTS = [(6, 4, 4), (5, 8, 3), (40, 30, 12), (64, 96, 32), (130, 70, 70), (266,
 
 
 @pytest.mark.parametrize("m,n,npiv", FRONTS)
-@pytest.mark.parametrize("bigcols", [128, 8])
+@pytest.mark.parametrize("bigcols", [64, 8])
 @pytest.mark.parametrize("stair", ["ramp", "full"])
 def test_qr_front(pkg, oracle, m, n, npiv, bigcols, stair):
     F0, St0 = make_front(m, n, 1234 + m + n, stair)
@@ -44,7 +44,7 @@ def test_qr_front(pkg, oracle, m, n, npiv, bigcols, stair):
     try:
         rg, Tg, Dg, flg = pkg.qr_front(m, n, npiv, -1.0, n, Fg, Sg)
     finally:
-        pkg.set_options(big_front_cols=128)
+        pkg.set_options(big_front_cols=64)
     ro, To, Do, flo = oracle.front(Fo, So, npiv, -1.0, n)
     assert rg == ro
     np.testing.assert_array_equal(Sg, So)
@@ -68,7 +68,7 @@ def test_qr_front_dead_columns(pkg, oracle):
         try:
             rg, Tg, Dg, _ = pkg.qr_front(m, n, npiv, tol, npiv, Fg, Sg)
         finally:
-            pkg.set_options(big_front_cols=128)
+            pkg.set_options(big_front_cols=64)
         ro, To, Do, _ = oracle.front(Fo, So, npiv, tol, npiv)
         assert rg == ro == npiv - 3
         np.testing.assert_array_equal(Dg, Do)
