@@ -92,6 +92,9 @@ def main():
     ap.add_argument("--workload", default="xenon1_standin")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--big-front-cols", type=int, default=None)
+    ap.add_argument("--mode", choices=["replicas", "sharded"], default="replicas",
+                    help="N>1: replicas = every rank factorizes its own matrix (weak scaling, default); "
+                         "sharded = ONE matrix, subtrees on the ranks, contribution blocks to rank 0 over RCCL (strong)")
     args = ap.parse_args()
 
     import torch
@@ -127,27 +130,45 @@ def main():
         torch.cuda.synchronize()
 
     st = None
+    sharded = args.mode == "sharded" and world > 1
+    if sharded:
+        sh = importlib.import_module(PKG + ".sharded")
+        comm = sh.Comm(dist, dev)
+        owner, phase = sh.partition(sym, world)
+
+        def step():
+            return sh.factorize_sharded(plan, sym, None, tol, ntol, comm, owner=owner, phase=phase,
+                                        device_ptr=Ax.data_ptr())[0]
+    else:
+        def step():
+            return plan.factorize(None, tol, ntol, device_ptr=Ax.data_ptr())
     for _ in range(args.warmup):
-        st = plan.factorize(None, tol, ntol, device_ptr=Ax.data_ptr())
+        st = step()
     barrier()
     t0 = time.perf_counter()
     dev_ms = 0.0
     for _ in range(args.steps):
-        st = plan.factorize(None, tol, ntol, device_ptr=Ax.data_ptr())
+        st = step()
         dev_ms += st["ms_total"]
     barrier()
     wall = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([wall], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        wall = float(t.item())
-    flops = st["flops"]
-    assert flops == scalar(g, "flopcount"), (flops, scalar(g, "flopcount"))
+        t = torch.tensor([wall, st["flops"]], device=dev, dtype=torch.float64)
+        tmax = t.clone(); dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        tsum = t.clone(); dist.all_reduce(tsum, op=dist.ReduceOp.SUM)
+        wall = float(tmax[0].item())
+        total_flops = float(tsum[1].item())          # replicas: world x flops; sharded: the shards add up to one matrix
+    else:
+        total_flops = st["flops"]
+    flops = scalar(g, "flopcount")
+    assert total_flops == (flops if (sharded or world == 1) else world * flops), (total_flops, flops)
 
     # one extra, un-timed step with per-category HIP events (forces a sync per level: not part of `value`)
+    if sharded:
+        plan.set_groups(np.zeros(S.nf, np.int32))
     det = plan.factorize(None, tol, ntol, device_ptr=Ax.data_ptr(), detail=True)
     if rank == 0:
-        value = world * flops * args.steps / wall * 1e-9
+        value = total_flops * args.steps / wall * 1e-9
         upd_tf = det["flops_update"] / max(det["ms_update"], 1e-9) * 1e-9 if det["ms_update"] > 0 else 0.0
         front_tf = flops / max(det["ms_front"], 1e-9) * 1e-9
         if det["ms_update"] > 0.5 * det["ms_front"]:
@@ -158,6 +179,19 @@ def main():
             roof = {"bound": "mfma", "kernel": "front kernels (k_front_wg + k_panel + k_update)", "achieved": front_tf,
                     "peak": PEAK_FP64_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": front_tf / PEAK_FP64_MFMA_TFLOPS,
                     "traffic": None}
+        pmc = ROOT / "profiles" / "r01_b_pmc_fetch_write_per_kernel.json"
+        if pmc.exists() and "standin" in name:
+            try:
+                pk = json.loads(pmc.read_text())["k_update"]
+                # KB units; FETCH_SIZE on gfx950 counts 64 B per 128-B request on wide streams (not corrected here)
+                per_launch = (pk["FETCH_SIZE"]["sum_kb"] / pk["FETCH_SIZE"]["calls"] +
+                              pk["WRITE_SIZE"]["sum_kb"] / pk["WRITE_SIZE"]["calls"]) * 1024.0
+                roof["update_kernel"] = {"bound": "mfma", "achieved": upd_tf, "peak": PEAK_FP64_MFMA_TFLOPS, "unit": "TFLOP/s",
+                                         "frac": upd_tf / PEAK_FP64_MFMA_TFLOPS,
+                                         "traffic_bytes_per_launch_pmc": per_launch,
+                                         "traffic_source": "profiles/r01_b_pmc_fetch_write_per_kernel.json (k_update, pre-split build)"}
+            except Exception:
+                pass
         roof["assembly"] = {"bound": "hbm", "achieved": det["bytes_assemble"] / max(det["ms_assemble"], 1e-9) * 1e-6,
                             "peak": PEAK_HBM_GBS, "unit": "GB/s",
                             "frac": det["bytes_assemble"] / max(det["ms_assemble"], 1e-9) * 1e-6 / PEAK_HBM_GBS}
@@ -165,11 +199,11 @@ def main():
         out = {
             "metric": "numerical-factorization GFLOP/s", "value": value, "unit": "GFLOP/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": wall / args.steps * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "higher_is_better": True, "scaling": "strong" if sharded else "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": f"{name}: m={S.m} n={S.n} nnz={S.anz} fronts={S.nf} "
                                    f"flops/step={flops:.4g} (stand-in for xenon1.mtx, absent from the reference checkout)"
                        if "standin" in name else f"{name}: m={S.m} n={S.n} nnz={S.anz} fronts={S.nf} flops/step={flops:.4g}",
-                       "inputs": "values resident in HBM, factors left in HBM", "parallelism": f"replica x{world}",
+                       "inputs": "values resident in HBM, factors left in HBM", "parallelism": (f"subtree-sharded x{world}" if sharded else f"replica x{world}"),
                        "device_ms_per_step": dev_ms / args.steps, "launches_per_step": st["nlaunch"],
                        "levels": st["nlevels"]},
             "roofline": roof,

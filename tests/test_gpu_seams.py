@@ -34,7 +34,7 @@ FRONTS = [(6, 4, 4), (5, 8, 3), (40, 30, 12), (64, 96, 32), (130, 70, 70), (266,
 
 
 @pytest.mark.parametrize("m,n,npiv", FRONTS)
-@pytest.mark.parametrize("bigcols", [64, 8])
+@pytest.mark.parametrize("bigcols", [128, 8])
 @pytest.mark.parametrize("stair", ["ramp", "full"])
 def test_qr_front(pkg, oracle, m, n, npiv, bigcols, stair):
     F0, St0 = make_front(m, n, 1234 + m + n, stair)
