@@ -5,6 +5,7 @@
 // anz < 2^31 is checked by the planner); arena offsets are 64-bit.
 #pragma once
 #include <stdint.h>
+#include <hip/hip_runtime.h>
 
 #define STM_NB 32            // Householder panel width (reference FCHUNK = 32, qrtest.c:152)
 #define STM_BIGROW 0x3fffffff
@@ -23,7 +24,7 @@ struct FrontSym {
     int fm_ub;               // symbolic upper bound on the number of rows
     int npanels;             // ceil(fn / STM_NB)
     int parent;              // parent front or -1
-    int pad0;
+    int fm_est;              // rows of F if no pivot column dies (exact for full-rank fronts): launch planning only
 };
 
 // one pending block reflector (written by the panel kernel, read by the update kernel)
@@ -31,9 +32,29 @@ struct PanelDesc {
     int pg1, pt;             // rows [pg1, pt)
     int pk1, pnb;            // built from columns [pk1, pk1+pnb)
     int pc0;                 // to be applied to columns [pc0, fn)
-    int pad;
+    int mode;                // tall-panel pipeline: 1 while sub-panels are pending, 0 whole panel finished, 2 finalised early
     int pdiag[STM_NB];       // row of the unit diagonal of each reflector (BIGROW: none)
+    // tall-panel pipeline state (sub-panels of STM_SW columns, one launch per sub-panel)
+    int tmax;                // rows [pg1, tmax) are touched by the panel
+    int nlive;               // live reflectors so far
+    int sg[STM_NB / 8];      // first active row (g) at the start of sub-panel s
+    int st[STM_NB / 8];      // one past the last row reached by the reflectors of sub-panel s
 };
+
+#define STM_SW 8             // sub-panel width of the tall-panel pipeline
+#define STM_TALL_MIN 768     // panels with more (estimated) rows than this take the pipeline
+#define STM_TALL_NTH 512     // threads of the panel kernel
+#define STM_TALL_MAX (8 * STM_TALL_NTH)   // rows a sub-panel can hold in registers (8 per thread)
+
+// Does panel p of this front take the tall-panel pipeline?  Planned on the host (number of launches) and re-evaluated
+// on the device from the same symbolic data, so both always agree.
+static inline __host__ __device__ int stm_tall_panel(const FrontSym &s, int p)
+{
+    int g = p * STM_NB;
+    if (g > s.fp) g = s.fp;
+    if (g > s.fm_est) g = s.fm_est;
+    return s.fm_est - g > STM_TALL_MIN;
+}
 
 // numeric, written by the kernels
 struct FrontNum {

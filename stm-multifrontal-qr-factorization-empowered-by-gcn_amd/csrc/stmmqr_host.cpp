@@ -100,6 +100,7 @@ struct Level {
     int lds_small = 0, lds_big = 0;      // dynamic LDS (doubles) for the panel staging
     std::vector<int> nbig_at;            // big fronts with npanels > p
     std::vector<int> maxcb_at;           // max trailing column blocks at panel p
+    std::vector<int> nsub_at;            // panel launches at p: STM_NB/STM_SW if any front takes the tall-panel pipeline
     std::vector<int> maxsl_at;           // max 256-row slabs of the fronts still active at panel p (0: small)
 };
 
@@ -264,6 +265,7 @@ void build_schedule(stmmqr_plan &P, std::vector<int> &tslot)
             L.lds_big = (int)std::min((long)LDS_CAP_DOUBLES, (maxfm_big | 1) * STM_NB);
             L.nbig_at.assign(maxp, 0);
             L.maxcb_at.assign(maxp, 0);
+            L.nsub_at.assign(maxp, 1);
             L.maxsl_at.assign(maxp, 0);
             for (int p = 0; p < maxp; p++) {
                 int cnt = 0, mcb = 0, msl = 0;
@@ -274,6 +276,7 @@ void build_schedule(stmmqr_plan &P, std::vector<int> &tslot)
                         const int k2 = std::min(s.fn, (p + 1) * STM_NB);
                         mcb = std::max(mcb, (s.fn - k2 + 31) / 32);
                         msl = std::max(msl, (s.fm_ub + 255) / 256);
+                        if (stm_tall_panel(s, p)) L.nsub_at[p] = STM_NB / STM_SW;
                     }
                 }
                 L.nbig_at[p] = cnt;
@@ -346,6 +349,18 @@ int build_plan(stmmqr_plan &P, const stmmqr_symbolic_view &v)
         }
     }
 
+    // the row count every front will have if no pivot column dies (exact for full-rank input): used only to plan the
+    // number of panel launches (stm_tall_panel); the kernels cope with any actual row count
+    std::vector<long> fmest(nf, 0), cmest(nf, 0);
+    for (long kf = 0; kf < nf; kf++) {
+        const long f = P.Post[kf];
+        const long fp = P.Super[f + 1] - P.Super[f], fn = P.Rp[f + 1] - P.Rp[f];
+        long fe = P.Sleft[P.Super[f + 1]] - P.Sleft[P.Super[f]];
+        for (long q = P.Childp[f]; q < P.Childp[f + 1]; q++) fe += cmest[P.Child[q]];
+        fmest[f] = std::min(fe, P.Fm[f]);
+        cmest[f] = std::min(std::max(fe - std::min(fe, fp), 0L), fn - fp);
+    }
+
     P.fs.assign(nf, FrontSym());
     long long foff = 0, coff = 0;
     for (long kf = 0; kf < nf; kf++) {
@@ -358,6 +373,7 @@ int build_plan(stmmqr_plan &P, const stmmqr_symbolic_view &v)
         s.child0 = (int)P.Childp[f]; s.child1 = (int)P.Childp[f + 1];
         s.srow0 = (int)P.Sleft[P.Super[f]]; s.srow1 = (int)P.Sleft[P.Super[f + 1]];
         s.fm_ub = (int)fm;
+        s.fm_est = (int)fmest[f];
         s.ld = (int)std::max(2L, (fm + 1) & ~1L);
         s.npanels = (int)((fn + STM_NB - 1) / STM_NB);
         s.parent = (int)parent[f];
@@ -524,7 +540,7 @@ int run_schedule(stmmqr_plan &P, bool detail, int grp, bool first)
         if (detail || !g_opt.lookahead) {
             for (size_t p = 0; p < L.nbig_at.size(); p++) {
                 e = timed(t_front, [&]() -> int {
-                    LCHK(stm_launch_panel(c, big, L.nbig_at[p], (int)p, L.lds_big, st));
+                    LCHK(stm_launch_panel(c, big, L.nbig_at[p], (int)p, L.nsub_at[p], L.lds_big, st));
                     return 0;
                 });
                 if (e) return e;
@@ -556,7 +572,7 @@ int run_schedule(stmmqr_plan &P, bool detail, int grp, bool first)
             hipStream_t s2 = P.stream2;
             hipEvent_t prev_rest = nullptr;
             for (size_t p = 0; p < L.nbig_at.size(); p++) {
-                LCHK(stm_launch_panel(c, big, L.nbig_at[p], (int)p, L.lds_big, st));
+                LCHK(stm_launch_panel(c, big, L.nbig_at[p], (int)p, L.nsub_at[p], L.lds_big, st));
                 hipEvent_t evp = next_event(), evr = next_event();
                 if (!evp || !evr) return fail(STMMQR_ERR_DEVICE, "hipEventCreate failed");
                 HIPCHK(hipEventRecord(evp, st));

@@ -21,6 +21,7 @@
 #include <stdint.h>
 #include "stmmqr_device.h"
 #include "stmmqr_kernels.h"
+#include "stmmqr_wave.h"
 
 typedef double d4 __attribute__((ext_vector_type(4)));
 
@@ -38,6 +39,7 @@ struct PanelShared {
     double T[STM_NB][STM_NB + 1];
     double part[8 * 32];
     double top[2][8];
+    double rsum[2][64];        // register sub-panel: per-wave sums of the 8 reductions of a column step (two buffers)
     double Ts[8][9];
     double gp[32];
 };
@@ -52,33 +54,6 @@ struct PanelShared {
 // ------------------------------------------------------------------------------------------------
 // small helpers
 // ------------------------------------------------------------------------------------------------
-// one DPP step of an fp64 butterfly: v + (v moved by the DPP control), both 32-bit halves moved separately
-template <int CTRL>
-__device__ __forceinline__ double dpp_add(double v)
-{
-    const int lo = __double2loint(v), hi = __double2hiint(v);
-    const int lo2 = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xf, 0xf, true);
-    const int hi2 = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xf, 0xf, true);
-    return v + __hiloint2double(hi2, lo2);
-}
-
-// sum over the 64 lanes of a wave, result in every lane.  Four DPP steps (quad_perm [1,0,3,2], [2,3,0,1],
-// row_half_mirror, row_mirror) give every lane the total of its row of 16; the four row totals are combined
-// through v_readlane -- no LDS crossbar traffic (ds_bpermute), which dominated the shuffle version.
-__device__ __forceinline__ double wave_sum(double v)
-{
-    v = dpp_add<0xB1>(v);
-    v = dpp_add<0x4E>(v);
-    v = dpp_add<0x141>(v);
-    v = dpp_add<0x140>(v);
-    const int lo = __double2loint(v), hi = __double2hiint(v);
-    double r = __hiloint2double(__builtin_amdgcn_readlane(hi, 0), __builtin_amdgcn_readlane(lo, 0));
-    r += __hiloint2double(__builtin_amdgcn_readlane(hi, 16), __builtin_amdgcn_readlane(lo, 16));
-    r += __hiloint2double(__builtin_amdgcn_readlane(hi, 32), __builtin_amdgcn_readlane(lo, 32));
-    r += __hiloint2double(__builtin_amdgcn_readlane(hi, 48), __builtin_amdgcn_readlane(lo, 48));
-    return r;
-}
-
 // sum over the whole workgroup of NTH threads; every thread gets the result.  s_red: NTH/64 doubles of LDS.
 template <int NTH>
 __device__ __forceinline__ double block_sum(double v, double *s_red)
@@ -551,6 +526,135 @@ __device__ __forceinline__ int panel_rows(const FrontSym &s, const FrontNum *num
 }
 
 // ------------------------------------------------------------------------------------------------
+// Register-resident sub-panel (qr_front's column loop, reference :1434-1609, for a sub-panel of <= 8 columns whose
+// active rows fit RPT rows per thread).  Thread tid owns rows gs + tid + NTH*r of ALL sub-panel columns, so a
+// column step touches no memory except its one workgroup reduction:
+//   pass 1 : part[x] = sum_{g<i<t} F(i,k) F(i,k+x)   (x = 0: |x|^2 of dlarfg; x > 0: the v'c of dlarf, unscaled)
+//            one 8-value workgroup reduction (halving butterfly + one LDS exchange, ONE barrier, double-buffered)
+//   scalar : beta / tau / 1/(alpha-beta), dead-column test -- every thread redundantly
+//   pass 2 : v = x * scal ;  c_x -= tau (top_x + scal part_x) v   for the remaining columns of the sub-panel
+// The current column always lives in register column 0: a finished column is retired to the LDS image
+// (lds[(i-gs) + j*pst], the layout dev_panel's write-back / apply tail expects) and the register columns rotate
+// down by one, so the loop body exists once (an unrolled body per column overflows the instruction cache) and every
+// register index is static.  State (g, rank, ...) follows dev_panel's conventions.
+// ------------------------------------------------------------------------------------------------
+template <int NTH, int RPT, int SWT>
+__device__ __forceinline__ void dev_subpanel_reg(PanelShared &ps, double *F, long long ld, int *St, double *Tau, char *Rdead,
+                                                 int k1, int j0, int sw, int nbp, int gs, int tmax, int m, int n, int npiv,
+                                                 int ntol, double tol, int &g, int &rank, double &flops, int &nlive,
+                                                 int &tlast, int &done, int &ncols_done, double *lds, long long pst)
+{
+    constexpr int NWV = NTH / 64;
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int msp = (max(tmax - gs, 0) + 63) & ~63;
+    double a[RPT][SWT];
+#pragma unroll
+    for (int x = 0; x < SWT; x++) {
+        const double *src = F + (long long)(k1 + j0 + x) * ld;
+#pragma unroll
+        for (int r = 0; r < RPT; r++) {
+            const int i = gs + tid + NTH * r;
+            a[r][x] = (x < sw && i < tmax) ? src[i] : 0.0;
+        }
+    }
+    for (int j = 0; j < sw; j++) {
+        const int jp = j0 + j, k = k1 + jp;
+        if (!done && g >= m) {
+            // no rows left: remaining pivotal columns are dead, remaining columns are empty (:1444-1458)
+            for (int kk = k + tid; kk < n; kk += NTH) {
+                if (kk < npiv) { Rdead[kk] = 1; St[kk] = 0; }
+                else St[kk] = m;
+                Tau[kk] = 0;
+            }
+            for (int jj = jp + tid; jj < nbp; jj += NTH) { ps.diag[jj] = STM_BIGROW; ps.tau[jj] = 0; }
+            done = 1;
+            ncols_done = jp;
+        }
+        if (!done) {
+            const int t = max(g + 1, ps.stair[jp]);
+            const int par = j & 1;
+            double part[8];
+#pragma unroll
+            for (int x = 0; x < 8; x++) part[x] = 0;
+#pragma unroll
+            for (int r = 0; r < RPT; r++) {
+                const int i = gs + tid + NTH * r;
+                const double xv = (i > g && i < t) ? a[r][0] : 0.0;
+#pragma unroll
+                for (int x = 0; x < SWT; x++) part[x] += xv * a[r][x];      // (part[SWT..7] stay zero)
+            }
+            const bool owner = (tid == g - gs);         // holds row g in a[0][.]  (g - gs < 8 <= NTH)
+            if (owner) {
+#pragma unroll
+                for (int x = 0; x < SWT; x++) ps.top[par][x] = a[0][x];
+            }
+            const double rw = wave_reduce8(part);
+            if (lane < 8) ps.rsum[par][wid * 8 + lane] = rw;
+            __syncthreads();
+            const double rb = wave_sum_stride8((lane < NWV * 8) ? ps.rsum[par][lane] : 0.0);
+            double sum[8];
+            sum[0] = lane_bcast<red8_lane(0)>(rb); sum[1] = lane_bcast<red8_lane(1)>(rb);
+            sum[2] = lane_bcast<red8_lane(2)>(rb); sum[3] = lane_bcast<red8_lane(3)>(rb);
+            sum[4] = lane_bcast<red8_lane(4)>(rb); sum[5] = lane_bcast<red8_lane(5)>(rb);
+            sum[6] = lane_bcast<red8_lane(6)>(rb); sum[7] = lane_bcast<red8_lane(7)>(rb);
+            const double alpha = ps.top[par][0];
+            const double ss = sum[0];
+            double tau = 0, beta = alpha, scal = 0;
+            if (ss != 0.0) {                            // (no active row below the diagonal gives ss == 0 exactly)
+                beta = -copysign(sqrt(alpha * alpha + ss), alpha);
+                tau = (beta - alpha) / beta;
+                scal = 1.0 / (alpha - beta);
+            }
+            const bool dead = (k < ntol) && (fabs(beta) <= tol);
+            if (dead) {
+                // zero the column from the diagonal down, no reflector, g does not advance (:1495-1544)
+#pragma unroll
+                for (int r = 0; r < RPT; r++)
+                    if (gs + tid + NTH * r >= g) a[r][0] = 0.0;
+                if (tid == 0) { ps.st_out[jp] = 0; ps.dead[jp] = 1; ps.diag[jp] = STM_BIGROW; ps.tau[jp] = 0; }
+                if (k == npiv - 1) rank = g;            // (:1604-1608) also taken on a dead last pivot
+            } else {
+                if (tid == 0) { ps.st_out[jp] = t; ps.dead[jp] = 0; ps.diag[jp] = g; ps.tau[jp] = tau; }
+                flops += (double)(t - g) * (3.0 + 4.0 * (double)(n - k - 1));
+                if (tau != 0.0) {
+                    nlive++;
+                    double w[8];
+#pragma unroll
+                    for (int x = 1; x < SWT; x++) w[x] = tau * (ps.top[par][x] + scal * sum[x]);
+#pragma unroll
+                    for (int r = 0; r < RPT; r++) {
+                        const int i = gs + tid + NTH * r;
+                        if (i > g && i < t) {
+                            const double v = a[r][0] * scal;
+                            a[r][0] = v;
+#pragma unroll
+                            for (int x = 1; x < SWT; x++) a[r][x] -= w[x] * v;
+                        }
+                    }
+                    if (owner) {
+#pragma unroll
+                        for (int x = 1; x < SWT; x++) a[0][x] -= w[x];
+                    }
+                }
+                if (owner) a[0][0] = beta;
+                tlast = t;
+                g++;
+                if (k == npiv - 1) rank = g;
+            }
+        }
+        // ---- retire register column 0 to the LDS image and rotate ----
+#pragma unroll
+        for (int r = 0; r < RPT; r++) {
+            const int il = tid + NTH * r;               // row - gs
+            if (il < msp) lds[il + j * pst] = a[r][0];
+#pragma unroll
+            for (int x = 0; x + 1 < SWT; x++) a[r][x] = a[r][x + 1];
+            a[r][SWT - 1] = 0.0;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // qr_front, one panel of <= STM_NB columns (reference: the column loop :1434-1609 with the panel policy
 // fixed to k1 = p*NB, which changes rounding only).  Executed by one whole workgroup.
 //
@@ -608,11 +712,20 @@ __device__ __forceinline__ void dev_panel(PanelShared &ps, const FrontSym &s, Fr
     // column norm and all v'c dot products of the rest of the sub-panel (<= 7) at once
     const bool tall = !in_place && mp > 768;
     if (tall) SW = min(SW, 8);
+    // register-resident sub-panels (<= 8 rows per thread, <= 8 columns): dev_subpanel_reg
+    const int reg_min = (dbg >> 16) ? (dbg >> 16) - 1 : 768;      // STMMQR_DBG bits 16.. override the threshold
+    const bool regpath = !in_place && mp > reg_min && mp <= 8 * NTH && !(dbg & 256);
+    if (regpath) SW = min(SW, mp > 4 * NTH ? 4 : 8);     // 8 rows per thread leave registers for 4 columns only
 
+#ifdef STMMQR_STAMPS                                    /* phase timers (debug builds only: they cost 24 live VGPRs) */
     unsigned long long tph[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, tc0 = 0, tc1 = 0;
 #define CSTAMP(idx) do { if (dbg & 32) { const unsigned long long t_ = clock64(); tph[idx] += t_ - tc1; tc1 = t_; } } while (0)
 #define STAMP(idx) do { if (dbg & 16) { __syncthreads(); const unsigned long long t_ = clock64(); tph[idx] += t_ - tc0; tc0 = t_; } } while (0)
     if (dbg & 16) tc0 = clock64();
+#else
+#define CSTAMP(idx) do { } while (0)
+#define STAMP(idx) do { } while (0)
+#endif
     for (int j0 = 0; j0 < nbp && !done; j0 += SW) {
         const int sw = min(SW, nbp - j0);
         const int gs = g;                               // first active row of this sub-panel
@@ -620,21 +733,39 @@ __device__ __forceinline__ void dev_panel(PanelShared &ps, const FrontSym &s, Fr
         long long pst;
         double *Pb;                                     // Pb[(i-roff) + (j-coff)*pst] = F(i, k1+j)
         int roff = 0, coff = 0;                         // (never form a pointer outside the LDS object)
+        bool use_reg = false;
         if constexpr (!INPLACE) {
             const int msp = (max(ms, 0) + 63) & ~63;    // zero-padded so that 64-row slots can be read unmasked
             pst = msp | 1;
-            for (int j = wid; j < sw; j += NWV) {
-                const double *src = F + (k1 + j0 + j) * ld;
-                for (int i = lane; i < msp; i += 64) lds[i + j * pst] = (i < ms) ? src[gs + i] : 0.0;
-            }
+            use_reg = regpath && ms <= 8 * NTH;
+            if (!use_reg)
+                for (int j = wid; j < sw; j += NWV) {
+                    const double *src = F + (k1 + j0 + j) * ld;
+                    for (int i = lane; i < msp; i += 64) lds[i + j * pst] = (i < ms) ? src[gs + i] : 0.0;
+                }
             Pb = lds; roff = gs; coff = j0;
         } else {
             pst = ld;
             Pb = F + k1 * ld;
         }
+        int nlive = 0;
+        if (use_reg) {
+            // ---- register-resident column loop; leaves the finished sub-panel in the LDS image ----
+            if (ms <= NTH)
+                dev_subpanel_reg<NTH, 1, 8>(ps, F, ld, St, Tau, Rdead, k1, j0, sw, nbp, gs, tmax, m, n, npiv, ntol, tol, g, rank,
+                                         flops, nlive, tlast, done, ncols_done, lds, pst);
+            else if (ms <= 2 * NTH)
+                dev_subpanel_reg<NTH, 2, 8>(ps, F, ld, St, Tau, Rdead, k1, j0, sw, nbp, gs, tmax, m, n, npiv, ntol, tol, g, rank,
+                                         flops, nlive, tlast, done, ncols_done, lds, pst);
+            else if (ms <= 4 * NTH)
+                dev_subpanel_reg<NTH, 4, 8>(ps, F, ld, St, Tau, Rdead, k1, j0, sw, nbp, gs, tmax, m, n, npiv, ntol, tol, g, rank,
+                                         flops, nlive, tlast, done, ncols_done, lds, pst);
+            else
+                dev_subpanel_reg<NTH, 8, 4>(ps, F, ld, St, Tau, Rdead, k1, j0, sw, nbp, gs, tmax, m, n, npiv, ntol, tol, g, rank,
+                                         flops, nlive, tlast, done, ncols_done, lds, pst);
+        } else {
         __syncthreads();
         STAMP(0);
-        int nlive = 0;
         for (int j = j0; j < j0 + sw; j++) {
             const int k = k1 + j;
             if (g >= m) {
@@ -653,7 +784,9 @@ __device__ __forceinline__ void dev_panel(PanelShared &ps, const FrontSym &s, Fr
             double *col = Pb + (g - roff) + (j - coff) * pst;   // col[0] = F(g,k)
             const int len = t - g;                      // >= 1
             // ---- dlarfg ----
+#ifdef STMMQR_STAMPS
             if (dbg & 32) tc1 = clock64();
+#endif
             const double alpha = col[0];                // read before the barriers below: thread 0 overwrites it
             const int nrest = tall ? (j0 + sw - 1 - j) : 0;     // remaining sub-panel columns (tall scheme, <= 7)
             double part[8];
@@ -774,6 +907,7 @@ __device__ __forceinline__ void dev_panel(PanelShared &ps, const FrontSym &s, Fr
             __syncthreads();
             CSTAMP(8);
         }
+        }
         __syncthreads();
         STAMP(1);
         if (!in_place) {
@@ -802,6 +936,7 @@ __device__ __forceinline__ void dev_panel(PanelShared &ps, const FrontSym &s, Fr
                                     ld, nbp - (j0 + sw));
             __syncthreads();
         }
+        STAMP(5);
     }
     __syncthreads();
     if (tid < ncols_done) {                            // HStair / HTau / Rdead of this panel, one coalesced flush
@@ -813,8 +948,10 @@ __device__ __forceinline__ void dev_panel(PanelShared &ps, const FrontSym &s, Fr
     // ---- T of the whole panel for the trailing update ----
     if (!(dbg & 2)) dev_gram_T<NTH>(F + (long long)k1 * ld, ld, g1, tlast, nbp, s_diag, s_tau, s_G, s_T, Tout, lds);
     STAMP(4);
+#ifdef STMMQR_STAMPS
     if ((dbg & 16) && tid == 0 && dbgbuf)
         for (int e = 0; e < 12; e++) atomicAdd(&dbgbuf[e], tph[e]);
+#endif
 #undef STAMP
 #undef CSTAMP
     PanelDesc *pd = &num->pd[p & 1];
@@ -830,6 +967,255 @@ __device__ __forceinline__ void dev_panel(PanelShared &ps, const FrontSym &s, Fr
         }
     }
     __syncthreads();
+}
+
+// ------------------------------------------------------------------------------------------------
+// Tall-panel pipeline (panels with more rows than one workgroup can stream through LDS cheaply).
+//
+// The panel's columns are cut into sub-panels of STM_SW = 8 columns.  Launch number `sidx` of the panel kernel runs one
+// workgroup per column group b >= sidx:
+//     * the group's rows [rb, tmax) x 8 columns are loaded ONCE into registers (thread tid owns rows rb + tid + NTH*r),
+//     * the reflectors of sub-panel sidx-1 (factorized by the previous launch, read back from F with the unit-diagonal
+//       mask) are applied to them -- dlarf semantics, reflector after reflector, each v'C an 8-value workgroup
+//       reduction (reference qr_private_apply1, :1359-1381),
+//     * group b == sidx is then factorized in the same registers (the column step of dev_subpanel_reg) and every
+//       finished column is stored straight to F; the other groups store their updated columns.
+// Compared with one workgroup per panel this keeps every column in registers for its whole life inside the panel
+// (one read, one write of F per column and launch), spreads the in-panel dlarfb over up to four CUs, and makes the
+// cost of a column step independent of the panel height (<= STM_TALL_MAX rows).
+// The last launch also builds T of the whole panel (dev_gram_T) and the block-reflector description for k_update.
+// ------------------------------------------------------------------------------------------------
+// barrier that orders LDS traffic only: the column stores to F stay in flight (a full __syncthreads would wait for them)
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+template <int NTH>
+__device__ __forceinline__ void block_reduce8(PanelShared &ps, int &par, const double (&part)[8], double (&sum)[8])
+{
+    constexpr int NWV = NTH / 64;
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const double rw = wave_reduce8(part);
+    if (lane < 8) ps.rsum[par][wid * 8 + lane] = rw;
+    lds_barrier();
+    const double rb = wave_sum_stride8((lane < NWV * 8) ? ps.rsum[par][lane] : 0.0);
+    sum[0] = lane_bcast<red8_lane(0)>(rb); sum[1] = lane_bcast<red8_lane(1)>(rb);
+    sum[2] = lane_bcast<red8_lane(2)>(rb); sum[3] = lane_bcast<red8_lane(3)>(rb);
+    sum[4] = lane_bcast<red8_lane(4)>(rb); sum[5] = lane_bcast<red8_lane(5)>(rb);
+    sum[6] = lane_bcast<red8_lane(6)>(rb); sum[7] = lane_bcast<red8_lane(7)>(rb);
+    par ^= 1;
+}
+
+template <int NTH, int RPT>
+__device__ __forceinline__ void dev_tall_group(PanelShared &ps, const FrontSym &s, FrontNum *num, PanelDesc *pd, double *F,
+                                               int *St, double *Tau, char *Rdead, int p, int sidx, int b, double tol,
+                                               int ntol_global, double *Tout, double *lds)
+{
+    constexpr int SWT = STM_SW;
+    const int tid = threadIdx.x;
+    const int m = num->fm, n = s.fn, npiv = s.fp;
+    const long long ld = s.ld;
+    const int k1 = p * STM_NB, k2 = min(n, k1 + STM_NB), nbp = k2 - k1;
+    const int tmax = pd->tmax, g1 = pd->pg1;
+    const int c0 = SWT * b, sw = min(SWT, nbp - c0);           // my columns: k1 + c0 + x, x < sw
+    const int rb = (sidx == 0) ? g1 : pd->sg[sidx - 1];        // first row of the register image
+    const bool factor = (b == sidx);
+    int par = 0;
+    if (tid < SWT) ps.stair[tid] = (tid < sw) ? St[k1 + c0 + tid] : 0;
+
+    double a[RPT][SWT];
+#pragma unroll
+    for (int x = 0; x < SWT; x++) {
+        const double *src = F + (long long)(k1 + c0 + x) * ld;
+#pragma unroll
+        for (int r = 0; r < RPT; r++) {
+            const int i = rb + tid + NTH * r;
+            a[r][x] = (x < sw && i < tmax) ? src[i] : 0.0;
+        }
+    }
+    // ---- apply the reflectors of the previous sub-panel ----
+    if (sidx > 0) {
+        const int pc0 = SWT * (sidx - 1);
+        const int tprev = pd->st[sidx - 1];
+        double vn[RPT];
+        {
+            const double *vc = F + (long long)(k1 + pc0) * ld;
+#pragma unroll
+            for (int r = 0; r < RPT; r++) {
+                const int i = rb + tid + NTH * r;
+                vn[r] = (i < tprev) ? vc[i] : 0.0;
+            }
+        }
+        for (int q = 0; q < SWT; q++) {
+            const int d = pd->pdiag[pc0 + q];
+            const double tau = Tau[k1 + pc0 + q];
+            double v[RPT];
+#pragma unroll
+            for (int r = 0; r < RPT; r++) {
+                const int i = rb + tid + NTH * r;
+                v[r] = (i < d) ? 0.0 : ((i == d) ? 1.0 : vn[r]);
+            }
+            if (q + 1 < SWT) {                                 // next reflector's column: in flight during the reduction
+                const double *vc = F + (long long)(k1 + pc0 + q + 1) * ld;
+#pragma unroll
+                for (int r = 0; r < RPT; r++) {
+                    const int i = rb + tid + NTH * r;
+                    vn[r] = (i < tprev) ? vc[i] : 0.0;
+                }
+            }
+            if (tau == 0.0 || d >= STM_BIGROW) continue;       // identity / dead column (uniform)
+            double part[8], sum[8];
+#pragma unroll
+            for (int x = 0; x < 8; x++) part[x] = 0;
+#pragma unroll
+            for (int r = 0; r < RPT; r++) {
+#pragma unroll
+                for (int x = 0; x < SWT; x++) part[x] += v[r] * a[r][x];
+            }
+            block_reduce8<NTH>(ps, par, part, sum);
+#pragma unroll
+            for (int r = 0; r < RPT; r++) {
+                const double tv = tau * v[r];
+#pragma unroll
+                for (int x = 0; x < SWT; x++) a[r][x] -= sum[x] * tv;
+            }
+        }
+    }
+    // the previous sub-panel ran out of rows (g reached fm): its reflectors were still due on the later column groups
+    // (applied above); nothing is left to factorize, the group that would have been next finalises the panel
+    const int was_done = num->done;
+    if (!factor || was_done) {
+#pragma unroll
+        for (int x = 0; x < SWT; x++) {
+            if (x < sw) {
+                double *dst = F + (long long)(k1 + c0 + x) * ld;
+#pragma unroll
+                for (int r = 0; r < RPT; r++) {
+                    const int i = rb + tid + NTH * r;
+                    if (i < tmax) dst[i] = a[r][x];
+                }
+            }
+        }
+        if (!factor) return;
+    }
+    // ---- factorize my sub-panel (column step as in dev_subpanel_reg; finished columns go straight to F) ----
+    int g = num->g, rank = num->rank, done = was_done, nlive = 0, tlast = pd->pt;
+    const int gs = g;
+    const int ntol = min(ntol_global - s.col1, npiv);
+    double flops = 0;
+    lds_barrier();                                             // ps.stair
+    for (int j = 0; j < sw && !was_done; j++) {
+        const int jp = c0 + j, k = k1 + jp;
+        if (!done && g >= m) {
+            // no rows left: remaining pivotal columns are dead, remaining columns are empty (:1444-1458)
+            for (int kk = k + tid; kk < n; kk += NTH) {
+                if (kk < npiv) { Rdead[kk] = 1; St[kk] = 0; }
+                else St[kk] = m;
+                Tau[kk] = 0;
+            }
+            for (int jj = jp + tid; jj < STM_NB; jj += NTH) pd->pdiag[jj] = STM_BIGROW;
+            done = 1;
+        }
+        if (!done) {
+            const int t = max(g + 1, ps.stair[j]);
+            double part[8], sum[8];
+#pragma unroll
+            for (int x = 0; x < 8; x++) part[x] = 0;
+#pragma unroll
+            for (int r = 0; r < RPT; r++) {
+                const int i = rb + tid + NTH * r;
+                const double xv = (i > g && i < t) ? a[r][0] : 0.0;
+#pragma unroll
+                for (int x = 0; x < SWT; x++) part[x] += xv * a[r][x];
+            }
+            const bool owner = (tid == g - rb);                // holds row g in a[0][.]  (g - rb < 2*SWT <= NTH)
+            const int tpar = par;
+            if (owner) {
+#pragma unroll
+                for (int x = 0; x < SWT; x++) ps.top[tpar][x] = a[0][x];
+            }
+            block_reduce8<NTH>(ps, par, part, sum);
+            const double alpha = ps.top[tpar][0];
+            const double ss = sum[0];
+            double tau = 0, beta = alpha, scal = 0;
+            if (ss != 0.0) {                                   // (no active row below the diagonal gives ss == 0 exactly)
+                beta = -copysign(sqrt(alpha * alpha + ss), alpha);
+                tau = (beta - alpha) / beta;
+                scal = 1.0 / (alpha - beta);
+            }
+            const bool dead = (k < ntol) && (fabs(beta) <= tol);
+            if (dead) {
+                // zero the column from the diagonal down, no reflector, g does not advance (:1495-1544)
+#pragma unroll
+                for (int r = 0; r < RPT; r++)
+                    if (rb + tid + NTH * r >= g) a[r][0] = 0.0;
+                if (tid == 0) { St[k] = 0; Rdead[k] = 1; Tau[k] = 0; pd->pdiag[jp] = STM_BIGROW; }
+                if (k == npiv - 1) rank = g;                   // (:1604-1608) also taken on a dead last pivot
+            } else {
+                if (tid == 0) { St[k] = t; Tau[k] = tau; pd->pdiag[jp] = g; }
+                flops += (double)(t - g) * (3.0 + 4.0 * (double)(n - k - 1));
+                if (tau != 0.0) {
+                    nlive++;
+                    double w[8];
+#pragma unroll
+                    for (int x = 1; x < SWT; x++) w[x] = tau * (ps.top[tpar][x] + scal * sum[x]);
+#pragma unroll
+                    for (int r = 0; r < RPT; r++) {
+                        const int i = rb + tid + NTH * r;
+                        if (i > g && i < t) {
+                            const double v = a[r][0] * scal;
+                            a[r][0] = v;
+#pragma unroll
+                            for (int x = 1; x < SWT; x++) a[r][x] -= w[x] * v;
+                        }
+                    }
+                    if (owner) {
+#pragma unroll
+                        for (int x = 1; x < SWT; x++) a[0][x] -= w[x];
+                    }
+                }
+                if (owner) a[0][0] = beta;
+                tlast = t;
+                g++;
+                if (k == npiv - 1) rank = g;
+            }
+        }
+        // ---- retire register column 0 to F and rotate ----
+        {
+            double *dst = F + (long long)k * ld;
+#pragma unroll
+            for (int r = 0; r < RPT; r++) {
+                const int i = rb + tid + NTH * r;
+                if (i < tmax) dst[i] = a[r][0];
+#pragma unroll
+                for (int x = 0; x + 1 < SWT; x++) a[r][x] = a[r][x + 1];
+                a[r][SWT - 1] = 0.0;
+            }
+        }
+    }
+    // ---- sub-panel bookkeeping; the last sub-panel (or the one that ran out of rows) finalises the panel ----
+    // (a sub-panel that runs out of rows before the last one leaves the finalisation to the next launch: the later
+    //  column groups still need its reflectors)
+    const int ns = (nbp + SWT - 1) / SWT;
+    const bool last = was_done || sidx == ns - 1;
+    const int nl_total = pd->nlive + nlive;
+    __syncthreads();                                           // all stores of this workgroup are complete and visible
+    if (tid == 0) {
+        num->g = g; num->rank = rank; num->done = done;
+        num->flops += flops;
+        pd->sg[sidx] = gs; pd->st[sidx] = tlast; pd->pt = tlast; pd->nlive = nl_total;
+        if (last) {
+            pd->mode = 2;
+            pd->pk1 = k1; pd->pnb = nbp; pd->pc0 = k2;
+            num->flops_upd += 4.0 * (double)(tlast - g1) * (double)(n - k2) * (double)nl_total;
+        }
+    }
+    if (last) {
+        if (tid < STM_NB) {
+            ps.diag[tid] = (tid < nbp) ? pd->pdiag[tid] : STM_BIGROW;  // (columns past a `done` point were reset there)
+            ps.tau[tid] = (tid < nbp) ? Tau[k1 + tid] : 0.0;
+        }
+        __syncthreads();
+        dev_gram_T<NTH>(F + (long long)k1 * ld, ld, g1, tlast, nbp, ps.diag, ps.tau, ps.G, ps.T, Tout, lds);
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -900,7 +1286,7 @@ __global__ __launch_bounds__(NT) void k_front_wg(DevCtx c, const int *__restrict
 // large fronts: panel and trailing update are separate launches (many workgroups per update)
 // ------------------------------------------------------------------------------------------------
 #define NTP 512               // threads of the large-front panel kernel (8 waves, <= 256 VGPRs each)
-__global__ __launch_bounds__(NTP) void k_panel(DevCtx c, const int *__restrict__ flist, int p, int lds_doubles)
+__global__ __launch_bounds__(NTP) void k_panel(DevCtx c, const int *__restrict__ flist, int p, int sidx, int lds_doubles)
 {
     extern __shared__ double dyn_lds[];
     __shared__ PanelShared ps;
@@ -910,12 +1296,49 @@ __global__ __launch_bounds__(NTP) void k_panel(DevCtx c, const int *__restrict__
     FrontNum *num = &c.fnum[f];
     double *F = c.Farena + s.foff;
     double *T = c.Tws + (long long)(2 * c.tslot[f] + (p & 1)) * STM_NB * STM_NB;
-    if ((c.dbg & 64) || panel_rows(s, num, c.Stair + s.rp, p) > lds_doubles - 65)
-        dev_panel<NTP, true>(ps, s, num, F, c.Stair + s.rp, c.Tau + s.rp, c.Rdead + s.col1, p, c.tol, c.ntol, T, dyn_lds,
+    int *St = c.Stair + s.rp;
+    PanelDesc *pd = &num->pd[p & 1];
+    const int b = sidx + blockIdx.y;
+    bool tall = stm_tall_panel(s, p) && !(c.dbg & 256);
+    if (!tall && (sidx > 0 || b > 0)) return;
+    if (tall) {
+        const int k1 = p * STM_NB, k2 = min(s.fn, k1 + STM_NB), nbp = k2 - k1;
+        if (b * STM_SW >= nbp) return;
+        if (sidx == 0) {
+            // first launch of the panel: decide the mode and publish the panel-wide constants
+            const int was_done = num->done, g1 = num->g;
+            const int tmax = min(num->fm, max(St[k2 - 1], g1 + nbp));
+            __syncthreads();
+            if (was_done) {
+                if (threadIdx.x == 0) { pd->pnb = 0; pd->mode = 0; }
+                return;
+            }
+            if (tmax - g1 > STM_TALL_MAX) tall = false;        // does not fit the register image: whole panel below
+            else if (threadIdx.x == 0) {
+                pd->mode = 1; pd->pg1 = g1; pd->pt = g1; pd->tmax = tmax; pd->nlive = 0;
+            }
+            __syncthreads();
+        } else if (pd->mode != 1) return;
+    }
+    if (tall) {
+        const int rows = pd->tmax - ((sidx == 0) ? pd->pg1 : pd->sg[sidx - 1]);
+        if (rows <= NTP)
+            dev_tall_group<NTP, 1>(ps, s, num, pd, F, St, c.Tau + s.rp, c.Rdead + s.col1, p, sidx, b, c.tol, c.ntol, T, dyn_lds);
+        else if (rows <= 2 * NTP)
+            dev_tall_group<NTP, 2>(ps, s, num, pd, F, St, c.Tau + s.rp, c.Rdead + s.col1, p, sidx, b, c.tol, c.ntol, T, dyn_lds);
+        else if (rows <= 4 * NTP)
+            dev_tall_group<NTP, 4>(ps, s, num, pd, F, St, c.Tau + s.rp, c.Rdead + s.col1, p, sidx, b, c.tol, c.ntol, T, dyn_lds);
+        else
+            dev_tall_group<NTP, 8>(ps, s, num, pd, F, St, c.Tau + s.rp, c.Rdead + s.col1, p, sidx, b, c.tol, c.ntol, T, dyn_lds);
+        return;
+    }
+    if ((c.dbg & 64) || panel_rows(s, num, St, p) > lds_doubles - 65)
+        dev_panel<NTP, true>(ps, s, num, F, St, c.Tau + s.rp, c.Rdead + s.col1, p, c.tol, c.ntol, T, dyn_lds,
                              lds_doubles, c.dbg, c.dbgbuf);
     else
-        dev_panel<NTP, false>(ps, s, num, F, c.Stair + s.rp, c.Tau + s.rp, c.Rdead + s.col1, p, c.tol, c.ntol, T, dyn_lds,
+        dev_panel<NTP, false>(ps, s, num, F, St, c.Tau + s.rp, c.Rdead + s.col1, p, c.tol, c.ntol, T, dyn_lds,
                               lds_doubles, c.dbg, c.dbgbuf);
+    if (threadIdx.x == 0) pd->mode = 0;
 }
 
 __global__ __launch_bounds__(NT) void k_update(DevCtx c, const int *__restrict__ flist, int p, int cb0)
@@ -1267,12 +1690,23 @@ int stm_launch_front_wg(const DevCtx &c, const int *flist, int nfr, int lds_doub
     hipLaunchKernelGGL(k_front_wg, dim3(nfr), dim3(NT), bytes, st, c, flist, (int)(bytes / sizeof(double)));
     return (int)hipGetLastError();
 }
-int stm_launch_panel(const DevCtx &c, const int *flist, int nfr, int p, int lds_doubles, hipStream_t st)
+int stm_launch_panel(const DevCtx &c, const int *flist, int nfr, int p, int nsub, int lds_doubles, hipStream_t st)
 {
     if (nfr <= 0) return 0;
     size_t bytes = (size_t)lds_doubles * sizeof(double);
     if (bytes < (size_t)stm_update_lds_bytes()) bytes = stm_update_lds_bytes();   // in-panel MFMA update + Gram scratch
-    hipLaunchKernelGGL(k_panel, dim3(nfr), dim3(NTP), bytes, st, c, flist, p, (int)(bytes / sizeof(double)));
+    // launch sidx of the tall-panel pipeline runs the column groups sidx .. nsub-1; fronts whose panel is not tall are
+    // done completely by launch 0
+    if (c.dbg & 512) {                                     // debugging: one front per launch
+        for (int i = 0; i < nfr; i++)
+            for (int sidx = 0; sidx < nsub; sidx++)
+                hipLaunchKernelGGL(k_panel, dim3(1, sidx == 0 ? 1 : nsub - sidx), dim3(NTP), bytes, st, c, flist + i, p, sidx,
+                                   (int)(bytes / sizeof(double)));
+        return (int)hipGetLastError();
+    }
+    for (int sidx = 0; sidx < nsub; sidx++)
+        hipLaunchKernelGGL(k_panel, dim3(nfr, sidx == 0 ? 1 : nsub - sidx), dim3(NTP), bytes, st, c, flist, p, sidx,
+                           (int)(bytes / sizeof(double)));
     return (int)hipGetLastError();
 }
 int stm_launch_update(const DevCtx &c, const int *flist, int nfr, int p, int cb0, int ncb, hipStream_t st)

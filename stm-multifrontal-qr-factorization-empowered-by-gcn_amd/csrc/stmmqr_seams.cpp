@@ -51,6 +51,7 @@ struct OneFront {
     Buf<double> d_F, d_C, d_T, d_Tau, d_RH;
     Buf<int> d_St, d_tslot, d_flist, d_Rhoff, d_parts;
     Buf<long long> d_Rboff;
+    Buf<unsigned long long> d_dbg;
     Buf<char> d_Rdead;
     DevCtx c{};
     long m = 0, n = 0;
@@ -60,7 +61,7 @@ struct OneFront {
         m = m_; n = n_;
         memset(&s, 0, sizeof s); memset(&nm, 0, sizeof nm);
         s.ld = (int)std::max(2L, (m + 1) & ~1L);
-        s.fn = (int)n; s.fp = (int)std::min(n, std::max(0L, npiv)); s.fm_ub = (int)m;
+        s.fn = (int)n; s.fp = (int)std::min(n, std::max(0L, npiv)); s.fm_ub = (int)m; s.fm_est = (int)m;
         s.npanels = (int)((n + STM_NB - 1) / STM_NB);
         s.parent = -1;
         nm.fm = (int)m; nm.rank = (int)std::min(m, (long)s.fp);
@@ -84,6 +85,11 @@ struct OneFront {
         c.fs = d_fs.p; c.fnum = d_nm.p; c.Farena = d_F.p; c.Carena = d_C.p; c.Tws = d_T.p; c.tslot = d_tslot.p;
         c.Stair = d_St.p; c.Tau = d_Tau.p; c.Rdead = d_Rdead.p; c.Rhoff = d_Rhoff.p; c.Rboff = d_Rboff.p;
         c.dbg = getenv("STMMQR_DBG") ? atoi(getenv("STMMQR_DBG")) : 0;
+#ifdef STMMQR_STAMPS
+        if (!d_dbg.alloc(16)) return false;
+        (void)hipMemset(d_dbg.p, 0, 16 * sizeof(unsigned long long));
+        c.dbgbuf = d_dbg.p;
+#endif
         return true;
     }
     bool push_num() { return hipMemcpy(d_nm.p, &nm, sizeof nm, hipMemcpyHostToDevice) == hipSuccess; }
@@ -124,12 +130,22 @@ stm_long stmmqr_front(stm_long m, stm_long n, stm_long npiv, double tol, stm_lon
         e = stm_launch_front_wg(X.c, X.d_flist.p, 1, lds_for(m), nullptr);
     } else {
         for (int p = 0; p < X.s.npanels && !e; p++) {
-            e = stm_launch_panel(X.c, X.d_flist.p, 1, p, lds_for(m), nullptr);
+            e = stm_launch_panel(X.c, X.d_flist.p, 1, p, stm_tall_panel(X.s, p) ? STM_NB / STM_SW : 1, lds_for(m), nullptr);
             const int k2 = (int)std::min<long>(n, (long)(p + 1) * STM_NB);
             if (!e) e = stm_launch_update(X.c, X.d_flist.p, 1, p, 0, (int)((n - k2 + 31) / 32), nullptr);
         }
     }
     if (e || hipDeviceSynchronize() != hipSuccess) return -1;
+#ifdef STMMQR_STAMPS
+    if (X.c.dbg & 48) {
+        unsigned long long hb[16];
+        (void)hipMemcpy(hb, X.c.dbgbuf, sizeof hb, hipMemcpyDeviceToHost);
+        fprintf(stderr, "[panel cycles] stage-in %llu  columns %llu  write-back %llu  flush %llu  gram %llu  apply %llu  |", hb[0],
+                hb[1], hb[2], hb[3], hb[4], hb[5]);
+        for (int i = 6; i < 12; i++) fprintf(stderr, " %llu", hb[i]);
+        fprintf(stderr, "\n");
+    }
+#endif
     if (!X.pull_num() || !X.pull_F(F, m)) return -1;
     std::vector<int> st32((size_t)std::max<stm_long>(1, n));
     if (!X.d_St.down(st32.data(), (size_t)n)) return -1;
@@ -340,7 +356,7 @@ void qr_assemble(stm_long f, stm_long fm, int keepH, stm_long *Super, stm_long *
     long rjpos = 0, hipos = 0;
     FrontSym &s = fs[0];
     s.ld = (int)std::max<stm_long>(2, (fm + 1) & ~1L); s.fn = (int)fn; s.fp = (int)fp; s.col1 = 0; s.rp = 0; s.hip = 0;
-    s.child0 = 0; s.child1 = (int)nch; s.fm_ub = (int)fm; s.parent = -1;
+    s.child0 = 0; s.child1 = (int)nch; s.fm_ub = (int)fm; s.fm_est = (int)fm; s.parent = -1;
     rjpos = fn; hipos = fm;
     rjrel.assign((size_t)fn, 0);
     hii.assign((size_t)std::max<stm_long>(1, fm), 0);

@@ -30,7 +30,11 @@ def make_front(m, n, seed, stair_kind="ramp"):
 
 
 FRONTS = [(6, 4, 4), (5, 8, 3), (40, 30, 12), (64, 96, 32), (130, 70, 70), (266, 422, 124), (380, 380, 380),
-          (97, 33, 0), (33, 97, 97), (1, 5, 2), (700, 64, 64)]
+          (97, 33, 0), (33, 97, 97), (1, 5, 2), (700, 64, 64),
+          # tall panels: the sub-panel pipeline (register-resident column groups, one launch per 8 columns)
+          (1500, 96, 64), (2600, 80, 80), (900, 200, 40), (1100, 72, 72), (4200, 40, 40), (800, 1000, 900),
+          # rows run out in the middle of a sub-panel of a pipelined panel
+          (1003, 1100, 900), (781, 900, 300), (1290, 1400, 64)]
 
 
 @pytest.mark.parametrize("m,n,npiv", FRONTS)
@@ -56,8 +60,9 @@ def test_qr_front(pkg, oracle, m, n, npiv, bigcols, stair):
     assert np.linalg.norm(Fg - Fo) <= 1e-11 * scale
 
 
-def test_qr_front_dead_columns(pkg, oracle):
-    m, n, npiv = 90, 60, 40
+@pytest.mark.parametrize("m", [90, 1300])
+def test_qr_front_dead_columns(pkg, oracle, m):
+    n, npiv = 60, 40
     F0, St0 = make_front(m, n, 77, "full")
     F0[:, 7] = F0[:, 3]; F0[:, 21] = 2 * F0[:, 20] - F0[:, 19]; F0[:, 33] = 0
     tol = 1e-9
