@@ -16,7 +16,7 @@ The R+H blocks stay on the rank that produced them; `gather_numeric` assembles t
 
 The per-rank compute object only has to offer the small "plan" interface of capi.HipQR
 (set_groups / begin / run_group / finish / export_front / import_front / download), so the CPU tests drive the
-very same orchestration with an oracle-backed stand-in.
+very same orchestration with a CPU stand-in plan.
 """
 from __future__ import annotations
 
