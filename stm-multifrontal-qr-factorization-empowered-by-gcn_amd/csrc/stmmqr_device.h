@@ -37,14 +37,17 @@ struct PanelDesc {
     // tall-panel pipeline state (sub-panels of STM_SW columns, one launch per sub-panel)
     int tmax;                // rows [pg1, tmax) are touched by the panel
     int nlive;               // live reflectors so far
-    int sg[STM_NB / 8];      // first active row (g) at the start of sub-panel s
-    int st[STM_NB / 8];      // one past the last row reached by the reflectors of sub-panel s
+    int sw;                  // sub-panel width of this panel: 8, or 4 when the rows need 8 registers per thread and column
+    int done_group;          // group that ran out of rows (g reached fm), -1 if none
+    int sg[STM_NB / 4];      // first active row (g) at the start of sub-panel s
+    int st[STM_NB / 4];      // one past the last row reached by the reflectors of sub-panel s
 };
 
-#define STM_SW 8             // sub-panel width of the tall-panel pipeline
+#define STM_SW 8             // sub-panel width of the tall-panel pipeline (4 above STM_TALL_WIDE rows)
 #define STM_TALL_MIN 768     // panels with more (estimated) rows than this take the pipeline
 #define STM_TALL_NTH 512     // threads of the panel kernel
 #define STM_TALL_MAX (8 * STM_TALL_NTH)   // rows a sub-panel can hold in registers (8 per thread)
+#define STM_TALL_WIDE (4 * STM_TALL_NTH)  // more rows than this: 4-column sub-panels (64 doubles of register image)
 
 // Does panel p of this front take the tall-panel pipeline?  Planned on the host (number of launches) and re-evaluated
 // on the device from the same symbolic data, so both always agree.
@@ -55,6 +58,15 @@ static inline __host__ __device__ int stm_tall_panel(const FrontSym &s, int p)
     if (g > s.fm_est) g = s.fm_est;
     return s.fm_est - g > STM_TALL_MIN;
 }
+// planned number of panel launches (sub-panels) for panel p: 1 (not tall), 4, or 8 when 4-column sub-panels may be needed
+static inline __host__ __device__ int stm_tall_launches(const FrontSym &s, int p)
+{
+    if (!stm_tall_panel(s, p)) return 1;
+    int g = p * STM_NB;
+    if (g > s.fp) g = s.fp;
+    if (g > s.fm_est) g = s.fm_est;
+    return (s.fm_est - g > STM_TALL_WIDE) ? STM_NB / 4 : STM_NB / STM_SW;
+}
 
 // numeric, written by the kernels
 struct FrontNum {
@@ -64,6 +76,8 @@ struct FrontNum {
     int done;                // 1 once g reached fm and the tail columns were finalised
     int cm;                  // rows of the contribution block      (qr_cpack's return value)
     int rsize;               // entries of the packed R+H block     (qr_rhpack's return value)
+    int hdr;                 // tall-panel pipeline: p+1 once the header (mode, pg1, tmax, sw) of panel p is published
+    int prog;                // ... 16*p + (number of finished sub-panels of panel p); monotone over the whole front
     double flops;            // reference flop count of this front  (FLOP_COUNT, :1571)
     double flops_upd;        // dlarfb flops handed to the MFMA update: 4 * rows * cols * reflectors
     // pending block reflectors, double buffered by panel parity so that the look-ahead schedule can factorize

@@ -100,7 +100,7 @@ struct Level {
     int lds_small = 0, lds_big = 0;      // dynamic LDS (doubles) for the panel staging
     std::vector<int> nbig_at;            // big fronts with npanels > p
     std::vector<int> maxcb_at;           // max trailing column blocks at panel p
-    std::vector<int> nsub_at;            // panel launches at p: STM_NB/STM_SW if any front takes the tall-panel pipeline
+    std::vector<int> nsub_at;            // panel launches at p: 4 or 8 if any front takes the tall-panel pipeline
     std::vector<int> maxsl_at;           // max 256-row slabs of the fronts still active at panel p (0: small)
 };
 
@@ -276,7 +276,7 @@ void build_schedule(stmmqr_plan &P, std::vector<int> &tslot)
                         const int k2 = std::min(s.fn, (p + 1) * STM_NB);
                         mcb = std::max(mcb, (s.fn - k2 + 31) / 32);
                         msl = std::max(msl, (s.fm_ub + 255) / 256);
-                        if (stm_tall_panel(s, p)) L.nsub_at[p] = STM_NB / STM_SW;
+                        L.nsub_at[p] = std::max(L.nsub_at[p], stm_tall_launches(s, p));
                     }
                 }
                 L.nbig_at[p] = cnt;

@@ -163,7 +163,7 @@ __global__ __launch_bounds__(NT) void k_setup(DevCtx c, const int *__restrict__ 
     }
     if (tid == 0) {
         FrontNum *nm = &c.fnum[f];
-        nm->fm = fm; nm->g = 0; nm->rank = min(fm, s.fp); nm->done = 0;
+        nm->fm = fm; nm->g = 0; nm->rank = min(fm, s.fp); nm->done = 0; nm->hdr = 0; nm->prog = 0;
         nm->pd[0].pnb = 0; nm->pd[1].pnb = 0; nm->cm = 0; nm->rsize = 0; nm->flops = 0; nm->flops_upd = 0;
     }
 }
@@ -550,11 +550,12 @@ __device__ __forceinline__ void dev_subpanel_reg(PanelShared &ps, double *F, lon
     double a[RPT][SWT];
 #pragma unroll
     for (int x = 0; x < SWT; x++) {
-        const double *src = F + (long long)(k1 + j0 + x) * ld;
+        const double *src = F + (long long)(k1 + j0 + min(x, sw - 1)) * ld;
 #pragma unroll
         for (int r = 0; r < RPT; r++) {
             const int i = gs + tid + NTH * r;
-            a[r][x] = (x < sw && i < tmax) ? src[i] : 0.0;
+            const double val = src[max(min(i, tmax - 1), 0)];           // unconditional load, masked afterwards
+            a[r][x] = (x < sw && i < tmax) ? val : 0.0;
         }
     }
     for (int j = 0; j < sw; j++) {
@@ -972,21 +973,57 @@ __device__ __forceinline__ void dev_panel(PanelShared &ps, const FrontSym &s, Fr
 // ------------------------------------------------------------------------------------------------
 // Tall-panel pipeline (panels with more rows than one workgroup can stream through LDS cheaply).
 //
-// The panel's columns are cut into sub-panels of STM_SW = 8 columns.  Launch number `sidx` of the panel kernel runs one
-// workgroup per column group b >= sidx:
-//     * the group's rows [rb, tmax) x 8 columns are loaded ONCE into registers (thread tid owns rows rb + tid + NTH*r),
-//     * the reflectors of sub-panel sidx-1 (factorized by the previous launch, read back from F with the unit-diagonal
-//       mask) are applied to them -- dlarf semantics, reflector after reflector, each v'C an 8-value workgroup
-//       reduction (reference qr_private_apply1, :1359-1381),
-//     * group b == sidx is then factorized in the same registers (the column step of dev_subpanel_reg) and every
-//       finished column is stored straight to F; the other groups store their updated columns.
+// The panel's columns are cut into sub-panels ("groups") of 8 columns (4 above STM_TALL_WIDE rows) and ONE launch runs
+// one workgroup per group, blockIdx.y = b:
+//     * the group's rows [g1, tmax) x 8 columns are loaded ONCE into registers (thread tid owns rows g1 + tid + NTH*r),
+//     * for s = 0 .. b-1: wait until group s has been factorized (FrontNum::prog, release/acquire at agent scope), then
+//       apply its reflectors, read back from F with the unit-diagonal mask -- dlarf semantics, reflector after
+//       reflector, each v'C one 8-value workgroup reduction (reference qr_private_apply1, :1359-1381),
+//     * factorize the group in the same registers (the column step of dev_subpanel_reg), store every finished column
+//       straight to F, publish prog.
+// A group only ever waits for groups with a smaller blockIdx.y of the same front, i.e. for workgroups that were
+// dispatched before it, so the wait cannot deadlock whatever the residency; the spin is bounded all the same.
 // Compared with one workgroup per panel this keeps every column in registers for its whole life inside the panel
-// (one read, one write of F per column and launch), spreads the in-panel dlarfb over up to four CUs, and makes the
-// cost of a column step independent of the panel height (<= STM_TALL_MAX rows).
-// The last launch also builds T of the whole panel (dev_gram_T) and the block-reflector description for k_update.
+// (one read, one write of F per column), spreads the in-panel dlarf over up to eight CUs, overlaps the loads of the
+// later groups with the factorization of the earlier ones, and makes the cost of a column step independent of the
+// panel height (<= STM_TALL_MAX rows).  The last group also builds T of the whole panel (dev_gram_T) and the
+// block-reflector description for the trailing update.
 // ------------------------------------------------------------------------------------------------
 // barrier that orders LDS traffic only: the column stores to F stay in flight (a full __syncthreads would wait for them)
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+__device__ __forceinline__ int ld_agent(const int *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void st_agent(int *p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ double ld_agent(const double *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void st_agent(double *p, double v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+// whole workgroup: wait until *flag >= target (written by another workgroup of this launch), then acquire.
+// Returns false if the bounded spin ran out (never expected; the caller gives up on the panel).
+__device__ __forceinline__ bool wait_progress(const int *flag, int target)
+{
+    __shared__ int s_ok;
+    __syncthreads();                               // (s_ok of a previous wait has been read by everyone)
+    if (threadIdx.x == 0) {
+        int ok = 0;
+        for (int it = 0; it < (1 << 26); it++) {
+            if (ld_agent(flag) >= target) { ok = 1; break; }
+            __builtin_amdgcn_s_sleep(1);
+        }
+        s_ok = ok;
+    }
+    __syncthreads();
+    __atomic_thread_fence(__ATOMIC_ACQUIRE);       // (system scope: invalidates this CU's L1 and stale L2 lines)
+    return s_ok != 0;
+}
+// publish: all global stores of this workgroup happen-before the flag value
+__device__ __forceinline__ void publish_progress(int *flag, int value)
+{
+    __syncthreads();                               // every wave's stores are complete (s_waitcnt vmcnt(0))
+    if (threadIdx.x == 0) {
+        __atomic_thread_fence(__ATOMIC_RELEASE);   // write back L2 so that other XCDs see them
+        st_agent(flag, value);
+    }
+}
 
 template <int NTH>
 __device__ __forceinline__ void block_reduce8(PanelShared &ps, int &par, const double (&part)[8], double (&sum)[8])
@@ -1004,49 +1041,54 @@ __device__ __forceinline__ void block_reduce8(PanelShared &ps, int &par, const d
     par ^= 1;
 }
 
-template <int NTH, int RPT>
+template <int NTH, int RPT, int SWT>
 __device__ __forceinline__ void dev_tall_group(PanelShared &ps, const FrontSym &s, FrontNum *num, PanelDesc *pd, double *F,
-                                               int *St, double *Tau, char *Rdead, int p, int sidx, int b, double tol,
-                                               int ntol_global, double *Tout, double *lds)
+                                               int *St, double *Tau, char *Rdead, int p, int b, int g1, int tmax,
+                                               double tol, int ntol_global, double *Tout, double *lds)
 {
-    constexpr int SWT = STM_SW;
     const int tid = threadIdx.x;
-    const int m = num->fm, n = s.fn, npiv = s.fp;
+    const int m = num->fm, n = s.fn, npiv = s.fp;              // (fm is fixed before the panel kernels run)
     const long long ld = s.ld;
     const int k1 = p * STM_NB, k2 = min(n, k1 + STM_NB), nbp = k2 - k1;
-    const int tmax = pd->tmax, g1 = pd->pg1;
     const int c0 = SWT * b, sw = min(SWT, nbp - c0);           // my columns: k1 + c0 + x, x < sw
-    const int rb = (sidx == 0) ? g1 : pd->sg[sidx - 1];        // first row of the register image
-    const bool factor = (b == sidx);
+    const int ns = (nbp + SWT - 1) / SWT;
+    const int rb = g1;                                         // first row of the register image
     int par = 0;
-    if (tid < SWT) ps.stair[tid] = (tid < sw) ? St[k1 + c0 + tid] : 0;
+    if (tid < SWT) ps.stair[tid] = (tid < sw) ? St[k1 + c0 + tid] : 0;     // (only this group ever writes these)
 
+    // (loads are unconditional on a clamped index and masked afterwards: a predicated load becomes a branch around
+    //  each access and the 8 x RPT loads would be issued one round trip at a time)
     double a[RPT][SWT];
 #pragma unroll
     for (int x = 0; x < SWT; x++) {
-        const double *src = F + (long long)(k1 + c0 + x) * ld;
+        const double *src = F + (long long)(k1 + c0 + min(x, sw - 1)) * ld;
 #pragma unroll
         for (int r = 0; r < RPT; r++) {
             const int i = rb + tid + NTH * r;
-            a[r][x] = (x < sw && i < tmax) ? src[i] : 0.0;
+            const double val = src[min(i, tmax - 1)];
+            a[r][x] = (x < sw && i < tmax) ? val : 0.0;
         }
     }
-    // ---- apply the reflectors of the previous sub-panel ----
-    if (sidx > 0) {
-        const int pc0 = SWT * (sidx - 1);
-        const int tprev = pd->st[sidx - 1];
+    // ---- apply the reflectors of the groups before mine, as they become available ----
+    int prev_done = 0;
+    for (int sp = 0; sp < b && !prev_done; sp++) {
+        if (!wait_progress(&num->prog, 16 * p + sp + 1)) return;
+        const int pc0 = SWT * sp;
+        const int tprev = ld_agent(&pd->st[sp]);
+        prev_done = ld_agent(&num->done);
         double vn[RPT];
         {
             const double *vc = F + (long long)(k1 + pc0) * ld;
 #pragma unroll
             for (int r = 0; r < RPT; r++) {
                 const int i = rb + tid + NTH * r;
-                vn[r] = (i < tprev) ? vc[i] : 0.0;
+                const double val = vc[min(i, tmax - 1)];
+                vn[r] = (i < tprev) ? val : 0.0;
             }
         }
         for (int q = 0; q < SWT; q++) {
-            const int d = pd->pdiag[pc0 + q];
-            const double tau = Tau[k1 + pc0 + q];
+            const int d = ld_agent(&pd->pdiag[pc0 + q]);
+            const double tau = ld_agent(&Tau[k1 + pc0 + q]);
             double v[RPT];
 #pragma unroll
             for (int r = 0; r < RPT; r++) {
@@ -1058,7 +1100,8 @@ __device__ __forceinline__ void dev_tall_group(PanelShared &ps, const FrontSym &
 #pragma unroll
                 for (int r = 0; r < RPT; r++) {
                     const int i = rb + tid + NTH * r;
-                    vn[r] = (i < tprev) ? vc[i] : 0.0;
+                    const double val = vc[min(i, tmax - 1)];
+                    vn[r] = (i < tprev) ? val : 0.0;
                 }
             }
             if (tau == 0.0 || d >= STM_BIGROW) continue;       // identity / dead column (uniform)
@@ -1079,10 +1122,9 @@ __device__ __forceinline__ void dev_tall_group(PanelShared &ps, const FrontSym &
             }
         }
     }
-    // the previous sub-panel ran out of rows (g reached fm): its reflectors were still due on the later column groups
-    // (applied above); nothing is left to factorize, the group that would have been next finalises the panel
-    const int was_done = num->done;
-    if (!factor || was_done) {
+    // a group before mine ran out of rows (g reached fm): its reflectors were still due on my columns (applied above);
+    // nothing is left to factorize.  The group right after it finalises the panel, the others only store.
+    if (prev_done) {
 #pragma unroll
         for (int x = 0; x < SWT; x++) {
             if (x < sw) {
@@ -1094,15 +1136,19 @@ __device__ __forceinline__ void dev_tall_group(PanelShared &ps, const FrontSym &
                 }
             }
         }
-        if (!factor) return;
+        if (ld_agent(&pd->done_group) != b - 1) return;
     }
     // ---- factorize my sub-panel (column step as in dev_subpanel_reg; finished columns go straight to F) ----
-    int g = num->g, rank = num->rank, done = was_done, nlive = 0, tlast = pd->pt;
+    // g / rank / pt / nlive / flops travel along the chain of groups: group b reads them after the acquire on group b-1
+    int g = (b == 0) ? g1 : ld_agent(&num->g);
+    int rank = ld_agent(&num->rank), done = prev_done, nlive = 0;
+    int tlast = (b == 0) ? g1 : ld_agent(&pd->pt);
+    const int nl_before = (b == 0) ? 0 : ld_agent(&pd->nlive);
     const int gs = g;
     const int ntol = min(ntol_global - s.col1, npiv);
     double flops = 0;
     lds_barrier();                                             // ps.stair
-    for (int j = 0; j < sw && !was_done; j++) {
+    for (int j = 0; j < sw && !prev_done; j++) {
         const int jp = c0 + j, k = k1 + jp;
         if (!done && g >= m) {
             // no rows left: remaining pivotal columns are dead, remaining columns are empty (:1444-1458)
@@ -1126,7 +1172,7 @@ __device__ __forceinline__ void dev_tall_group(PanelShared &ps, const FrontSym &
 #pragma unroll
                 for (int x = 0; x < SWT; x++) part[x] += xv * a[r][x];
             }
-            const bool owner = (tid == g - rb);                // holds row g in a[0][.]  (g - rb < 2*SWT <= NTH)
+            const bool owner = (tid == g - rb);                // holds row g in a[0][.]  (g - rb < STM_NB <= NTH)
             const int tpar = par;
             if (owner) {
 #pragma unroll
@@ -1191,31 +1237,34 @@ __device__ __forceinline__ void dev_tall_group(PanelShared &ps, const FrontSym &
             }
         }
     }
-    // ---- sub-panel bookkeeping; the last sub-panel (or the one that ran out of rows) finalises the panel ----
-    // (a sub-panel that runs out of rows before the last one leaves the finalisation to the next launch: the later
-    //  column groups still need its reflectors)
-    const int ns = (nbp + SWT - 1) / SWT;
-    const bool last = was_done || sidx == ns - 1;
-    const int nl_total = pd->nlive + nlive;
+    // ---- sub-panel bookkeeping; the last sub-panel (or the group after one that ran out of rows) finalises ----
+    const bool last = prev_done || b == ns - 1;
+    const int nl_total = nl_before + nlive;
+    if (tid == 0 && !prev_done) {
+        st_agent(&num->g, g); st_agent(&num->rank, rank); st_agent(&num->done, done);
+        st_agent(&num->flops, ((b == 0) ? num->flops : ld_agent(&num->flops)) + flops);
+        st_agent(&pd->sg[b], gs); st_agent(&pd->st[b], tlast); st_agent(&pd->pt, tlast); st_agent(&pd->nlive, nl_total);
+        if (done) st_agent(&pd->done_group, b);
+    }
+    if (!last) {
+        publish_progress(&num->prog, 16 * p + b + 1);
+        return;
+    }
     __syncthreads();                                           // all stores of this workgroup are complete and visible
     if (tid == 0) {
-        num->g = g; num->rank = rank; num->done = done;
-        num->flops += flops;
-        pd->sg[sidx] = gs; pd->st[sidx] = tlast; pd->pt = tlast; pd->nlive = nl_total;
-        if (last) {
-            pd->mode = 2;
-            pd->pk1 = k1; pd->pnb = nbp; pd->pc0 = k2;
-            num->flops_upd += 4.0 * (double)(tlast - g1) * (double)(n - k2) * (double)nl_total;
-        }
+        pd->mode = 2;
+        pd->pk1 = k1; pd->pnb = nbp; pd->pc0 = k2;
+        num->flops_upd += 4.0 * (double)(tlast - g1) * (double)(n - k2) * (double)nl_total;
     }
-    if (last) {
-        if (tid < STM_NB) {
-            ps.diag[tid] = (tid < nbp) ? pd->pdiag[tid] : STM_BIGROW;  // (columns past a `done` point were reset there)
-            ps.tau[tid] = (tid < nbp) ? Tau[k1 + tid] : 0.0;
-        }
-        __syncthreads();
-        dev_gram_T<NTH>(F + (long long)k1 * ld, ld, g1, tlast, nbp, ps.diag, ps.tau, ps.G, ps.T, Tout, lds);
+    if (tid < STM_NB) {
+        ps.diag[tid] = (tid < nbp) ? ld_agent(&pd->pdiag[tid]) : STM_BIGROW;    // (columns past a `done` point were reset there)
+        ps.tau[tid] = (tid < nbp) ? ld_agent(&Tau[k1 + tid]) : 0.0;
     }
+    __syncthreads();
+    dev_gram_T<NTH>(F + (long long)k1 * ld, ld, g1, tlast, nbp, ps.diag, ps.tau, ps.G, ps.T, Tout, lds);
+    // (when an earlier group ran out of rows the groups after mine are still storing their columns: the kernel
+    //  boundary orders those stores before the trailing update)
+    publish_progress(&num->prog, 16 * p + b + 1);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1286,7 +1335,7 @@ __global__ __launch_bounds__(NT) void k_front_wg(DevCtx c, const int *__restrict
 // large fronts: panel and trailing update are separate launches (many workgroups per update)
 // ------------------------------------------------------------------------------------------------
 #define NTP 512               // threads of the large-front panel kernel (8 waves, <= 256 VGPRs each)
-__global__ __launch_bounds__(NTP) void k_panel(DevCtx c, const int *__restrict__ flist, int p, int sidx, int lds_doubles)
+__global__ __launch_bounds__(NTP) void k_panel(DevCtx c, const int *__restrict__ flist, int p, int nsub, int lds_doubles)
 {
     extern __shared__ double dyn_lds[];
     __shared__ PanelShared ps;
@@ -1298,39 +1347,44 @@ __global__ __launch_bounds__(NTP) void k_panel(DevCtx c, const int *__restrict__
     double *T = c.Tws + (long long)(2 * c.tslot[f] + (p & 1)) * STM_NB * STM_NB;
     int *St = c.Stair + s.rp;
     PanelDesc *pd = &num->pd[p & 1];
-    const int b = sidx + blockIdx.y;
+    const int b = blockIdx.y;
     bool tall = stm_tall_panel(s, p) && !(c.dbg & 256);
-    if (!tall && (sidx > 0 || b > 0)) return;
+    if (!tall && b > 0) return;
     if (tall) {
         const int k1 = p * STM_NB, k2 = min(s.fn, k1 + STM_NB), nbp = k2 - k1;
-        if (b * STM_SW >= nbp) return;
-        if (sidx == 0) {
-            // first launch of the panel: decide the mode and publish the panel-wide constants
-            const int was_done = num->done, g1 = num->g;
-            const int tmax = min(num->fm, max(St[k2 - 1], g1 + nbp));
+        int mode, g1, tmax, w;
+        if (b == 0) {
+            // group 0 decides the mode and publishes the panel-wide constants (the header) to the other groups
+            const int was_done = num->done;
+            g1 = num->g;
+            tmax = min(num->fm, max(St[k2 - 1], g1 + nbp));
+            w = (tmax - g1 > STM_TALL_WIDE) ? 4 : STM_SW;
+            // mode 0: nothing to do or the whole panel is done below by this workgroup (it does not fit the register
+            // image, or needs more groups than were launched: more rows than the full-rank estimate)
+            mode = (was_done || tmax - g1 > STM_TALL_MAX || (nbp + w - 1) / w > nsub) ? 0 : 1;
             __syncthreads();
-            if (was_done) {
-                if (threadIdx.x == 0) { pd->pnb = 0; pd->mode = 0; }
-                return;
+            if (threadIdx.x == 0) {
+                st_agent(&pd->mode, mode); st_agent(&pd->pg1, g1); st_agent(&pd->pt, g1); st_agent(&pd->tmax, tmax);
+                st_agent(&pd->nlive, 0); st_agent(&pd->sw, w); st_agent(&pd->done_group, -1);
+                if (was_done) pd->pnb = 0;
             }
-            if (tmax - g1 > STM_TALL_MAX) tall = false;        // does not fit the register image: whole panel below
-            else if (threadIdx.x == 0) {
-                pd->mode = 1; pd->pg1 = g1; pd->pt = g1; pd->tmax = tmax; pd->nlive = 0;
-            }
-            __syncthreads();
-        } else if (pd->mode != 1) return;
-    }
-    if (tall) {
-        const int rows = pd->tmax - ((sidx == 0) ? pd->pg1 : pd->sg[sidx - 1]);
-        if (rows <= NTP)
-            dev_tall_group<NTP, 1>(ps, s, num, pd, F, St, c.Tau + s.rp, c.Rdead + s.col1, p, sidx, b, c.tol, c.ntol, T, dyn_lds);
-        else if (rows <= 2 * NTP)
-            dev_tall_group<NTP, 2>(ps, s, num, pd, F, St, c.Tau + s.rp, c.Rdead + s.col1, p, sidx, b, c.tol, c.ntol, T, dyn_lds);
-        else if (rows <= 4 * NTP)
-            dev_tall_group<NTP, 4>(ps, s, num, pd, F, St, c.Tau + s.rp, c.Rdead + s.col1, p, sidx, b, c.tol, c.ntol, T, dyn_lds);
-        else
-            dev_tall_group<NTP, 8>(ps, s, num, pd, F, St, c.Tau + s.rp, c.Rdead + s.col1, p, sidx, b, c.tol, c.ntol, T, dyn_lds);
-        return;
+            publish_progress(&num->hdr, p + 1);
+            if (was_done) return;
+        } else {
+            if (!wait_progress(&num->hdr, p + 1)) return;
+            mode = ld_agent(&pd->mode); g1 = ld_agent(&pd->pg1); tmax = ld_agent(&pd->tmax); w = ld_agent(&pd->sw);
+            if (mode != 1 || b * w >= nbp) return;
+        }
+        if (mode == 1) {
+            const int rows = tmax - g1;
+#define TALL_ARGS ps, s, num, pd, F, St, c.Tau + s.rp, c.Rdead + s.col1, p, b, g1, tmax, c.tol, c.ntol, T, dyn_lds
+            if (w == 4) dev_tall_group<NTP, 8, 4>(TALL_ARGS);
+            else if (rows <= NTP) dev_tall_group<NTP, 1, 8>(TALL_ARGS);
+            else if (rows <= 2 * NTP) dev_tall_group<NTP, 2, 8>(TALL_ARGS);
+            else dev_tall_group<NTP, 4, 8>(TALL_ARGS);
+#undef TALL_ARGS
+            return;
+        }
     }
     if ((c.dbg & 64) || panel_rows(s, num, St, p) > lds_doubles - 65)
         dev_panel<NTP, true>(ps, s, num, F, St, c.Tau + s.rp, c.Rdead + s.col1, p, c.tol, c.ntol, T, dyn_lds,
@@ -1697,16 +1751,8 @@ int stm_launch_panel(const DevCtx &c, const int *flist, int nfr, int p, int nsub
     if (bytes < (size_t)stm_update_lds_bytes()) bytes = stm_update_lds_bytes();   // in-panel MFMA update + Gram scratch
     // launch sidx of the tall-panel pipeline runs the column groups sidx .. nsub-1; fronts whose panel is not tall are
     // done completely by launch 0
-    if (c.dbg & 512) {                                     // debugging: one front per launch
-        for (int i = 0; i < nfr; i++)
-            for (int sidx = 0; sidx < nsub; sidx++)
-                hipLaunchKernelGGL(k_panel, dim3(1, sidx == 0 ? 1 : nsub - sidx), dim3(NTP), bytes, st, c, flist + i, p, sidx,
-                                   (int)(bytes / sizeof(double)));
-        return (int)hipGetLastError();
-    }
-    for (int sidx = 0; sidx < nsub; sidx++)
-        hipLaunchKernelGGL(k_panel, dim3(nfr, sidx == 0 ? 1 : nsub - sidx), dim3(NTP), bytes, st, c, flist, p, sidx,
-                           (int)(bytes / sizeof(double)));
+    // one workgroup per column group of the tall-panel pipeline (blockIdx.y); fronts whose panel is not tall use group 0
+    hipLaunchKernelGGL(k_panel, dim3(nfr, nsub), dim3(NTP), bytes, st, c, flist, p, nsub, (int)(bytes / sizeof(double)));
     return (int)hipGetLastError();
 }
 int stm_launch_update(const DevCtx &c, const int *flist, int nfr, int p, int cb0, int ncb, hipStream_t st)

@@ -130,7 +130,7 @@ stm_long stmmqr_front(stm_long m, stm_long n, stm_long npiv, double tol, stm_lon
         e = stm_launch_front_wg(X.c, X.d_flist.p, 1, lds_for(m), nullptr);
     } else {
         for (int p = 0; p < X.s.npanels && !e; p++) {
-            e = stm_launch_panel(X.c, X.d_flist.p, 1, p, stm_tall_panel(X.s, p) ? STM_NB / STM_SW : 1, lds_for(m), nullptr);
+            e = stm_launch_panel(X.c, X.d_flist.p, 1, p, stm_tall_launches(X.s, p), lds_for(m), nullptr);
             const int k2 = (int)std::min<long>(n, (long)(p + 1) * STM_NB);
             if (!e) e = stm_launch_update(X.c, X.d_flist.p, 1, p, 0, (int)((n - k2 + 31) / 32), nullptr);
         }
@@ -142,7 +142,7 @@ stm_long stmmqr_front(stm_long m, stm_long n, stm_long npiv, double tol, stm_lon
         (void)hipMemcpy(hb, X.c.dbgbuf, sizeof hb, hipMemcpyDeviceToHost);
         fprintf(stderr, "[panel cycles] stage-in %llu  columns %llu  write-back %llu  flush %llu  gram %llu  apply %llu  |", hb[0],
                 hb[1], hb[2], hb[3], hb[4], hb[5]);
-        for (int i = 6; i < 12; i++) fprintf(stderr, " %llu", hb[i]);
+        fprintf(stderr, " tall: load %llu apply %llu store %llu factor %llu gram %llu", hb[6], hb[7], hb[8], hb[9], hb[10]);
         fprintf(stderr, "\n");
     }
 #endif
