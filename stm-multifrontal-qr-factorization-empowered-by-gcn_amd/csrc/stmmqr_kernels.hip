@@ -1012,7 +1012,7 @@ __device__ __forceinline__ bool wait_progress(const int *flag, int target)
         s_ok = ok;
     }
     __syncthreads();
-    __atomic_thread_fence(__ATOMIC_ACQUIRE);       // (system scope: invalidates this CU's L1 and stale L2 lines)
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");     // invalidates this CU's L1 and stale (other-XCD) L2 lines
     return s_ok != 0;
 }
 // publish: all global stores of this workgroup happen-before the flag value
@@ -1020,7 +1020,7 @@ __device__ __forceinline__ void publish_progress(int *flag, int value)
 {
     __syncthreads();                               // every wave's stores are complete (s_waitcnt vmcnt(0))
     if (threadIdx.x == 0) {
-        __atomic_thread_fence(__ATOMIC_RELEASE);   // write back L2 so that other XCDs see them
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");  // write back L2 so that other XCDs see them
         st_agent(flag, value);
     }
 }
