@@ -216,6 +216,7 @@ typedef struct stmmqr_options {
     int use_graph;          /* capture the level schedule into a hipGraph                                 */
     int lookahead;          /* overlap panel p+1 with the rest of the trailing update of panel p (2 streams) */
     int split_update;       /* row-parallel (3-launch) trailing update for tall panels                      */
+    int tall_min_rows;      /* panels with more rows than this run as a pipeline of 8-column groups (plan time) */
 } stmmqr_options;
 void stmmqr_get_options(stmmqr_options *opt);
 void stmmqr_set_options(const stmmqr_options *opt);

@@ -44,24 +44,24 @@ struct PanelDesc {
 };
 
 #define STM_SW 8             // sub-panel width of the tall-panel pipeline (4 above STM_TALL_WIDE rows)
-#define STM_TALL_MIN 768     // panels with more (estimated) rows than this take the pipeline
+#define STM_TALL_MIN 256     // default of stmmqr_options::tall_min_rows: panels with more (estimated) rows take the pipeline
 #define STM_TALL_NTH 512     // threads of the panel kernel
 #define STM_TALL_MAX (8 * STM_TALL_NTH)   // rows a sub-panel can hold in registers (8 per thread)
 #define STM_TALL_WIDE (4 * STM_TALL_NTH)  // more rows than this: 4-column sub-panels (64 doubles of register image)
 
 // Does panel p of this front take the tall-panel pipeline?  Planned on the host (number of launches) and re-evaluated
 // on the device from the same symbolic data, so both always agree.
-static inline __host__ __device__ int stm_tall_panel(const FrontSym &s, int p)
+static inline __host__ __device__ int stm_tall_panel(const FrontSym &s, int p, int tall_min)
 {
     int g = p * STM_NB;
     if (g > s.fp) g = s.fp;
     if (g > s.fm_est) g = s.fm_est;
-    return s.fm_est - g > STM_TALL_MIN;
+    return s.fm_est - g > tall_min;
 }
 // planned number of panel launches (sub-panels) for panel p: 1 (not tall), 4, or 8 when 4-column sub-panels may be needed
-static inline __host__ __device__ int stm_tall_launches(const FrontSym &s, int p)
+static inline __host__ __device__ int stm_tall_launches(const FrontSym &s, int p, int tall_min)
 {
-    if (!stm_tall_panel(s, p)) return 1;
+    if (!stm_tall_panel(s, p, tall_min)) return 1;
     int g = p * STM_NB;
     if (g > s.fp) g = s.fp;
     if (g > s.fm_est) g = s.fm_est;

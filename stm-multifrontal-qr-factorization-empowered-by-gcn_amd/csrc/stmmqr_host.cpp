@@ -29,7 +29,7 @@
 namespace {
 
 thread_local std::string g_err;
-stmmqr_options g_opt = {STM_NB, 64, 0, 0, 0, 1};
+stmmqr_options g_opt = {STM_NB, 64, 0, 0, 0, 1, STM_TALL_MIN};
 size_t g_chunk[4] = {32, 5000, 4, 4};     // FCHUNK, SMALL, MINCHUNK, MINCHUNK_RATIO (SparseQR.h:16-19)
 
 // offsets inside the reference's sparse_common for the stock LP64 build; verified against the real header
@@ -113,6 +113,7 @@ struct stmmqr_plan {
     std::vector<hipEvent_t> evpool;                    // ordering events of the look-ahead schedule
     long m = 0, n = 0, anz = 0, nf = 0, maxfn = 0, rjsize = 0, hisize = 0;
     int do_rank = 1;
+    int tall_min = STM_TALL_MIN;                       // g_opt.tall_min_rows when the schedule was built
     std::vector<long> Sp, Sj, Qfill, PLinv, Sleft, Child, Childp, Super, Rp, Rj, Post, Hip, Fm;
     bool has_qfill = false;
     std::vector<FrontSym> fs;
@@ -154,6 +155,7 @@ struct stmmqr_plan {
         c.Rdead = d_Rdead.p; c.Cmap = d_Cmap.p; c.Cursor = d_Cursor.p; c.Rhoff = d_Rhoff.p; c.Rboff = d_Rboff.p;
         c.tol = last_tol; c.ntol = (int)last_ntol;
         c.dbg = getenv("STMMQR_DBG") ? atoi(getenv("STMMQR_DBG")) : 0;
+        c.tall_min = tall_min;
         c.dbgbuf = d_dbg.p;
         return c;
     }
@@ -196,6 +198,7 @@ int ensure_device(int device)
 // ------------------------------------------------------------------------------------------------
 void build_schedule(stmmqr_plan &P, std::vector<int> &tslot)
 {
+    P.tall_min = g_opt.tall_min_rows;
     const long nf = P.nf;
     int ngroups = 1;
     for (long f = 0; f < nf; f++) ngroups = std::max(ngroups, P.group[f] + 1);
@@ -276,7 +279,7 @@ void build_schedule(stmmqr_plan &P, std::vector<int> &tslot)
                         const int k2 = std::min(s.fn, (p + 1) * STM_NB);
                         mcb = std::max(mcb, (s.fn - k2 + 31) / 32);
                         msl = std::max(msl, (s.fm_ub + 255) / 256);
-                        L.nsub_at[p] = std::max(L.nsub_at[p], stm_tall_launches(s, p));
+                        L.nsub_at[p] = std::max(L.nsub_at[p], stm_tall_launches(s, p, P.tall_min));
                     }
                 }
                 L.nbig_at[p] = cnt;

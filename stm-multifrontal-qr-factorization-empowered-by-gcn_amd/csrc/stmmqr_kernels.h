@@ -29,6 +29,7 @@ struct DevCtx {
     double tol;
     int ntol;
     unsigned long long *dbgbuf; // [8] phase cycle sums of the panel kernel (STMMQR_DBG bit 4), else unused
+    int tall_min;              // stmmqr_options::tall_min_rows at plan time (stm_tall_panel)
     int dbg;                   // timing ablations only (bit0: no in-panel apply, bit1: no T, bit2: no dlarf in sub-panel,
                                //  bit3: LDS sub-panel path for every tall panel)
 };

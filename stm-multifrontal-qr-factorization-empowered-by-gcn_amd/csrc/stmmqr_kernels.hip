@@ -1161,6 +1161,8 @@ __device__ __forceinline__ void dev_tall_group(PanelShared &ps, const FrontSym &
             done = 1;
         }
         if (!done) {
+            // Straight-line column step: the dead-column and tau == 0 cases are folded into the scalars (a branch
+            // around the update would make the compiler copy the whole register image at the join).
             const int t = max(g + 1, ps.stair[j]);
             double part[8], sum[8];
 #pragma unroll
@@ -1181,48 +1183,42 @@ __device__ __forceinline__ void dev_tall_group(PanelShared &ps, const FrontSym &
             block_reduce8<NTH>(ps, par, part, sum);
             const double alpha = ps.top[tpar][0];
             const double ss = sum[0];
-            double tau = 0, beta = alpha, scal = 0;
-            if (ss != 0.0) {                                   // (no active row below the diagonal gives ss == 0 exactly)
-                beta = -copysign(sqrt(alpha * alpha + ss), alpha);
-                tau = (beta - alpha) / beta;
-                scal = 1.0 / (alpha - beta);
+            // dlarfg; ss == 0 (no active row below the diagonal, or all of them zero) gives H = I
+            const double bb = -copysign(sqrt(alpha * alpha + ss), alpha);
+            const bool ident = (ss == 0.0);
+            const double beta = ident ? alpha : bb;
+            const bool dead = (k < ntol) && (fabs(beta) <= tol);    // (:1495-1544) column zeroed, g does not advance
+            const bool upd = !ident && !dead;
+            const double tau = upd ? (bb - alpha) / bb : 0.0;
+            const double scal = upd ? 1.0 / (alpha - bb) : 0.0;
+            double w[8];
+#pragma unroll
+            for (int x = 1; x < SWT; x++) w[x] = tau * (ps.top[tpar][x] + scal * sum[x]);     // 0 unless upd
+#pragma unroll
+            for (int r = 0; r < RPT; r++) {
+                const int i = rb + tid + NTH * r;
+                const bool act = (i > g && i < t);
+                const double v = act ? a[r][0] * scal : 0.0;    // (upd false: the entries are zero already, or dead)
+                a[r][0] = act ? v : ((dead && i >= g) ? 0.0 : a[r][0]);
+#pragma unroll
+                for (int x = 1; x < SWT; x++) a[r][x] -= w[x] * v;
             }
-            const bool dead = (k < ntol) && (fabs(beta) <= tol);
-            if (dead) {
-                // zero the column from the diagonal down, no reflector, g does not advance (:1495-1544)
+            if (owner) {
 #pragma unroll
-                for (int r = 0; r < RPT; r++)
-                    if (rb + tid + NTH * r >= g) a[r][0] = 0.0;
-                if (tid == 0) { St[k] = 0; Rdead[k] = 1; Tau[k] = 0; pd->pdiag[jp] = STM_BIGROW; }
-                if (k == npiv - 1) rank = g;                   // (:1604-1608) also taken on a dead last pivot
-            } else {
-                if (tid == 0) { St[k] = t; Tau[k] = tau; pd->pdiag[jp] = g; }
+                for (int x = 1; x < SWT; x++) a[0][x] -= w[x];
+                a[0][0] = dead ? 0.0 : beta;
+            }
+            if (tid == 0) {
+                St[k] = dead ? 0 : t; Tau[k] = tau; pd->pdiag[jp] = dead ? STM_BIGROW : g;
+                if (dead) Rdead[k] = 1;
+            }
+            if (!dead) {
                 flops += (double)(t - g) * (3.0 + 4.0 * (double)(n - k - 1));
-                if (tau != 0.0) {
-                    nlive++;
-                    double w[8];
-#pragma unroll
-                    for (int x = 1; x < SWT; x++) w[x] = tau * (ps.top[tpar][x] + scal * sum[x]);
-#pragma unroll
-                    for (int r = 0; r < RPT; r++) {
-                        const int i = rb + tid + NTH * r;
-                        if (i > g && i < t) {
-                            const double v = a[r][0] * scal;
-                            a[r][0] = v;
-#pragma unroll
-                            for (int x = 1; x < SWT; x++) a[r][x] -= w[x] * v;
-                        }
-                    }
-                    if (owner) {
-#pragma unroll
-                        for (int x = 1; x < SWT; x++) a[0][x] -= w[x];
-                    }
-                }
-                if (owner) a[0][0] = beta;
+                nlive += (tau != 0.0);
                 tlast = t;
                 g++;
-                if (k == npiv - 1) rank = g;
             }
+            if (k == npiv - 1) rank = g;                       // (:1604-1608) also taken on a dead last pivot
         }
         // ---- retire register column 0 to F and rotate ----
         {
@@ -1348,7 +1344,7 @@ __global__ __launch_bounds__(NTP) void k_panel(DevCtx c, const int *__restrict__
     int *St = c.Stair + s.rp;
     PanelDesc *pd = &num->pd[p & 1];
     const int b = blockIdx.y;
-    bool tall = stm_tall_panel(s, p) && !(c.dbg & 256);
+    bool tall = stm_tall_panel(s, p, c.tall_min) && !(c.dbg & 256);
     if (!tall && b > 0) return;
     if (tall) {
         const int k1 = p * STM_NB, k2 = min(s.fn, k1 + STM_NB), nbp = k2 - k1;
@@ -1440,23 +1436,32 @@ __global__ __launch_bounds__(NT) void k_larft(DevCtx c, int f)
 // ------------------------------------------------------------------------------------------------
 #define SLAB 256
 
-__device__ __forceinline__ void upd_load_chunk(const double *Vg, const double *Cg, long long ld, int i, int mp, int nbp,
-                                               int nc, const int *s_pd, int g1, int lrow, int lcg, double *Vs,
-                                               double *Cs, bool want_c)
+// One 64-row chunk of V (panel columns, unit-lower-trapezoidal mask applied) and of C (one column block) goes through
+// registers into LDS.  The loads are unconditional on clamped indices (a predicated load is a branch around each
+// access, and the 16 loads of a thread would be issued one round trip at a time); the callers issue the loads of the
+// next chunk before the MFMA loop of the current one.
+struct UpdChunk { double v[8], c[8]; };
+__device__ __forceinline__ void upd_chunk_load(UpdChunk &ck, const double *Vg, const double *Cg, long long ld, int i, int mp,
+                                               int nbp, int nc, int lcg)
+{
+    const int ic = min(i, mp - 1);
+#pragma unroll
+    for (int q = 0; q < 8; q++) {
+        const int col = lcg * 8 + q;
+        ck.v[q] = Vg[ic + (long long)min(col, nbp - 1) * ld];
+        ck.c[q] = Cg[ic + (long long)min(col, nc - 1) * ld];
+    }
+}
+__device__ __forceinline__ void upd_chunk_to_lds(const UpdChunk &ck, int i, int mp, int nbp, int nc, const int *s_pd, int g1,
+                                                 int lrow, int lcg, double *Vs, double *Cs)
 {
 #pragma unroll
     for (int q = 0; q < 8; q++) {
         const int col = lcg * 8 + q;
-        double v = 0, cv = 0;
-        if (i < mp) {
-            if (col < nbp) {
-                const int d = s_pd[col] - g1;
-                v = (i < d) ? 0.0 : ((i == d) ? 1.0 : Vg[i + col * ld]);
-            }
-            if (want_c && col < nc) cv = Cg[i + col * ld];
-        }
+        const int d = s_pd[col] - g1;                          // (BIGROW beyond nbp: everything masked)
+        const double v = (i < mp && col < nbp && i >= d) ? ((i == d) ? 1.0 : ck.v[q]) : 0.0;
         Vs[col * VS + lrow] = v;
-        if (want_c) Cs[col * VS + lrow] = cv;
+        Cs[col * VS + lrow] = (i < mp && col < nc) ? ck.c[q] : 0.0;
     }
 }
 
@@ -1484,9 +1489,12 @@ __global__ __launch_bounds__(NT) void k_upd_w(DevCtx c, const int *__restrict__ 
     const int mi = wid >> 1, ni = wid & 1;
     d4 acc = {0, 0, 0, 0};
     const int rend = min(mp, (sl + 1) * SLAB);
+    UpdChunk ck;
+    upd_chunk_load(ck, Vg, Cg, ld, sl * SLAB + (tid & 63), mp, nbp, nc, tid >> 6);
     for (int r0 = sl * SLAB; r0 < rend; r0 += RB) {
-        upd_load_chunk(Vg, Cg, ld, r0 + (tid & 63), mp, nbp, nc, s_pd, g1, tid & 63, tid >> 6, Vs, Cs, true);
+        upd_chunk_to_lds(ck, r0 + (tid & 63), mp, nbp, nc, s_pd, g1, tid & 63, tid >> 6, Vs, Cs);
         __syncthreads();
+        if (r0 + RB < rend) upd_chunk_load(ck, Vg, Cg, ld, r0 + RB + (tid & 63), mp, nbp, nc, tid >> 6);
 #pragma unroll
         for (int kk = 0; kk < RB / 4; kk++) {
             const double a = Vs[(16 * mi + l15) * VS + 4 * kk + l4];
@@ -1558,10 +1566,13 @@ __global__ __launch_bounds__(NT) void k_upd_c(DevCtx c, const int *__restrict__ 
     double *Cg = c.Farena + s.foff + g1 + (long long)c0 * ld;
     const int lrow = tid & 63, lcg = tid >> 6;
     const int rend = min(mp, (sl + 1) * SLAB);
+    UpdChunk ck;
+    upd_chunk_load(ck, Vg, Cg, ld, sl * SLAB + lrow, mp, nbp, nc, lcg);
     for (int r0 = sl * SLAB; r0 < rend; r0 += RB) {
         const int i = r0 + lrow;
-        upd_load_chunk(Vg, Cg, ld, i, mp, nbp, nc, s_pd, g1, lrow, lcg, Vs, Cs, true);
+        upd_chunk_to_lds(ck, i, mp, nbp, nc, s_pd, g1, lrow, lcg, Vs, Cs);
         __syncthreads();
+        if (r0 + RB < rend) upd_chunk_load(ck, Vg, Cg, ld, i + RB, mp, nbp, nc, lcg);
         d4 u0 = {0, 0, 0, 0}, u1 = {0, 0, 0, 0};
 #pragma unroll
         for (int kk = 0; kk < STM_NB / 4; kk++) {

@@ -85,6 +85,7 @@ struct OneFront {
         c.fs = d_fs.p; c.fnum = d_nm.p; c.Farena = d_F.p; c.Carena = d_C.p; c.Tws = d_T.p; c.tslot = d_tslot.p;
         c.Stair = d_St.p; c.Tau = d_Tau.p; c.Rdead = d_Rdead.p; c.Rhoff = d_Rhoff.p; c.Rboff = d_Rboff.p;
         c.dbg = getenv("STMMQR_DBG") ? atoi(getenv("STMMQR_DBG")) : 0;
+        { stmmqr_options o; stmmqr_get_options(&o); c.tall_min = o.tall_min_rows; }
 #ifdef STMMQR_STAMPS
         if (!d_dbg.alloc(16)) return false;
         (void)hipMemset(d_dbg.p, 0, 16 * sizeof(unsigned long long));
@@ -130,7 +131,7 @@ stm_long stmmqr_front(stm_long m, stm_long n, stm_long npiv, double tol, stm_lon
         e = stm_launch_front_wg(X.c, X.d_flist.p, 1, lds_for(m), nullptr);
     } else {
         for (int p = 0; p < X.s.npanels && !e; p++) {
-            e = stm_launch_panel(X.c, X.d_flist.p, 1, p, stm_tall_launches(X.s, p), lds_for(m), nullptr);
+            e = stm_launch_panel(X.c, X.d_flist.p, 1, p, stm_tall_launches(X.s, p, X.c.tall_min), lds_for(m), nullptr);
             const int k2 = (int)std::min<long>(n, (long)(p + 1) * STM_NB);
             if (!e) e = stm_launch_update(X.c, X.d_flist.p, 1, p, 0, (int)((n - k2 + 31) / 32), nullptr);
         }
