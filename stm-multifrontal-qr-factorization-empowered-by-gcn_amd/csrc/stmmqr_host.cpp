@@ -550,7 +550,7 @@ int run_schedule(stmmqr_plan &P, bool detail, int grp, bool first)
                 e = timed(t_upd, [&]() -> int {
                     if (L.maxsl_at[p] > 0 && g_opt.split_update) {
                         LCHK(stm_launch_update_split(c, big, L.nbig_at[p], (int)p, 0, L.maxcb_at[p], L.maxsl_at[p], P.d_Wp.p, st));
-                        nlaunch += 2;
+                        nlaunch += 1;
                     } else
                         LCHK(stm_launch_update(c, big, L.nbig_at[p], (int)p, 0, L.maxcb_at[p], st));
                     return 0;

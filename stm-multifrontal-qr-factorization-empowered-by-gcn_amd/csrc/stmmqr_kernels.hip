@@ -223,6 +223,35 @@ __global__ __launch_bounds__(NT) void k_assemble(DevCtx c, const int *__restrict
     dev_assemble(c, s, blockIdx.x, nparts);
 }
 
+// One 64-row chunk of V (panel columns, unit-lower-trapezoidal mask applied) and of C (one column block) goes through
+// registers into LDS.  The loads are unconditional on clamped indices (a predicated load is a branch around each
+// access, and the 16 loads of a thread would be issued one round trip at a time); the callers issue the loads of the
+// next chunk before the MFMA loop of the current one.
+struct UpdChunk { double v[8], c[8]; };
+__device__ __forceinline__ void upd_chunk_load(UpdChunk &ck, const double *Vg, const double *Cg, long long ld, int i, int mp,
+                                               int nbp, int nc, int lcg)
+{
+    const int ic = min(i, mp - 1);
+#pragma unroll
+    for (int q = 0; q < 8; q++) {
+        const int col = lcg * 8 + q;
+        ck.v[q] = Vg[ic + (long long)min(col, nbp - 1) * ld];
+        ck.c[q] = Cg[ic + (long long)min(col, nc - 1) * ld];
+    }
+}
+__device__ __forceinline__ void upd_chunk_to_lds(const UpdChunk &ck, int i, int mp, int nbp, int nc, const int *s_pd, int g1,
+                                                 int lrow, int lcg, double *Vs, double *Cs)
+{
+#pragma unroll
+    for (int q = 0; q < 8; q++) {
+        const int col = lcg * 8 + q;
+        const int d = s_pd[col] - g1;                          // (BIGROW beyond nbp: everything masked)
+        const double v = (i < mp && col < nbp && i >= d) ? ((i == d) ? 1.0 : ck.v[q]) : 0.0;
+        Vs[col * VS + lrow] = v;
+        Cs[col * VS + lrow] = (i < mp && col < nc) ? ck.c[q] : 0.0;
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // qr_larftb(QR_QTX): C <- (I - V T V')' C for one block of <= BN columns, on fp64 MFMA.
 //   C = F(g1:g1+mp, c0:c0+nc), V = F(g1:g1+mp, k1:k1+nbp) with the unit diagonal of reflector j at absolute row
@@ -254,23 +283,13 @@ __device__ void dev_update_block(double *F, long long ld, int g1, int mp, int k1
     // ---- phase 1: W1 = V' C ----
     const int mi = wid >> 1, ni = wid & 1;
     d4 acc = {0, 0, 0, 0};
+    UpdChunk ck;
+    upd_chunk_load(ck, Vg, Cg, ld, lrow, mp, nbp, nc, lcg);
     for (int r0 = 0; r0 < mp; r0 += RB) {
         const int i = r0 + lrow;
-#pragma unroll
-        for (int q = 0; q < 8; q++) {
-            const int col = lcg * 8 + q;
-            double v = 0, cv = 0;
-            if (i < mp) {
-                if (col < nbp) {
-                    const int d = s_pd[col] - g1;
-                    v = (i < d) ? 0.0 : ((i == d) ? 1.0 : Vg[i + col * ld]);
-                }
-                if (col < nc) cv = Cg[i + col * ld];
-            }
-            Vs[col * VS + lrow] = v;
-            Cs[col * VS + lrow] = cv;
-        }
+        upd_chunk_to_lds(ck, i, mp, nbp, nc, s_pd, g1, lrow, lcg, Vs, Cs);
         __syncthreads();
+        if (r0 + RB < mp) upd_chunk_load(ck, Vg, Cg, ld, i + RB, mp, nbp, nc, lcg);
 #pragma unroll
         for (int kk = 0; kk < RB / 4; kk++) {
             const double a = Vs[(16 * mi + l15) * VS + 4 * kk + l4];
@@ -299,23 +318,12 @@ __device__ void dev_update_block(double *F, long long ld, int g1, int mp, int k1
     __syncthreads();
 
     // ---- phase 3: C -= V W2 ----
+    upd_chunk_load(ck, Vg, Cg, ld, lrow, mp, nbp, nc, lcg);
     for (int r0 = 0; r0 < mp; r0 += RB) {
         const int i = r0 + lrow;
-#pragma unroll
-        for (int q = 0; q < 8; q++) {
-            const int col = lcg * 8 + q;
-            double v = 0, cv = 0;
-            if (i < mp) {
-                if (col < nbp) {
-                    const int d = s_pd[col] - g1;
-                    v = (i < d) ? 0.0 : ((i == d) ? 1.0 : Vg[i + col * ld]);
-                }
-                if (col < nc) cv = Cg[i + col * ld];
-            }
-            Vs[col * VS + lrow] = v;
-            Cs[col * VS + lrow] = cv;
-        }
+        upd_chunk_to_lds(ck, i, mp, nbp, nc, s_pd, g1, lrow, lcg, Vs, Cs);
         __syncthreads();
+        if (r0 + RB < mp) upd_chunk_load(ck, Vg, Cg, ld, i + RB, mp, nbp, nc, lcg);
         d4 u0 = {0, 0, 0, 0}, u1 = {0, 0, 0, 0};
 #pragma unroll
         for (int kk = 0; kk < STM_NB / 4; kk++) {
@@ -361,7 +369,10 @@ __device__ void dev_gram_T(const double *Vg, long long ld, int r0, int r1, int n
     const bool two = nc > 16;
     const int d0 = (l15 < nc) ? diag[l15] : STM_BIGROW;
     const int d1 = (16 + l15 < nc) ? diag[16 + l15] : STM_BIGROW;
-    const double *V0 = Vg + (long long)l15 * ld, *V1 = Vg + (long long)(16 + l15) * ld;
+    // (columns and rows are clamped so that every load is unconditional -- a predicated load is a branch around the
+    //  access and the loads of a trip would be issued one round trip at a time -- and masked afterwards)
+    const int ncc = max(nc, 1);
+    const double *V0 = Vg + (long long)min(l15, ncc - 1) * ld, *V1 = Vg + (long long)min(16 + l15, ncc - 1) * ld;
     d4 g00 = {0, 0, 0, 0}, g01 = {0, 0, 0, 0}, g11 = {0, 0, 0, 0};
     const int nk = (r1 - r0 + 3) / 4;
     // four row groups per trip: the 8 loads are issued before the first MFMA needs one (latency-bound otherwise)
@@ -370,11 +381,11 @@ __device__ void dev_gram_T(const double *Vg, long long ld, int r0, int r1, int n
 #pragma unroll
         for (int u = 0; u < 4; u++) {
             const int i = r0 + 4 * (kk + u * NWV) + l4;
-            a0[u] = 0; a1[u] = 0;
-            if (kk + u * NWV < nk && i < r1) {
-                if (i >= d0) a0[u] = (i == d0) ? 1.0 : V0[i];
-                if (two && i >= d1) a1[u] = (i == d1) ? 1.0 : V1[i];
-            }
+            const int ic = max(min(i, r1 - 1), 0);
+            const double x0 = V0[ic], x1 = V1[ic];
+            const bool in = (kk + u * NWV < nk) && (i < r1);
+            a0[u] = (in && i >= d0) ? ((i == d0) ? 1.0 : x0) : 0.0;
+            a1[u] = (in && two && i >= d1) ? ((i == d1) ? 1.0 : x1) : 0.0;
         }
 #pragma unroll
         for (int u = 0; u < 4; u++) {
@@ -742,7 +753,11 @@ __device__ __forceinline__ void dev_panel(PanelShared &ps, const FrontSym &s, Fr
             if (!use_reg)
                 for (int j = wid; j < sw; j += NWV) {
                     const double *src = F + (k1 + j0 + j) * ld;
-                    for (int i = lane; i < msp; i += 64) lds[i + j * pst] = (i < ms) ? src[gs + i] : 0.0;
+                    // (unconditional loads on a clamped row, masked afterwards: see dev_tall_group)
+                    for (int i = lane; i < msp; i += 64) {
+                        const double val = src[gs + max(min(i, ms - 1), 0)];
+                        lds[i + j * pst] = (i < ms) ? val : 0.0;
+                    }
                 }
             Pb = lds; roff = gs; coff = j0;
         } else {
@@ -1426,44 +1441,14 @@ __global__ __launch_bounds__(NT) void k_larft(DevCtx c, int f)
 }
 
 // ------------------------------------------------------------------------------------------------
-// Row-parallel trailing update for tall panels: the three phases of dev_update_block as three launches so that
+// Row-parallel trailing update for tall panels: the phases of dev_update_block as two launches so that
 // the rows are split over workgroups too (a 4000-row update has 126 column blocks x 16 row slabs instead of
 // 126 workgroups that each walk 63 chunks):
 //   k_upd_w : partial W1 = V(slab)' C(slab, cb)            grid (cb, slab, front)   -> Wp[front][cb][slab]
-//   k_upd_t : W2 = T' sum_slabs W1                          grid (cb, front)         -> Wp[front][cb][0]
-//   k_upd_c : C(slab, cb) -= V(slab) W2                     grid (cb, slab, front)
+//   k_upd_c : W2 = T' sum_slabs W1 ;  C(slab, cb) -= V(slab) W2     grid (cb, slab, front)
 // SLAB rows per slab; the summation order over slabs is fixed (deterministic results).
 // ------------------------------------------------------------------------------------------------
 #define SLAB 256
-
-// One 64-row chunk of V (panel columns, unit-lower-trapezoidal mask applied) and of C (one column block) goes through
-// registers into LDS.  The loads are unconditional on clamped indices (a predicated load is a branch around each
-// access, and the 16 loads of a thread would be issued one round trip at a time); the callers issue the loads of the
-// next chunk before the MFMA loop of the current one.
-struct UpdChunk { double v[8], c[8]; };
-__device__ __forceinline__ void upd_chunk_load(UpdChunk &ck, const double *Vg, const double *Cg, long long ld, int i, int mp,
-                                               int nbp, int nc, int lcg)
-{
-    const int ic = min(i, mp - 1);
-#pragma unroll
-    for (int q = 0; q < 8; q++) {
-        const int col = lcg * 8 + q;
-        ck.v[q] = Vg[ic + (long long)min(col, nbp - 1) * ld];
-        ck.c[q] = Cg[ic + (long long)min(col, nc - 1) * ld];
-    }
-}
-__device__ __forceinline__ void upd_chunk_to_lds(const UpdChunk &ck, int i, int mp, int nbp, int nc, const int *s_pd, int g1,
-                                                 int lrow, int lcg, double *Vs, double *Cs)
-{
-#pragma unroll
-    for (int q = 0; q < 8; q++) {
-        const int col = lcg * 8 + q;
-        const int d = s_pd[col] - g1;                          // (BIGROW beyond nbp: everything masked)
-        const double v = (i < mp && col < nbp && i >= d) ? ((i == d) ? 1.0 : ck.v[q]) : 0.0;
-        Vs[col * VS + lrow] = v;
-        Cs[col * VS + lrow] = (i < mp && col < nc) ? ck.c[q] : 0.0;
-    }
-}
 
 __global__ __launch_bounds__(NT) void k_upd_w(DevCtx c, const int *__restrict__ flist, int p, int cb0, double *Wp,
                                               int maxcb, int maxsl)
@@ -1558,9 +1543,31 @@ __global__ __launch_bounds__(NT) void k_upd_c(DevCtx c, const int *__restrict__ 
     const long long ld = s.ld;
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, l15 = lane & 15, l4 = lane >> 4;
     double *Vs = dyn_lds, *Cs = Vs + STM_NB * VS, *Ws = Cs + BN * VS;
+    __shared__ double s_W1[STM_NB * WS], s_T[STM_NB * WS];
     if (tid < STM_NB) s_pd[tid] = (tid < nbp) ? pd->pdiag[tid] : STM_BIGROW;
-    const double *W2 = Wp + ((long long)(fi * maxcb + cb) * maxsl) * (STM_NB * BN);
-    for (int e = tid; e < STM_NB * BN; e += NT) Ws[(e / BN) * WS + (e % BN)] = W2[e];
+    // W2 = T' sum_slabs W1 (every slab workgroup of a column block recomputes it: 32^3 multiply-adds against one
+    // launch less per panel); the summation order over the slabs is fixed
+    {
+        const int nsl = (mp + SLAB - 1) / SLAB;
+        const double *W0 = Wp + ((long long)(fi * maxcb + cb) * maxsl) * (STM_NB * BN);
+        const double *T = c.Tws + (long long)(2 * c.tslot[f] + (p & 1)) * STM_NB * STM_NB;
+        for (int e = tid; e < STM_NB * BN; e += NT) {
+            double v = 0;
+            for (int q = 0; q < nsl; q++) v += W0[(long long)q * (STM_NB * BN) + e];
+            s_W1[(e / BN) * WS + (e % BN)] = v;
+            s_T[(e / STM_NB) * WS + (e % STM_NB)] = T[e];          // s_T[col][row] = T(row, col)
+        }
+        __syncthreads();
+        const int l = tid & 31, cg = tid >> 5;
+        double w2[4] = {0, 0, 0, 0};
+        for (int q = 0; q <= l; q++) {
+            const double tq = s_T[l * WS + q];                     // T(q, l)
+#pragma unroll
+            for (int x = 0; x < 4; x++) w2[x] += tq * s_W1[q * WS + cg * 4 + x];
+        }
+#pragma unroll
+        for (int x = 0; x < 4; x++) Ws[l * WS + cg * 4 + x] = w2[x];
+    }
     __syncthreads();
     const double *Vg = c.Farena + s.foff + g1 + (long long)pd->pk1 * ld;
     double *Cg = c.Farena + s.foff + g1 + (long long)c0 * ld;
@@ -1778,7 +1785,6 @@ int stm_launch_update_split(const DevCtx &c, const int *flist, int nfr, int p, i
     if (nfr <= 0 || ncb <= 0 || maxsl <= 0) return 0;
     const size_t lds = (size_t)stm_update_lds_bytes();
     hipLaunchKernelGGL(k_upd_w, dim3(ncb, maxsl, nfr), dim3(NT), lds, st, c, flist, p, cb0, Wp, ncb, maxsl);
-    hipLaunchKernelGGL(k_upd_t, dim3(ncb, nfr), dim3(NT), 0, st, c, flist, p, cb0, Wp, ncb, maxsl);
     hipLaunchKernelGGL(k_upd_c, dim3(ncb, maxsl, nfr), dim3(NT), lds, st, c, flist, p, cb0, (const double *)Wp, ncb, maxsl);
     return (int)hipGetLastError();
 }
