@@ -169,29 +169,50 @@ def main():
     det = plan.factorize(None, tol, ntol, device_ptr=Ax.data_ptr(), detail=True)
     if rank == 0:
         value = total_flops * args.steps / wall * 1e-9
+        # Roofline of the dominant kernel.  Times are HIP-event sums on the plan's stream from the detail pass (one event
+        # pair per launch category and level).  Algorithmic work: the reference's flop count (FLOP_COUNT, :1571) splits
+        # into the dlarfb flops handed to the trailing update (4 * rows * cols * reflectors per panel) and the rest,
+        # which the panel kernels do (dlarfg + in-panel dlarf + T).
         upd_tf = det["flops_update"] / max(det["ms_update"], 1e-9) * 1e-9 if det["ms_update"] > 0 else 0.0
-        front_tf = flops / max(det["ms_front"], 1e-9) * 1e-9
-        if det["ms_update"] > 0.5 * det["ms_front"]:
-            roof = {"bound": "mfma", "kernel": "k_update (dlarfb on v_mfma_f64_16x16x4_f64)", "achieved": upd_tf,
-                    "peak": PEAK_FP64_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": upd_tf / PEAK_FP64_MFMA_TFLOPS,
-                    "traffic": None}
-        else:
-            roof = {"bound": "mfma", "kernel": "front kernels (k_front_wg + k_panel + k_update)", "achieved": front_tf,
-                    "peak": PEAK_FP64_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": front_tf / PEAK_FP64_MFMA_TFLOPS,
-                    "traffic": None}
-        pmc = ROOT / "profiles" / "r01_b_pmc_fetch_write_per_kernel.json"
-        if pmc.exists() and "standin" in name:
+        panel_flops = max(flops - det["flops_update"], 0.0)
+        panel_tf = panel_flops / max(det["ms_front"], 1e-9) * 1e-9
+        # trailing update: 2 reads + 1 write of the trailing block per panel = 24 B per (row, col), i.e. per 4*nb flops
+        upd_bytes = det["flops_update"] * 24.0 / (4.0 * 32.0)
+        upd_gbs = upd_bytes / max(det["ms_update"], 1e-9) * 1e-6
+        pmc = {}
+        for cand in sorted((ROOT / "profiles").glob("r*_pmc_fetch_write_per_kernel.json")):
+            pmc_file = cand
             try:
-                pk = json.loads(pmc.read_text())["k_update"]
-                # KB units; FETCH_SIZE on gfx950 counts 64 B per 128-B request on wide streams (not corrected here)
-                per_launch = (pk["FETCH_SIZE"]["sum_kb"] / pk["FETCH_SIZE"]["calls"] +
-                              pk["WRITE_SIZE"]["sum_kb"] / pk["WRITE_SIZE"]["calls"]) * 1024.0
-                roof["update_kernel"] = {"bound": "mfma", "achieved": upd_tf, "peak": PEAK_FP64_MFMA_TFLOPS, "unit": "TFLOP/s",
-                                         "frac": upd_tf / PEAK_FP64_MFMA_TFLOPS,
-                                         "traffic_bytes_per_launch_pmc": per_launch,
-                                         "traffic_source": "profiles/r01_b_pmc_fetch_write_per_kernel.json (k_update, pre-split build)"}
+                pmc = json.loads(cand.read_text())
             except Exception:
-                pass
+                pmc = {}
+
+        def pmc_traffic(kernels):
+            """HBM bytes per launch from the committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (KB units)."""
+            tot, calls = 0.0, 0
+            for k in kernels:
+                e = pmc.get(k, {})
+                if "FETCH_SIZE" in e and "WRITE_SIZE" in e:
+                    tot += (e["FETCH_SIZE"]["sum_kb"] + e["WRITE_SIZE"]["sum_kb"]) * 1024.0
+                    calls += e["FETCH_SIZE"]["calls"]
+            return (tot / calls) if calls and "standin" in name else None
+
+        if det["ms_front"] >= det["ms_update"]:
+            roof = {"bound": "mfma", "kernel": "k_panel (+ k_front_wg): Householder panels, fp64 vector/MFMA rate",
+                    "achieved": panel_tf, "peak": PEAK_FP64_MFMA_TFLOPS, "unit": "TFLOP/s",
+                    "frac": panel_tf / PEAK_FP64_MFMA_TFLOPS, "traffic": pmc_traffic(["k_panel"]),
+                    "note": "latency-bound: one workgroup reduction per Householder column (DESIGN.md 4)"}
+        else:
+            roof = {"bound": "hbm", "kernel": "k_upd_w + k_upd_c (dlarfb on v_mfma_f64_16x16x4_f64)", "achieved": upd_gbs,
+                    "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": upd_gbs / PEAK_HBM_GBS,
+                    "traffic": pmc_traffic(["k_upd_w", "k_upd_c"])}
+        roof["whole_factorization"] = {"bound": "mfma", "achieved": flops / max(det["ms_total"], 1e-9) * 1e-9,
+                                       "peak": PEAK_FP64_MFMA_TFLOPS, "unit": "TFLOP/s",
+                                       "frac": flops / max(det["ms_total"], 1e-9) * 1e-9 / PEAK_FP64_MFMA_TFLOPS}
+        roof["update_kernels"] = {"bound": "hbm", "kernel": "k_upd_w + k_upd_c", "achieved": upd_gbs, "peak": PEAK_HBM_GBS,
+                                  "unit": "GB/s", "frac": upd_gbs / PEAK_HBM_GBS, "tflops": upd_tf,
+                                  "traffic": pmc_traffic(["k_upd_w", "k_upd_c"]),
+                                  "traffic_source": str(pmc_file.relative_to(ROOT)) if pmc else None}
         roof["assembly"] = {"bound": "hbm", "achieved": det["bytes_assemble"] / max(det["ms_assemble"], 1e-9) * 1e-6,
                             "peak": PEAK_HBM_GBS, "unit": "GB/s",
                             "frac": det["bytes_assemble"] / max(det["ms_assemble"], 1e-9) * 1e-6 / PEAK_HBM_GBS}

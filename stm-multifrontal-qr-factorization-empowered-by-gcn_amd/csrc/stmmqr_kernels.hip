@@ -1059,7 +1059,8 @@ __device__ __forceinline__ void block_reduce8(PanelShared &ps, int &par, const d
 template <int NTH, int RPT, int SWT>
 __device__ __forceinline__ void dev_tall_group(PanelShared &ps, const FrontSym &s, FrontNum *num, PanelDesc *pd, double *F,
                                                int *St, double *Tau, char *Rdead, int p, int b, int g1, int tmax,
-                                               double tol, int ntol_global, double *Tout, double *lds)
+                                               double tol, int ntol_global, double *Tout, double *lds, int dbg = 0,
+                                               unsigned long long *dbgbuf = nullptr)
 {
     const int tid = threadIdx.x;
     const int m = num->fm, n = s.fn, npiv = s.fp;              // (fm is fixed before the panel kernels run)
@@ -1070,6 +1071,13 @@ __device__ __forceinline__ void dev_tall_group(PanelShared &ps, const FrontSym &
     const int rb = g1;                                         // first row of the register image
     int par = 0;
     if (tid < SWT) ps.stair[tid] = (tid < sw) ? St[k1 + c0 + tid] : 0;     // (only this group ever writes these)
+#ifdef STMMQR_STAMPS
+    unsigned long long ts0 = clock64(), ts1;
+    const bool stamp_me = (dbg & 16) && dbgbuf && (b == ns - 1);
+#define TSTAMP(idx) do { if (stamp_me) { __syncthreads(); ts1 = clock64(); if (tid == 0) atomicAdd(&dbgbuf[idx], ts1 - ts0); ts0 = ts1; } } while (0)
+#else
+#define TSTAMP(idx) do { } while (0)
+#endif
 
     // (loads are unconditional on a clamped index and masked afterwards: a predicated load becomes a branch around
     //  each access and the 8 x RPT loads would be issued one round trip at a time)
@@ -1084,10 +1092,12 @@ __device__ __forceinline__ void dev_tall_group(PanelShared &ps, const FrontSym &
             a[r][x] = (x < sw && i < tmax) ? val : 0.0;
         }
     }
+    TSTAMP(6);
     // ---- apply the reflectors of the groups before mine, as they become available ----
     int prev_done = 0;
     for (int sp = 0; sp < b && !prev_done; sp++) {
         if (!wait_progress(&num->prog, 16 * p + sp + 1)) return;
+        TSTAMP(7);
         const int pc0 = SWT * sp;
         const int tprev = ld_agent(&pd->st[sp]);
         prev_done = ld_agent(&num->done);
@@ -1137,6 +1147,7 @@ __device__ __forceinline__ void dev_tall_group(PanelShared &ps, const FrontSym &
             }
         }
     }
+    TSTAMP(8);
     // a group before mine ran out of rows (g reached fm): its reflectors were still due on my columns (applied above);
     // nothing is left to factorize.  The group right after it finalises the panel, the others only store.
     if (prev_done) {
@@ -1248,6 +1259,7 @@ __device__ __forceinline__ void dev_tall_group(PanelShared &ps, const FrontSym &
             }
         }
     }
+    TSTAMP(9);
     // ---- sub-panel bookkeeping; the last sub-panel (or the group after one that ran out of rows) finalises ----
     const bool last = prev_done || b == ns - 1;
     const int nl_total = nl_before + nlive;
@@ -1273,9 +1285,11 @@ __device__ __forceinline__ void dev_tall_group(PanelShared &ps, const FrontSym &
     }
     __syncthreads();
     dev_gram_T<NTH>(F + (long long)k1 * ld, ld, g1, tlast, nbp, ps.diag, ps.tau, ps.G, ps.T, Tout, lds);
+    TSTAMP(10);
     // (when an earlier group ran out of rows the groups after mine are still storing their columns: the kernel
     //  boundary orders those stores before the trailing update)
     publish_progress(&num->prog, 16 * p + b + 1);
+#undef TSTAMP
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1388,7 +1402,7 @@ __global__ __launch_bounds__(NTP) void k_panel(DevCtx c, const int *__restrict__
         }
         if (mode == 1) {
             const int rows = tmax - g1;
-#define TALL_ARGS ps, s, num, pd, F, St, c.Tau + s.rp, c.Rdead + s.col1, p, b, g1, tmax, c.tol, c.ntol, T, dyn_lds
+#define TALL_ARGS ps, s, num, pd, F, St, c.Tau + s.rp, c.Rdead + s.col1, p, b, g1, tmax, c.tol, c.ntol, T, dyn_lds, c.dbg, c.dbgbuf
             if (w == 4) dev_tall_group<NTP, 8, 4>(TALL_ARGS);
             else if (rows <= NTP) dev_tall_group<NTP, 1, 8>(TALL_ARGS);
             else if (rows <= 2 * NTP) dev_tall_group<NTP, 2, 8>(TALL_ARGS);
