@@ -78,6 +78,8 @@ struct FrontNum {
     int rsize;               // entries of the packed R+H block     (qr_rhpack's return value)
     int hdr;                 // tall-panel pipeline: p+1 once the header (mode, pg1, tmax, sw) of panel p is published
     int prog;                // ... 16*p + (number of finished sub-panels of panel p); monotone over the whole front
+    int perr;                // ... set when a bounded wait ran out (the factorization is reported as failed)
+    int pad2;
     double flops;            // reference flop count of this front  (FLOP_COUNT, :1571)
     double flops_upd;        // dlarfb flops handed to the MFMA update: 4 * rows * cols * reflectors
     // pending block reflectors, double buffered by panel parity so that the look-ahead schedule can factorize

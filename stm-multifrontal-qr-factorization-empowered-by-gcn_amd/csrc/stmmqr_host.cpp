@@ -779,6 +779,7 @@ int stmmqr_factorize_finish(stmmqr_plan *plan, stmmqr_stats *stats)
         flops += nm.flops;
         fl_upd += nm.flops_upd;
         rank += nm.rank;
+        if (nm.perr) return fail(STMMQR_ERR_DEVICE, "a panel workgroup gave up waiting for its neighbours (device shared with another job?)");
         const double cn = s.fn - s.fp, cm = nm.cm;
         const double csize = cm * (cm + 1) / 2 + cm * (cn - cm);
         bytes_asm += 8.0 * ((double)nm.fm * s.fn) + 8.0 * csize;   // F first write + child C read (as a child)

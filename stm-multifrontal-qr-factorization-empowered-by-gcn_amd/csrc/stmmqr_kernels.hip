@@ -163,7 +163,7 @@ __global__ __launch_bounds__(NT) void k_setup(DevCtx c, const int *__restrict__ 
     }
     if (tid == 0) {
         FrontNum *nm = &c.fnum[f];
-        nm->fm = fm; nm->g = 0; nm->rank = min(fm, s.fp); nm->done = 0; nm->hdr = 0; nm->prog = 0;
+        nm->fm = fm; nm->g = 0; nm->rank = min(fm, s.fp); nm->done = 0; nm->hdr = 0; nm->prog = 0; nm->perr = 0;
         nm->pd[0].pnb = 0; nm->pd[1].pnb = 0; nm->cm = 0; nm->rsize = 0; nm->flops = 0; nm->flops_upd = 0;
     }
 }
@@ -1096,7 +1096,7 @@ __device__ __forceinline__ void dev_tall_group(PanelShared &ps, const FrontSym &
     // ---- apply the reflectors of the groups before mine, as they become available ----
     int prev_done = 0;
     for (int sp = 0; sp < b && !prev_done; sp++) {
-        if (!wait_progress(&num->prog, 16 * p + sp + 1)) return;
+        if (!wait_progress(&num->prog, 16 * p + sp + 1)) { if (tid == 0) st_agent(&num->perr, 1); return; }
         TSTAMP(7);
         const int pc0 = SWT * sp;
         const int tprev = ld_agent(&pd->st[sp]);
@@ -1396,7 +1396,7 @@ __global__ __launch_bounds__(NTP) void k_panel(DevCtx c, const int *__restrict__
             publish_progress(&num->hdr, p + 1);
             if (was_done) return;
         } else {
-            if (!wait_progress(&num->hdr, p + 1)) return;
+            if (!wait_progress(&num->hdr, p + 1)) { if (threadIdx.x == 0) st_agent(&num->perr, 1); return; }
             mode = ld_agent(&pd->mode); g1 = ld_agent(&pd->pg1); tmax = ld_agent(&pd->tmax); w = ld_agent(&pd->sw);
             if (mode != 1 || b * w >= nbp) return;
         }

@@ -58,6 +58,26 @@ def test_against_golden_and_oracle(pkg, oracle, name, bigcols):
         assert np.linalg.norm(G.Stack[:G.rh_total] - ref) <= 1e-10 * max(np.linalg.norm(ref), 1e-300)
 
 
+@pytest.mark.parametrize("name", ["syn_grid3d", "syn_rankdef_grid", "bcsstk14", "grid20_standin"])
+@pytest.mark.parametrize("tall_min", [0, 48, 1 << 30])
+def test_panel_pipeline_threshold(pkg, oracle, name, tall_min):
+    """tall_min_rows = 0 sends every panel of a large front through the pipeline of 8-column groups (register-resident
+    column steps, inter-workgroup progress flags), 1<<30 none: integers, R rows and the factors must not care."""
+    if name not in NAMES:
+        pytest.skip("fixture not present")
+    g = load_golden(name)
+    pkg.set_options(tall_min_rows=tall_min, big_front_cols=16)
+    try:
+        S, G = gpu_run(pkg, g)
+    finally:
+        pkg.set_options(tall_min_rows=256, big_front_cols=64)
+    N = numeric_from_gpu(S, G)
+    compare_integers(S, N, g)
+    assert G.stats["flops"] == scalar(g, "flopcount")
+    No = oracle.factorize(S, g["in_Ap"], g["in_Ai"], g["in_Ax"], scalar(g, "in_tol"), int(scalar(g, "in_ntol")))
+    compare_numeric(oracle, S, G, No, g, ftol=1e-10, name=name)
+
+
 def test_plan_reuse_and_device_resident_values(pkg, oracle):
     """One plan, several numeric factorizations with different values; second call reuses the pattern."""
     g = load_golden("syn_grid3d")
