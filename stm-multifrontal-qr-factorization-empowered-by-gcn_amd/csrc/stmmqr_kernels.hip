@@ -1559,6 +1559,12 @@ __global__ __launch_bounds__(NT) void k_upd_c(DevCtx c, const int *__restrict__ 
     double *Vs = dyn_lds, *Cs = Vs + STM_NB * VS, *Ws = Cs + BN * VS;
     __shared__ double s_W1[STM_NB * WS], s_T[STM_NB * WS];
     if (tid < STM_NB) s_pd[tid] = (tid < nbp) ? pd->pdiag[tid] : STM_BIGROW;
+    // the first chunk of V and C is requested before the W2 prologue so that its latency hides behind it
+    const double *Vg = c.Farena + s.foff + g1 + (long long)pd->pk1 * ld;
+    double *Cg = c.Farena + s.foff + g1 + (long long)c0 * ld;
+    const int lrow = tid & 63, lcg = tid >> 6;
+    UpdChunk ck;
+    upd_chunk_load(ck, Vg, Cg, ld, sl * SLAB + lrow, mp, nbp, nc, lcg);
     // W2 = T' sum_slabs W1 (every slab workgroup of a column block recomputes it: 32^3 multiply-adds against one
     // launch less per panel); the summation order over the slabs is fixed
     {
@@ -1583,12 +1589,7 @@ __global__ __launch_bounds__(NT) void k_upd_c(DevCtx c, const int *__restrict__ 
         for (int x = 0; x < 4; x++) Ws[l * WS + cg * 4 + x] = w2[x];
     }
     __syncthreads();
-    const double *Vg = c.Farena + s.foff + g1 + (long long)pd->pk1 * ld;
-    double *Cg = c.Farena + s.foff + g1 + (long long)c0 * ld;
-    const int lrow = tid & 63, lcg = tid >> 6;
     const int rend = min(mp, (sl + 1) * SLAB);
-    UpdChunk ck;
-    upd_chunk_load(ck, Vg, Cg, ld, sl * SLAB + lrow, mp, nbp, nc, lcg);
     for (int r0 = sl * SLAB; r0 < rend; r0 += RB) {
         const int i = r0 + lrow;
         upd_chunk_to_lds(ck, i, mp, nbp, nc, s_pd, g1, lrow, lcg, Vs, Cs);
