@@ -200,6 +200,17 @@ int stmmqr_factorize_arrays(const stmmqr_symbolic_view *sym, const stm_long *Ap,
                             stm_long *Rblock_off, char *Rdead, stm_long *HStair, double *HTau, stm_long *Hii,
                             stm_long *HPinv, stm_long *Hm, stm_long *Hr, stm_long *scalars, stmmqr_stats *stats);
 
+/* Q-apply and least-squares solve on the factors that are still resident in HBM after
+ * stmmqr_factorize_device -- no download of the packed R+H.
+ *   stmmqr_plan_qmult  replaces QR_qmult (STMMQR/include/SparseQR.h:403-409; SparseQR.c:1790-2020) for the methods
+ *                      QR_QTX (0: X <- Q'X) and QR_QX (1: X <- Q X) on a dense m x nrhs array, in place.  Row order as in
+ *                      the reference: Q'X comes back in the row order of R (HPinv applied), Q X expects it.
+ *   stmmqr_plan_solve  replaces QR_solve(QR_RETX_EQUALS_B) (SparseQR.h:411-417; SparseQR.c:2024-2216 + qr_rsolve
+ *                      :2218-2517): X = E * R^{-1} * (Q'B)(1:n), the solution the driver's residual check uses
+ *                      (qrtest.c:11-53).  Full-rank factorizations (rank == n) only: otherwise STMMQR_ERR_INVALID. */
+int stmmqr_plan_qmult(stmmqr_plan *plan, int method, double *X, stm_long ldx, stm_long nrhs);
+int stmmqr_plan_solve(stmmqr_plan *plan, const double *B, stm_long ldb, double *X, stm_long ldx, stm_long nrhs);
+
 /* dense single-front kernels on host buffers (inner seams without the cc argument) */
 stm_long stmmqr_front(stm_long m, stm_long n, stm_long npiv, double tol, stm_long ntol, double *F,
                       stm_long *Stair, char *Rdead, double *Tau, double *flops);

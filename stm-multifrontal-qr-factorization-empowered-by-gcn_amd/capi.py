@@ -93,6 +93,8 @@ lib.stmmqr_plan_set_groups.argtypes = [C.c_void_p, C.POINTER(C.c_int)]
 lib.stmmqr_plan_front_info.argtypes = [C.c_void_p, C.c_long, c_long_p]
 lib.stmmqr_plan_export_front.argtypes = [C.c_void_p, C.c_long, C.c_void_p, c_long_p, C.c_int]
 lib.stmmqr_plan_import_front.argtypes = [C.c_void_p, C.c_long, C.c_long, C.c_long, C.c_long, C.c_void_p, c_long_p, C.c_int]
+lib.stmmqr_plan_qmult.argtypes = [C.c_void_p, C.c_int, c_double_p, C.c_long, C.c_long]
+lib.stmmqr_plan_solve.argtypes = [C.c_void_p, c_double_p, C.c_long, c_double_p, C.c_long, C.c_long]
 lib.stmmqr_get_options.argtypes = [C.POINTER(Options)]
 lib.stmmqr_set_options.argtypes = [C.POINTER(Options)]
 
@@ -240,6 +242,22 @@ class HipQR:
         Cb = np.ascontiguousarray(Cb, np.float64); rows = np.ascontiguousarray(rows, I64)
         _check(lib.stmmqr_plan_import_front(self._h, int(f), int(fm), int(rank), int(cm), Cb.ctypes.data_as(C.c_void_p),
                                             _ip(rows), 0), "stmmqr_plan_import_front")
+
+    def qmult(self, method: int, X: np.ndarray) -> np.ndarray:
+        """QR_qmult (SparseQR.h:403-409) on the resident factors: method 0 = QR_QTX (Q'X), 1 = QR_QX (Q X).
+        X: m or m x nrhs; returns a new array (row order of the reference: Q'X in R's row order)."""
+        m = self.sym["m"]
+        Xf = np.array(X, dtype=np.float64, order="F", copy=True).reshape(m, -1, order="F")
+        _check(lib.stmmqr_plan_qmult(self._h, int(method), _dp(Xf), m, Xf.shape[1]), "stmmqr_plan_qmult")
+        return Xf.reshape(np.shape(X), order="F")
+
+    def solve(self, B: np.ndarray) -> np.ndarray:
+        """QR_solve(QR_RETX_EQUALS_B) (SparseQR.h:411-417): X = E R^-1 (Q'B)(1:n), least-squares solution; rank == n only."""
+        m, n = self.sym["m"], self.sym["n"]
+        Bf = np.array(B, dtype=np.float64, order="F", copy=True).reshape(m, -1, order="F")
+        X = np.zeros((n, Bf.shape[1]), order="F")
+        _check(lib.stmmqr_plan_solve(self._h, _dp(Bf), m, _dp(X), n, Bf.shape[1]), "stmmqr_plan_solve")
+        return X[:, 0] if np.ndim(B) == 1 else X
 
     def download(self) -> QRNumeric:
         rh = C.c_long(0); rk = C.c_long(0)

@@ -142,6 +142,11 @@ struct stmmqr_plan {
     long long rh_total = 0;
     long rank = 0;
     std::vector<FrontNum> h_fnum;
+    // Q-apply / solve on the resident factors
+    DevBuf<int> d_Rj, d_PLinv, d_Qfill, d_Wmap, d_err;
+    DevBuf<double> d_W, d_Xs, d_Io;
+    bool rowmap_ready = false;         // d_Wmap belongs to the factorization currently held
+    std::vector<int> level_lds_qa, level_lds_rs;   // dynamic LDS of k_qapply / k_rsolve per level of group 0
     double last_tol = 0;
     long last_ntol = 0;
     stmmqr_stats stats = {};
@@ -726,6 +731,7 @@ int stmmqr_factorize_begin(stmmqr_plan *plan, const stm_long *Ap, const stm_long
     P.stats = stmmqr_stats();
     P.stats.ms_host = host_ms_plan;
     P.factored = false;
+    P.rowmap_ready = false;
     P.begun = true;
     P.first_group = true;
     if (!P.do_rank) tol = -1;                                  // SparseQR_factorize.c:285-289
@@ -906,6 +912,162 @@ int stmmqr_plan_result_sizes(const stmmqr_plan *plan, stm_long *rh_total, stm_lo
     if (!plan || !plan->factored) return fail(STMMQR_ERR_INVALID, "no factorization held by the plan");
     if (rh_total) *rh_total = (stm_long)plan->rh_total;
     if (rank) *rank = plan->rank;
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// QR_qmult (SparseQR.c:1790-2020, methods QR_QTX / QR_QX) and QR_solve (RETX_EQUALS_B, :2024-2216)
+// on the factors that are still in HBM -- no download of the packed R+H.
+// ---------------------------------------------------------------------------------------------
+namespace {
+// host half of qr_hpinv for the device: Wmap[S-row id] = position in the permuted row order (same rule as in
+// stmmqr_plan_download); uploaded once per factorization together with the static maps
+int ensure_rowmap(stmmqr_plan &P)
+{
+    if (P.rowmap_ready) return 0;
+    hipStream_t st = P.stream;
+    const long nf = P.nf, m = P.m, n = P.n;
+    for (long f = 0; f < nf; f++)
+        if (P.group[f] < 0) return fail(STMMQR_ERR_INVALID, "Q-apply / solve need every front on this device");
+    std::vector<int> hii32((size_t)std::max(1L, P.hisize));
+    if (P.hisize > 0)
+        HIPCHK(hipMemcpyAsync(hii32.data(), P.d_Hii.p, (size_t)P.hisize * sizeof(int), hipMemcpyDeviceToHost, st));
+    if (P.h_fnum.size() != (size_t)nf) P.h_fnum.resize((size_t)nf);
+    if (nf > 0)
+        HIPCHK(hipMemcpyAsync(P.h_fnum.data(), P.d_fnum.p, (size_t)nf * sizeof(FrontNum), hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    std::vector<int> W((size_t)std::max(1L, m), 0);
+    long row1 = 0, row2 = m;
+    for (long i = P.Sleft[n]; i < m; i++) W[i] = (int)--row2;
+    for (long f = 0; f < nf; f++) {
+        const int *Hi = hii32.data() + P.Hip[f];
+        const FrontNum &nm = P.h_fnum[f];
+        const long rm = nm.rank, fm = nm.fm;
+        for (long i = 0; i < rm; i++) W[Hi[i]] = (int)row1++;
+        const long cn = P.fs[f].fn - P.fs[f].fp;
+        const long cm = std::min(fm - rm, cn);
+        for (long i = fm - 1; i >= rm + cm; i--) W[Hi[i]] = (int)--row2;
+    }
+    LCHK(P.d_Wmap.upload(W, st));
+    HIPCHK(hipStreamSynchronize(st));
+    if (!P.d_Rj.p) {
+        std::vector<int> t((size_t)std::max(1L, P.rjsize));
+        for (long i = 0; i < P.rjsize; i++) t[i] = (int)P.Rj[i];
+        LCHK(P.d_Rj.upload(t, st));
+        HIPCHK(hipStreamSynchronize(st));
+        t.assign((size_t)std::max(1L, m), 0);
+        for (long i = 0; i < m; i++) t[i] = (int)P.PLinv[i];
+        LCHK(P.d_PLinv.upload(t, st));
+        HIPCHK(hipStreamSynchronize(st));
+        if (P.has_qfill) {
+            t.assign((size_t)std::max(1L, n), 0);
+            for (long j = 0; j < n; j++) t[j] = (int)P.Qfill[j];
+            LCHK(P.d_Qfill.upload(t, st));
+            HIPCHK(hipStreamSynchronize(st));
+        }
+        LCHK(P.d_W.alloc((size_t)std::max(1L, m)));
+        LCHK(P.d_Xs.alloc((size_t)std::max(1L, n)));
+        LCHK(P.d_Io.alloc((size_t)std::max(1L, std::max(m, n))));
+        LCHK(P.d_err.alloc(1));
+        // dynamic LDS per level: k_qapply holds fm doubles + fn ints, k_rsolve fp + (fn - fp) doubles
+        const auto &LV = P.glevels[0];
+        P.level_lds_qa.assign(LV.size(), 0);
+        P.level_lds_rs.assign(LV.size(), 0);
+        for (size_t l = 0; l < LV.size(); l++)
+            for (int q = 0; q < LV[l].n_all; q++) {
+                const FrontSym &s = P.fs[P.lists[LV[l].all_off + q]];
+                P.level_lds_qa[l] = std::max(P.level_lds_qa[l], (int)(((s.fm_ub + 1) & ~1) * 8 + s.fn * 4 + 16));
+                P.level_lds_rs[l] = std::max(P.level_lds_rs[l], (int)((((s.fp + 1) & ~1) + (s.fn - s.fp) + 2) * 8));
+            }
+    }
+    for (int b : P.level_lds_qa)
+        if (b > 131072) return fail(STMMQR_ERR_TOO_LARGE, "a front has more rows than the Q-apply kernel holds in LDS");
+    P.rowmap_ready = true;
+    return 0;
+}
+
+int check_device_err(stmmqr_plan &P, const char *what)
+{
+    int e = 0;
+    HIPCHK(hipMemcpyAsync(&e, P.d_err.p, sizeof(int), hipMemcpyDeviceToHost, P.stream));
+    HIPCHK(hipStreamSynchronize(P.stream));
+    if (e) return fail(STMMQR_ERR_INVALID, what);
+    return 0;
+}
+
+// W (device, S-row order) <- Q' W or Q W
+int run_qapply(stmmqr_plan &P, int method)
+{
+    DevCtx c = P.ctx();
+    const int *L0 = P.d_lists.p;
+    const auto &LV = P.glevels[0];
+    if (method == 0) {
+        for (size_t l = 0; l < LV.size(); l++)
+            LCHK(stm_launch_qapply(c, L0 + LV[l].all_off, LV[l].n_all, 0, P.d_W.p, P.level_lds_qa[l], P.d_err.p, P.stream));
+    } else {
+        for (size_t l = LV.size(); l-- > 0;)
+            LCHK(stm_launch_qapply(c, L0 + LV[l].all_off, LV[l].n_all, 1, P.d_W.p, P.level_lds_qa[l], P.d_err.p, P.stream));
+    }
+    return 0;
+}
+}  // namespace
+
+// X (m x nrhs, column-major, ldx >= m, host) <- Q' X (method 0 = QR_QTX) or Q X (method 1 = QR_QX), in place.
+// Row order as in the reference: Q'X is returned in the permuted order of the factorization (HPinv), Q X takes it.
+int stmmqr_plan_qmult(stmmqr_plan *plan, int method, double *X, stm_long ldx, stm_long nrhs)
+{
+    if (!plan || !plan->factored) return fail(STMMQR_ERR_INVALID, "no factorization held by the plan");
+    if (!X || ldx < plan->m || nrhs < 0 || (method != 0 && method != 1)) return fail(STMMQR_ERR_INVALID, "bad qmult arguments");
+    stmmqr_plan &P = *plan;
+    HIPCHK(hipSetDevice(P.device));
+    LCHK(ensure_rowmap(P));
+    hipStream_t st = P.stream;
+    const int m = (int)P.m;
+    for (stm_long j = 0; j < nrhs; j++) {
+        double *xj = X + j * ldx;
+        HIPCHK(hipMemcpyAsync(P.d_Io.p, xj, (size_t)m * sizeof(double), hipMemcpyHostToDevice, st));
+        if (method == 0) {
+            LCHK(stm_launch_perm(P.d_Io.p, P.d_PLinv.p, P.d_W.p, m, 1, st));               // W[PLinv[i]] = x[i]
+            LCHK(run_qapply(P, 0));
+            LCHK(stm_launch_perm(P.d_W.p, P.d_Wmap.p, P.d_Io.p, m, 1, st));                // out[Wmap[r]] = W[r]
+        } else {
+            LCHK(stm_launch_perm(P.d_Io.p, P.d_Wmap.p, P.d_W.p, m, 0, st));                // W[r] = x[Wmap[r]]
+            LCHK(run_qapply(P, 1));
+            LCHK(stm_launch_perm(P.d_W.p, P.d_PLinv.p, P.d_Io.p, m, 0, st));               // out[i] = W[PLinv[i]]
+        }
+        HIPCHK(hipMemcpyAsync(xj, P.d_Io.p, (size_t)m * sizeof(double), hipMemcpyDeviceToHost, st));
+    }
+    HIPCHK(hipStreamSynchronize(st));
+    return 0;
+}
+
+// X (n x nrhs, ldx >= n) = E * R^{-1} * (Q' B)(1:n)  for B (m x nrhs, ldb >= m): QR_solve(QR_RETX_EQUALS_B) of the reference
+// (the least-squares solution; the driver's residual check, qrtest.c:11-53).  Full-rank factorizations only.
+int stmmqr_plan_solve(stmmqr_plan *plan, const double *B, stm_long ldb, double *X, stm_long ldx, stm_long nrhs)
+{
+    if (!plan || !plan->factored) return fail(STMMQR_ERR_INVALID, "no factorization held by the plan");
+    if (!B || !X || ldb < plan->m || ldx < plan->n || nrhs < 0) return fail(STMMQR_ERR_INVALID, "bad solve arguments");
+    stmmqr_plan &P = *plan;
+    HIPCHK(hipSetDevice(P.device));
+    LCHK(ensure_rowmap(P));
+    if (P.rank != P.n) return fail(STMMQR_ERR_INVALID, "rank-deficient factorization: solve on the device needs rank == n");
+    hipStream_t st = P.stream;
+    const int m = (int)P.m, n = (int)P.n;
+    DevCtx c = P.ctx();
+    const int *L0 = P.d_lists.p;
+    const auto &LV = P.glevels[0];
+    HIPCHK(hipMemsetAsync(P.d_err.p, 0, sizeof(int), st));
+    for (stm_long j = 0; j < nrhs; j++) {
+        HIPCHK(hipMemcpyAsync(P.d_Io.p, B + j * ldb, (size_t)m * sizeof(double), hipMemcpyHostToDevice, st));
+        LCHK(stm_launch_perm(P.d_Io.p, P.d_PLinv.p, P.d_W.p, m, 1, st));
+        LCHK(run_qapply(P, 0));
+        for (size_t l = LV.size(); l-- > 0;)
+            LCHK(stm_launch_rsolve(c, L0 + LV[l].all_off, LV[l].n_all, P.d_Rj.p, P.d_W.p, P.d_Xs.p, P.level_lds_rs[l],
+                                   P.d_err.p, st));
+        LCHK(stm_launch_perm(P.d_Xs.p, P.has_qfill ? P.d_Qfill.p : nullptr, P.d_Io.p, n, 1, st));   // X[Qfill[j]] = x[j]
+        HIPCHK(hipMemcpyAsync(X + j * ldx, P.d_Io.p, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, st));
+    }
+    LCHK(check_device_err(P, "a front is rank deficient: solve on the device needs full-rank fronts"));
     return 0;
 }
 

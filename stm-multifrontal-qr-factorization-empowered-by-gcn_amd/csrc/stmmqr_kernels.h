@@ -50,3 +50,8 @@ int stm_launch_rh_count(const DevCtx &c, const int *flist, int nfr, hipStream_t 
 int stm_launch_rh_scan(const DevCtx &c, const int *post, int nf, long long *rh_total, hipStream_t st);
 int stm_launch_rh_copy(const DevCtx &c, const int *flist, const int *nparts, int nfr, int maxparts, double *RH,
                        hipStream_t st);
+// Q-apply / triangular solve on the resident factors
+int stm_launch_qapply(const DevCtx &c, const int *flist, int nfr, int method, double *W, int lds_bytes, int *err, hipStream_t st);
+int stm_launch_rsolve(const DevCtx &c, const int *flist, int nfr, const int *Rj, const double *W, double *X, int lds_bytes,
+                      int *err, hipStream_t st);
+int stm_launch_perm(const double *in, const int *perm, double *out, int n, int scatter, hipStream_t st);

@@ -1743,6 +1743,153 @@ __global__ __launch_bounds__(NT) void k_rh_copy(DevCtx c, const int *__restrict_
     }
 }
 
+// ================================================================================================
+// Q-apply and triangular solve on the factors that are still resident in HBM
+// (reference: qr_private_Happly / QR_qmult, STMMQR/src/qr/SparseQR.c:1455-1790; qr_rsolve :2218-2517).
+// The Householder vectors are read in place from the front arena (unit diagonal of the q-th live reflector of a front
+// at front row q, entries below it up to the column's HStair), rows of a front are global rows through Hii.
+// Work vector W: one entry per row of A, indexed by the row id of S = A(P,:)  (Hii holds exactly these ids).
+// ================================================================================================
+#define QA_NT 256
+// live-reflector numbering of one front: dq[k] = number of live reflectors before column k, or -1 if column k has none
+// (dead pivot column, or the rows ran out).  Mirrors the enumeration of the packed format (qr_rhpack :1691-1784).
+__device__ void qa_number_reflectors(const FrontSym &s, int fm, const int *St, const double *Tau, int *dq, int *s_scan)
+{
+    const int tid = threadIdx.x;
+    const int per = (s.fn + QA_NT - 1) / QA_NT;
+    const int k0 = tid * per, k1 = min(s.fn, k0 + per);
+    int cnt = 0;
+    for (int k = k0; k < k1; k++) cnt += (k >= s.fp || St[k] != 0);
+    int total;
+    const int incl = block_incl_scan(cnt, s_scan, &total);
+    int d = incl - cnt;
+    for (int k = k0; k < k1; k++) {
+        const bool live = (k >= s.fp || St[k] != 0);
+        dq[k] = (live && d < fm && Tau[k] != 0.0) ? d : -1;     // (tau == 0: H = I, nothing to apply)
+        d += live;
+    }
+    __syncthreads();
+}
+
+// method 0: x <- H_last ... H_1 x = Q'x (fronts leaves -> root, reflectors ascending); method 1: x <- Q x (reverse)
+__global__ __launch_bounds__(QA_NT) void k_qapply(DevCtx c, const int *__restrict__ flist, int method, double *W, int *err)
+{
+    extern __shared__ double dyn_lds[];
+    __shared__ int s_scan[NW];
+    __shared__ double s_red[NW];
+    const int f = flist[blockIdx.x];
+    const FrontSym s = c.fs[f];
+    const int fm = c.fnum[f].fm;
+    if (fm <= 0 || s.fn <= 0) return;
+    const int tid = threadIdx.x;
+    const int *St = c.Stair + s.rp;
+    const double *Tau = c.Tau + s.rp;
+    const int *Hi = c.Hii + s.hip;
+    const double *F = c.Farena + s.foff;
+    const long long ld = s.ld;
+    double *xs = dyn_lds;                               // [fm]
+    int *dq = (int *)(xs + ((fm + 1) & ~1));            // [fn]
+    for (int i = tid; i < fm; i += QA_NT) xs[i] = W[Hi[i]];
+    qa_number_reflectors(s, fm, St, Tau, dq, s_scan);
+    // one reflector after the other: v'x by a workgroup reduction, then the rank-1 update of the LDS-resident x
+    // (requesting the next column ahead of the reduction was measured and did not pay: 21.9 -> 26 ms on the stand-in)
+    const int kbeg = method ? s.fn - 1 : 0, kend = method ? -1 : s.fn, kinc = method ? -1 : 1;
+    for (int k = kbeg; k != kend; k += kinc) {
+        const int d = dq[k];
+        if (d < 0) continue;
+        const double tau = Tau[k];
+        const int h = min(d + 1, fm), t = St[k];
+        const double *v = F + (long long)k * ld;
+        double part = 0;
+        for (int i = h + tid; i < t; i += QA_NT) part += v[i] * xs[i];
+        double sdot = block_sum<QA_NT>(part, s_red);
+        sdot = (sdot + xs[d]) * tau;
+        __syncthreads();                                // everyone has read xs[d]
+        for (int i = h + tid; i < t; i += QA_NT) xs[i] -= sdot * v[i];
+        if (tid == 0) xs[d] -= sdot;
+        __syncthreads();
+    }
+    for (int i = tid; i < fm; i += QA_NT) W[Hi[i]] = xs[i];
+    (void)err;
+}
+
+// One front of the back substitution R x = y (fronts root -> leaves): y = the first `rank` rows of the front's slice
+// of W, x of the non-pivotal columns comes from the ancestors.  Full-rank fronts only (rank == fp, no dead column):
+// otherwise *err is set and the host reports STMMQR_ERR_UNSUPPORTED.
+__global__ __launch_bounds__(QA_NT) void k_rsolve(DevCtx c, const int *__restrict__ flist, const int *__restrict__ Rj,
+                                                  const double *W, double *X, int *err)
+{
+    extern __shared__ double dyn_lds[];
+    const int f = flist[blockIdx.x];
+    const FrontSym s = c.fs[f];
+    const FrontNum nm = c.fnum[f];
+    const int fp = s.fp, fn = s.fn, r = nm.rank;
+    if (fp <= 0) return;
+    const int tid = threadIdx.x;
+    if (r != fp || nm.fm < fp) { if (tid == 0) atomicExch(err, 1); return; }
+    const int *Hi = c.Hii + s.hip;
+    const int *rj = Rj + s.rp;
+    const double *F = c.Farena + s.foff;
+    const long long ld = s.ld;
+    double *acc = dyn_lds;                              // [fp]
+    double *xo = acc + ((fp + 1) & ~1);                 // [fn - fp] x of the non-pivotal columns
+    for (int k = fp + tid; k < fn; k += QA_NT) xo[k - fp] = X[rj[k]];
+    __syncthreads();
+    // acc = y - R12 x_others : thread per row, columns streamed (coalesced over the rows)
+    for (int i = tid; i < fp; i += QA_NT) {
+        double a = W[Hi[i]];
+        for (int k = fp; k < fn; k++) a -= F[i + (long long)k * ld] * xo[k - fp];
+        acc[i] = a;
+    }
+    __syncthreads();
+    // R11 x1 = acc: blocked back substitution.  Per block of QS_NB columns: the diagonal triangle goes to LDS and one
+    // wave solves it there (no global latency inside the 32 dependent steps), then every thread updates its rows of acc
+    // with the block's 32 columns (coalesced over the rows, 32 independent loads in flight).
+    constexpr int QS_NB = 32;
+    __shared__ double s_tri[QS_NB][QS_NB + 1];
+    __shared__ double s_x[QS_NB];
+    for (int kb = ((fp - 1) / QS_NB) * QS_NB; kb >= 0; kb -= QS_NB) {
+        const int nb = min(QS_NB, fp - kb);
+        for (int e = tid; e < QS_NB * QS_NB; e += QA_NT) {
+            const int i = e % QS_NB, j = e / QS_NB;
+            s_tri[i][j] = (i < nb && j < nb && i <= j) ? F[(kb + i) + (long long)(kb + j) * ld] : 0.0;
+        }
+        __syncthreads();
+        if (tid < 64) {
+            // lane i owns row i of the triangle (i < nb): x_j for j = nb-1 .. 0
+            const int i = tid;
+            double a = (i < nb) ? acc[kb + i] : 0.0;
+            for (int j = nb - 1; j >= 0; j--) {
+                // x_j = a_j / R_jj, broadcast from lane j
+                const double aj = __shfl(a, j, 64);
+                const double xj = aj / s_tri[j][j];
+                if (i < j) a -= s_tri[i][j] * xj;
+                if (i == j) s_x[j] = xj;
+            }
+        }
+        __syncthreads();
+        if (tid < nb) X[s.col1 + kb + tid] = s_x[tid];
+        for (int i = tid; i < kb; i += QA_NT) {
+            double a = acc[i];
+#pragma unroll 8
+            for (int j = 0; j < nb; j++) a -= F[i + (long long)(kb + j) * ld] * s_x[j];
+            acc[i] = a;
+        }
+        __syncthreads();
+    }
+}
+
+// scatter: out[perm[i]] = in[i]   gather: out[i] = in[perm[i]]   (perm == nullptr: identity)
+__global__ __launch_bounds__(256) void k_perm(const double *__restrict__ in, const int *__restrict__ perm, double *out, int n,
+                                               int scatter)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const int j = perm ? perm[i] : i;
+    if (scatter) out[j] = in[i];
+    else out[i] = in[j];
+}
+
 // ------------------------------------------------------------------------------------------------
 // launchers (host side calls these; no HIP types leak into the C ABI)
 // ------------------------------------------------------------------------------------------------
@@ -1832,11 +1979,33 @@ int stm_launch_rh_copy(const DevCtx &c, const int *flist, const int *nparts, int
     hipLaunchKernelGGL(k_rh_copy, dim3(maxparts, nfr), dim3(NT), 0, st, c, flist, nparts, RH);
     return (int)hipGetLastError();
 }
+int stm_launch_qapply(const DevCtx &c, const int *flist, int nfr, int method, double *W, int lds_bytes, int *err, hipStream_t st)
+{
+    if (nfr <= 0) return 0;
+    hipLaunchKernelGGL(k_qapply, dim3(nfr), dim3(QA_NT), (size_t)lds_bytes, st, c, flist, method, W, err);
+    return (int)hipGetLastError();
+}
+int stm_launch_rsolve(const DevCtx &c, const int *flist, int nfr, const int *Rj, const double *W, double *X, int lds_bytes,
+                      int *err, hipStream_t st)
+{
+    if (nfr <= 0) return 0;
+    hipLaunchKernelGGL(k_rsolve, dim3(nfr), dim3(QA_NT), (size_t)lds_bytes, st, c, flist, Rj, W, X, err);
+    return (int)hipGetLastError();
+}
+int stm_launch_perm(const double *in, const int *perm, double *out, int n, int scatter, hipStream_t st)
+{
+    if (n <= 0) return 0;
+    hipLaunchKernelGGL(k_perm, dim3((n + 255) / 256), dim3(256), 0, st, in, perm, out, n, scatter);
+    return (int)hipGetLastError();
+}
+
 int stm_configure_kernels(void)
 {
     // allow the panel kernels to ask for up to 144 KiB of dynamic LDS (160 KiB per CU on gfx950)
     CK(hipFuncSetAttribute((const void *)k_front_wg, hipFuncAttributeMaxDynamicSharedMemorySize, 122880));
     CK(hipFuncSetAttribute((const void *)k_panel, hipFuncAttributeMaxDynamicSharedMemorySize, 131072));
     CK(hipFuncSetAttribute((const void *)k_update, hipFuncAttributeMaxDynamicSharedMemorySize, 65536));
+    CK(hipFuncSetAttribute((const void *)k_qapply, hipFuncAttributeMaxDynamicSharedMemorySize, 131072));
+    CK(hipFuncSetAttribute((const void *)k_rsolve, hipFuncAttributeMaxDynamicSharedMemorySize, 131072));
     return 0;
 }

@@ -1,0 +1,110 @@
+"""SURVEY.md 8 (f1) on the GPU: Q-apply and least-squares solve on the factors that stay resident in HBM
+(stmmqr_plan_qmult / stmmqr_plan_solve; reference QR_qmult / QR_solve, STMMQR/include/SparseQR.h:403-417), checked
+against the CPU oracle working on the downloaded factors of the SAME factorization, and through the residual the
+reference's driver prints (qrtest.c:11-53)."""
+import importlib
+
+import numpy as np
+import pytest
+
+from stmmqr_testlib import Symbolic, csc_matvec, golden_names, load_golden, numeric_from_gpu, scalar
+
+pytestmark = pytest.mark.gpu
+NAMES = golden_names()
+
+
+@pytest.fixture(scope="module")
+def pkg():
+    p = importlib.import_module("stm-multifrontal-qr-factorization-empowered-by-gcn_amd")
+    assert p.device_count() >= 1
+    return p
+
+
+def factorized_plan(pkg, g, bigcols=64):
+    S = Symbolic(g)
+    pkg.set_options(big_front_cols=bigcols)
+    try:
+        plan = pkg.HipQR({**S.sc, **{k: v for k, v in S.arr.items() if v is not None}})
+        plan.factorize(g["in_Ax"], scalar(g, "in_tol"), int(scalar(g, "in_ntol")), g["in_Ap"], g["in_Ai"])
+    finally:
+        pkg.set_options(big_front_cols=64)
+    return S, plan
+
+
+@pytest.mark.parametrize("name", NAMES)
+@pytest.mark.parametrize("bigcols", [64, 16])
+def test_qmult_against_oracle(pkg, oracle, name, bigcols):
+    g = load_golden(name)
+    S, plan = factorized_plan(pkg, g, bigcols)
+    try:
+        N = numeric_from_gpu(S, plan.download())
+        rng = np.random.default_rng(11)
+        X = rng.standard_normal((S.m, 3))
+        QtX = plan.qmult(0, X)
+        for j in range(3):
+            ref = oracle.qmult(0, S, N, X[:, j])
+            assert np.linalg.norm(QtX[:, j] - ref) <= 1e-12 * max(np.linalg.norm(ref), 1e-300)
+        # Q (Q' X) = X, and ||Q' x|| = ||x||
+        back = plan.qmult(1, QtX)
+        assert np.linalg.norm(back - X) <= 1e-12 * np.linalg.norm(X)
+        assert abs(np.linalg.norm(QtX) - np.linalg.norm(X)) <= 1e-12 * np.linalg.norm(X)
+        QX = plan.qmult(1, X[:, 0])
+        ref = oracle.qmult(1, S, N, X[:, 0])
+        assert np.linalg.norm(QX - ref) <= 1e-12 * np.linalg.norm(ref)
+    finally:
+        plan.close()
+
+
+@pytest.mark.parametrize("name", NAMES)
+def test_solve_residual_and_oracle(pkg, oracle, name):
+    g = load_golden(name)
+    S, plan = factorized_plan(pkg, g)
+    try:
+        G = plan.download()
+        N = numeric_from_gpu(S, G)
+        rng = np.random.default_rng(5)
+        if G.rank != S.n:
+            with pytest.raises(pkg.StmmqrError):
+                plan.solve(rng.standard_normal(S.m))
+            return
+        Ap, Ai, Ax = g["in_Ap"], g["in_Ai"], g["in_Ax"]
+        xtrue = rng.standard_normal((S.n, 2))
+        B = np.stack([csc_matvec(S.m, Ap, Ai, Ax, xtrue[:, j]) for j in range(2)], axis=1)
+        B[:, 1] += 1e-3 * rng.standard_normal(S.m)            # an inconsistent right-hand side as well (m >= n)
+        X = plan.solve(B)
+        q = S.Qfill if S.Qfill is not None else np.arange(S.n)
+        for j in range(2):
+            y = oracle.qmult(0, S, N, B[:, j])[:S.n]
+            xo = np.zeros(S.n)
+            xo[q] = oracle.rsolve(S, N, y)
+            assert np.linalg.norm(X[:, j] - xo) <= 1e-9 * max(np.linalg.norm(xo), 1e-300)
+        # the driver's check (qrtest.c:11-53): res = ||A x - b|| / (||A|| ||x|| + ||b||) for a consistent system
+        r = csc_matvec(S.m, Ap, Ai, Ax, X[:, 0]) - B[:, 0]
+        res = np.linalg.norm(r) / (np.linalg.norm(Ax) * np.linalg.norm(X[:, 0]) + np.linalg.norm(B[:, 0]))
+        assert res <= 1e-10
+        # least squares: A'(A x - b) = 0 for the inconsistent one
+        r1 = csc_matvec(S.m, Ap, Ai, Ax, X[:, 1]) - B[:, 1]
+        cols = np.repeat(np.arange(S.n), np.diff(Ap))
+        Atr = np.zeros(S.n)
+        np.add.at(Atr, cols, Ax * r1[Ai])
+        assert np.linalg.norm(Atr) <= 1e-8 * np.linalg.norm(Ax) * np.linalg.norm(B[:, 1])
+    finally:
+        plan.close()
+
+
+def test_solve_full_size_standin(pkg):
+    """BASELINE configs[2] size: residual of the device solve, factors never leave HBM."""
+    g = load_golden("xenon1_standin")
+    S, plan = factorized_plan(pkg, g)
+    try:
+        Ap, Ai, Ax = g["in_Ap"], g["in_Ai"], g["in_Ax"]
+        xtrue = np.random.default_rng(2).standard_normal(S.n)
+        b = csc_matvec(S.m, Ap, Ai, Ax, xtrue)
+        x = plan.solve(b)
+        res = np.linalg.norm(csc_matvec(S.m, Ap, Ai, Ax, x) - b) / (np.linalg.norm(Ax) * np.linalg.norm(x) + np.linalg.norm(b))
+        assert res <= 1e-12
+        assert np.linalg.norm(x - xtrue) <= 1e-8 * np.linalg.norm(xtrue)
+        y = plan.qmult(0, b)
+        assert abs(np.linalg.norm(y) - np.linalg.norm(b)) <= 1e-12 * np.linalg.norm(b)
+    finally:
+        plan.close()
