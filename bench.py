@@ -67,10 +67,16 @@ def cpu_baseline(name, g, budget_s=20.0):
                         sec = float(line.split(":")[1].split()[0])
                         rfl = [l for l in out.splitlines() if l.startswith("nf =")][0]
                         rflops = float(rfl.split("flops =")[1].split()[0])
-                        return {"value": rflops / sec * 1e-9, "unit": "GFLOP/s", "cores": 1, "kind": "reference",
-                                "sample": f"{name}: best of {reps} qr_factorize runs of the compiled reference "
-                                          f"(SPQR_grain=1, MKL sequential), {sec * 1e3:.2f} ms each",
-                                "seconds": sec}
+                        cb = {"value": rflops / sec * 1e-9, "unit": "GFLOP/s", "cores": 1, "kind": "reference",
+                              "sample": f"{name}: best of {reps} qr_factorize runs of the compiled reference "
+                                        f"(SPQR_grain=1, MKL sequential), {sec * 1e3:.2f} ms each",
+                              "seconds": sec}
+                        for l2 in out.splitlines():
+                            if l2.startswith("REF qmult(QTX) seconds"):
+                                t = l2.replace(":", " ").split()
+                                cb["qmult_qtx_seconds"] = float(t[3])
+                                cb["solve_seconds"] = float(t[6])
+                        return cb
         except Exception as e:  # fall through to the port
             print(f"[bench] reference baseline failed: {e}", file=sys.stderr)
     from stmmqr_testlib import Oracle, Symbolic, scalar
@@ -229,6 +235,22 @@ def main():
                        "levels": st["nlevels"]},
             "roofline": roof,
         }
+        # SURVEY 8 (f1), outside the timed region: Q'b and the least-squares solve on the factors still resident in HBM
+        # (wall time including the copies of the vectors), with the residual the reference's driver prints
+        try:
+            if not sharded:
+                from stmmqr_testlib import csc_matvec
+                Ap_, Ai_, Ax_ = g["in_Ap"], g["in_Ai"], g["in_Ax"]
+                xt = np.arange(S.n, dtype=np.float64)
+                b = csc_matvec(S.m, Ap_, Ai_, Ax_, xt)
+                plan.qmult(0, b)
+                t0 = time.perf_counter(); plan.qmult(0, b); t1 = time.perf_counter()
+                xs = plan.solve(b); t2 = time.perf_counter()
+                res = float(np.linalg.norm(csc_matvec(S.m, Ap_, Ai_, Ax_, xs) - b) /
+                            (np.linalg.norm(Ax_) * np.linalg.norm(xs) + np.linalg.norm(b)))
+                out["f1_resident_factors"] = {"qmult_qtx_ms": (t1 - t0) * 1e3, "solve_ms": (t2 - t1) * 1e3, "residual": res}
+        except Exception as e:  # rank-deficient inputs: the device solve refuses them
+            out["f1_resident_factors"] = {"error": str(e)}
         if not args.no_cpu:
             cb = cpu_baseline(name, g)
             out["cpu_baseline"] = cb

@@ -184,8 +184,12 @@ static double solve_residual(sparse_csc *A, SparseQR_factorization *QR, sparse_c
     double *x = (double *)X->x;
     for (Long i = 0; i < n; i++) x[i] = (double)i;
     SparseCore_sdmult(A, 0, one, zero, X, B, cc);
+    double tq0 = now();
     dense_array *Y = QR_qmult(QR_QTX, QR, B, cc);
+    double tq1 = now();
     dense_array *Xs = QR_solve(QR_RETX_EQUALS_B, QR, Y, cc);
+    double tq2 = now();
+    printf("REF qmult(QTX) seconds: %.6f   solve(RETX_EQUALS_B) seconds: %.6f\n", tq1 - tq0, tq2 - tq1);
     double *xs = (double *)Xs->x, d = 0;
     for (Long j = 0; j < n; j++) { double e = xs[j] - (double)j; d += e * e; }
     put("solve_x", 'd', n, xs);
