@@ -207,7 +207,8 @@ int stmmqr_factorize_arrays(const stmmqr_symbolic_view *sym, const stm_long *Ap,
  *                      the reference: Q'X comes back in the row order of R (HPinv applied), Q X expects it.
  *   stmmqr_plan_solve  replaces QR_solve(QR_RETX_EQUALS_B) (SparseQR.h:411-417; SparseQR.c:2024-2216 + qr_rsolve
  *                      :2218-2517): X = E * R^{-1} * (Q'B)(1:n), the solution the driver's residual check uses
- *                      (qrtest.c:11-53).  Full-rank factorizations (rank == n) only: otherwise STMMQR_ERR_INVALID. */
+ *                      (qrtest.c:11-53); dead pivot columns get x = 0 (the reference's basic solution).  The singleton
+ *                      block R1 of SparseQR() is not part of the plan: it stays with the caller. */
 int stmmqr_plan_qmult(stmmqr_plan *plan, int method, double *X, stm_long ldx, stm_long nrhs);
 int stmmqr_plan_solve(stmmqr_plan *plan, const double *B, stm_long ldb, double *X, stm_long ldx, stm_long nrhs);
 

@@ -568,37 +568,44 @@ void orc_rmult(const orc_symbolic *S, const orc_numeric *N, const double *x, dou
 
 int orc_rsolve(const orc_symbolic *S, const orc_numeric *N, const double *y, double *x)
 {
+    /* qr_rsolve, STMMQR/src/qr/SparseQR.c:2218-2470 (multifrontal rows; no singletons here): back substitution over the
+     * fronts in reverse order; a dead pivot column gets x = 0 (basic solution), the live pivot columns of a front form
+     * an rm x rm upper triangle whose row i is the i-th live column; y is indexed by the row order of R */
     orc_int n = S->n, nf = S->nf;
-    if (N->rank != n) return -1;
     orc_int *row0 = malloc(sizeof(orc_int) * (size_t)(nf + 1));
     row0[0] = 0;
     for (orc_int f = 0; f < nf; f++) row0[f + 1] = row0[f] + N->Hr[f];
     orc_int *coff = malloc(sizeof(orc_int) * (size_t)(S->maxfn + 1));
+    orc_int *live = malloc(sizeof(orc_int) * (size_t)(S->maxfn + 1));
     double *acc = malloc(sizeof(double) * (size_t)(S->maxfn + 1));
+    for (orc_int j = 0; j < n; j++) x[j] = 0;
     for (orc_int f = nf - 1; f >= 0; f--) {
         orc_int fp = S->Super[f + 1] - S->Super[f], pr = S->Rp[f], fn = S->Rp[f + 1] - pr, fm = N->Hm[f];
         const orc_int *Stair = N->HStair + pr;
         const double *R = N->Stack + N->Rblock_off[f];
         orc_int rm = 0, h = 0, p = 0;
-        /* column offsets inside the packed block; full rank => every pivot is live */
+        /* column offsets inside the packed block (qr_rhpack order) and the list of live pivot columns */
         for (orc_int k = 0; k < fn; k++) {
             coff[k] = p;
             orc_int t = Stair[k];
-            if (k < fp) { if (rm < fm) rm++; h = rm; p += t; }
-            else { h = IMIN(h + 1, fm); p += rm + IMAX(t - h, 0); }
+            if (k < fp) {
+                if (t == 0) { p += rm; }                       /* dead: rm R entries, no H */
+                else { if (rm < fm) { live[rm] = k; rm++; } h = rm; p += t; }
+            } else { h = IMIN(h + 1, fm); p += rm + IMAX(t - h, 0); }
         }
-        orc_int r = N->Hr[f];
-        for (orc_int i = 0; i < r; i++) acc[i] = y[row0[f] + i];
+        /* (rm at the non-pivotal columns is the final rm: every pivot column comes first) */
+        for (orc_int i = 0; i < rm; i++) acc[i] = y[row0[f] + i];
         for (orc_int k = fp; k < fn; k++) {
             double xk = x[S->Rj[pr + k]];
-            for (orc_int i = 0; i < r; i++) acc[i] -= R[coff[k] + i] * xk;
+            if (xk != 0) for (orc_int i = 0; i < rm; i++) acc[i] -= R[coff[k] + i] * xk;
         }
-        for (orc_int k = r - 1; k >= 0; k--) {
-            double xk = acc[k] / R[coff[k] + k];
+        for (orc_int q = rm - 1; q >= 0; q--) {
+            orc_int k = live[q];
+            double xk = acc[q] / R[coff[k] + q];
             x[S->Super[f] + k] = xk;
-            for (orc_int i = 0; i < k; i++) acc[i] -= R[coff[k] + i] * xk;
+            for (orc_int i = 0; i < q; i++) acc[i] -= R[coff[k] + i] * xk;
         }
     }
-    free(row0); free(coff); free(acc);
+    free(row0); free(coff); free(live); free(acc);
     return 0;
 }

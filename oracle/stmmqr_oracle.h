@@ -87,7 +87,7 @@ void   orc_larft(orc_int n, orc_int k, const double *V, orc_int ldv, const doubl
 void orc_qmult(int method, const orc_symbolic *S, const orc_numeric *N, double *x, double *work);
 /* y(0:m) <- R x, R is rank-by-n upper trapezoidal (squeezed form) */
 void orc_rmult(const orc_symbolic *S, const orc_numeric *N, const double *x, double *y);
-/* solve R x = y for a full-rank factorization (rank == n); returns 0 ok */
+/* solve R x = y (qr_rsolve): dead pivot columns get x = 0 (basic solution); returns 0 */
 int  orc_rsolve(const orc_symbolic *S, const orc_numeric *N, const double *y, double *x);
 
 #ifdef __cplusplus

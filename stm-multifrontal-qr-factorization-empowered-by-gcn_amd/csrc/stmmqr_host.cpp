@@ -977,7 +977,7 @@ int ensure_rowmap(stmmqr_plan &P)
             for (int q = 0; q < LV[l].n_all; q++) {
                 const FrontSym &s = P.fs[P.lists[LV[l].all_off + q]];
                 P.level_lds_qa[l] = std::max(P.level_lds_qa[l], (int)(((s.fm_ub + 1) & ~1) * 8 + s.fn * 4 + 16));
-                P.level_lds_rs[l] = std::max(P.level_lds_rs[l], (int)((((s.fp + 1) & ~1) + (s.fn - s.fp) + 2) * 8));
+                P.level_lds_rs[l] = std::max(P.level_lds_rs[l], (int)((((s.fp + 1) & ~1) + (s.fn - s.fp) + 2) * 8 + s.fp * 4 + 16));
             }
     }
     for (int b : P.level_lds_qa)
@@ -1042,7 +1042,7 @@ int stmmqr_plan_qmult(stmmqr_plan *plan, int method, double *X, stm_long ldx, st
 }
 
 // X (n x nrhs, ldx >= n) = E * R^{-1} * (Q' B)(1:n)  for B (m x nrhs, ldb >= m): QR_solve(QR_RETX_EQUALS_B) of the reference
-// (the least-squares solution; the driver's residual check, qrtest.c:11-53).  Full-rank factorizations only.
+// (the least-squares solution; the driver's residual check, qrtest.c:11-53); dead columns get x = 0 (basic solution).
 int stmmqr_plan_solve(stmmqr_plan *plan, const double *B, stm_long ldb, double *X, stm_long ldx, stm_long nrhs)
 {
     if (!plan || !plan->factored) return fail(STMMQR_ERR_INVALID, "no factorization held by the plan");
@@ -1050,7 +1050,6 @@ int stmmqr_plan_solve(stmmqr_plan *plan, const double *B, stm_long ldb, double *
     stmmqr_plan &P = *plan;
     HIPCHK(hipSetDevice(P.device));
     LCHK(ensure_rowmap(P));
-    if (P.rank != P.n) return fail(STMMQR_ERR_INVALID, "rank-deficient factorization: solve on the device needs rank == n");
     hipStream_t st = P.stream;
     const int m = (int)P.m, n = (int)P.n;
     DevCtx c = P.ctx();
@@ -1067,7 +1066,7 @@ int stmmqr_plan_solve(stmmqr_plan *plan, const double *B, stm_long ldb, double *
         LCHK(stm_launch_perm(P.d_Xs.p, P.has_qfill ? P.d_Qfill.p : nullptr, P.d_Io.p, n, 1, st));   // X[Qfill[j]] = x[j]
         HIPCHK(hipMemcpyAsync(X + j * ldx, P.d_Io.p, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, st));
     }
-    LCHK(check_device_err(P, "a front is rank deficient: solve on the device needs full-rank fronts"));
+    LCHK(check_device_err(P, "internal: live pivot count of a front differs from its rank"));
     return 0;
 }
 

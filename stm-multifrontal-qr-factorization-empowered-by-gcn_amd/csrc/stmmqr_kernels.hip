@@ -1813,46 +1813,67 @@ __global__ __launch_bounds__(QA_NT) void k_qapply(DevCtx c, const int *__restric
     (void)err;
 }
 
-// One front of the back substitution R x = y (fronts root -> leaves): y = the first `rank` rows of the front's slice
-// of W, x of the non-pivotal columns comes from the ancestors.  Full-rank fronts only (rank == fp, no dead column):
-// otherwise *err is set and the host reports STMMQR_ERR_UNSUPPORTED.
+// One front of the back substitution R x = y (fronts root -> leaves; reference qr_rsolve, SparseQR.c:2218-2470):
+// y = the first rm rows of the front's slice of W (rm = live pivot columns), x of the non-pivotal columns comes from
+// the ancestors, a dead pivot column gets x = 0 (basic solution), the live pivot columns form an rm x rm upper triangle
+// whose row q is the q-th live column.
 __global__ __launch_bounds__(QA_NT) void k_rsolve(DevCtx c, const int *__restrict__ flist, const int *__restrict__ Rj,
                                                   const double *W, double *X, int *err)
 {
     extern __shared__ double dyn_lds[];
+    __shared__ int s_scan[NW];
     const int f = flist[blockIdx.x];
     const FrontSym s = c.fs[f];
     const FrontNum nm = c.fnum[f];
-    const int fp = s.fp, fn = s.fn, r = nm.rank;
+    const int fp = s.fp, fn = s.fn, fm = nm.fm;
     if (fp <= 0) return;
     const int tid = threadIdx.x;
-    if (r != fp || nm.fm < fp) { if (tid == 0) atomicExch(err, 1); return; }
+    const int *St = c.Stair + s.rp;
     const int *Hi = c.Hii + s.hip;
     const int *rj = Rj + s.rp;
     const double *F = c.Farena + s.foff;
     const long long ld = s.ld;
     double *acc = dyn_lds;                              // [fp]
     double *xo = acc + ((fp + 1) & ~1);                 // [fn - fp] x of the non-pivotal columns
+    int *lc = (int *)(xo + ((fn - fp + 1) & ~1));       // [fp] live pivot columns, compact
+    // ---- live pivot columns (HStair != 0 and a row left for the diagonal), dead ones: x = 0 ----
+    int rm;
+    {
+        const int per = (fp + QA_NT - 1) / QA_NT;
+        const int k0 = min(fp, tid * per), k1 = min(fp, k0 + per);
+        int cnt = 0;
+        for (int k = k0; k < k1; k++) cnt += (St[k] != 0);
+        int total;
+        const int incl = block_incl_scan(cnt, s_scan, &total);
+        int q = incl - cnt;
+        for (int k = k0; k < k1; k++) {
+            if (St[k] != 0 && q < fm) lc[q] = k;
+            else if (St[k] == 0) X[s.col1 + k] = 0.0;
+            q += (St[k] != 0);
+        }
+        rm = min(total, fm);
+    }
     for (int k = fp + tid; k < fn; k += QA_NT) xo[k - fp] = X[rj[k]];
     __syncthreads();
+    if (rm != nm.rank && tid == 0) atomicExch(err, 1);  // (cannot happen: same rule as the factorization)
     // acc = y - R12 x_others : thread per row, columns streamed (coalesced over the rows)
-    for (int i = tid; i < fp; i += QA_NT) {
+    for (int i = tid; i < rm; i += QA_NT) {
         double a = W[Hi[i]];
         for (int k = fp; k < fn; k++) a -= F[i + (long long)k * ld] * xo[k - fp];
         acc[i] = a;
     }
     __syncthreads();
-    // R11 x1 = acc: blocked back substitution.  Per block of QS_NB columns: the diagonal triangle goes to LDS and one
-    // wave solves it there (no global latency inside the 32 dependent steps), then every thread updates its rows of acc
-    // with the block's 32 columns (coalesced over the rows, 32 independent loads in flight).
+    // triangle: blocked back substitution over the compact list.  Per block of QS_NB live columns: the diagonal triangle
+    // goes to LDS and one wave solves it there (no global latency inside the 32 dependent steps), then every thread
+    // updates its rows of acc with the block's columns (coalesced over the rows, 32 independent loads in flight).
     constexpr int QS_NB = 32;
     __shared__ double s_tri[QS_NB][QS_NB + 1];
     __shared__ double s_x[QS_NB];
-    for (int kb = ((fp - 1) / QS_NB) * QS_NB; kb >= 0; kb -= QS_NB) {
-        const int nb = min(QS_NB, fp - kb);
+    for (int kb = ((max(rm, 1) - 1) / QS_NB) * QS_NB; kb >= 0 && rm > 0; kb -= QS_NB) {
+        const int nb = min(QS_NB, rm - kb);
         for (int e = tid; e < QS_NB * QS_NB; e += QA_NT) {
             const int i = e % QS_NB, j = e / QS_NB;
-            s_tri[i][j] = (i < nb && j < nb && i <= j) ? F[(kb + i) + (long long)(kb + j) * ld] : 0.0;
+            s_tri[i][j] = (i < nb && j < nb && i <= j) ? F[(kb + i) + (long long)lc[kb + j] * ld] : 0.0;
         }
         __syncthreads();
         if (tid < 64) {
@@ -1860,7 +1881,6 @@ __global__ __launch_bounds__(QA_NT) void k_rsolve(DevCtx c, const int *__restric
             const int i = tid;
             double a = (i < nb) ? acc[kb + i] : 0.0;
             for (int j = nb - 1; j >= 0; j--) {
-                // x_j = a_j / R_jj, broadcast from lane j
                 const double aj = __shfl(a, j, 64);
                 const double xj = aj / s_tri[j][j];
                 if (i < j) a -= s_tri[i][j] * xj;
@@ -1868,11 +1888,11 @@ __global__ __launch_bounds__(QA_NT) void k_rsolve(DevCtx c, const int *__restric
             }
         }
         __syncthreads();
-        if (tid < nb) X[s.col1 + kb + tid] = s_x[tid];
+        if (tid < nb) X[s.col1 + lc[kb + tid]] = s_x[tid];
         for (int i = tid; i < kb; i += QA_NT) {
             double a = acc[i];
 #pragma unroll 8
-            for (int j = 0; j < nb; j++) a -= F[i + (long long)(kb + j) * ld] * s_x[j];
+            for (int j = 0; j < nb; j++) a -= F[i + (long long)lc[kb + j] * ld] * s_x[j];
             acc[i] = a;
         }
         __syncthreads();

@@ -114,3 +114,25 @@ def test_solve_matches_reference_driver(oracle, name):
     xp = oracle.rsolve(S, N, y)
     x = np.zeros(n); x[q] = xp
     assert np.linalg.norm(x - xt) / n < 1e-8
+
+
+@pytest.mark.parametrize("name", [n for n in NAMES if n.startswith("syn_")])
+def test_rsolve_matches_reference_solution(oracle, name):
+    """QR_solve(RETX_EQUALS_B) of the REAL reference (golden `solve_x`, b = A [0..n-1]') against the oracle's
+    qmult + rsolve, including the rank-deficient fixtures (dead columns get x = 0: the basic solution,
+    SparseQR.c:2330-2375).  Fixtures without singleton rows only (the golden solution of the others also goes through
+    the singleton block R1, which is outside this path)."""
+    g = load_golden(name)
+    if int(scalar(g, "n1rows")) != 0 or int(scalar(g, "n1cols")) != 0 or "solve_x" not in g:
+        pytest.skip("singletons removed before the factorization")
+    S, N = run_oracle(oracle, g)
+    from stmmqr_testlib import csc_matvec
+    n, m = S.n, S.m
+    q = S.Qfill if S.Qfill is not None else np.arange(n)
+    b = csc_matvec(m, g["in_Ap"], g["in_Ai"], g["in_Ax"], np.arange(n, dtype=float))
+    xp = oracle.rsolve(S, N, oracle.qmult(0, S, N, b))
+    x = np.zeros(n); x[q] = xp
+    ref = g["solve_x"][:n]
+    # dead columns: exactly zero in both
+    np.testing.assert_array_equal(x == 0.0, ref == 0.0)
+    assert np.linalg.norm(x - ref) <= 1e-8 * max(np.linalg.norm(ref), 1.0)
