@@ -25,6 +25,8 @@ struct FrontSym {
     int npanels;             // ceil(fn / STM_NB)
     int parent;              // parent front or -1
     int fm_est;              // rows of F if no pivot column dies (exact for full-rank fronts): launch planning only
+    int tpan;                // index of this front's first panel in the kept-T array (DevCtx::Tall), panel p at tpan + p
+    int pad4;
 };
 
 // one pending block reflector (written by the panel kernel, read by the update kernel)

@@ -124,13 +124,14 @@ struct stmmqr_plan {
     int post_off = 0, rh_parts_off = 0, rh_maxparts = 1;
     long long farena = 0, carena = 0;
     int tslots = 1;
+    long long tpanels = 0;               // panels of all fronts: one kept T each (Q-apply on the resident factors)
     long long wp_doubles = 0;            // workspace of the row-parallel update (partial W blocks)
     bool pattern_set = false;
     double bytes_assemble_idx = 0;       // index bytes of the assembly (symbolic part of SURVEY 8d formula)
 
     DevBuf<FrontSym> d_fs;
     DevBuf<FrontNum> d_fnum;
-    DevBuf<double> d_F, d_C, d_T, d_Sx, d_Ax, d_Tau, d_RH, d_Wp, d_Wp2;
+    DevBuf<double> d_F, d_C, d_T, d_Tall, d_Sx, d_Ax, d_Tau, d_RH, d_Wp, d_Wp2;
     DevBuf<int> d_tslot, d_Sp, d_Sjrel, d_Sj0, d_Sleft, d_Child, d_Rjrel, d_Stair, d_Hii, d_Cmap, d_Cursor,
         d_Rhoff, d_lists, d_smap;
     DevBuf<long long> d_Rboff, d_total;
@@ -155,6 +156,7 @@ struct stmmqr_plan {
     {
         DevCtx c;
         c.fs = d_fs.p; c.fnum = d_fnum.p; c.Farena = d_F.p; c.Carena = d_C.p; c.Tws = d_T.p; c.tslot = d_tslot.p;
+        c.Tall = d_Tall.p;
         c.Sx = d_Sx.p; c.Sp = d_Sp.p; c.Sjrel = d_Sjrel.p; c.Sj0 = d_Sj0.p; c.Sleft = d_Sleft.p;
         c.Child = d_Child.p; c.Rjrel = d_Rjrel.p; c.Stair = d_Stair.p; c.Tau = d_Tau.p; c.Hii = d_Hii.p;
         c.Rdead = d_Rdead.p; c.Cmap = d_Cmap.p; c.Cursor = d_Cursor.p; c.Rhoff = d_Rhoff.p; c.Rboff = d_Rboff.p;
@@ -370,7 +372,7 @@ int build_plan(stmmqr_plan &P, const stmmqr_symbolic_view &v)
     }
 
     P.fs.assign(nf, FrontSym());
-    long long foff = 0, coff = 0;
+    long long foff = 0, coff = 0, tpan_total = 0;
     for (long kf = 0; kf < nf; kf++) {
         const long f = P.Post[kf];
         FrontSym &s = P.fs[f];
@@ -384,6 +386,8 @@ int build_plan(stmmqr_plan &P, const stmmqr_symbolic_view &v)
         s.fm_est = (int)fmest[f];
         s.ld = (int)std::max(2L, (fm + 1) & ~1L);
         s.npanels = (int)((fn + STM_NB - 1) / STM_NB);
+        s.tpan = (int)tpan_total;
+        tpan_total += s.npanels;
         s.parent = (int)parent[f];
         s.foff = foff;
         foff += (long long)s.ld * fn;
@@ -393,7 +397,7 @@ int build_plan(stmmqr_plan &P, const stmmqr_symbolic_view &v)
         coff += (long long)cm * (cm + 1) / 2 + (long long)cm * (cn - cm);
         coff = (coff + 1) & ~1LL;
     }
-    P.farena = foff; P.carena = coff;
+    P.farena = foff; P.carena = coff; P.tpanels = tpan_total;
 
     // ---- relative indices (value independent): child column -> parent column, S entry -> front column ----
     std::vector<int> Rjrel(std::max(1L, v.rjsize), 0), Sjrel(std::max(1L, v.anz), 0), Sj0(std::max(1L, m), -1);
@@ -424,7 +428,8 @@ int build_plan(stmmqr_plan &P, const stmmqr_symbolic_view &v)
     // ---- device memory ----------------------------------------------------------------------------
     size_t freeb = 0, totalb = 0;
     HIPCHK(hipMemGetInfo(&freeb, &totalb));
-    const double need = 8.0 * ((double)P.farena + (double)P.carena) * 1.05 + 64.0 * (double)(v.rjsize + v.anz);
+    const double need = 8.0 * ((double)P.farena + (double)P.carena + 1024.0 * (double)P.tpanels) * 1.05 +
+                        64.0 * (double)(v.rjsize + v.anz);
     if (need > 0.92 * (double)freeb)
         return fail(STMMQR_ERR_OUT_OF_MEMORY, "front arena does not fit in free HBM");
     hipStream_t st = P.stream;
@@ -438,6 +443,7 @@ int build_plan(stmmqr_plan &P, const stmmqr_symbolic_view &v)
     LCHK(P.d_F.alloc((size_t)P.farena));
     LCHK(P.d_C.alloc((size_t)P.carena));
     LCHK(P.d_T.alloc((size_t)2 * P.tslots * STM_NB * STM_NB));
+    LCHK(P.d_Tall.alloc((size_t)std::max(1LL, P.tpanels) * STM_NB * STM_NB));
     LCHK(P.d_Wp.alloc((size_t)P.wp_doubles));
     LCHK(P.d_Wp2.alloc((size_t)P.wp_doubles));
     LCHK(P.d_tslot.upload(tslot, st));
@@ -1001,12 +1007,17 @@ int run_qapply(stmmqr_plan &P, int method)
     DevCtx c = P.ctx();
     const int *L0 = P.d_lists.p;
     const auto &LV = P.glevels[0];
+    // blocked form with the kept T factors; STMMQR_DBG bit 13 selects the reflector-by-reflector kernel (same result up
+    // to rounding: used by the tests to cross-check the two)
+    const bool blocked = c.Tall && !(c.dbg & 8192);
+    auto launch = [&](size_t l, int m) -> int {
+        if (blocked) return stm_launch_qapply_t(c, L0 + LV[l].all_off, LV[l].n_all, m, P.d_W.p, P.level_lds_qa[l], P.stream);
+        return stm_launch_qapply(c, L0 + LV[l].all_off, LV[l].n_all, m, P.d_W.p, P.level_lds_qa[l], P.d_err.p, P.stream);
+    };
     if (method == 0) {
-        for (size_t l = 0; l < LV.size(); l++)
-            LCHK(stm_launch_qapply(c, L0 + LV[l].all_off, LV[l].n_all, 0, P.d_W.p, P.level_lds_qa[l], P.d_err.p, P.stream));
+        for (size_t l = 0; l < LV.size(); l++) LCHK(launch(l, 0));
     } else {
-        for (size_t l = LV.size(); l-- > 0;)
-            LCHK(stm_launch_qapply(c, L0 + LV[l].all_off, LV[l].n_all, 1, P.d_W.p, P.level_lds_qa[l], P.d_err.p, P.stream));
+        for (size_t l = LV.size(); l-- > 0;) LCHK(launch(l, 1));
     }
     return 0;
 }

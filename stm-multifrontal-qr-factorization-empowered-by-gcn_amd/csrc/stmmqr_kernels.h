@@ -11,6 +11,7 @@ struct DevCtx {
     double *Carena;            // packed contribution blocks
     double *Tws;               // T factors of the large fronts in flight, [slots][NB*NB]
     const int *tslot;          // [nf] slot in Tws (large fronts only)
+    double *Tall;              // [sum of npanels][NB*NB] T of EVERY panel, kept for the Q-apply (nullptr: not kept)
     const double *Sx;          // [anz] values of S = A(P,Q), row form
     const int *Sp;             // [m+1]
     const int *Sjrel;          // [anz] column of each S entry inside its front
@@ -52,6 +53,7 @@ int stm_launch_rh_copy(const DevCtx &c, const int *flist, const int *nparts, int
                        hipStream_t st);
 // Q-apply / triangular solve on the resident factors
 int stm_launch_qapply(const DevCtx &c, const int *flist, int nfr, int method, double *W, int lds_bytes, int *err, hipStream_t st);
+int stm_launch_qapply_t(const DevCtx &c, const int *flist, int nfr, int method, double *W, int lds_bytes, hipStream_t st);
 int stm_launch_rsolve(const DevCtx &c, const int *flist, int nfr, const int *Rj, const double *W, double *X, int lds_bytes,
                       int *err, hipStream_t st);
 int stm_launch_perm(const double *in, const int *perm, double *out, int n, int scatter, hipStream_t st);

@@ -682,7 +682,7 @@ __device__ __forceinline__ void dev_subpanel_reg(PanelShared &ps, double *F, lon
 template <int NTH, bool INPLACE>
 __device__ __forceinline__ void dev_panel(PanelShared &ps, const FrontSym &s, FrontNum *num, double *F, int *St, double *Tau, char *Rdead,
                           int p, double tol, int ntol_global, double *Tout, double *lds, int lds_doubles, int dbg = 0,
-                          unsigned long long *dbgbuf = nullptr)
+                          unsigned long long *dbgbuf = nullptr, double *Tkeep = nullptr)
 {
     constexpr int NWV = NTH / 64;
     double *s_red = ps.red;
@@ -963,6 +963,11 @@ __device__ __forceinline__ void dev_panel(PanelShared &ps, const FrontSym &s, Fr
     STAMP(3);
     // ---- T of the whole panel for the trailing update ----
     if (!(dbg & 2)) dev_gram_T<NTH>(F + (long long)k1 * ld, ld, g1, tlast, nbp, s_diag, s_tau, s_G, s_T, Tout, lds);
+    if (Tkeep)                                           // the same T, kept for the Q-apply on the resident factors
+        for (int e = tid; e < STM_NB * STM_NB; e += NTH) {
+            const int a = e % STM_NB, b = e / STM_NB;
+            Tkeep[e] = (a < nbp && b < nbp && a <= b) ? s_T[a][b] : 0.0;
+        }
     STAMP(4);
 #ifdef STMMQR_STAMPS
     if ((dbg & 16) && tid == 0 && dbgbuf)
@@ -1060,7 +1065,7 @@ template <int NTH, int RPT, int SWT>
 __device__ __forceinline__ void dev_tall_group(PanelShared &ps, const FrontSym &s, FrontNum *num, PanelDesc *pd, double *F,
                                                int *St, double *Tau, char *Rdead, int p, int b, int g1, int tmax,
                                                double tol, int ntol_global, double *Tout, double *lds, int dbg = 0,
-                                               unsigned long long *dbgbuf = nullptr)
+                                               unsigned long long *dbgbuf = nullptr, double *Tkeep = nullptr)
 {
     const int tid = threadIdx.x;
     const int m = num->fm, n = s.fn, npiv = s.fp;              // (fm is fixed before the panel kernels run)
@@ -1285,6 +1290,11 @@ __device__ __forceinline__ void dev_tall_group(PanelShared &ps, const FrontSym &
     }
     __syncthreads();
     dev_gram_T<NTH>(F + (long long)k1 * ld, ld, g1, tlast, nbp, ps.diag, ps.tau, ps.G, ps.T, Tout, lds);
+    if (Tkeep)
+        for (int e = tid; e < STM_NB * STM_NB; e += NTH) {
+            const int ai = e % STM_NB, bi = e / STM_NB;
+            Tkeep[e] = (ai < nbp && bi < nbp && ai <= bi) ? ps.T[ai][bi] : 0.0;
+        }
     TSTAMP(10);
     // (when an earlier group ran out of rows the groups after mine are still storing their columns: the kernel
     //  boundary orders those stores before the trailing update)
@@ -1338,13 +1348,14 @@ __global__ __launch_bounds__(NT) void k_front_wg(DevCtx c, const int *__restrict
     const FrontSym s = c.fs[f];
     FrontNum *num = &c.fnum[f];
     double *F = c.Farena + s.foff;
+    auto Tkeep = [&](int p) { return c.Tall ? c.Tall + (long long)(s.tpan + p) * STM_NB * STM_NB : (double *)nullptr; };
     for (int p = 0; p < s.npanels; p++) {
         if ((c.dbg & 64) || panel_rows(s, num, c.Stair + s.rp, p) > lds_doubles - 65)
             dev_panel<NT, true>(ps, s, num, F, c.Stair + s.rp, c.Tau + s.rp, c.Rdead + s.col1, p, c.tol, c.ntol, s_Tw,
-                                dyn_lds, lds_doubles, c.dbg);
+                                dyn_lds, lds_doubles, c.dbg, nullptr, Tkeep(p));
         else
             dev_panel<NT, false>(ps, s, num, F, c.Stair + s.rp, c.Tau + s.rp, c.Rdead + s.col1, p, c.tol, c.ntol, s_Tw,
-                                 dyn_lds, lds_doubles, c.dbg);
+                                 dyn_lds, lds_doubles, c.dbg, nullptr, Tkeep(p));
         const int k2 = min(s.fn, (p + 1) * STM_NB);
         const int ncb = (s.fn - k2 + BN - 1) / BN;
         const PanelDesc *pd = &num->pd[p & 1];
@@ -1371,6 +1382,7 @@ __global__ __launch_bounds__(NTP) void k_panel(DevCtx c, const int *__restrict__
     double *F = c.Farena + s.foff;
     double *T = c.Tws + (long long)(2 * c.tslot[f] + (p & 1)) * STM_NB * STM_NB;
     int *St = c.Stair + s.rp;
+    double *Tkeep = c.Tall ? c.Tall + (long long)(s.tpan + p) * STM_NB * STM_NB : nullptr;
     PanelDesc *pd = &num->pd[p & 1];
     const int b = blockIdx.y;
     bool tall = stm_tall_panel(s, p, c.tall_min) && !(c.dbg & 256);
@@ -1402,7 +1414,7 @@ __global__ __launch_bounds__(NTP) void k_panel(DevCtx c, const int *__restrict__
         }
         if (mode == 1) {
             const int rows = tmax - g1;
-#define TALL_ARGS ps, s, num, pd, F, St, c.Tau + s.rp, c.Rdead + s.col1, p, b, g1, tmax, c.tol, c.ntol, T, dyn_lds, c.dbg, c.dbgbuf
+#define TALL_ARGS ps, s, num, pd, F, St, c.Tau + s.rp, c.Rdead + s.col1, p, b, g1, tmax, c.tol, c.ntol, T, dyn_lds, c.dbg, c.dbgbuf, Tkeep
             if (w == 4) dev_tall_group<NTP, 8, 4>(TALL_ARGS);
             else if (rows <= NTP) dev_tall_group<NTP, 1, 8>(TALL_ARGS);
             else if (rows <= 2 * NTP) dev_tall_group<NTP, 2, 8>(TALL_ARGS);
@@ -1413,10 +1425,10 @@ __global__ __launch_bounds__(NTP) void k_panel(DevCtx c, const int *__restrict__
     }
     if ((c.dbg & 64) || panel_rows(s, num, St, p) > lds_doubles - 65)
         dev_panel<NTP, true>(ps, s, num, F, St, c.Tau + s.rp, c.Rdead + s.col1, p, c.tol, c.ntol, T, dyn_lds,
-                             lds_doubles, c.dbg, c.dbgbuf);
+                             lds_doubles, c.dbg, c.dbgbuf, Tkeep);
     else
         dev_panel<NTP, false>(ps, s, num, F, St, c.Tau + s.rp, c.Rdead + s.col1, p, c.tol, c.ntol, T, dyn_lds,
-                              lds_doubles, c.dbg, c.dbgbuf);
+                              lds_doubles, c.dbg, c.dbgbuf, Tkeep);
     if (threadIdx.x == 0) pd->mode = 0;
 }
 
@@ -1813,6 +1825,112 @@ __global__ __launch_bounds__(QA_NT) void k_qapply(DevCtx c, const int *__restric
     (void)err;
 }
 
+// Blocked form of k_qapply with the T factors the factorization kept (DevCtx::Tall): per panel of <= 32 reflectors
+//     w = V'x  (one sweep over the panel rows, 32 dot products per thread, ONE workgroup reduction of 32 values),
+//     y = T'w  (Q'x)  or  T w  (Q x),      x -= V y  (second sweep).
+// V is read in place with the unit-diagonal / staircase mask (reflector j of the panel: diagonal row dq[k], entries up
+// to HStair[k]); identity and dead columns have zero rows/columns in T and are masked out of V.
+__global__ __launch_bounds__(QA_NT) void k_qapply_t(DevCtx c, const int *__restrict__ flist, int method, double *W)
+{
+    extern __shared__ double dyn_lds[];
+    __shared__ int s_scan[NW];
+    __shared__ int s_d[STM_NB], s_t[STM_NB];
+    __shared__ double s_part[NW][STM_NB], s_w[STM_NB], s_y[STM_NB], s_T[STM_NB][STM_NB + 1];
+    const int f = flist[blockIdx.x];
+    const FrontSym s = c.fs[f];
+    const int fm = c.fnum[f].fm;
+    if (fm <= 0 || s.fn <= 0) return;
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int *St = c.Stair + s.rp;
+    const double *Tau = c.Tau + s.rp;
+    const int *Hi = c.Hii + s.hip;
+    const double *F = c.Farena + s.foff;
+    const long long ld = s.ld;
+    double *xs = dyn_lds;                               // [fm]
+    int *dq = (int *)(xs + ((fm + 1) & ~1));            // [fn]
+    for (int i = tid; i < fm; i += QA_NT) xs[i] = W[Hi[i]];
+    qa_number_reflectors(s, fm, St, Tau, dq, s_scan);
+    const int pbeg = method ? s.npanels - 1 : 0, pend = method ? -1 : s.npanels, pinc = method ? -1 : 1;
+    for (int p = pbeg; p != pend; p += pinc) {
+        const int k1 = p * STM_NB, nbp = min(STM_NB, s.fn - k1);
+        if (tid < STM_NB) {
+            const int d = (tid < nbp) ? dq[k1 + tid] : -1;
+            s_d[tid] = (d >= 0) ? d : STM_BIGROW;
+            s_t[tid] = (d >= 0) ? St[k1 + tid] : 0;
+        }
+        __syncthreads();
+        int r0 = STM_BIGROW, r1 = 0;
+#pragma unroll
+        for (int j = 0; j < STM_NB; j++) { r0 = min(r0, s_d[j]); r1 = max(r1, max(s_t[j], (s_d[j] < STM_BIGROW) ? s_d[j] + 1 : 0)); }
+        if (r0 >= STM_BIGROW) { __syncthreads(); continue; }   // no live reflector in this panel (uniform)
+        const double *Vp = F + (long long)k1 * ld;
+        // T of this panel: requested now (coalesced), parked in LDS after the first sweep
+        double treg[STM_NB * STM_NB / QA_NT];
+        {
+            const double *T = c.Tall + (long long)(s.tpan + p) * STM_NB * STM_NB;
+#pragma unroll
+            for (int q = 0; q < STM_NB * STM_NB / QA_NT; q++) treg[q] = T[tid + QA_NT * q];
+        }
+        // ---- w = V'x ----
+        double acc[STM_NB];
+#pragma unroll
+        for (int j = 0; j < STM_NB; j++) acc[j] = 0;
+        for (int i = r0 + tid; i < r1; i += QA_NT) {
+            const double xi = xs[i];
+#pragma unroll
+            for (int j = 0; j < STM_NB; j++) {
+                const double val = Vp[i + (long long)min(j, nbp - 1) * ld];        // unconditional, masked below
+                const double v = (i > s_d[j] && i < s_t[j]) ? val : ((i == s_d[j]) ? 1.0 : 0.0);
+                acc[j] += v * xi;
+            }
+        }
+        {
+            double part[8];
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+#pragma unroll
+                for (int x = 0; x < 8; x++) part[x] = acc[8 * q + x];
+                const double rw = wave_reduce8(part);                             // lane l: total of value red8_idx(l)
+                if (lane < 8) s_part[wid][8 * q + red8_idx(lane)] = rw;
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < STM_NB * STM_NB / QA_NT; q++) {
+            const int e = tid + QA_NT * q;
+            s_T[e % STM_NB][e / STM_NB] = treg[q];                // s_T[row][col], padded rows: no bank conflicts below
+        }
+        __syncthreads();
+        if (tid < STM_NB) {
+            double v = 0;
+#pragma unroll
+            for (int w = 0; w < NW; w++) v += s_part[w][tid];
+            s_w[tid] = v;
+        }
+        __syncthreads();
+        // ---- y = T'w (Q'x) or T w (Q x); T upper triangular ----
+        if (tid < STM_NB) {
+            double y = 0;
+            if (method == 0) { for (int q = 0; q <= tid; q++) y += s_T[q][tid] * s_w[q]; }
+            else { for (int q = tid; q < STM_NB; q++) y += s_T[tid][q] * s_w[q]; }
+            s_y[tid] = y;
+        }
+        __syncthreads();
+        // ---- x -= V y ----
+        for (int i = r0 + tid; i < r1; i += QA_NT) {
+            double a = xs[i];
+#pragma unroll
+            for (int j = 0; j < STM_NB; j++) {
+                const double val = Vp[i + (long long)min(j, nbp - 1) * ld];
+                const double v = (i > s_d[j] && i < s_t[j]) ? val : ((i == s_d[j]) ? 1.0 : 0.0);
+                a -= v * s_y[j];
+            }
+            xs[i] = a;
+        }
+        __syncthreads();
+    }
+    for (int i = tid; i < fm; i += QA_NT) W[Hi[i]] = xs[i];
+}
+
 // One front of the back substitution R x = y (fronts root -> leaves; reference qr_rsolve, SparseQR.c:2218-2470):
 // y = the first rm rows of the front's slice of W (rm = live pivot columns), x of the non-pivotal columns comes from
 // the ancestors, a dead pivot column gets x = 0 (basic solution), the live pivot columns form an rm x rm upper triangle
@@ -2005,6 +2123,12 @@ int stm_launch_qapply(const DevCtx &c, const int *flist, int nfr, int method, do
     hipLaunchKernelGGL(k_qapply, dim3(nfr), dim3(QA_NT), (size_t)lds_bytes, st, c, flist, method, W, err);
     return (int)hipGetLastError();
 }
+int stm_launch_qapply_t(const DevCtx &c, const int *flist, int nfr, int method, double *W, int lds_bytes, hipStream_t st)
+{
+    if (nfr <= 0) return 0;
+    hipLaunchKernelGGL(k_qapply_t, dim3(nfr), dim3(QA_NT), (size_t)lds_bytes, st, c, flist, method, W);
+    return (int)hipGetLastError();
+}
 int stm_launch_rsolve(const DevCtx &c, const int *flist, int nfr, const int *Rj, const double *W, double *X, int lds_bytes,
                       int *err, hipStream_t st)
 {
@@ -2026,6 +2150,7 @@ int stm_configure_kernels(void)
     CK(hipFuncSetAttribute((const void *)k_panel, hipFuncAttributeMaxDynamicSharedMemorySize, 131072));
     CK(hipFuncSetAttribute((const void *)k_update, hipFuncAttributeMaxDynamicSharedMemorySize, 65536));
     CK(hipFuncSetAttribute((const void *)k_qapply, hipFuncAttributeMaxDynamicSharedMemorySize, 131072));
+    CK(hipFuncSetAttribute((const void *)k_qapply_t, hipFuncAttributeMaxDynamicSharedMemorySize, 131072));
     CK(hipFuncSetAttribute((const void *)k_rsolve, hipFuncAttributeMaxDynamicSharedMemorySize, 131072));
     return 0;
 }
