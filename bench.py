@@ -182,7 +182,8 @@ def main():
         upd_tf = det["flops_update"] / max(det["ms_update"], 1e-9) * 1e-9 if det["ms_update"] > 0 else 0.0
         panel_flops = max(flops - det["flops_update"], 0.0)
         panel_tf = panel_flops / max(det["ms_front"], 1e-9) * 1e-9
-        # trailing update: 2 reads + 1 write of the trailing block per panel = 24 B per (row, col), i.e. per 4*nb flops
+        # trailing update: 2 reads + 1 write of the trailing block per panel = 24 B per (row, col); flops_update counts
+        # 4 flops per (live column, row below its diagonal, trailing col), i.e. <= 4*32 per (row, col): a lower bound
         upd_bytes = det["flops_update"] * 24.0 / (4.0 * 32.0)
         upd_gbs = upd_bytes / max(det["ms_update"], 1e-9) * 1e-6
         pmc = {}

@@ -43,6 +43,7 @@ struct PanelDesc {
     int done_group;          // group that ran out of rows (g reached fm), -1 if none
     int sg[STM_NB / 4];      // first active row (g) at the start of sub-panel s
     int st[STM_NB / 4];      // one past the last row reached by the reflectors of sub-panel s
+    double lensum;           // sum of (t - g) over the live columns so far (flop accounting of the trailing update)
 };
 
 #define STM_SW 8             // sub-panel width of the tall-panel pipeline (4 above STM_TALL_WIDE rows)
@@ -83,7 +84,7 @@ struct FrontNum {
     int perr;                // ... set when a bounded wait ran out (the factorization is reported as failed)
     int pad2;
     double flops;            // reference flop count of this front  (FLOP_COUNT, :1571)
-    double flops_upd;        // dlarfb flops handed to the MFMA update: 4 * rows * cols * reflectors
+    double flops_upd;        // the part of `flops` that the trailing update does: sum (t-g) * 4 * (fn - k2), k2 = panel end
     // pending block reflectors, double buffered by panel parity so that the look-ahead schedule can factorize
     // panel p+1 while the tail of update p is still reading the description of panel p
     PanelDesc pd[2];

@@ -552,7 +552,7 @@ __device__ __forceinline__ int panel_rows(const FrontSym &s, const FrontNum *num
 template <int NTH, int RPT, int SWT>
 __device__ __forceinline__ void dev_subpanel_reg(PanelShared &ps, double *F, long long ld, int *St, double *Tau, char *Rdead,
                                                  int k1, int j0, int sw, int nbp, int gs, int tmax, int m, int n, int npiv,
-                                                 int ntol, double tol, int &g, int &rank, double &flops, int &nlive,
+                                                 int ntol, double tol, int &g, int &rank, double &flops, double &lensum, int &nlive,
                                                  int &tlast, int &done, int &ncols_done, double *lds, long long pst)
 {
     constexpr int NWV = NTH / 64;
@@ -628,6 +628,7 @@ __device__ __forceinline__ void dev_subpanel_reg(PanelShared &ps, double *F, lon
             } else {
                 if (tid == 0) { ps.st_out[jp] = t; ps.dead[jp] = 0; ps.diag[jp] = g; ps.tau[jp] = tau; }
                 flops += (double)(t - g) * (3.0 + 4.0 * (double)(n - k - 1));
+                lensum += (double)(t - g);
                 if (tau != 0.0) {
                     nlive++;
                     double w[8];
@@ -711,7 +712,7 @@ __device__ __forceinline__ void dev_panel(PanelShared &ps, const FrontSym &s, Fr
     __syncthreads();                                   //  step would sit on the critical path)
     const int tmax = min(m, max(ps.stair[nbp - 1], g1 + nbp));
     const int mp = tmax - g1;
-    double flops = 0;
+    double flops = 0, lensum = 0;
     int done = 0, tlast = g1, ncols_done = nbp;
 
     // sub-panel width: as many columns as fit in LDS with the rows of the first sub-panel
@@ -769,16 +770,16 @@ __device__ __forceinline__ void dev_panel(PanelShared &ps, const FrontSym &s, Fr
             // ---- register-resident column loop; leaves the finished sub-panel in the LDS image ----
             if (ms <= NTH)
                 dev_subpanel_reg<NTH, 1, 8>(ps, F, ld, St, Tau, Rdead, k1, j0, sw, nbp, gs, tmax, m, n, npiv, ntol, tol, g, rank,
-                                         flops, nlive, tlast, done, ncols_done, lds, pst);
+                                         flops, lensum, nlive, tlast, done, ncols_done, lds, pst);
             else if (ms <= 2 * NTH)
                 dev_subpanel_reg<NTH, 2, 8>(ps, F, ld, St, Tau, Rdead, k1, j0, sw, nbp, gs, tmax, m, n, npiv, ntol, tol, g, rank,
-                                         flops, nlive, tlast, done, ncols_done, lds, pst);
+                                         flops, lensum, nlive, tlast, done, ncols_done, lds, pst);
             else if (ms <= 4 * NTH)
                 dev_subpanel_reg<NTH, 4, 8>(ps, F, ld, St, Tau, Rdead, k1, j0, sw, nbp, gs, tmax, m, n, npiv, ntol, tol, g, rank,
-                                         flops, nlive, tlast, done, ncols_done, lds, pst);
+                                         flops, lensum, nlive, tlast, done, ncols_done, lds, pst);
             else
                 dev_subpanel_reg<NTH, 8, 4>(ps, F, ld, St, Tau, Rdead, k1, j0, sw, nbp, gs, tmax, m, n, npiv, ntol, tol, g, rank,
-                                         flops, nlive, tlast, done, ncols_done, lds, pst);
+                                         flops, lensum, nlive, tlast, done, ncols_done, lds, pst);
         } else {
         __syncthreads();
         STAMP(0);
@@ -834,7 +835,6 @@ __device__ __forceinline__ void dev_panel(PanelShared &ps, const FrontSym &s, Fr
             const double ss = part[0];
             double tau = 0, beta = alpha, scal = 0;
             if (len > 1 && ss != 0.0) {
-                const double xnorm = sqrt(ss);
                 beta = -copysign(sqrt(alpha * alpha + ss), alpha);   // |x|^2 is unscaled anyway: no hypot
                 tau = (beta - alpha) / beta;
                 scal = 1.0 / (alpha - beta);
@@ -852,6 +852,7 @@ __device__ __forceinline__ void dev_panel(PanelShared &ps, const FrontSym &s, Fr
             if (tid == 0) { ps.st_out[j] = t; ps.dead[j] = 0; s_diag[j] = g; s_tau[j] = tau; if (tall) col[0] = beta; }
             CSTAMP(7);
             flops += (double)len * (3.0 + 4.0 * (double)(n - k - 1));
+            lensum += (double)len;
             if (tall) {
                 // ---- scale x and apply H_k to the rest of the sub-panel in the same sweep over the rows ----
                 if (tau != 0.0) {
@@ -981,11 +982,7 @@ __device__ __forceinline__ void dev_panel(PanelShared &ps, const FrontSym &s, Fr
         num->g = g; num->rank = rank; num->done = done;
         pd->pg1 = g1; pd->pt = tlast; pd->pk1 = k1; pd->pnb = nbp; pd->pc0 = k2;
         num->flops += flops;
-        {
-            int nl = 0;
-            for (int j = 0; j < nbp; j++) nl += (s_tau[j] != 0.0);
-            num->flops_upd += 4.0 * (double)(tlast - g1) * (double)(n - k2) * (double)nl;
-        }
+        num->flops_upd += 4.0 * (double)(n - k2) * lensum;
     }
     __syncthreads();
 }
@@ -1175,6 +1172,8 @@ __device__ __forceinline__ void dev_tall_group(PanelShared &ps, const FrontSym &
     int rank = ld_agent(&num->rank), done = prev_done, nlive = 0;
     int tlast = (b == 0) ? g1 : ld_agent(&pd->pt);
     const int nl_before = (b == 0) ? 0 : ld_agent(&pd->nlive);
+    const double ls_before = (b == 0) ? 0.0 : ld_agent(&pd->lensum);
+    double lensum = 0;
     const int gs = g;
     const int ntol = min(ntol_global - s.col1, npiv);
     double flops = 0;
@@ -1245,6 +1244,7 @@ __device__ __forceinline__ void dev_tall_group(PanelShared &ps, const FrontSym &
             }
             if (!dead) {
                 flops += (double)(t - g) * (3.0 + 4.0 * (double)(n - k - 1));
+                lensum += (double)(t - g);
                 nlive += (tau != 0.0);
                 tlast = t;
                 g++;
@@ -1272,6 +1272,7 @@ __device__ __forceinline__ void dev_tall_group(PanelShared &ps, const FrontSym &
         st_agent(&num->g, g); st_agent(&num->rank, rank); st_agent(&num->done, done);
         st_agent(&num->flops, ((b == 0) ? num->flops : ld_agent(&num->flops)) + flops);
         st_agent(&pd->sg[b], gs); st_agent(&pd->st[b], tlast); st_agent(&pd->pt, tlast); st_agent(&pd->nlive, nl_total);
+        st_agent(&pd->lensum, ls_before + lensum);
         if (done) st_agent(&pd->done_group, b);
     }
     if (!last) {
@@ -1282,7 +1283,7 @@ __device__ __forceinline__ void dev_tall_group(PanelShared &ps, const FrontSym &
     if (tid == 0) {
         pd->mode = 2;
         pd->pk1 = k1; pd->pnb = nbp; pd->pc0 = k2;
-        num->flops_upd += 4.0 * (double)(tlast - g1) * (double)(n - k2) * (double)nl_total;
+        num->flops_upd += 4.0 * (double)(n - k2) * (prev_done ? ls_before : ls_before + lensum);
     }
     if (tid < STM_NB) {
         ps.diag[tid] = (tid < nbp) ? ld_agent(&pd->pdiag[tid]) : STM_BIGROW;    // (columns past a `done` point were reset there)
