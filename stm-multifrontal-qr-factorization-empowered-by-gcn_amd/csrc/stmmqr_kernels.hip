@@ -375,17 +375,28 @@ __device__ void dev_gram_T(const double *Vg, long long ld, int r0, int r1, int n
     const double *V0 = Vg + (long long)min(l15, ncc - 1) * ld, *V1 = Vg + (long long)min(16 + l15, ncc - 1) * ld;
     d4 g00 = {0, 0, 0, 0}, g01 = {0, 0, 0, 0}, g11 = {0, 0, 0, 0};
     const int nk = (r1 - r0 + 3) / 4;
-    // four row groups per trip: the 8 loads are issued before the first MFMA needs one (latency-bound otherwise)
-    for (int kk = wid; kk < nk; kk += 4 * NWV) {
-        double a0[4], a1[4];
+    // four row groups per trip: the 8 loads of the NEXT trip are issued before the MFMAs of the current one (the loop is
+    // bound by the memory latency of a trip otherwise)
+    double x0[4], x1[4], y0[4], y1[4];
+    auto load_trip = [&](int kk, double (&p0)[4], double (&p1)[4]) {
 #pragma unroll
         for (int u = 0; u < 4; u++) {
             const int i = r0 + 4 * (kk + u * NWV) + l4;
             const int ic = max(min(i, r1 - 1), 0);
-            const double x0 = V0[ic], x1 = V1[ic];
+            p0[u] = V0[ic]; p1[u] = V1[ic];
+        }
+    };
+    if (wid < nk) load_trip(wid, x0, x1);
+    for (int kk = wid; kk < nk; kk += 4 * NWV) {
+        const int kn = kk + 4 * NWV;
+        if (kn < nk) load_trip(kn, y0, y1);
+        double a0[4], a1[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const int i = r0 + 4 * (kk + u * NWV) + l4;
             const bool in = (kk + u * NWV < nk) && (i < r1);
-            a0[u] = (in && i >= d0) ? ((i == d0) ? 1.0 : x0) : 0.0;
-            a1[u] = (in && two && i >= d1) ? ((i == d1) ? 1.0 : x1) : 0.0;
+            a0[u] = (in && i >= d0) ? ((i == d0) ? 1.0 : x0[u]) : 0.0;
+            a1[u] = (in && two && i >= d1) ? ((i == d1) ? 1.0 : x1[u]) : 0.0;
         }
 #pragma unroll
         for (int u = 0; u < 4; u++) {
@@ -395,6 +406,8 @@ __device__ void dev_gram_T(const double *Vg, long long ld, int r0, int r1, int n
                 g11 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1[u], a1[u], g11, 0, 0, 0);
             }
         }
+#pragma unroll
+        for (int u = 0; u < 4; u++) { x0[u] = y0[u]; x1[u] = y1[u]; }
     }
     __syncthreads();                                    // scratch is free
     // cross-wave sum in groups of 4 waves (scratch: 4 * 768 doubles)
