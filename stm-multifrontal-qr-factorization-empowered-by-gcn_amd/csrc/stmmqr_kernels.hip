@@ -1776,7 +1776,34 @@ __global__ __launch_bounds__(NT) void k_rh_copy(DevCtx c, const int *__restrict_
 // at front row q, entries below it up to the column's HStair), rows of a front are global rows through Hii.
 // Work vector W: one entry per row of A, indexed by the row id of S = A(P,:)  (Hii holds exactly these ids).
 // ================================================================================================
-#define QA_NT 256
+#ifndef QA_NT
+#define QA_NT 512
+#endif
+#define QA_NW (QA_NT / 64)
+// inclusive scan of one int per thread over NWV waves; *total = sum.  s_scan: NWV ints.
+template <int NWV>
+__device__ __forceinline__ int qa_incl_scan(int v, int *s_scan, int *total)
+{
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    int x = v;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        int y = __shfl_up(x, o, 64);
+        if (lane >= o) x += y;
+    }
+    __syncthreads();
+    if (lane == 63) s_scan[wid] = x;
+    __syncthreads();
+    int base = 0, tot = 0;
+#pragma unroll
+    for (int w = 0; w < NWV; w++) {
+        int sw = s_scan[w];
+        if (w < wid) base += sw;
+        tot += sw;
+    }
+    *total = tot;
+    return x + base;
+}
 // live-reflector numbering of one front: dq[k] = number of live reflectors before column k, or -1 if column k has none
 // (dead pivot column, or the rows ran out).  Mirrors the enumeration of the packed format (qr_rhpack :1691-1784).
 __device__ void qa_number_reflectors(const FrontSym &s, int fm, const int *St, const double *Tau, int *dq, int *s_scan)
@@ -1787,7 +1814,7 @@ __device__ void qa_number_reflectors(const FrontSym &s, int fm, const int *St, c
     int cnt = 0;
     for (int k = k0; k < k1; k++) cnt += (k >= s.fp || St[k] != 0);
     int total;
-    const int incl = block_incl_scan(cnt, s_scan, &total);
+    const int incl = qa_incl_scan<QA_NW>(cnt, s_scan, &total);
     int d = incl - cnt;
     for (int k = k0; k < k1; k++) {
         const bool live = (k >= s.fp || St[k] != 0);
@@ -1801,8 +1828,8 @@ __device__ void qa_number_reflectors(const FrontSym &s, int fm, const int *St, c
 __global__ __launch_bounds__(QA_NT) void k_qapply(DevCtx c, const int *__restrict__ flist, int method, double *W, int *err)
 {
     extern __shared__ double dyn_lds[];
-    __shared__ int s_scan[NW];
-    __shared__ double s_red[NW];
+    __shared__ int s_scan[QA_NW];
+    __shared__ double s_red[QA_NW];
     const int f = flist[blockIdx.x];
     const FrontSym s = c.fs[f];
     const int fm = c.fnum[f].fm;
@@ -1847,9 +1874,9 @@ __global__ __launch_bounds__(QA_NT) void k_qapply(DevCtx c, const int *__restric
 __global__ __launch_bounds__(QA_NT) void k_qapply_t(DevCtx c, const int *__restrict__ flist, int method, double *W)
 {
     extern __shared__ double dyn_lds[];
-    __shared__ int s_scan[NW];
+    __shared__ int s_scan[QA_NW];
     __shared__ int s_d[STM_NB], s_t[STM_NB];
-    __shared__ double s_part[NW][STM_NB], s_w[STM_NB], s_y[STM_NB], s_T[STM_NB][STM_NB + 1];
+    __shared__ double s_part[QA_NW][STM_NB], s_w[STM_NB], s_y[STM_NB], s_T[STM_NB][STM_NB + 1];
     const int f = flist[blockIdx.x];
     const FrontSym s = c.fs[f];
     const int fm = c.fnum[f].fm;
@@ -1879,11 +1906,11 @@ __global__ __launch_bounds__(QA_NT) void k_qapply_t(DevCtx c, const int *__restr
         if (r0 >= STM_BIGROW) { __syncthreads(); continue; }   // no live reflector in this panel (uniform)
         const double *Vp = F + (long long)k1 * ld;
         // T of this panel: requested now (coalesced), parked in LDS after the first sweep
-        double treg[STM_NB * STM_NB / QA_NT];
+        double treg[(STM_NB * STM_NB + QA_NT - 1) / QA_NT];
         {
             const double *T = c.Tall + (long long)(s.tpan + p) * STM_NB * STM_NB;
 #pragma unroll
-            for (int q = 0; q < STM_NB * STM_NB / QA_NT; q++) treg[q] = T[tid + QA_NT * q];
+            for (int q = 0; q < (STM_NB * STM_NB + QA_NT - 1) / QA_NT; q++) treg[q] = T[min(tid + QA_NT * q, STM_NB * STM_NB - 1)];
         }
         // ---- w = V'x ----
         double acc[STM_NB];
@@ -1909,15 +1936,15 @@ __global__ __launch_bounds__(QA_NT) void k_qapply_t(DevCtx c, const int *__restr
             }
         }
 #pragma unroll
-        for (int q = 0; q < STM_NB * STM_NB / QA_NT; q++) {
+        for (int q = 0; q < (STM_NB * STM_NB + QA_NT - 1) / QA_NT; q++) {
             const int e = tid + QA_NT * q;
-            s_T[e % STM_NB][e / STM_NB] = treg[q];                // s_T[row][col], padded rows: no bank conflicts below
+            if (e < STM_NB * STM_NB) s_T[e % STM_NB][e / STM_NB] = treg[q];                // s_T[row][col], padded rows: no bank conflicts below
         }
         __syncthreads();
         if (tid < STM_NB) {
             double v = 0;
 #pragma unroll
-            for (int w = 0; w < NW; w++) v += s_part[w][tid];
+            for (int w = 0; w < QA_NW; w++) v += s_part[w][tid];
             s_w[tid] = v;
         }
         __syncthreads();
@@ -1949,11 +1976,12 @@ __global__ __launch_bounds__(QA_NT) void k_qapply_t(DevCtx c, const int *__restr
 // y = the first rm rows of the front's slice of W (rm = live pivot columns), x of the non-pivotal columns comes from
 // the ancestors, a dead pivot column gets x = 0 (basic solution), the live pivot columns form an rm x rm upper triangle
 // whose row q is the q-th live column.
-__global__ __launch_bounds__(QA_NT) void k_rsolve(DevCtx c, const int *__restrict__ flist, const int *__restrict__ Rj,
+#define RS_NT 1024               // the back substitution streams R through one workgroup: more loads in flight
+__global__ __launch_bounds__(RS_NT) void k_rsolve(DevCtx c, const int *__restrict__ flist, const int *__restrict__ Rj,
                                                   const double *W, double *X, int *err)
 {
     extern __shared__ double dyn_lds[];
-    __shared__ int s_scan[NW];
+    __shared__ int s_scan[RS_NT / 64];
     const int f = flist[blockIdx.x];
     const FrontSym s = c.fs[f];
     const FrontNum nm = c.fnum[f];
@@ -1971,12 +1999,12 @@ __global__ __launch_bounds__(QA_NT) void k_rsolve(DevCtx c, const int *__restric
     // ---- live pivot columns (HStair != 0 and a row left for the diagonal), dead ones: x = 0 ----
     int rm;
     {
-        const int per = (fp + QA_NT - 1) / QA_NT;
+        const int per = (fp + RS_NT - 1) / RS_NT;
         const int k0 = min(fp, tid * per), k1 = min(fp, k0 + per);
         int cnt = 0;
         for (int k = k0; k < k1; k++) cnt += (St[k] != 0);
         int total;
-        const int incl = block_incl_scan(cnt, s_scan, &total);
+        const int incl = qa_incl_scan<RS_NT / 64>(cnt, s_scan, &total);
         int q = incl - cnt;
         for (int k = k0; k < k1; k++) {
             if (St[k] != 0 && q < fm) lc[q] = k;
@@ -1985,11 +2013,11 @@ __global__ __launch_bounds__(QA_NT) void k_rsolve(DevCtx c, const int *__restric
         }
         rm = min(total, fm);
     }
-    for (int k = fp + tid; k < fn; k += QA_NT) xo[k - fp] = X[rj[k]];
+    for (int k = fp + tid; k < fn; k += RS_NT) xo[k - fp] = X[rj[k]];
     __syncthreads();
     if (rm != nm.rank && tid == 0) atomicExch(err, 1);  // (cannot happen: same rule as the factorization)
     // acc = y - R12 x_others : thread per row, columns streamed (coalesced over the rows)
-    for (int i = tid; i < rm; i += QA_NT) {
+    for (int i = tid; i < rm; i += RS_NT) {
         double a = W[Hi[i]];
         for (int k = fp; k < fn; k++) a -= F[i + (long long)k * ld] * xo[k - fp];
         acc[i] = a;
@@ -2003,7 +2031,7 @@ __global__ __launch_bounds__(QA_NT) void k_rsolve(DevCtx c, const int *__restric
     __shared__ double s_x[QS_NB];
     for (int kb = ((max(rm, 1) - 1) / QS_NB) * QS_NB; kb >= 0 && rm > 0; kb -= QS_NB) {
         const int nb = min(QS_NB, rm - kb);
-        for (int e = tid; e < QS_NB * QS_NB; e += QA_NT) {
+        for (int e = tid; e < QS_NB * QS_NB; e += RS_NT) {
             const int i = e % QS_NB, j = e / QS_NB;
             s_tri[i][j] = (i < nb && j < nb && i <= j) ? F[(kb + i) + (long long)lc[kb + j] * ld] : 0.0;
         }
@@ -2021,7 +2049,7 @@ __global__ __launch_bounds__(QA_NT) void k_rsolve(DevCtx c, const int *__restric
         }
         __syncthreads();
         if (tid < nb) X[s.col1 + lc[kb + tid]] = s_x[tid];
-        for (int i = tid; i < kb; i += QA_NT) {
+        for (int i = tid; i < kb; i += RS_NT) {
             double a = acc[i];
 #pragma unroll 8
             for (int j = 0; j < nb; j++) a -= F[i + (long long)lc[kb + j] * ld] * s_x[j];
@@ -2147,7 +2175,7 @@ int stm_launch_rsolve(const DevCtx &c, const int *flist, int nfr, const int *Rj,
                       int *err, hipStream_t st)
 {
     if (nfr <= 0) return 0;
-    hipLaunchKernelGGL(k_rsolve, dim3(nfr), dim3(QA_NT), (size_t)lds_bytes, st, c, flist, Rj, W, X, err);
+    hipLaunchKernelGGL(k_rsolve, dim3(nfr), dim3(RS_NT), (size_t)lds_bytes, st, c, flist, Rj, W, X, err);
     return (int)hipGetLastError();
 }
 int stm_launch_perm(const double *in, const int *perm, double *out, int n, int scatter, hipStream_t st)
