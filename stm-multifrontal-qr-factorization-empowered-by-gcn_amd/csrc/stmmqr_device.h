@@ -80,7 +80,7 @@ struct FrontNum {
     int cm;                  // rows of the contribution block      (qr_cpack's return value)
     int rsize;               // entries of the packed R+H block     (qr_rhpack's return value)
     int hdr;                 // tall-panel pipeline: p+1 once the header (mode, pg1, tmax, sw) of panel p is published
-    int prog;                // ... 16*p + (number of finished sub-panels of panel p); monotone over the whole front
+    int prog;                // ... 32*p + 2*(finished groups of panel p) + (1: first half of the next one); monotone
     int perr;                // ... set when a bounded wait ran out (the factorization is reported as failed)
     int pad2;
     double flops;            // reference flop count of this front  (FLOP_COUNT, :1571)

@@ -1110,12 +1110,14 @@ __device__ __forceinline__ void dev_tall_group(PanelShared &ps, const FrontSym &
     TSTAMP(6);
     // ---- apply the reflectors of the groups before mine, as they become available ----
     int prev_done = 0;
-    for (int sp = 0; sp < b && !prev_done; sp++) {
-        if (!wait_progress(&num->prog, 16 * p + sp + 1)) { if (tid == 0) st_agent(&num->perr, 1); return; }
+    // (a group publishes twice: after the first half of its columns and at the end, so that the next group applies the
+    //  first half of the reflectors while the second half is still being factorized)
+    for (int sp = 0; sp < b && !prev_done; sp++)
+    for (int half = 0; half < 2; half++) {
+        if (!wait_progress(&num->prog, 32 * p + 2 * sp + 1 + half)) { if (tid == 0) st_agent(&num->perr, 1); return; }
         TSTAMP(7);
-        const int pc0 = SWT * sp;
-        const int tprev = ld_agent(&pd->st[sp]);
-        prev_done = ld_agent(&num->done);
+        const int pc0 = SWT * sp + half * (SWT / 2);
+        if (half == 1) prev_done = ld_agent(&num->done);
         double vn[RPT];
         {
             const double *vc = F + (long long)(k1 + pc0) * ld;
@@ -1123,10 +1125,10 @@ __device__ __forceinline__ void dev_tall_group(PanelShared &ps, const FrontSym &
             for (int r = 0; r < RPT; r++) {
                 const int i = rb + tid + NTH * r;
                 const double val = vc[min(i, tmax - 1)];
-                vn[r] = (i < tprev) ? val : 0.0;
+                vn[r] = (i < tmax) ? val : 0.0;                // (rows beyond a column's staircase are zero in F)
             }
         }
-        for (int q = 0; q < SWT; q++) {
+        for (int q = 0; q < SWT / 2; q++) {
             const int d = ld_agent(&pd->pdiag[pc0 + q]);
             const double tau = ld_agent(&Tau[k1 + pc0 + q]);
             double v[RPT];
@@ -1135,13 +1137,13 @@ __device__ __forceinline__ void dev_tall_group(PanelShared &ps, const FrontSym &
                 const int i = rb + tid + NTH * r;
                 v[r] = (i < d) ? 0.0 : ((i == d) ? 1.0 : vn[r]);
             }
-            if (q + 1 < SWT) {                                 // next reflector's column: in flight during the reduction
+            if (q + 1 < SWT / 2) {                             // next reflector's column: in flight during the reduction
                 const double *vc = F + (long long)(k1 + pc0 + q + 1) * ld;
 #pragma unroll
                 for (int r = 0; r < RPT; r++) {
                     const int i = rb + tid + NTH * r;
                     const double val = vc[min(i, tmax - 1)];
-                    vn[r] = (i < tprev) ? val : 0.0;
+                    vn[r] = (i < tmax) ? val : 0.0;
                 }
             }
             if (tau == 0.0 || d >= STM_BIGROW) continue;       // identity / dead column (uniform)
@@ -1193,6 +1195,7 @@ __device__ __forceinline__ void dev_tall_group(PanelShared &ps, const FrontSym &
     lds_barrier();                                             // ps.stair
     for (int j = 0; j < sw && !prev_done; j++) {
         const int jp = c0 + j, k = k1 + jp;
+        if (j == SWT / 2 && b + 1 < ns) publish_progress(&num->prog, 32 * p + 2 * b + 1);   // first half is in F
         if (!done && g >= m) {
             // no rows left: remaining pivotal columns are dead, remaining columns are empty (:1444-1458)
             for (int kk = k + tid; kk < n; kk += NTH) {
@@ -1289,7 +1292,7 @@ __device__ __forceinline__ void dev_tall_group(PanelShared &ps, const FrontSym &
         if (done) st_agent(&pd->done_group, b);
     }
     if (!last) {
-        publish_progress(&num->prog, 16 * p + b + 1);
+        publish_progress(&num->prog, 32 * p + 2 * b + 2);
         return;
     }
     __syncthreads();                                           // all stores of this workgroup are complete and visible
@@ -1312,7 +1315,7 @@ __device__ __forceinline__ void dev_tall_group(PanelShared &ps, const FrontSym &
     TSTAMP(10);
     // (when an earlier group ran out of rows the groups after mine are still storing their columns: the kernel
     //  boundary orders those stores before the trailing update)
-    publish_progress(&num->prog, 16 * p + b + 1);
+    publish_progress(&num->prog, 32 * p + 2 * b + 2);
 #undef TSTAMP
 }
 
