@@ -41,6 +41,8 @@ struct PanelDesc {
     int nlive;               // live reflectors so far
     int sw;                  // sub-panel width of this panel: 8, or 4 when the rows need 8 registers per thread and column
     int done_group;          // group that ran out of rows (g reached fm), -1 if none
+    int t_deferred;          // 1: the panel kernel left T to k_upd_w (Gram block + the last slab workgroup builds T)
+    int pad3;
     int sg[STM_NB / 4];      // first active row (g) at the start of sub-panel s
     int st[STM_NB / 4];      // one past the last row reached by the reflectors of sub-panel s
     double lensum;           // sum of (t - g) over the live columns so far (flop accounting of the trailing update)
@@ -82,7 +84,7 @@ struct FrontNum {
     int hdr;                 // tall-panel pipeline: p+1 once the header (mode, pg1, tmax, sw) of panel p is published
     int prog;                // ... 32*p + 2*(finished groups of panel p) + (1: first half of the next one); monotone
     int perr;                // ... set when a bounded wait ran out (the factorization is reported as failed)
-    int pad2;
+    int gcnt;                // arrival counter of the Gram slabs in k_upd_w (back to 0 after every panel)
     double flops;            // reference flop count of this front  (FLOP_COUNT, :1571)
     double flops_upd;        // the part of `flops` that the trailing update does: sum (t-g) * 4 * (fn - k2), k2 = panel end
     // pending block reflectors, double buffered by panel parity so that the look-ahead schedule can factorize

@@ -292,7 +292,7 @@ void build_schedule(stmmqr_plan &P, std::vector<int> &tslot)
                 L.nbig_at[p] = cnt;
                 L.maxcb_at[p] = mcb;
                 L.maxsl_at[p] = msl >= 3 ? msl : 0;          // row-parallel update only when it pays (>= 3 slabs)
-                P.wp_doubles = std::max(P.wp_doubles, (long long)cnt * mcb * msl * (STM_NB * 32));
+                P.wp_doubles = std::max(P.wp_doubles, (long long)cnt * (mcb + 1) * msl * (STM_NB * 32));   // (+1: Gram block)
             }
         }
     }
@@ -554,13 +554,15 @@ int run_schedule(stmmqr_plan &P, bool detail, int grp, bool first)
         if (detail || !g_opt.lookahead) {
             for (size_t p = 0; p < L.nbig_at.size(); p++) {
                 e = timed(t_front, [&]() -> int {
-                    LCHK(stm_launch_panel(c, big, L.nbig_at[p], (int)p, L.nsub_at[p], L.lds_big, st));
+                    // the split update may build T itself (its Gram block), see dev_tall_group
+                    const int defer_ok = (L.maxsl_at[p] > 0 && g_opt.split_update && L.maxcb_at[p] > 0) ? 1 : 0;
+                    LCHK(stm_launch_panel(c, big, L.nbig_at[p], (int)p, L.nsub_at[p], defer_ok, L.lds_big, st));
                     return 0;
                 });
                 if (e) return e;
                 e = timed(t_upd, [&]() -> int {
                     if (L.maxsl_at[p] > 0 && g_opt.split_update) {
-                        LCHK(stm_launch_update_split(c, big, L.nbig_at[p], (int)p, 0, L.maxcb_at[p], L.maxsl_at[p], P.d_Wp.p, st));
+                        LCHK(stm_launch_update_split(c, big, L.nbig_at[p], (int)p, 0, L.maxcb_at[p], L.maxsl_at[p], P.d_Wp.p, 1, st));
                         nlaunch += 1;
                     } else
                         LCHK(stm_launch_update(c, big, L.nbig_at[p], (int)p, 0, L.maxcb_at[p], st));
@@ -586,20 +588,20 @@ int run_schedule(stmmqr_plan &P, bool detail, int grp, bool first)
             hipStream_t s2 = P.stream2;
             hipEvent_t prev_rest = nullptr;
             for (size_t p = 0; p < L.nbig_at.size(); p++) {
-                LCHK(stm_launch_panel(c, big, L.nbig_at[p], (int)p, L.nsub_at[p], L.lds_big, st));
+                LCHK(stm_launch_panel(c, big, L.nbig_at[p], (int)p, L.nsub_at[p], 0, L.lds_big, st));
                 hipEvent_t evp = next_event(), evr = next_event();
                 if (!evp || !evr) return fail(STMMQR_ERR_DEVICE, "hipEventCreate failed");
                 HIPCHK(hipEventRecord(evp, st));
                 if (prev_rest) HIPCHK(hipStreamWaitEvent(st, prev_rest, 0));      // same columns: keep the order
                 const bool split = L.maxsl_at[p] > 0 && g_opt.split_update;
                 if (split)
-                    LCHK(stm_launch_update_split(c, big, L.nbig_at[p], (int)p, 0, std::min(1, L.maxcb_at[p]), L.maxsl_at[p], P.d_Wp.p, st));
+                    LCHK(stm_launch_update_split(c, big, L.nbig_at[p], (int)p, 0, std::min(1, L.maxcb_at[p]), L.maxsl_at[p], P.d_Wp.p, 0, st));
                 else
                     LCHK(stm_launch_update(c, big, L.nbig_at[p], (int)p, 0, std::min(1, L.maxcb_at[p]), st));
                 if (L.maxcb_at[p] > 1) {
                     HIPCHK(hipStreamWaitEvent(s2, evp, 0));
                     if (split)
-                        LCHK(stm_launch_update_split(c, big, L.nbig_at[p], (int)p, 1, L.maxcb_at[p] - 1, L.maxsl_at[p], P.d_Wp2.p, s2));
+                        LCHK(stm_launch_update_split(c, big, L.nbig_at[p], (int)p, 1, L.maxcb_at[p] - 1, L.maxsl_at[p], P.d_Wp2.p, 0, s2));
                     else
                         LCHK(stm_launch_update(c, big, L.nbig_at[p], (int)p, 1, L.maxcb_at[p] - 1, s2));
                     HIPCHK(hipEventRecord(evr, s2));

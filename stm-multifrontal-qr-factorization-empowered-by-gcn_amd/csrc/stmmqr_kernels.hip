@@ -163,7 +163,7 @@ __global__ __launch_bounds__(NT) void k_setup(DevCtx c, const int *__restrict__ 
     }
     if (tid == 0) {
         FrontNum *nm = &c.fnum[f];
-        nm->fm = fm; nm->g = 0; nm->rank = min(fm, s.fp); nm->done = 0; nm->hdr = 0; nm->prog = 0; nm->perr = 0;
+        nm->fm = fm; nm->g = 0; nm->rank = min(fm, s.fp); nm->done = 0; nm->hdr = 0; nm->prog = 0; nm->perr = 0; nm->gcnt = 0;
         nm->pd[0].pnb = 0; nm->pd[1].pnb = 0; nm->cm = 0; nm->rsize = 0; nm->flops = 0; nm->flops_upd = 0;
     }
 }
@@ -240,7 +240,7 @@ __device__ __forceinline__ void upd_chunk_load(UpdChunk &ck, const double *Vg, c
     }
 }
 __device__ __forceinline__ void upd_chunk_to_lds(const UpdChunk &ck, int i, int mp, int nbp, int nc, const int *s_pd, int g1,
-                                                 int lrow, int lcg, double *Vs, double *Cs)
+                                                 int lrow, int lcg, double *Vs, double *Cs, bool c_is_v = false)
 {
 #pragma unroll
     for (int q = 0; q < 8; q++) {
@@ -248,7 +248,7 @@ __device__ __forceinline__ void upd_chunk_to_lds(const UpdChunk &ck, int i, int 
         const int d = s_pd[col] - g1;                          // (BIGROW beyond nbp: everything masked)
         const double v = (i < mp && col < nbp && i >= d) ? ((i == d) ? 1.0 : ck.v[q]) : 0.0;
         Vs[col * VS + lrow] = v;
-        Cs[col * VS + lrow] = (i < mp && col < nc) ? ck.c[q] : 0.0;
+        Cs[col * VS + lrow] = c_is_v ? v : ((i < mp && col < nc) ? ck.c[q] : 0.0);     // (Gram block: C = V)
     }
 }
 
@@ -1075,7 +1075,7 @@ template <int NTH, int RPT, int SWT>
 __device__ __forceinline__ void dev_tall_group(PanelShared &ps, const FrontSym &s, FrontNum *num, PanelDesc *pd, double *F,
                                                int *St, double *Tau, char *Rdead, int p, int b, int g1, int tmax,
                                                double tol, int ntol_global, double *Tout, double *lds, int dbg = 0,
-                                               unsigned long long *dbgbuf = nullptr, double *Tkeep = nullptr)
+                                               unsigned long long *dbgbuf = nullptr, double *Tkeep = nullptr, int defer_ok = 0)
 {
     const int tid = threadIdx.x;
     const int m = num->fm, n = s.fn, npiv = s.fp;              // (fm is fixed before the panel kernels run)
@@ -1296,10 +1296,20 @@ __device__ __forceinline__ void dev_tall_group(PanelShared &ps, const FrontSym &
         return;
     }
     __syncthreads();                                           // all stores of this workgroup are complete and visible
+    // T of a panel with >= 3 row slabs and trailing columns is left to the trailing update (k_upd_w: a Gram block per
+    // slab, the last slab to arrive builds T): the Gram pass over the whole panel leaves the critical path.  The rule
+    // depends on this front alone (such a front always takes the split update), so the results do not depend on which
+    // fronts share a level.
+    const int defer_t = (defer_ok && tlast - g1 >= 3 * 256 && k2 < n) ? 1 : 0;
     if (tid == 0) {
         pd->mode = 2;
+        pd->t_deferred = defer_t;
         pd->pk1 = k1; pd->pnb = nbp; pd->pc0 = k2;
         num->flops_upd += 4.0 * (double)(n - k2) * (prev_done ? ls_before : ls_before + lensum);
+    }
+    if (defer_t) {
+        publish_progress(&num->prog, 32 * p + 2 * b + 2);
+        return;
     }
     if (tid < STM_NB) {
         ps.diag[tid] = (tid < nbp) ? ld_agent(&pd->pdiag[tid]) : STM_BIGROW;    // (columns past a `done` point were reset there)
@@ -1388,7 +1398,7 @@ __global__ __launch_bounds__(NT) void k_front_wg(DevCtx c, const int *__restrict
 // large fronts: panel and trailing update are separate launches (many workgroups per update)
 // ------------------------------------------------------------------------------------------------
 #define NTP 512               // threads of the large-front panel kernel (8 waves, <= 256 VGPRs each)
-__global__ __launch_bounds__(NTP) void k_panel(DevCtx c, const int *__restrict__ flist, int p, int nsub, int lds_doubles)
+__global__ __launch_bounds__(NTP) void k_panel(DevCtx c, const int *__restrict__ flist, int p, int nsub, int defer_ok, int lds_doubles)
 {
     extern __shared__ double dyn_lds[];
     __shared__ PanelShared ps;
@@ -1420,7 +1430,7 @@ __global__ __launch_bounds__(NTP) void k_panel(DevCtx c, const int *__restrict__
             if (threadIdx.x == 0) {
                 st_agent(&pd->mode, mode); st_agent(&pd->pg1, g1); st_agent(&pd->pt, g1); st_agent(&pd->tmax, tmax);
                 st_agent(&pd->nlive, 0); st_agent(&pd->sw, w); st_agent(&pd->done_group, -1);
-                if (was_done) pd->pnb = 0;
+                if (was_done) { pd->pnb = 0; pd->t_deferred = 0; }
             }
             publish_progress(&num->hdr, p + 1);
             if (was_done) return;
@@ -1431,7 +1441,7 @@ __global__ __launch_bounds__(NTP) void k_panel(DevCtx c, const int *__restrict__
         }
         if (mode == 1) {
             const int rows = tmax - g1;
-#define TALL_ARGS ps, s, num, pd, F, St, c.Tau + s.rp, c.Rdead + s.col1, p, b, g1, tmax, c.tol, c.ntol, T, dyn_lds, c.dbg, c.dbgbuf, Tkeep
+#define TALL_ARGS ps, s, num, pd, F, St, c.Tau + s.rp, c.Rdead + s.col1, p, b, g1, tmax, c.tol, c.ntol, T, dyn_lds, c.dbg, c.dbgbuf, Tkeep, defer_ok
             if (w == 4) dev_tall_group<NTP, 8, 4>(TALL_ARGS);
             else if (rows <= NTP) dev_tall_group<NTP, 1, 8>(TALL_ARGS);
             else if (rows <= 2 * NTP) dev_tall_group<NTP, 2, 8>(TALL_ARGS);
@@ -1446,7 +1456,7 @@ __global__ __launch_bounds__(NTP) void k_panel(DevCtx c, const int *__restrict__
     else
         dev_panel<NTP, false>(ps, s, num, F, St, c.Tau + s.rp, c.Rdead + s.col1, p, c.tol, c.ntol, T, dyn_lds,
                               lds_doubles, c.dbg, c.dbgbuf, Tkeep);
-    if (threadIdx.x == 0) pd->mode = 0;
+    if (threadIdx.x == 0) { pd->mode = 0; pd->t_deferred = 0; }
 }
 
 __global__ __launch_bounds__(NT) void k_update(DevCtx c, const int *__restrict__ flist, int p, int cb0)
@@ -1504,9 +1514,14 @@ __global__ __launch_bounds__(NT) void k_upd_w(DevCtx c, const int *__restrict__ 
     const PanelDesc *pd = &c.fnum[f].pd[p & 1];
     const int g1 = pd->pg1, mp = pd->pt - pd->pg1, nbp = pd->pnb;
     const int cb = blockIdx.x, sl = blockIdx.y;
-    const int c0 = pd->pc0 + (cb0 + cb) * BN;
+    // the column block after the last one (cb == maxcb; launched when T may have been left to this kernel) is the Gram
+    // block: C = V, partial V'V per slab; the last slab workgroup of a front to arrive sums them in slab order and
+    // builds T (dlarft recurrence) for k_upd_c
+    const bool gram = (cb == maxcb);
+    if (gram && !pd->t_deferred) return;
+    const int c0 = gram ? pd->pk1 : pd->pc0 + (cb0 + cb) * BN;
     if (nbp <= 0 || mp <= 0 || c0 >= s.fn || sl * SLAB >= mp) return;
-    const int nc = min(BN, s.fn - c0);
+    const int nc = gram ? nbp : min(BN, s.fn - c0);
     const long long ld = s.ld;
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, l15 = lane & 15, l4 = lane >> 4;
     double *Vs = dyn_lds, *Cs = Vs + STM_NB * VS;
@@ -1520,7 +1535,7 @@ __global__ __launch_bounds__(NT) void k_upd_w(DevCtx c, const int *__restrict__ 
     UpdChunk ck;
     upd_chunk_load(ck, Vg, Cg, ld, sl * SLAB + (tid & 63), mp, nbp, nc, tid >> 6);
     for (int r0 = sl * SLAB; r0 < rend; r0 += RB) {
-        upd_chunk_to_lds(ck, r0 + (tid & 63), mp, nbp, nc, s_pd, g1, tid & 63, tid >> 6, Vs, Cs);
+        upd_chunk_to_lds(ck, r0 + (tid & 63), mp, nbp, nc, s_pd, g1, tid & 63, tid >> 6, Vs, Cs, gram);
         __syncthreads();
         if (r0 + RB < rend) upd_chunk_load(ck, Vg, Cg, ld, r0 + RB + (tid & 63), mp, nbp, nc, tid >> 6);
 #pragma unroll
@@ -1531,9 +1546,54 @@ __global__ __launch_bounds__(NT) void k_upd_w(DevCtx c, const int *__restrict__ 
         }
         __syncthreads();
     }
-    double *W = Wp + ((long long)(fi * maxcb + cb) * maxsl + sl) * (STM_NB * BN);
+    double *W = Wp + ((long long)(fi * (maxcb + 1) + cb) * maxsl + sl) * (STM_NB * BN);
 #pragma unroll
     for (int r = 0; r < 4; r++) W[(16 * mi + l4 + 4 * r) * BN + 16 * ni + l15] = acc[r];
+    if (!gram) return;
+    // ---- Gram block: the last slab to arrive builds T ----
+    __shared__ int s_ticket;
+    __syncthreads();                                           // this workgroup's partial G is complete in memory
+    FrontNum *num = &c.fnum[f];
+    const int nsl = (mp + SLAB - 1) / SLAB;
+    if (tid == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        s_ticket = __hip_atomic_fetch_add(&num->gcnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __syncthreads();
+    if (s_ticket != nsl - 1) return;
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    if (tid == 0) __hip_atomic_store(&num->gcnt, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    double *s_G = Vs;                                          // [row * WS + col] (the chunk images are free now)
+    __shared__ double s_tau[STM_NB];
+    const double *G0 = Wp + ((long long)(fi * (maxcb + 1) + maxcb) * maxsl) * (STM_NB * BN);
+    if (tid < STM_NB) s_tau[tid] = (tid < nbp) ? c.Tau[s.rp + pd->pk1 + tid] : 0.0;
+    for (int e = tid; e < STM_NB * BN; e += NT) {
+        double gsum = 0;
+        for (int q = 0; q < nsl; q++) gsum += G0[(long long)q * (STM_NB * BN) + e];     // fixed order: deterministic
+        s_G[(e / BN) * WS + (e % BN)] = gsum;                  // G(row, col) = v_row' v_col
+    }
+    __syncthreads();
+    double *Tout = c.Tws + (long long)(2 * c.tslot[f] + (p & 1)) * STM_NB * STM_NB;
+    double *Tkeep = c.Tall ? c.Tall + (long long)(s.tpan + p) * STM_NB * STM_NB : nullptr;
+    if (tid < STM_NB) {
+        // dlarft from the Gram matrix (as dev_T_from_gram): lane a owns row a of T
+        const int a = tid;
+        double trow[STM_NB];
+#pragma unroll
+        for (int b = 0; b < STM_NB; b++) {
+            double v = 0;
+            if (b < nbp) {
+                const double tb = s_tau[b];
+#pragma unroll
+                for (int l = 0; l < b; l++) v += trow[l] * s_G[l * WS + b];
+                v = (a < b && tb != 0.0) ? -tb * v : ((a == b) ? tb : 0.0);
+            }
+            trow[b] = v;
+            const double tv = (a <= b && a < nbp && b < nbp) ? v : 0.0;
+            Tout[a + b * STM_NB] = tv;
+            if (Tkeep) Tkeep[a + b * STM_NB] = tv;
+        }
+    }
 }
 
 __global__ __launch_bounds__(NT) void k_upd_t(DevCtx c, const int *__restrict__ flist, int p, int cb0, double *Wp,
@@ -1550,7 +1610,7 @@ __global__ __launch_bounds__(NT) void k_upd_t(DevCtx c, const int *__restrict__ 
     if (nbp <= 0 || mp <= 0 || c0 >= s.fn) return;
     const int nsl = (mp + SLAB - 1) / SLAB;
     const int tid = threadIdx.x;
-    double *W0 = Wp + ((long long)(fi * maxcb + cb) * maxsl) * (STM_NB * BN);
+    double *W0 = Wp + ((long long)(fi * (maxcb + 1) + cb) * maxsl) * (STM_NB * BN);
     const double *T = c.Tws + (long long)(2 * c.tslot[f] + (p & 1)) * STM_NB * STM_NB;
     for (int e = tid; e < STM_NB * BN; e += NT) {
         double v = 0;
@@ -1598,7 +1658,7 @@ __global__ __launch_bounds__(NT) void k_upd_c(DevCtx c, const int *__restrict__ 
     // launch less per panel); the summation order over the slabs is fixed
     {
         const int nsl = (mp + SLAB - 1) / SLAB;
-        const double *W0 = Wp + ((long long)(fi * maxcb + cb) * maxsl) * (STM_NB * BN);
+        const double *W0 = Wp + ((long long)(fi * (maxcb + 1) + cb) * maxsl) * (STM_NB * BN);
         const double *T = c.Tws + (long long)(2 * c.tslot[f] + (p & 1)) * STM_NB * STM_NB;
         for (int e = tid; e < STM_NB * BN; e += NT) {
             double v = 0;
@@ -2107,7 +2167,7 @@ int stm_launch_front_wg(const DevCtx &c, const int *flist, int nfr, int lds_doub
     hipLaunchKernelGGL(k_front_wg, dim3(nfr), dim3(NT), bytes, st, c, flist, (int)(bytes / sizeof(double)));
     return (int)hipGetLastError();
 }
-int stm_launch_panel(const DevCtx &c, const int *flist, int nfr, int p, int nsub, int lds_doubles, hipStream_t st)
+int stm_launch_panel(const DevCtx &c, const int *flist, int nfr, int p, int nsub, int defer_ok, int lds_doubles, hipStream_t st)
 {
     if (nfr <= 0) return 0;
     size_t bytes = (size_t)lds_doubles * sizeof(double);
@@ -2115,7 +2175,7 @@ int stm_launch_panel(const DevCtx &c, const int *flist, int nfr, int p, int nsub
     // launch sidx of the tall-panel pipeline runs the column groups sidx .. nsub-1; fronts whose panel is not tall are
     // done completely by launch 0
     // one workgroup per column group of the tall-panel pipeline (blockIdx.y); fronts whose panel is not tall use group 0
-    hipLaunchKernelGGL(k_panel, dim3(nfr, nsub), dim3(NTP), bytes, st, c, flist, p, nsub, (int)(bytes / sizeof(double)));
+    hipLaunchKernelGGL(k_panel, dim3(nfr, nsub), dim3(NTP), bytes, st, c, flist, p, nsub, defer_ok, (int)(bytes / sizeof(double)));
     return (int)hipGetLastError();
 }
 int stm_launch_update(const DevCtx &c, const int *flist, int nfr, int p, int cb0, int ncb, hipStream_t st)
@@ -2125,11 +2185,12 @@ int stm_launch_update(const DevCtx &c, const int *flist, int nfr, int p, int cb0
     return (int)hipGetLastError();
 }
 int stm_launch_update_split(const DevCtx &c, const int *flist, int nfr, int p, int cb0, int ncb, int maxsl, double *Wp,
-                            hipStream_t st)
+                            int with_gram, hipStream_t st)
 {
     if (nfr <= 0 || ncb <= 0 || maxsl <= 0) return 0;
     const size_t lds = (size_t)stm_update_lds_bytes();
-    hipLaunchKernelGGL(k_upd_w, dim3(ncb, maxsl, nfr), dim3(NT), lds, st, c, flist, p, cb0, Wp, ncb, maxsl);
+    // (with_gram: one more column block, V'V for the fronts whose panel kernel left T to the update)
+    hipLaunchKernelGGL(k_upd_w, dim3(ncb + (with_gram ? 1 : 0), maxsl, nfr), dim3(NT), lds, st, c, flist, p, cb0, Wp, ncb, maxsl);
     hipLaunchKernelGGL(k_upd_c, dim3(ncb, maxsl, nfr), dim3(NT), lds, st, c, flist, p, cb0, (const double *)Wp, ncb, maxsl);
     return (int)hipGetLastError();
 }
