@@ -31,8 +31,10 @@ struct DevCtx {
     int ntol;
     unsigned long long *dbgbuf; // [8] phase cycle sums of the panel kernel (STMMQR_DBG bit 4), else unused
     int tall_min;              // stmmqr_options::tall_min_rows at plan time (stm_tall_panel)
-    int dbg;                   // timing ablations only (bit0: no in-panel apply, bit1: no T, bit2: no dlarf in sub-panel,
-                               //  bit3: LDS sub-panel path for every tall panel)
+    int dbg;                   // env STMMQR_DBG, ablations / cross-checks only: 1 no in-panel apply (LDS panel path),
+                               //  2 no T, 4 no dlarf in the LDS sub-panel, 16/32 phase timers (-DSTMMQR_STAMPS builds),
+                               //  64 in-place panel path, 128 no folded norms, 256 no panel pipeline (LDS panels only),
+                               //  8192 reflector-by-reflector Q-apply instead of the blocked one
 };
 
 int stm_configure_kernels(void);
