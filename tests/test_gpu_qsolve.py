@@ -104,6 +104,26 @@ def test_solve_residual_and_oracle(pkg, oracle, name):
         plan.close()
 
 
+@pytest.mark.parametrize("name", ["grid20_standin", "epb1", "syn_rankdef_grid"])
+def test_blocked_qapply_equals_reflector_by_reflector(pkg, name, monkeypatch):
+    """k_qapply_t (per panel: w = V'x, y = T'w, x -= V y with the T factors kept by the factorization) against k_qapply
+    (one reflector after the other, STMMQR_DBG bit 13) on the same resident factors."""
+    if name not in NAMES:
+        pytest.skip("fixture not present")
+    g = load_golden(name)
+    S, plan = factorized_plan(pkg, g, 16)
+    try:
+        X = np.random.default_rng(3).standard_normal((S.m, 2))
+        a0, a1 = plan.qmult(0, X), plan.qmult(1, X)
+        monkeypatch.setenv("STMMQR_DBG", "8192")
+        b0, b1 = plan.qmult(0, X), plan.qmult(1, X)
+        monkeypatch.delenv("STMMQR_DBG")
+        assert np.linalg.norm(a0 - b0) <= 1e-12 * np.linalg.norm(X)
+        assert np.linalg.norm(a1 - b1) <= 1e-12 * np.linalg.norm(X)
+    finally:
+        plan.close()
+
+
 def test_solve_full_size_standin(pkg):
     """BASELINE configs[2] size: residual of the device solve, factors never leave HBM."""
     g = load_golden("xenon1_standin")
