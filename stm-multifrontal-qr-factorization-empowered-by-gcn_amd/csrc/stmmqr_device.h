@@ -34,7 +34,7 @@ struct PanelDesc {
     int pg1, pt;             // rows [pg1, pt)
     int pk1, pnb;            // built from columns [pk1, pk1+pnb)
     int pc0;                 // to be applied to columns [pc0, fn)
-    int mode;                // tall-panel pipeline: 1 while sub-panels are pending, 0 whole panel finished, 2 finalised early
+    int mode;                // header of the panel pipeline: 1 the column groups run, 0 nothing to do / whole panel by group 0
     int pdiag[STM_NB];       // row of the unit diagonal of each reflector (BIGROW: none)
     // tall-panel pipeline state (sub-panels of STM_SW columns, one launch per sub-panel)
     int tmax;                // rows [pg1, tmax) are touched by the panel

@@ -551,6 +551,11 @@ int run_schedule(stmmqr_plan &P, bool detail, int grp, bool first)
         });
         if (e) return e;
         const int *big = all + L.n_small;
+        if (getenv("STMMQR_DUMPLV")) {
+            fprintf(stderr, "[level] nbig %d:", L.n_big);
+            for (int q = 0; q < L.n_big; q++) fprintf(stderr, " %d", P.lists[L.all_off + L.n_small + q]);
+            fprintf(stderr, "\n");
+        }
         if (detail || !g_opt.lookahead) {
             for (size_t p = 0; p < L.nbig_at.size(); p++) {
                 e = timed(t_front, [&]() -> int {

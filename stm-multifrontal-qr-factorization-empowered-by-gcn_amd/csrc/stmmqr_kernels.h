@@ -34,7 +34,9 @@ struct DevCtx {
     int dbg;                   // env STMMQR_DBG, ablations / cross-checks only: 1 no in-panel apply (LDS panel path),
                                //  2 no T, 4 no dlarf in the LDS sub-panel, 16/32 phase timers (-DSTMMQR_STAMPS builds),
                                //  64 in-place panel path, 128 no folded norms, 256 no panel pipeline (LDS panels only),
-                               //  8192 reflector-by-reflector Q-apply instead of the blocked one
+                               //  8192 reflector-by-reflector Q-apply instead of the blocked one,
+                               //  512 panel launches in chunks of env STMMQR_CHUNK fronts (default 1),
+                               //  2048 column group (dbg >> 20) & 7 of every pipelined panel starts late (tests)
 };
 
 int stm_configure_kernels(void);

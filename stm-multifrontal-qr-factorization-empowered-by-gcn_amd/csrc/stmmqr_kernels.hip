@@ -19,6 +19,7 @@
 //    C -= V W; V is read in place from F with the unit-diagonal/zero mask applied on the fly.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 #include "stmmqr_device.h"
 #include "stmmqr_kernels.h"
 #include "stmmqr_wave.h"
@@ -739,7 +740,7 @@ __device__ __forceinline__ void dev_panel(PanelShared &ps, const FrontSym &s, Fr
     const bool tall = !in_place && mp > 768;
     if (tall) SW = min(SW, 8);
     // register-resident sub-panels (<= 8 rows per thread, <= 8 columns): dev_subpanel_reg
-    const int reg_min = (dbg >> 16) ? (dbg >> 16) - 1 : 768;      // STMMQR_DBG bits 16.. override the threshold
+    const int reg_min = 768;
     const bool regpath = !in_place && mp > reg_min && mp <= 8 * NTH && !(dbg & 256);
     if (regpath) SW = min(SW, mp > 4 * NTH ? 4 : 8);     // 8 rows per thread leave registers for 4 columns only
 
@@ -1048,9 +1049,13 @@ __device__ __forceinline__ bool wait_progress(const int *flag, int target)
 // publish: all global stores of this workgroup happen-before the flag value
 __device__ __forceinline__ void publish_progress(int *flag, int value)
 {
-    __syncthreads();                               // every wave's stores are complete (s_waitcnt vmcnt(0))
+    // EVERY wave first waits for its own global stores to reach the L2 (a workgroup barrier alone does not: hipcc emits
+    // no vmcnt wait for workgroup scope, so a release by thread 0 only could publish the flag ahead of the other waves'
+    // data); then one agent-scope release writes the L2 back for the other XCDs and the flag goes out.
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
     if (threadIdx.x == 0) {
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");  // write back L2 so that other XCDs see them
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
         st_agent(flag, value);
     }
 }
@@ -1117,7 +1122,9 @@ __device__ __forceinline__ void dev_tall_group(PanelShared &ps, const FrontSym &
         if (!wait_progress(&num->prog, 32 * p + 2 * sp + 1 + half)) { if (tid == 0) st_agent(&num->perr, 1); return; }
         TSTAMP(7);
         const int pc0 = SWT * sp + half * (SWT / 2);
-        if (half == 1) prev_done = ld_agent(&num->done);
+        // (group sp ran out of rows?  Not num->done: a group that starts late would see the flag of a LATER group and
+        //  skip the reflectors of the groups in between)
+        if (half == 1) prev_done = (ld_agent(&pd->done_group) == sp);
         double vn[RPT];
         {
             const double *vc = F + (long long)(k1 + pc0) * ld;
@@ -1302,7 +1309,8 @@ __device__ __forceinline__ void dev_tall_group(PanelShared &ps, const FrontSym &
     // fronts share a level.
     const int defer_t = (defer_ok && tlast - g1 >= 3 * 256 && k2 < n) ? 1 : 0;
     if (tid == 0) {
-        pd->mode = 2;
+        // (pd->mode stays 1: it belongs to the header, and a column group that starts late -- the finalising group is
+        //  not always the last one -- must still find it there)
         pd->t_deferred = defer_t;
         pd->pk1 = k1; pd->pnb = nbp; pd->pc0 = k2;
         num->flops_upd += 4.0 * (double)(n - k2) * (prev_done ? ls_before : ls_before + lensum);
@@ -1412,6 +1420,9 @@ __global__ __launch_bounds__(NTP) void k_panel(DevCtx c, const int *__restrict__
     double *Tkeep = c.Tall ? c.Tall + (long long)(s.tpan + p) * STM_NB * STM_NB : nullptr;
     PanelDesc *pd = &num->pd[p & 1];
     const int b = blockIdx.y;
+    if ((c.dbg & 2048) && b == ((c.dbg >> 20) & 7)) {          // tests: column group (dbg >> 20) & 7 starts ~1 ms late
+        for (int it = 0; it < 4000; it++) __builtin_amdgcn_s_sleep(100);
+    }
     bool tall = stm_tall_panel(s, p, c.tall_min) && !(c.dbg & 256);
     if (!tall && b > 0) return;
     if (tall) {
@@ -1552,7 +1563,8 @@ __global__ __launch_bounds__(NT) void k_upd_w(DevCtx c, const int *__restrict__ 
     if (!gram) return;
     // ---- Gram block: the last slab to arrive builds T ----
     __shared__ int s_ticket;
-    __syncthreads();                                           // this workgroup's partial G is complete in memory
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // every wave: its part of the partial G has reached the L2
+    __syncthreads();
     FrontNum *num = &c.fnum[f];
     const int nsl = (mp + SLAB - 1) / SLAB;
     if (tid == 0) {
@@ -2175,6 +2187,12 @@ int stm_launch_panel(const DevCtx &c, const int *flist, int nfr, int p, int nsub
     // launch sidx of the tall-panel pipeline runs the column groups sidx .. nsub-1; fronts whose panel is not tall are
     // done completely by launch 0
     // one workgroup per column group of the tall-panel pipeline (blockIdx.y); fronts whose panel is not tall use group 0
+    if (c.dbg & 512) {                                     // debugging: at most (dbg >> 16) fronts per launch (default 1)
+        const int K = getenv("STMMQR_CHUNK") ? atoi(getenv("STMMQR_CHUNK")) : 1;
+        for (int i = 0; i < nfr; i += K)
+            hipLaunchKernelGGL(k_panel, dim3(nfr - i < K ? nfr - i : K, nsub), dim3(NTP), bytes, st, c, flist + i, p, nsub, defer_ok, (int)(bytes / sizeof(double)));
+        return (int)hipGetLastError();
+    }
     hipLaunchKernelGGL(k_panel, dim3(nfr, nsub), dim3(NTP), bytes, st, c, flist, p, nsub, defer_ok, (int)(bytes / sizeof(double)));
     return (int)hipGetLastError();
 }

@@ -58,8 +58,8 @@ def test_against_golden_and_oracle(pkg, oracle, name, bigcols):
         assert np.linalg.norm(G.Stack[:G.rh_total] - ref) <= 1e-10 * max(np.linalg.norm(ref), 1e-300)
 
 
-@pytest.mark.parametrize("name", ["syn_grid3d", "syn_rankdef_grid", "bcsstk14", "grid20_standin"])
-@pytest.mark.parametrize("tall_min", [0, 48, 1 << 30])
+@pytest.mark.parametrize("name,tall_min", [(n, 0) for n in NAMES] +
+                         [(n, t) for n in ("syn_grid3d", "syn_rankdef_grid", "bcsstk14", "grid20_standin") for t in (48, 1 << 30)])
 def test_panel_pipeline_threshold(pkg, oracle, name, tall_min):
     """tall_min_rows = 0 sends every panel of a large front through the pipeline of 8-column groups (register-resident
     column steps, inter-workgroup progress flags), 1<<30 none: integers, R rows and the factors must not care."""

@@ -21,6 +21,9 @@ def make_front(m, n, seed, stair_kind="ramp"):
     rng = np.random.default_rng(seed)
     if stair_kind == "full":
         St = np.full(n, m, I64)
+    elif stair_kind == "steps":     # irregular increments (1..3 rows per column), as the fronts of epb1 have
+        inc = rng.integers(1, 4, n)
+        St = np.minimum(m, 2 + np.cumsum(inc)).astype(I64)
     else:  # SURVEY.md 8d microbench staircase
         St = np.minimum(m, (np.arange(1, n + 1) * m) // n + 8).astype(I64)
     F = np.zeros((m, n), order="F")
@@ -38,17 +41,18 @@ FRONTS = [(6, 4, 4), (5, 8, 3), (40, 30, 12), (64, 96, 32), (130, 70, 70), (266,
 
 
 @pytest.mark.parametrize("m,n,npiv", FRONTS)
-@pytest.mark.parametrize("bigcols", [128, 8])
-@pytest.mark.parametrize("stair", ["ramp", "full"])
-def test_qr_front(pkg, oracle, m, n, npiv, bigcols, stair):
+@pytest.mark.parametrize("bigcols,tall_min", [(128, 256), (8, 256), (8, 0)])
+@pytest.mark.parametrize("stair", ["ramp", "full", "steps"])
+def test_qr_front(pkg, oracle, m, n, npiv, bigcols, tall_min, stair):
+    """tall_min = 0: every panel of the large-front path runs as a pipeline of 8-column groups, whatever its height."""
     F0, St0 = make_front(m, n, 1234 + m + n, stair)
     Fg, Sg = F0.copy(order="F"), St0.copy()
     Fo, So = F0.copy(order="F"), St0.copy()
-    pkg.set_options(big_front_cols=bigcols)
+    pkg.set_options(big_front_cols=bigcols, tall_min_rows=tall_min)
     try:
         rg, Tg, Dg, flg = pkg.qr_front(m, n, npiv, -1.0, n, Fg, Sg)
     finally:
-        pkg.set_options(big_front_cols=64)
+        pkg.set_options(big_front_cols=64, tall_min_rows=256)
     ro, To, Do, flo = oracle.front(Fo, So, npiv, -1.0, n)
     assert rg == ro
     np.testing.assert_array_equal(Sg, So)
@@ -58,6 +62,29 @@ def test_qr_front(pkg, oracle, m, n, npiv, bigcols, stair):
     scale = np.linalg.norm(Fo)
     assert np.linalg.norm(Tg - To) <= 1e-11 * max(np.linalg.norm(To), 1)
     assert np.linalg.norm(Fg - Fo) <= 1e-11 * scale
+
+
+@pytest.mark.parametrize("late", [1, 2, 3])
+@pytest.mark.parametrize("m,n,npiv", [(266, 422, 124), (781, 900, 300), (1290, 1400, 64), (1500, 96, 64), (33, 97, 97)])
+def test_pipeline_with_a_late_column_group(pkg, oracle, monkeypatch, late, m, n, npiv):
+    """The column groups of a pipelined panel may start in any order and arbitrarily late (a launch with more
+    workgroups than the GPU holds at once): STMMQR_DBG bit 11 delays group `late` by ~1 ms.  Fronts whose rows run out
+    in the middle of a panel are the interesting ones (the finalising group is then not the last one)."""
+    F0, St0 = make_front(m, n, 4321 + m + n, "steps")
+    Fg, Sg = F0.copy(order="F"), St0.copy()
+    Fo, So = F0.copy(order="F"), St0.copy()
+    pkg.set_options(big_front_cols=8, tall_min_rows=0)
+    monkeypatch.setenv("STMMQR_DBG", str(2048 + (late << 20)))
+    try:
+        rg, Tg, Dg, flg = pkg.qr_front(m, n, npiv, -1.0, n, Fg, Sg)
+    finally:
+        monkeypatch.delenv("STMMQR_DBG")
+        pkg.set_options(big_front_cols=64, tall_min_rows=256)
+    ro, To, Do, flo = oracle.front(Fo, So, npiv, -1.0, n)
+    assert rg == ro and flg == flo
+    np.testing.assert_array_equal(Sg, So)
+    assert np.linalg.norm(Tg - To) <= 1e-11 * max(np.linalg.norm(To), 1)
+    assert np.linalg.norm(Fg - Fo) <= 1e-11 * np.linalg.norm(Fo)
 
 
 @pytest.mark.parametrize("m", [90, 1300])
