@@ -78,6 +78,28 @@ def test_panel_pipeline_threshold(pkg, oracle, name, tall_min):
     compare_numeric(oracle, S, G, No, g, ftol=1e-10, name=name)
 
 
+@pytest.mark.parametrize("name", ["epb1", "bcsstk14", "syn_rankdef_grid", "lns_3937"])
+@pytest.mark.parametrize("late", [1, 3])
+def test_pipeline_late_group_whole_factorization(pkg, oracle, monkeypatch, name, late):
+    """Every panel through the pipeline, with one column group of every pipelined panel started ~1 ms late (levels with
+    more workgroups than the GPU holds at once behave like this): results must not depend on the arrival order."""
+    if name not in NAMES:
+        pytest.skip("fixture not present")
+    g = load_golden(name)
+    pkg.set_options(tall_min_rows=0, big_front_cols=16)
+    monkeypatch.setenv("STMMQR_DBG", str(2048 + (late << 20)))
+    try:
+        S, G = gpu_run(pkg, g)
+    finally:
+        monkeypatch.delenv("STMMQR_DBG")
+        pkg.set_options(tall_min_rows=256, big_front_cols=64)
+    N = numeric_from_gpu(S, G)
+    compare_integers(S, N, g)
+    assert G.stats["flops"] == scalar(g, "flopcount")
+    No = oracle.factorize(S, g["in_Ap"], g["in_Ai"], g["in_Ax"], scalar(g, "in_tol"), int(scalar(g, "in_ntol")))
+    compare_numeric(oracle, S, G, No, g, ftol=1e-10, name=name)
+
+
 def test_plan_reuse_and_device_resident_values(pkg, oracle):
     """One plan, several numeric factorizations with different values; second call reuses the pattern."""
     g = load_golden("syn_grid3d")
