@@ -64,7 +64,7 @@ def test_qr_front(pkg, oracle, m, n, npiv, bigcols, tall_min, stair):
     assert np.linalg.norm(Fg - Fo) <= 1e-11 * scale
 
 
-@pytest.mark.parametrize("late", [1, 2, 3])
+@pytest.mark.parametrize("late", [0, 1, 2, 3])
 @pytest.mark.parametrize("m,n,npiv", [(266, 422, 124), (781, 900, 300), (1290, 1400, 64), (1500, 96, 64), (33, 97, 97)])
 def test_pipeline_with_a_late_column_group(pkg, oracle, monkeypatch, late, m, n, npiv):
     """The column groups of a pipelined panel may start in any order and arbitrarily late (a launch with more
