@@ -2184,16 +2184,18 @@ int stm_launch_panel(const DevCtx &c, const int *flist, int nfr, int p, int nsub
     if (nfr <= 0) return 0;
     size_t bytes = (size_t)lds_doubles * sizeof(double);
     if (bytes < (size_t)stm_update_lds_bytes()) bytes = stm_update_lds_bytes();   // in-panel MFMA update + Gram scratch
-    // launch sidx of the tall-panel pipeline runs the column groups sidx .. nsub-1; fronts whose panel is not tall are
-    // done completely by launch 0
-    // one workgroup per column group of the tall-panel pipeline (blockIdx.y); fronts whose panel is not tall use group 0
-    if (c.dbg & 512) {                                     // debugging: at most (dbg >> 16) fronts per launch (default 1)
-        const int K = getenv("STMMQR_CHUNK") ? atoi(getenv("STMMQR_CHUNK")) : 1;
-        for (int i = 0; i < nfr; i += K)
-            hipLaunchKernelGGL(k_panel, dim3(nfr - i < K ? nfr - i : K, nsub), dim3(NTP), bytes, st, c, flist + i, p, nsub, defer_ok, (int)(bytes / sizeof(double)));
-        return (int)hipGetLastError();
-    }
-    hipLaunchKernelGGL(k_panel, dim3(nfr, nsub), dim3(NTP), bytes, st, c, flist, p, nsub, defer_ok, (int)(bytes / sizeof(double)));
+    // One workgroup per column group of the panel pipeline (blockIdx.y); fronts whose panel is not pipelined use group 0.
+    // The column groups of a pipelined panel wait for each other, but only ever for groups with a smaller blockIdx.y of the
+    // same front, i.e. for workgroups that the in-order dispatch has already started (the assumption of every
+    // decoupled-look-back scan); the waits are bounded and fail the factorization loudly if that ever breaks.
+    // Oversubscribed launches (more workgroups than the GPU holds: groups start late) are exercised by the tests;
+    // STMMQR_DBG bit 9 + STMMQR_CHUNK launch the fronts in chunks instead (tests).
+    int K = nfr;
+    if (nsub > 1 && (c.dbg & 512)) K = getenv("STMMQR_CHUNK") ? atoi(getenv("STMMQR_CHUNK")) : 1;
+    if (K < 1) K = 1;
+    for (int i = 0; i < nfr; i += K)
+        hipLaunchKernelGGL(k_panel, dim3(nfr - i < K ? nfr - i : K, nsub), dim3(NTP), bytes, st, c, flist + i, p, nsub, defer_ok,
+                           (int)(bytes / sizeof(double)));
     return (int)hipGetLastError();
 }
 int stm_launch_update(const DevCtx &c, const int *flist, int nfr, int p, int cb0, int ncb, hipStream_t st)

@@ -100,6 +100,31 @@ def test_pipeline_late_group_whole_factorization(pkg, oracle, monkeypatch, name,
     compare_numeric(oracle, S, G, No, g, ftol=1e-10, name=name)
 
 
+@pytest.mark.parametrize("chunk", [None, 3, 40])
+def test_pipeline_oversubscribed_and_chunked_launches(pkg, oracle, monkeypatch, chunk):
+    """epb1 with every panel pipelined has a level of 97 large fronts = 388 workgroups in one launch, more than the GPU
+    holds at once (groups start late, in dispatch order).  STMMQR_DBG bit 9 + STMMQR_CHUNK launch the fronts in chunks
+    instead: the oversubscribed launch and the chunked ones must give the same (correct) result."""
+    if "epb1" not in NAMES:
+        pytest.skip("fixture not present")
+    g = load_golden("epb1")
+    pkg.set_options(tall_min_rows=0, big_front_cols=16)
+    if chunk is not None:
+        monkeypatch.setenv("STMMQR_DBG", "512")
+        monkeypatch.setenv("STMMQR_CHUNK", str(chunk))
+    try:
+        S, G = gpu_run(pkg, g)
+    finally:
+        if chunk is not None:
+            monkeypatch.delenv("STMMQR_DBG")
+            monkeypatch.delenv("STMMQR_CHUNK")
+        pkg.set_options(tall_min_rows=256, big_front_cols=64)
+    N = numeric_from_gpu(S, G)
+    compare_integers(S, N, g)
+    No = oracle.factorize(S, g["in_Ap"], g["in_Ai"], g["in_Ax"], scalar(g, "in_tol"), int(scalar(g, "in_ntol")))
+    compare_numeric(oracle, S, G, No, g, ftol=1e-10, name="epb1")
+
+
 def test_plan_reuse_and_device_resident_values(pkg, oracle):
     """One plan, several numeric factorizations with different values; second call reuses the pattern."""
     g = load_golden("syn_grid3d")
