@@ -2,6 +2,7 @@
 (/root/reference/.MISSING_LARGE_BLOBS: xenon1, sme3Dc, 3D_51448_3D).  SURVEY.md 8(d) fixes the generators:
 
   xenon1 stand-in  : gen3d(36, 36, 38, stencil 27pt, dof 1, values U(-1,1), diag += 27, seed 0x58454E31)  n = 49 248
+  sme3Dc stand-in  : gen3d(24, 24, 25, stencil 27pt, dof 3, seed 0x534D4533)                               n = 43 200
 
 Every report that uses them says "stand-in".  Pure numpy; used by make_golden.py (build container) and by bench.py /
 tests on the GPU box to regenerate the VALUES (the symbolic analysis of the pattern is a committed fixture).
@@ -9,8 +10,9 @@ tests on the GPU box to regenerate the VALUES (the symbolic analysis of the patt
 import numpy as np
 
 
-def gen3d(nx, ny, nz, seed, stencil27=True):
-    """CSC (Ap, Ai, Ax) of an unsymmetric-valued 7/27-point operator on an nx*ny*nz grid."""
+def gen3d(nx, ny, nz, seed, stencil27=True, dof=1):
+    """CSC (Ap, Ai, Ax) of an unsymmetric-valued 7/27-point operator on an nx*ny*nz grid, `dof` unknowns per grid point
+    (every pair of neighbouring points couples all their unknowns: dof x dof blocks)."""
     rng = np.random.default_rng(seed)
     idx = np.arange(nx * ny * nz).reshape(nx, ny, nz)
     rows, cols = [], []
@@ -24,9 +26,13 @@ def gen3d(nx, ny, nz, seed, stencil27=True):
                 zs = slice(max(0, -dz), nz - max(0, dz)); zt = slice(max(0, dz), nz - max(0, -dz))
                 rows.append(idx[xs, ys, zs].ravel()); cols.append(idx[xt, yt, zt].ravel())
     r = np.concatenate(rows); c = np.concatenate(cols)
+    if dof > 1:
+        a, b = np.meshgrid(np.arange(dof), np.arange(dof), indexing="ij")
+        r = (r[:, None] * dof + a.ravel()[None, :]).ravel()
+        c = (c[:, None] * dof + b.ravel()[None, :]).ravel()
     v = rng.uniform(-1, 1, r.size)
-    v[r == c] += 27 if stencil27 else 7
-    n = idx.size
+    v[r == c] += (27 if stencil27 else 7) * dof
+    n = idx.size * dof
     o = np.lexsort((r, c))
     r, c, v = r[o], c[o], v[o]
     Ap = np.zeros(n + 1, np.int64)
@@ -39,9 +45,12 @@ STANDINS = {
     # name: (nx, ny, nz, seed, 27-point?, ordering for the reference run: 2 = METIS)
     "xenon1_standin": (36, 36, 38, 0x58454E31, True, 2),
     "grid20_standin": (20, 20, 20, 0x58454E31, True, 2),
+    # BASELINE configs[3] (sme3Dc.mtx, absent): 3 unknowns per grid point, ~81 nnz per row
+    "sme3dc_standin": (24, 24, 25, 0x534D4533, True, 2, 3),
 }
 
 
 def standin_matrix(name):
-    nx, ny, nz, seed, s27, _ = STANDINS[name]
-    return gen3d(nx, ny, nz, seed, s27)
+    nx, ny, nz, seed, s27, _ = STANDINS[name][:6]
+    dof = STANDINS[name][6] if len(STANDINS[name]) > 6 else 1
+    return gen3d(nx, ny, nz, seed, s27, dof)
