@@ -271,8 +271,10 @@ void build_schedule(stmmqr_plan &P, std::vector<int> &tslot)
                 tslot[big[i]] = (int)i;
             }
             P.tslots = std::max(P.tslots, (int)big.size());
-            L.lds_small = (int)std::min((long)LDS_CAP_SMALL, (maxfm_small | 1) * STM_NB);
-            L.lds_big = (int)std::min((long)LDS_CAP_DOUBLES, (maxfm_big | 1) * STM_NB);
+            // (rows padded as dev_panel pads them, so that a whole panel fits whenever the cap allows: the sub-panel width
+            //  of a front -- and with it the rounding -- must not depend on which other fronts share its level)
+            L.lds_small = (int)std::min((long)LDS_CAP_SMALL, (((maxfm_small + 63) & ~63L) | 1) * STM_NB + 64);
+            L.lds_big = (int)std::min((long)LDS_CAP_DOUBLES, (((maxfm_big + 63) & ~63L) | 1) * STM_NB + 64);
             L.nbig_at.assign(maxp, 0);
             L.maxcb_at.assign(maxp, 0);
             L.nsub_at.assign(maxp, 1);

@@ -283,7 +283,10 @@ __device__ void dev_update_block(double *F, long long ld, int g1, int mp, int k1
 
     // ---- phase 1: W1 = V' C ----
     const int mi = wid >> 1, ni = wid & 1;
-    d4 acc = {0, 0, 0, 0};
+    // W1 is accumulated per slab of 256 rows and the slabs are added in order -- exactly the association of the
+    // row-parallel form (k_upd_w partials summed by k_upd_c), so that a front gets bit-identical results whichever of the
+    // two its level happens to use
+    d4 acc = {0, 0, 0, 0}, tot = {0, 0, 0, 0};
     UpdChunk ck;
     upd_chunk_load(ck, Vg, Cg, ld, lrow, mp, nbp, nc, lcg);
     for (int r0 = 0; r0 < mp; r0 += RB) {
@@ -297,10 +300,14 @@ __device__ void dev_update_block(double *F, long long ld, int g1, int mp, int k1
             const double b = Cs[(16 * ni + l15) * VS + 4 * kk + l4];
             acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
         }
+        if ((r0 + RB) % 256 == 0 || r0 + RB >= mp) {            // end of a 256-row slab (SLAB of the row-parallel form)
+#pragma unroll
+            for (int r = 0; r < 4; r++) { tot[r] += acc[r]; acc[r] = 0; }
+        }
         __syncthreads();
     }
 #pragma unroll
-    for (int r = 0; r < 4; r++) Ws[(16 * mi + l4 + 4 * r) * WS + 16 * ni + l15] = acc[r];
+    for (int r = 0; r < 4; r++) Ws[(16 * mi + l4 + 4 * r) * WS + 16 * ni + l15] = tot[r];
     __syncthreads();
 
     // ---- phase 2: W2 = T' W1 (T upper triangular) ----

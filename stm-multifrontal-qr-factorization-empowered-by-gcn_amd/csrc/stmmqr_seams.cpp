@@ -104,7 +104,7 @@ struct OneFront {
     }
 };
 
-int lds_for(long m) { return (int)std::min(15360L, (m | 1) * STM_NB); }
+int lds_for(long m) { return (int)std::min(15360L, (((m + 63) & ~63L) | 1) * STM_NB + 64); }
 
 }  // namespace
 

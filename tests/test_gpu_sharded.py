@@ -12,8 +12,8 @@ pytestmark = pytest.mark.gpu
 PKG = "stm-multifrontal-qr-factorization-empowered-by-gcn_amd"
 
 
-@pytest.mark.parametrize("name", ["epb1", "grid20_standin", "syn_rankdef_grid", "lns_3937"])
-@pytest.mark.parametrize("nranks", [2, 4])
+@pytest.mark.parametrize("name,nranks", [(n, r) for n in ("epb1", "grid20_standin", "syn_rankdef_grid", "lns_3937") for r in (2, 4)] +
+                         [("sme3dc_standin", 4)])     # BASELINE configs[3]: the sme3Dc stand-in on 4 ranks
 def test_sharded_equals_unsharded(name, nranks):
     pkg = importlib.import_module(PKG)
     sh = importlib.import_module(PKG + ".sharded")
