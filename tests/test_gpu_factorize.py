@@ -142,6 +142,45 @@ def test_plan_reuse_and_device_resident_values(pkg, oracle):
     plan.close()
 
 
+@pytest.mark.parametrize("tall_min", [256, 0])
+def test_plan_reuse_across_rank_changes(pkg, oracle, tall_min):
+    """One plan, values that change the numerical rank from call to call (rank-deficient -> full rank -> rank-deficient):
+    dead columns change the row counts of the fronts, so the launch plan (made from the full-rank estimate), the kept T
+    factors and the solve's row maps must all follow the CURRENT factorization."""
+    g = load_golden("syn_rankdef_grid")
+    S = Symbolic(g)
+    pkg.set_options(tall_min_rows=tall_min, big_front_cols=16)
+    try:
+        plan = pkg.HipQR(sym_dict(S))
+    finally:
+        pkg.set_options(tall_min_rows=256, big_front_cols=64)
+    rng = np.random.default_rng(9)
+    tol, ntol = scalar(g, "in_tol"), int(scalar(g, "in_ntol"))
+    ranks = []
+    try:
+        for it in range(4):
+            Ax = g["in_Ax"].copy()
+            if it % 2 == 1:                               # generic values on the same pattern: full column rank
+                Ax = Ax + rng.standard_normal(Ax.size)
+            plan.factorize(Ax, tol, ntol, *((g["in_Ap"], g["in_Ai"]) if it == 0 else (None, None)))
+            G = plan.download()
+            No = oracle.factorize(S, g["in_Ap"], g["in_Ai"], Ax, tol, ntol)
+            gg = dict(g); gg["in_Ax"] = Ax
+            compare_numeric(oracle, S, G, No, gg, ftol=1e-10)
+            ranks.append(G.rank)
+            # the resident-factor solve follows the same factorization
+            from stmmqr_testlib import csc_matvec
+            N = numeric_from_gpu(S, G)
+            b = csc_matvec(S.m, g["in_Ap"], g["in_Ai"], Ax, np.arange(S.n, dtype=float))
+            x = plan.solve(b)
+            q = S.Qfill if S.Qfill is not None else np.arange(S.n)
+            xo = np.zeros(S.n); xo[q] = oracle.rsolve(S, N, oracle.qmult(0, S, N, b))
+            assert np.linalg.norm(x - xo) <= 1e-9 * max(np.linalg.norm(xo), 1.0)
+    finally:
+        plan.close()
+    assert ranks[0] == ranks[2] < ranks[1] == ranks[3] == S.n
+
+
 def test_no_rank_detection_tol_negative(pkg, oracle):
     g = load_golden("syn_rankdef_grid")
     S = Symbolic(g)
