@@ -812,8 +812,8 @@ int stmmqr_factorize_finish(stmmqr_plan *plan, stmmqr_stats *stats)
         HIPCHK(hipMemcpy(hb, P.d_dbg.p, sizeof hb, hipMemcpyDeviceToHost));
         fprintf(stderr, "[panel cycles, summed over workgroups] stage-in+apply %llu  columns %llu  write-back %llu  - %llu  gram %llu\n",
                 hb[0], hb[1], hb[2], hb[3], hb[4]);
-        fprintf(stderr, "[last group of the panel pipeline, cycles] load %llu  waits %llu  applies %llu  factor %llu  gram %llu\n", hb[6],
-                hb[7], hb[8], hb[9], hb[10]);
+        fprintf(stderr, "[last group of the panel pipeline, cycles] load %llu  waits %llu  apply-loads %llu  applies %llu  factor %llu  gram %llu\n", hb[6],
+                hb[7], hb[12], hb[8] + hb[11], hb[9], hb[10]);
         HIPCHK(hipMemset(P.d_dbg.p, 0, sizeof hb));
     }
     P.rank = rank;

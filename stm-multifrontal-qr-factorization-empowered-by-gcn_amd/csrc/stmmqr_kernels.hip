@@ -41,6 +41,7 @@ struct PanelShared {
     double part[8 * 32];
     double top[2][8];
     double rsum[2][64];        // register sub-panel: per-wave sums of the 8 reductions of a column step (two buffers)
+    double rsumB[5][64];       // blocked application of a half group of reflectors: up to 40 sums in one exchange
     double Ts[8][9];
     double gp[32];
 };
@@ -367,9 +368,66 @@ __device__ void dev_update_block(double *F, long long ld, int g1, int mp, int k1
 //   operand of the diagonal tiles), cross-wave sum through LDS scratch, then
 //   T(0:b-1,b) = -tau_b T(0:b-1,0:b-1) G(0:b-1,b)   (SURVEY.md A.4).   scratch: >= NW*3*256 doubles.
 // ------------------------------------------------------------------------------------------------
+// ------------------------------------------------------------------------------------------------
+// dlarft (forward, columnwise) from the Gram matrix G = V'V of a panel, tau = 0 columns included as zero columns:
+//   T(a,b) = -tau_b sum_{a <= l < b} T(a,l) G(l,b),  T(b,b) = tau_b.
+// Blocked 16 + 16: the two diagonal blocks are independent recurrences (one row of T per lane, two waves side by
+// side), the off-diagonal block is T12 = -T11 (G12 T22), two 16 x 16 products by 256 threads -- the chain of
+// dependent LDS reads + FMAs is a quarter of the 32-column recurrence's.  G's lower-left block is used as scratch.
+// G, T: LDS, row stride STM_NB + 1; needs >= 256 threads; T is written completely (zeros below the diagonal and for
+// columns >= nc).  Ends with a barrier.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void dev_T_from_gram(double (*G)[STM_NB + 1], double (*T)[STM_NB + 1], const double *tau, int nc)
+{
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    if (wid < 2 && lane < 16) {
+        const int o = 16 * wid, a = lane;
+        double trow[16];
+#pragma unroll
+        for (int b = 0; b < 16; b++) {
+            double v = 0;
+            if (o + b < nc) {
+                const double tb = tau[o + b];
+                double g[16];
+#pragma unroll
+                for (int l = 0; l < b; l++) g[l] = G[o + l][o + b];      // (broadcast reads, all in flight together)
+                double p0 = 0, p1 = 0, p2 = 0, p3 = 0;
+#pragma unroll
+                for (int l = 0; l < b; l += 4) {
+                    p0 += trow[l] * g[l];
+                    if (l + 1 < b) p1 += trow[l + 1] * g[l + 1];
+                    if (l + 2 < b) p2 += trow[l + 2] * g[l + 2];
+                    if (l + 3 < b) p3 += trow[l + 3] * g[l + 3];
+                }
+                v = (p0 + p1) + (p2 + p3);                           // (T(a,l) = 0 for l < a: no per-lane bounds)
+                v = (a < b && tb != 0.0) ? -tb * v : ((a == b) ? tb : 0.0);
+            }
+            trow[b] = v;
+            T[o + a][o + b] = v;
+        }
+    }
+    __syncthreads();
+    const int bi = (tid >> 4) & 15, bj = tid & 15;
+    if (tid < 256) {
+        double acc = 0;                                              // X = G12 T22 (T22 is zero below its diagonal)
+#pragma unroll
+        for (int k = 0; k < 16; k++) acc += G[bi][16 + k] * T[16 + k][16 + bj];
+        G[16 + bi][bj] = acc;
+        T[16 + bi][bj] = 0.0;
+    }
+    __syncthreads();
+    if (tid < 256) {
+        double acc = 0;                                              // T12 = -T11 X
+#pragma unroll
+        for (int k = 0; k < 16; k++) acc += T[bi][k] * G[16 + k][bj];
+        T[bi][16 + bj] = -acc;
+    }
+    __syncthreads();
+}
+
 template <int NTH>
 __device__ void dev_gram_T(const double *Vg, long long ld, int r0, int r1, int nc, const int *diag, const double *tau,
-                           double (*s_G)[STM_NB + 1], double (*s_T)[STM_NB + 1], double *Tout, double *scratch)
+                           double (*s_G)[STM_NB + 1], double (*s_T)[STM_NB + 1], double *Tout, double *scratch, unsigned long long *tl = nullptr)
 {
     constexpr int NWV = NTH / 64;
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
@@ -418,6 +476,7 @@ __device__ void dev_gram_T(const double *Vg, long long ld, int r0, int r1, int n
         for (int u = 0; u < 4; u++) { x0[u] = y0[u]; x1[u] = y1[u]; }
     }
     __syncthreads();                                    // scratch is free
+    if (tl && tid == 0) tl[1] = wall_clock64();
     // cross-wave sum in groups of 4 waves (scratch: 4 * 768 doubles)
     for (int grp = 0; grp < NWV / 4; grp++) {
         if ((wid >> 2) == grp) {
@@ -437,25 +496,9 @@ __device__ void dev_gram_T(const double *Vg, long long ld, int r0, int r1, int n
         s_G[a + (tile == 2 ? 16 : 0)][b + (tile >= 1 ? 16 : 0)] = v;
     }
     __syncthreads();
-    if (wid == 0 && lane < STM_NB) {
-        // lane a owns row a of T and keeps it in registers: T(a,b) = -tau_b sum_{l<b} T(a,l) G(l,b); T(a,l) = 0 for
-        // l < a, so no per-lane bounds are needed and G(l,b) is a broadcast LDS read
-        const int a = lane;
-        double trow[STM_NB];
-#pragma unroll
-        for (int b = 0; b < STM_NB; b++) {
-            double v = 0;
-            if (b < nc) {
-                const double tb = tau[b];
-#pragma unroll
-                for (int l = 0; l < b; l++) v += trow[l] * s_G[l][b];
-                v = (a < b && tb != 0.0) ? -tb * v : ((a == b) ? tb : 0.0);
-            }
-            trow[b] = v;
-            s_T[a][b] = v;
-        }
-    }
-    __syncthreads();
+    if (tl && tid == 0) tl[2] = wall_clock64();
+    dev_T_from_gram(s_G, s_T, tau, nc);
+    if (tl && tid == 0) tl[3] = wall_clock64();
     for (int e = tid; e < STM_NB * STM_NB; e += NTH) {
         const int a = e % STM_NB, b = e / STM_NB;
         Tout[e] = (a < nc && b < nc && a <= b) ? s_T[a][b] : 0.0;
@@ -1034,37 +1077,42 @@ __device__ __forceinline__ int ld_agent(const int *p) { return __hip_atomic_load
 __device__ __forceinline__ void st_agent(int *p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ double ld_agent(const double *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void st_agent(double *p, double v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void st_agent(char *p, char v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
 // whole workgroup: wait until *flag >= target (written by another workgroup of this launch), then acquire.
 // Returns false if the bounded spin ran out (never expected; the caller gives up on the panel).
-__device__ __forceinline__ bool wait_progress(const int *flag, int target)
+// `seen` (thread 0): a value of the flag loaded earlier (the poll of a consumer that is behind its producer costs a
+// memory round trip although the flag has long been set: it loads the flag before its previous block of work instead).
+__device__ __forceinline__ bool wait_progress(const int *flag, int target, int seen = -1)
 {
     __shared__ int s_ok;
     __syncthreads();                               // (s_ok of a previous wait has been read by everyone)
     if (threadIdx.x == 0) {
-        int ok = 0;
-        for (int it = 0; it < (1 << 26); it++) {
+        int ok = (seen >= target);
+        for (int it = 0; !ok && it < (1 << 26); it++) {
             if (ld_agent(flag) >= target) { ok = 1; break; }
             __builtin_amdgcn_s_sleep(1);
         }
         s_ok = ok;
+        // ONE lane acquires for the whole CU (the invalidate acts on the CU's L1 and on stale other-XCD lines; every
+        // wave fencing costs 2-4x as much); the wait holds the barrier until the invalidate has completed.
+        // (Dropping the acquire in favour of sc1 loads of the handed-over columns was measured: no gain.)
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
     __syncthreads();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");     // invalidates this CU's L1 and stale (other-XCD) L2 lines
     return s_ok != 0;
 }
-// publish: all global stores of this workgroup happen-before the flag value
+// publish: all global stores of this workgroup happen-before the flag value.
+// Everything handed from one workgroup of the panel launch to another is stored WRITE-THROUGH (st_agent: sc1 stores, the
+// panel columns included), so no L2 write-back (agent-scope release: buffer_wbl2 writes back every dirty line of the XCD's
+// L2, microseconds when other fronts' updates have just run there) is needed: every wave waits for its own stores to be
+// acknowledged (a workgroup barrier alone does not wait for them), the barrier joins the waves, one lane stores the flag.
 __device__ __forceinline__ void publish_progress(int *flag, int value)
 {
-    // EVERY wave first waits for its own global stores to reach the L2 (a workgroup barrier alone does not: hipcc emits
-    // no vmcnt wait for workgroup scope, so a release by thread 0 only could publish the flag ahead of the other waves'
-    // data); then one agent-scope release writes the L2 back for the other XCDs and the flag goes out.
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    if (threadIdx.x == 0) {
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-        st_agent(flag, value);
-    }
+    if (threadIdx.x == 0) st_agent(flag, value);
 }
 
 template <int NTH>
@@ -1102,9 +1150,16 @@ __device__ __forceinline__ void dev_tall_group(PanelShared &ps, const FrontSym &
     unsigned long long ts0 = clock64(), ts1;
     const bool stamp_me = (dbg & 16) && dbgbuf && (b == ns - 1);
 #define TSTAMP(idx) do { if (stamp_me) { __syncthreads(); ts1 = clock64(); if (tid == 0) atomicAdd(&dbgbuf[idx], ts1 - ts0); ts0 = ts1; } } while (0)
+    // timeline of panel 1 (dbg & 32): wall clock (100 MHz) of thread 0 at the events of every group, dbgbuf[16 + 64 b + idx]
+    const bool tl_on = (dbg & 32) && dbgbuf && p == 1 && tid == 0;
+#define TL(idx) do { if (tl_on) dbgbuf[16 + 64 * b + (idx)] = wall_clock64(); } while (0)
+#define TLW(idx) do { if ((dbg & 32) && p == 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); TL(idx); } while (0)
 #else
 #define TSTAMP(idx) do { } while (0)
+#define TL(idx) do { } while (0)
+#define TLW(idx) do { } while (0)
 #endif
+    TL(0);
 
     // (loads are unconditional on a clamped index and masked afterwards: a predicated load becomes a branch around
     //  each access and the 8 x RPT loads would be issued one round trip at a time)
@@ -1120,63 +1175,149 @@ __device__ __forceinline__ void dev_tall_group(PanelShared &ps, const FrontSym &
         }
     }
     TSTAMP(6);
+    TLW(1);
+#ifdef STMMQR_STAMPS
+    int tl_h = 0;
+#endif
     // ---- apply the reflectors of the groups before mine, as they become available ----
     int prev_done = 0;
+    constexpr int HW = SWT / 2;                                // reflectors per published half group
+    constexpr int NGP = (HW * SWT) / 8;                        // exchange groups of eight V'C products
     // (a group publishes twice: after the first half of its columns and at the end, so that the next group applies the
     //  first half of the reflectors while the second half is still being factorized)
+    int seen = -1;
+    bool have_chain = false;
+    int ch_g = 0, ch_rank = 0, ch_pt = 0, ch_nl = 0;
+    double ch_ls = 0, ch_fl = 0;
     for (int sp = 0; sp < b && !prev_done; sp++)
     for (int half = 0; half < 2; half++) {
-        if (!wait_progress(&num->prog, 32 * p + 2 * sp + 1 + half)) { if (tid == 0) st_agent(&num->perr, 1); return; }
+        if (!wait_progress(&num->prog, 32 * p + 2 * sp + 1 + half, seen)) { if (tid == 0) st_agent(&num->perr, 1); return; }
         TSTAMP(7);
+        TL(2 + 3 * tl_h);
         const int pc0 = SWT * sp + half * (SWT / 2);
         // (group sp ran out of rows?  Not num->done: a group that starts late would see the flag of a LATER group and
         //  skip the reflectors of the groups in between)
         if (half == 1) prev_done = (ld_agent(&pd->done_group) == sp);
-        double vn[RPT];
-        {
-            const double *vc = F + (long long)(k1 + pc0) * ld;
-#pragma unroll
-            for (int r = 0; r < RPT; r++) {
-                const int i = rb + tid + NTH * r;
-                const double val = vc[min(i, tmax - 1)];
-                vn[r] = (i < tmax) ? val : 0.0;                // (rows beyond a column's staircase are zero in F)
-            }
+        if (half == 1 && sp == b - 1) {
+            // the scalars that travel along the chain of groups were stored before this flag: load them now, the
+            // round trip hides behind the block application below (after the loop it would delay my first column)
+            ch_g = ld_agent(&num->g); ch_rank = ld_agent(&num->rank); ch_pt = ld_agent(&pd->pt);
+            ch_nl = ld_agent(&pd->nlive); ch_ls = ld_agent(&pd->lensum); ch_fl = ld_agent(&num->flops);
+            have_chain = true;
         }
-        for (int q = 0; q < SWT / 2; q++) {
+        // The HW reflectors of this half are applied as ONE block reflector, C -= V T' (V'C): the HW x SWT products V'C
+        // and the strict upper triangle of V'V go through a single workgroup exchange (one barrier instead of one per
+        // reflector), T is the HW x HW dlarft recurrence done redundantly by every thread.  tau == 0 / dead columns enter
+        // as v = 0, tau = 0.  (The blocking is fixed -- half groups -- so the rounding does not depend on the timing.)
+        double v[HW][RPT], tq[HW];
+#pragma unroll
+        for (int q = 0; q < HW; q++) {
             const int d = ld_agent(&pd->pdiag[pc0 + q]);
             const double tau = ld_agent(&Tau[k1 + pc0 + q]);
-            double v[RPT];
+            const bool live = !(tau == 0.0 || d >= STM_BIGROW);
+            tq[q] = live ? tau : 0.0;
+            const double *vc = F + (long long)(k1 + pc0 + q) * ld;
 #pragma unroll
             for (int r = 0; r < RPT; r++) {
                 const int i = rb + tid + NTH * r;
-                v[r] = (i < d) ? 0.0 : ((i == d) ? 1.0 : vn[r]);
-            }
-            if (q + 1 < SWT / 2) {                             // next reflector's column: in flight during the reduction
-                const double *vc = F + (long long)(k1 + pc0 + q + 1) * ld;
-#pragma unroll
-                for (int r = 0; r < RPT; r++) {
-                    const int i = rb + tid + NTH * r;
-                    const double val = vc[min(i, tmax - 1)];
-                    vn[r] = (i < tmax) ? val : 0.0;
-                }
-            }
-            if (tau == 0.0 || d >= STM_BIGROW) continue;       // identity / dead column (uniform)
-            double part[8], sum[8];
-#pragma unroll
-            for (int x = 0; x < 8; x++) part[x] = 0;
-#pragma unroll
-            for (int r = 0; r < RPT; r++) {
-#pragma unroll
-                for (int x = 0; x < SWT; x++) part[x] += v[r] * a[r][x];
-            }
-            block_reduce8<NTH>(ps, par, part, sum);
-#pragma unroll
-            for (int r = 0; r < RPT; r++) {
-                const double tv = tau * v[r];
-#pragma unroll
-                for (int x = 0; x < SWT; x++) a[r][x] -= sum[x] * tv;
+                const double val = vc[min(i, tmax - 1)];       // (rows beyond a column's staircase are zero in F)
+                v[q][r] = (!live || i < d || i >= tmax) ? 0.0 : ((i == d) ? 1.0 : val);
             }
         }
+#ifdef STMMQR_STAMPS
+        if (stamp_me) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        TSTAMP(12);
+        TLW(3 + 3 * tl_h);
+#endif
+        if (tid == 0) seen = ld_agent(&num->prog);             // for the next wait: in flight during the block below
+        // exchange group 0: the strict upper triangle of V'V; groups 1..: V'C, eight products per group
+        const int lane = tid & 63, wid = tid >> 6;
+        {
+            double gv[8];
+#pragma unroll
+            for (int e = 0; e < 8; e++) gv[e] = 0.0;
+#pragma unroll
+            for (int q1 = 0; q1 < HW; q1++) {
+#pragma unroll
+                for (int q2 = q1 + 1; q2 < HW; q2++) {
+                    double acc = 0.0;
+#pragma unroll
+                    for (int r = 0; r < RPT; r++) acc += v[q1][r] * v[q2][r];
+                    gv[q1 * HW - (q1 * (q1 + 1)) / 2 + (q2 - q1 - 1)] = acc;
+                }
+            }
+            const double rw = wave_reduce8(gv);
+            if (lane < 8) ps.rsumB[0][wid * 8 + lane] = rw;
+        }
+#pragma unroll
+        for (int gi = 0; gi < NGP; gi++) {
+            double pv[8];
+#pragma unroll
+            for (int e = 0; e < 8; e++) {
+                const int q = (gi * 8 + e) / SWT, x = (gi * 8 + e) % SWT;
+                double acc = 0.0;
+#pragma unroll
+                for (int r = 0; r < RPT; r++) acc += v[q][r] * a[r][x];
+                pv[e] = acc;
+            }
+            const double rw = wave_reduce8(pv);
+            if (lane < 8) ps.rsumB[1 + gi][wid * 8 + lane] = rw;
+        }
+        lds_barrier();
+        // T (upper triangular, dlarft forward/columnwise): T(0:j,j) = -tau_j T(0:j,0:j) (V(:,0:j)' v_j)
+        double Tq[HW][HW];
+        {
+            const double rs = wave_sum_stride8((lane < (NTH / 64) * 8) ? ps.rsumB[0][lane] : 0.0);
+            const double G8[8] = {lane_bcast<red8_lane(0)>(rs), lane_bcast<red8_lane(1)>(rs), lane_bcast<red8_lane(2)>(rs),
+                                  lane_bcast<red8_lane(3)>(rs), lane_bcast<red8_lane(4)>(rs), lane_bcast<red8_lane(5)>(rs),
+                                  lane_bcast<red8_lane(6)>(rs), lane_bcast<red8_lane(7)>(rs)};
+#pragma unroll
+            for (int j = 0; j < HW; j++) {
+#pragma unroll
+                for (int i = 0; i < HW; i++) Tq[i][j] = 0.0;
+                Tq[j][j] = tq[j];
+#pragma unroll
+                for (int i = 0; i < j; i++) {
+                    double acc = 0.0;
+#pragma unroll
+                    for (int l = i; l < j; l++) acc += Tq[i][l] * G8[l * HW - (l * (l + 1)) / 2 + (j - l - 1)];
+                    Tq[i][j] = -tq[j] * acc;
+                }
+            }
+        }
+        // W = T' (V'C), accumulated group by group (eight products live at a time), then C -= V W
+        double Wq[HW][SWT];
+#pragma unroll
+        for (int q = 0; q < HW; q++) {
+#pragma unroll
+            for (int x = 0; x < SWT; x++) Wq[q][x] = 0.0;
+        }
+#pragma unroll
+        for (int gi = 0; gi < NGP; gi++) {
+            const double rs = wave_sum_stride8((lane < (NTH / 64) * 8) ? ps.rsumB[1 + gi][lane] : 0.0);
+            const double P8[8] = {lane_bcast<red8_lane(0)>(rs), lane_bcast<red8_lane(1)>(rs), lane_bcast<red8_lane(2)>(rs),
+                                  lane_bcast<red8_lane(3)>(rs), lane_bcast<red8_lane(4)>(rs), lane_bcast<red8_lane(5)>(rs),
+                                  lane_bcast<red8_lane(6)>(rs), lane_bcast<red8_lane(7)>(rs)};
+#pragma unroll
+            for (int e = 0; e < 8; e++) {
+                const int l = (gi * 8 + e) / SWT, x = (gi * 8 + e) % SWT;
+#pragma unroll
+                for (int q = l; q < HW; q++) Wq[q][x] += Tq[l][q] * P8[e];
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < RPT; r++) {
+#pragma unroll
+            for (int q = 0; q < HW; q++) {
+#pragma unroll
+                for (int x = 0; x < SWT; x++) a[r][x] -= v[q][r] * Wq[q][x];
+            }
+        }
+        TSTAMP(11);
+        TL(4 + 3 * tl_h);
+#ifdef STMMQR_STAMPS
+        tl_h++;
+#endif
     }
     TSTAMP(8);
     // a group before mine ran out of rows (g reached fm): its reflectors were still due on my columns (applied above);
@@ -1197,11 +1338,15 @@ __device__ __forceinline__ void dev_tall_group(PanelShared &ps, const FrontSym &
     }
     // ---- factorize my sub-panel (column step as in dev_subpanel_reg; finished columns go straight to F) ----
     // g / rank / pt / nlive / flops travel along the chain of groups: group b reads them after the acquire on group b-1
-    int g = (b == 0) ? g1 : ld_agent(&num->g);
-    int rank = ld_agent(&num->rank), done = prev_done, nlive = 0;
-    int tlast = (b == 0) ? g1 : ld_agent(&pd->pt);
-    const int nl_before = (b == 0) ? 0 : ld_agent(&pd->nlive);
-    const double ls_before = (b == 0) ? 0.0 : ld_agent(&pd->lensum);
+    if (!have_chain) {
+        ch_g = ld_agent(&num->g); ch_rank = ld_agent(&num->rank); ch_pt = ld_agent(&pd->pt);
+        ch_nl = ld_agent(&pd->nlive); ch_ls = ld_agent(&pd->lensum); ch_fl = (b == 0) ? num->flops : ld_agent(&num->flops);
+    }
+    int g = (b == 0) ? g1 : ch_g;
+    int rank = ch_rank, done = prev_done, nlive = 0;
+    int tlast = (b == 0) ? g1 : ch_pt;
+    const int nl_before = (b == 0) ? 0 : ch_nl;
+    const double ls_before = (b == 0) ? 0.0 : ch_ls;
     double lensum = 0;
     const int gs = g;
     const int ntol = min(ntol_global - s.col1, npiv);
@@ -1213,11 +1358,11 @@ __device__ __forceinline__ void dev_tall_group(PanelShared &ps, const FrontSym &
         if (!done && g >= m) {
             // no rows left: remaining pivotal columns are dead, remaining columns are empty (:1444-1458)
             for (int kk = k + tid; kk < n; kk += NTH) {
-                if (kk < npiv) { Rdead[kk] = 1; St[kk] = 0; }
-                else St[kk] = m;
-                Tau[kk] = 0;
+                if (kk < npiv) { st_agent(&Rdead[kk], (char)1); st_agent(&St[kk], 0); }
+                else st_agent(&St[kk], m);
+                st_agent(&Tau[kk], 0.0);
             }
-            for (int jj = jp + tid; jj < STM_NB; jj += NTH) pd->pdiag[jj] = STM_BIGROW;
+            for (int jj = jp + tid; jj < STM_NB; jj += NTH) st_agent(&pd->pdiag[jj], STM_BIGROW);
             done = 1;
         }
         if (!done) {
@@ -1269,8 +1414,8 @@ __device__ __forceinline__ void dev_tall_group(PanelShared &ps, const FrontSym &
                 a[0][0] = dead ? 0.0 : beta;
             }
             if (tid == 0) {
-                St[k] = dead ? 0 : t; Tau[k] = tau; pd->pdiag[jp] = dead ? STM_BIGROW : g;
-                if (dead) Rdead[k] = 1;
+                st_agent(&St[k], dead ? 0 : t); st_agent(&Tau[k], tau); st_agent(&pd->pdiag[jp], dead ? STM_BIGROW : g);
+                if (dead) st_agent(&Rdead[k], (char)1);
             }
             if (!dead) {
                 flops += (double)(t - g) * (3.0 + 4.0 * (double)(n - k - 1));
@@ -1287,12 +1432,13 @@ __device__ __forceinline__ void dev_tall_group(PanelShared &ps, const FrontSym &
 #pragma unroll
             for (int r = 0; r < RPT; r++) {
                 const int i = rb + tid + NTH * r;
-                if (i < tmax) dst[i] = a[r][0];
+                if (i < tmax) st_agent(&dst[i], a[r][0]);       // write-through: read by the other groups of this launch
 #pragma unroll
                 for (int x = 0; x + 1 < SWT; x++) a[r][x] = a[r][x + 1];
                 a[r][SWT - 1] = 0.0;
             }
         }
+        TL(20 + j);
     }
     TSTAMP(9);
     // ---- sub-panel bookkeeping; the last sub-panel (or the group after one that ran out of rows) finalises ----
@@ -1300,15 +1446,17 @@ __device__ __forceinline__ void dev_tall_group(PanelShared &ps, const FrontSym &
     const int nl_total = nl_before + nlive;
     if (tid == 0 && !prev_done) {
         st_agent(&num->g, g); st_agent(&num->rank, rank); st_agent(&num->done, done);
-        st_agent(&num->flops, ((b == 0) ? num->flops : ld_agent(&num->flops)) + flops);
+        st_agent(&num->flops, ch_fl + flops);
         st_agent(&pd->sg[b], gs); st_agent(&pd->st[b], tlast); st_agent(&pd->pt, tlast); st_agent(&pd->nlive, nl_total);
         st_agent(&pd->lensum, ls_before + lensum);
         if (done) st_agent(&pd->done_group, b);
     }
     if (!last) {
         publish_progress(&num->prog, 32 * p + 2 * b + 2);
+        TL(30);
         return;
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // (the write-through column stores of every wave: acknowledged)
     __syncthreads();                                           // all stores of this workgroup are complete and visible
     // T of a panel with >= 3 row slabs and trailing columns is left to the trailing update (k_upd_w: a Gram block per
     // slab, the last slab to arrive builds T): the Gram pass over the whole panel leaves the critical path.  The rule
@@ -1331,17 +1479,24 @@ __device__ __forceinline__ void dev_tall_group(PanelShared &ps, const FrontSym &
         ps.tau[tid] = (tid < nbp) ? ld_agent(&Tau[k1 + tid]) : 0.0;
     }
     __syncthreads();
-    dev_gram_T<NTH>(F + (long long)k1 * ld, ld, g1, tlast, nbp, ps.diag, ps.tau, ps.G, ps.T, Tout, lds);
+    dev_gram_T<NTH>(F + (long long)k1 * ld, ld, g1, tlast, nbp, ps.diag, ps.tau, ps.G, ps.T, Tout, lds
+#ifdef STMMQR_STAMPS
+                    , ((dbg & 32) && dbgbuf && p == 1) ? dbgbuf + 16 + 64 * b + 40 : nullptr
+#endif
+                    );
     if (Tkeep)
         for (int e = tid; e < STM_NB * STM_NB; e += NTH) {
             const int ai = e % STM_NB, bi = e / STM_NB;
             Tkeep[e] = (ai < nbp && bi < nbp && ai <= bi) ? ps.T[ai][bi] : 0.0;
         }
     TSTAMP(10);
+    TL(31);
     // (when an earlier group ran out of rows the groups after mine are still storing their columns: the kernel
     //  boundary orders those stores before the trailing update)
     publish_progress(&num->prog, 32 * p + 2 * b + 2);
 #undef TSTAMP
+#undef TL
+#undef TLW
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1594,24 +1749,13 @@ __global__ __launch_bounds__(NT) void k_upd_w(DevCtx c, const int *__restrict__ 
     __syncthreads();
     double *Tout = c.Tws + (long long)(2 * c.tslot[f] + (p & 1)) * STM_NB * STM_NB;
     double *Tkeep = c.Tall ? c.Tall + (long long)(s.tpan + p) * STM_NB * STM_NB : nullptr;
-    if (tid < STM_NB) {
-        // dlarft from the Gram matrix (as dev_T_from_gram): lane a owns row a of T
-        const int a = tid;
-        double trow[STM_NB];
-#pragma unroll
-        for (int b = 0; b < STM_NB; b++) {
-            double v = 0;
-            if (b < nbp) {
-                const double tb = s_tau[b];
-#pragma unroll
-                for (int l = 0; l < b; l++) v += trow[l] * s_G[l * WS + b];
-                v = (a < b && tb != 0.0) ? -tb * v : ((a == b) ? tb : 0.0);
-            }
-            trow[b] = v;
-            const double tv = (a <= b && a < nbp && b < nbp) ? v : 0.0;
-            Tout[a + b * STM_NB] = tv;
-            if (Tkeep) Tkeep[a + b * STM_NB] = tv;
-        }
+    __shared__ double s_Tb[STM_NB][STM_NB + 1];
+    dev_T_from_gram(reinterpret_cast<double (*)[STM_NB + 1]>(s_G), s_Tb, s_tau, nbp);
+    for (int e = tid; e < STM_NB * STM_NB; e += NT) {
+        const int a = e % STM_NB, b = e / STM_NB;
+        const double tv = (a <= b && a < nbp && b < nbp) ? s_Tb[a][b] : 0.0;
+        Tout[e] = tv;
+        if (Tkeep) Tkeep[e] = tv;
     }
 }
 

@@ -87,8 +87,8 @@ struct OneFront {
         c.dbg = getenv("STMMQR_DBG") ? atoi(getenv("STMMQR_DBG")) : 0;
         { stmmqr_options o; stmmqr_get_options(&o); c.tall_min = o.tall_min_rows; }
 #ifdef STMMQR_STAMPS
-        if (!d_dbg.alloc(16)) return false;
-        (void)hipMemset(d_dbg.p, 0, 16 * sizeof(unsigned long long));
+        if (!d_dbg.alloc(1024)) return false;
+        (void)hipMemset(d_dbg.p, 0, 1024 * sizeof(unsigned long long));
         c.dbgbuf = d_dbg.p;
 #endif
         return true;
@@ -145,6 +145,17 @@ stm_long stmmqr_front(stm_long m, stm_long n, stm_long npiv, double tol, stm_lon
                 hb[1], hb[2], hb[3], hb[4], hb[5]);
         fprintf(stderr, " tall: load %llu apply %llu store %llu factor %llu gram %llu", hb[6], hb[7], hb[8], hb[9], hb[10]);
         fprintf(stderr, "\n");
+        if (X.c.dbg & 32) {
+            std::vector<unsigned long long> tl(1024);
+            (void)hipMemcpy(tl.data(), X.c.dbgbuf, 1024 * sizeof(unsigned long long), hipMemcpyDeviceToHost);
+            const unsigned long long t0 = tl[16];
+            for (int b = 0; b < 8 && tl[16 + 64 * b]; b++) {
+                fprintf(stderr, "[timeline panel 1, group %d, us]", b);
+                for (int i = 0; i < 48; i++)
+                    if (tl[16 + 64 * b + i]) fprintf(stderr, " %d:%.2f", i, 0.01 * (double)(long long)(tl[16 + 64 * b + i] - t0));
+                fprintf(stderr, "\n");
+            }
+        }
     }
 #endif
     if (!X.pull_num() || !X.pull_F(F, m)) return -1;
