@@ -1720,23 +1720,32 @@ __global__ __launch_bounds__(NT) void k_upd_w(DevCtx c, const int *__restrict__ 
         __syncthreads();
     }
     double *W = Wp + ((long long)(fi * (maxcb + 1) + cb) * maxsl + sl) * (STM_NB * BN);
+    if (!gram) {
 #pragma unroll
-    for (int r = 0; r < 4; r++) W[(16 * mi + l4 + 4 * r) * BN + 16 * ni + l15] = acc[r];
-    if (!gram) return;
+        for (int r = 0; r < 4; r++) W[(16 * mi + l4 + 4 * r) * BN + 16 * ni + l15] = acc[r];
+        return;
+    }
     // ---- Gram block: the last slab to arrive builds T ----
+    // The partial G is stored write-through (as the panel pipeline's hand-offs: no L2 write-back before the ticket),
+    // every wave waits for its stores, the barrier joins them, one lane takes the ticket; the last arriver acquires
+    // with one lane.
+#pragma unroll
+    for (int r = 0; r < 4; r++) st_agent(&W[(16 * mi + l4 + 4 * r) * BN + 16 * ni + l15], acc[r]);
     __shared__ int s_ticket;
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // every wave: its part of the partial G has reached the L2
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     FrontNum *num = &c.fnum[f];
     const int nsl = (mp + SLAB - 1) / SLAB;
     if (tid == 0) {
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
         s_ticket = __hip_atomic_fetch_add(&num->gcnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (s_ticket == nsl - 1) {
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __hip_atomic_store(&num->gcnt, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
     }
     __syncthreads();
     if (s_ticket != nsl - 1) return;
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-    if (tid == 0) __hip_atomic_store(&num->gcnt, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     double *s_G = Vs;                                          // [row * WS + col] (the chunk images are free now)
     __shared__ double s_tau[STM_NB];
     const double *G0 = Wp + ((long long)(fi * (maxcb + 1) + maxcb) * maxsl) * (STM_NB * BN);
@@ -1749,7 +1758,7 @@ __global__ __launch_bounds__(NT) void k_upd_w(DevCtx c, const int *__restrict__ 
     __syncthreads();
     double *Tout = c.Tws + (long long)(2 * c.tslot[f] + (p & 1)) * STM_NB * STM_NB;
     double *Tkeep = c.Tall ? c.Tall + (long long)(s.tpan + p) * STM_NB * STM_NB : nullptr;
-    __shared__ double s_Tb[STM_NB][STM_NB + 1];
+    double (*s_Tb)[STM_NB + 1] = reinterpret_cast<double (*)[STM_NB + 1]>(Cs);            // (the C chunk image is free as well)
     dev_T_from_gram(reinterpret_cast<double (*)[STM_NB + 1]>(s_G), s_Tb, s_tau, nbp);
     for (int e = tid; e < STM_NB * STM_NB; e += NT) {
         const int a = e % STM_NB, b = e / STM_NB;
@@ -1809,7 +1818,9 @@ __global__ __launch_bounds__(NT) void k_upd_c(DevCtx c, const int *__restrict__ 
     const long long ld = s.ld;
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, l15 = lane & 15, l4 = lane >> 4;
     double *Vs = dyn_lds, *Cs = Vs + STM_NB * VS, *Ws = Cs + BN * VS;
-    __shared__ double s_W1[STM_NB * WS], s_T[STM_NB * WS];
+    // (the prologue's W1 / T images live in the chunk images, which are first written after it: 42 KB of LDS per
+    //  workgroup instead of 59, three workgroups per CU instead of two)
+    double *s_W1 = Vs, *s_T = Cs;
     if (tid < STM_NB) s_pd[tid] = (tid < nbp) ? pd->pdiag[tid] : STM_BIGROW;
     // the first chunk of V and C is requested before the W2 prologue so that its latency hides behind it
     const double *Vg = c.Farena + s.foff + g1 + (long long)pd->pk1 * ld;
@@ -2361,7 +2372,9 @@ int stm_launch_update_split(const DevCtx &c, const int *flist, int nfr, int p, i
     if (nfr <= 0 || ncb <= 0 || maxsl <= 0) return 0;
     const size_t lds = (size_t)stm_update_lds_bytes();
     // (with_gram: one more column block, V'V for the fronts whose panel kernel left T to the update)
-    hipLaunchKernelGGL(k_upd_w, dim3(ncb + (with_gram ? 1 : 0), maxsl, nfr), dim3(NT), lds, st, c, flist, p, cb0, Wp, ncb, maxsl);
+    // (k_upd_w stages V and C chunks only: 34 KB, four workgroups per CU)
+    hipLaunchKernelGGL(k_upd_w, dim3(ncb + (with_gram ? 1 : 0), maxsl, nfr), dim3(NT), (size_t)(2 * BN * VS) * sizeof(double), st, c,
+                       flist, p, cb0, Wp, ncb, maxsl);
     hipLaunchKernelGGL(k_upd_c, dim3(ncb, maxsl, nfr), dim3(NT), lds, st, c, flist, p, cb0, (const double *)Wp, ncb, maxsl);
     return (int)hipGetLastError();
 }
