@@ -90,6 +90,113 @@ def cpu_baseline(name, g, budget_s=20.0):
             "seconds": sec}
 
 
+# ---------------------------------------------------------------------------------------------------------------
+# kernel micro-benchmarks of SURVEY.md 8(d): synthetic single fronts through the qr_front seam, one synthetic
+# assembly through the qr_assemble seam; device time = HIP events around the seam's kernels (stmmqr_last_seam_ms)
+# ---------------------------------------------------------------------------------------------------------------
+MICRO_FRONTS = [(64, 96, 32), (266, 422, 124), (380, 380, 380), (2048, 3072, 1024), (8192, 12288, 4096)]
+
+
+def micro_front_input(idx, fm, fn, dense=False):
+    """entries N(0,1), seed 1234 + idx, staircase Stair[k] = min(fm, (k+1) fm / fn + 8), zeros below it (SURVEY.md 8d:
+    with fm < fn the diagonal overtakes this staircase after a few dozen columns, so these fronts are almost triangular
+    and measure per-panel latency); dense = True: Stair[k] = fm, the full Householder QR of the same entries"""
+    rng = np.random.default_rng(1234 + idx)
+    F = np.asfortranarray(rng.standard_normal((fm, fn)))
+    if dense:
+        return F, np.full(fn, fm, np.int64)
+    stair = np.minimum(fm, (np.arange(fn, dtype=np.int64) + 1) * fm // fn + 8).astype(np.int64)
+    for k in range(fn):
+        F[stair[k]:, k] = 0.0
+    return F, stair
+
+
+def micro_assembly_input(seed=99, P=8, FN=6144, FP=1024, CN=3000, NS=96):
+    """Parent front with FN columns (FP pivotal), NS rows of S and two children with cm = cn = CN whose columns map to
+    random monotone subsets of the parent's columns (SURVEY.md 8d names the parent 4096 x 6144; with two children of
+    3000 rows each the parent has NS + 2 CN rows, so fm = 6096 here)."""
+    rng = np.random.default_rng(seed)
+    n = 2 * P + FN
+    Super = np.array([0, P, 2 * P, 2 * P + FP], np.int64)
+    Rp = np.array([0, P + CN, 2 * (P + CN), 2 * (P + CN) + FN], np.int64)
+    Rj = np.zeros(Rp[-1], np.int64)
+    for c in range(2):
+        Rj[Rp[c]:Rp[c] + P] = np.arange(c * P, (c + 1) * P)
+        Rj[Rp[c] + P:Rp[c + 1]] = 2 * P + np.sort(rng.choice(FN, CN, replace=False))
+    Rj[Rp[2]:] = 2 * P + np.arange(FN)
+    Fmap = np.zeros(n, np.int64)
+    Fmap[2 * P:] = np.arange(FN)
+    left = 2 * P + (np.arange(NS) * FP) // NS                      # leftmost column of S row r (a parent pivot)
+    Sp, Sj = [0], []
+    for r in range(NS):
+        rest = 2 * P + np.sort(rng.choice(np.arange(left[r] - 2 * P + 1, FN), 7, replace=False))
+        Sj.extend([left[r]] + list(rest))
+        Sp.append(len(Sj))
+    Sp, Sj = np.array(Sp, np.int64), np.array(Sj, np.int64)
+    Sx = rng.standard_normal(len(Sj))
+    Sleft = np.searchsorted(left, np.arange(n + 2), side="left").astype(np.int64)
+    Child, Childp = np.array([0, 1], np.int64), np.array([0, 0, 0, 2], np.int64)
+    Cm, Hr, Hip = np.array([CN, CN, 0], np.int64), np.zeros(3, np.int64), np.array([0, CN, 2 * CN], np.int64)
+    fm = NS + 2 * CN
+    Hii = np.zeros(2 * CN + fm, np.int64)
+    Hii[:2 * CN] = 1000 + np.arange(2 * CN)
+    csize = CN * (CN + 1) // 2
+    Cb = {0: rng.standard_normal(csize), 1: rng.standard_normal(csize)}
+    nbytes = 8 * (fm * FN + 2 * csize + len(Sj)) + 4 * (len(Sj) + 2 * (CN + CN))
+    return dict(f=2, fm=fm, Super=Super, Rp=Rp, Rj=Rj, Sp=Sp, Sj=Sj, Sleft=Sleft, Child=Child, Childp=Childp, Sx=Sx,
+                Fmap=Fmap, Cm=Cm, Cblocks=Cb, Hr=Hr, Stair=np.zeros(FN, np.int64), Hii=Hii, Hip=Hip), nbytes, (fm, FN)
+
+
+def run_micro(pkg, args):
+    fronts = []
+    orc = None
+    if not args.no_cpu:
+        from stmmqr_testlib import Oracle                # CPU baseline leg only
+        orc = Oracle()
+    for idx, (fm, fn, fp, dense) in enumerate([(a, b, c, d) for d in (False, True) for (a, b, c) in MICRO_FRONTS]):
+        idx %= len(MICRO_FRONTS)
+        F0, st0 = micro_front_input(idx, fm, fn, dense)
+        best, flops, rank = None, 0.0, 0
+        for _ in range(max(1, args.warmup) + max(1, min(args.steps, 3))):
+            F, st = F0.copy(order="F"), st0.copy()
+            rank, _, _, flops = pkg.qr_front(fm, fn, fp, -1.0, fp, F, st)
+            ms = pkg.last_seam_ms()
+            best = ms if best is None else min(best, ms)
+        row = {"fm": fm, "fn": fn, "fp": fp, "staircase": "dense" if dense else "survey", "rank": rank, "flops": flops,
+               "device_ms": best,
+               "gflops": flops / best * 1e-6, "frac_fp64_peak": flops / best * 1e-9 / PEAK_FP64_MFMA_TFLOPS}
+        if orc is not None and flops <= 5e9:                 # (bounded CPU sample: the scalar port does ~1 GFLOP/s)
+            F, st = F0.copy(order="F"), st0.copy()
+            t0 = time.perf_counter()
+            r2, _, _, fl2 = orc.front(F, st, fp, -1.0, fp)
+            sec = time.perf_counter() - t0
+            row["cpu_port_ms"] = sec * 1e3
+            row["cpu_port_gflops"] = fl2 / sec * 1e-9
+            row["rank_matches_cpu"] = bool(r2 == rank and fl2 == flops)
+        fronts.append(row)
+        del F0
+    a, nbytes, shape = micro_assembly_input()
+    best = None
+    for _ in range(3):
+        a["Stair"][:] = 0
+        F, _ = pkg.qr_assemble(**a)
+        ms = pkg.last_seam_ms()
+        best = ms if best is None else min(best, ms)
+    total_in = a["Sx"].sum() + a["Cblocks"][0].sum() + a["Cblocks"][1].sum()
+    asm = {"parent": f"{shape[0]}x{shape[1]}, 2 children cm=cn=3000, 96 S rows", "algorithmic_bytes": nbytes,
+           "device_ms": best, "GBps": nbytes / best * 1e-6, "frac_hbm": nbytes / best * 1e-6 / PEAK_HBM_GBS,
+           "entries_conserved": bool(abs(F.sum() - total_in) <= 1e-9 * (abs(total_in) + 1.0))}
+    big = [r for r in fronts if r["staircase"] == "dense" and r["fm"] == 2048][0]
+    print(json.dumps({
+        "metric": "numerical-factorization GFLOP/s", "value": big["gflops"], "unit": "GFLOP/s", "n_gpus": 1,
+        "steps": args.steps, "warmup": args.warmup, "ms_per_step": big["device_ms"], "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+        "config": {"workload": "micro: single synthetic fronts (SURVEY.md 8d), value = the dense 2048x3072 front "
+                               "through the qr_front seam (device time of its kernels); not the headline workload"},
+        "fronts": fronts, "assembly": asm}))
+    return 0
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -119,6 +226,8 @@ def main():
     if args.big_front_cols:
         pkg.set_options(big_front_cols=args.big_front_cols)
     name = args.workload
+    if name == "micro":
+        return run_micro(pkg, args)
     g = load_golden(name)
     S = Symbolic(g)
     sym = {**S.sc, **{k: v for k, v in S.arr.items() if v is not None}}

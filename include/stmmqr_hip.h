@@ -217,6 +217,10 @@ stm_long stmmqr_front(stm_long m, stm_long n, stm_long npiv, double tol, stm_lon
                       stm_long *Stair, char *Rdead, double *Tau, double *flops);
 int stmmqr_larftb_qtx(stm_long m, stm_long n, stm_long k, stm_long ldc, stm_long ldv, const double *V,
                       const double *Tau, double *C);
+/* device time (ms, HIP events) of the kernels of the last qr_front / stmmqr_front / qr_assemble seam call on this
+ * thread's device, -1 if none: the seams take host buffers, so their wall time is dominated by the copies; the kernel
+ * micro-benchmarks of SURVEY.md 8(d) (bench.py --workload micro) read this instead */
+double stmmqr_last_seam_ms(void);
 
 /* ================================================================================================
  * 3. Configuration / introspection
@@ -225,7 +229,7 @@ typedef struct stmmqr_options {
     int panel_width;        /* Householder panel width on device (<= 32); reference FCHUNK = 32          */
     int big_front_cols;     /* fronts with fn >= this use the multi-workgroup panel/update path           */
     int verbose;
-    int use_graph;          /* capture the level schedule into a hipGraph                                 */
+    int use_graph;          /* reserved (ignored): the level schedule is enqueued ahead of the device as it is     */
     int lookahead;          /* overlap panel p+1 with the rest of the trailing update of panel p (2 streams) */
     int split_update;       /* row-parallel (3-launch) trailing update for tall panels                      */
     int tall_min_rows;      /* panels with more rows than this run as a pipeline of 8-column groups (plan time) */

@@ -5,5 +5,5 @@ The product is the C-ABI shared library ``libstmmqr_hip.so`` (sources in ``csrc/
 path (same names and argument meaning as STMMQR/include/SparseQR.h) on numpy arrays; it contains no numeric
 code and no CPU fallback: importing :mod:`capi` raises if the HIP library has not been built.
 """
-from .capi import (HipQR, QRNumeric, StmmqrError, device_count, device_name, get_options, lib, lib_path,  # noqa: F401
-                   qr_assemble, qr_cpack, qr_factorize, qr_fcsize, qr_front, qr_larftb, qr_rhpack, set_options)
+from .capi import (HipQR, QRNumeric, StmmqrError, device_count, device_name, get_options, last_seam_ms, lib,  # noqa: F401
+                   lib_path, qr_assemble, qr_cpack, qr_factorize, qr_fcsize, qr_front, qr_larftb, qr_rhpack, set_options)

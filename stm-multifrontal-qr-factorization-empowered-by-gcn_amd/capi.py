@@ -76,6 +76,8 @@ lib.stmmqr_front.restype = C.c_long
 lib.stmmqr_front.argtypes = [C.c_long, C.c_long, C.c_long, C.c_double, C.c_long, c_double_p, c_long_p, C.c_char_p,
                              c_double_p, c_double_p]
 lib.stmmqr_larftb_qtx.argtypes = [C.c_long] * 5 + [c_double_p, c_double_p, c_double_p]
+lib.stmmqr_last_seam_ms.restype = C.c_double
+lib.stmmqr_last_seam_ms.argtypes = []
 lib.qr_cpack.restype = C.c_long
 lib.qr_cpack.argtypes = [C.c_long] * 4 + [c_double_p, c_double_p]
 lib.qr_rhpack.restype = C.c_long
@@ -298,6 +300,11 @@ def qr_front(m, n, npiv, tol, ntol, F, Stair):
     if r < 0:
         raise StmmqrError(f"stmmqr_front failed: {last_error()}")
     return int(r), Tau[:n], Rdead[:min(n, max(npiv, 0))], fl.value
+
+
+def last_seam_ms() -> float:
+    """Device time (ms) of the kernels of the last qr_front / qr_assemble seam call (-1: none)."""
+    return float(lib.stmmqr_last_seam_ms())
 
 
 def qr_larftb(method, m, n, k, ldc, ldv, V, Tau, Cmat):

@@ -39,20 +39,22 @@ struct PanelDesc {
     // tall-panel pipeline state (sub-panels of STM_SW columns, one launch per sub-panel)
     int tmax;                // rows [pg1, tmax) are touched by the panel
     int nlive;               // live reflectors so far
-    int sw;                  // sub-panel width of this panel: 8, or 4 when the rows need 8 registers per thread and column
+    int sw;                  // sub-panel width of this panel: 8; 4 / 2 when the rows need 8 / 16 registers per thread and column
     int done_group;          // group that ran out of rows (g reached fm), -1 if none
     int t_deferred;          // 1: the panel kernel left T to k_upd_w (Gram block + the last slab workgroup builds T)
     int pad3;
-    int sg[STM_NB / 4];      // first active row (g) at the start of sub-panel s
-    int st[STM_NB / 4];      // one past the last row reached by the reflectors of sub-panel s
+    int sg[STM_NB / 2];      // first active row (g) at the start of sub-panel s
+    int st[STM_NB / 2];      // one past the last row reached by the reflectors of sub-panel s
     double lensum;           // sum of (t - g) over the live columns so far (flop accounting of the trailing update)
 };
 
 #define STM_SW 8             // sub-panel width of the tall-panel pipeline (4 above STM_TALL_WIDE rows)
 #define STM_TALL_MIN 256     // default of stmmqr_options::tall_min_rows: panels with more (estimated) rows take the pipeline
 #define STM_TALL_NTH 512     // threads of the panel kernel
-#define STM_TALL_MAX (8 * STM_TALL_NTH)   // rows a sub-panel can hold in registers (8 per thread)
+#define STM_TALL_MAX (16 * STM_TALL_NTH)  // rows a sub-panel can hold in registers (16 per thread)
 #define STM_TALL_WIDE (4 * STM_TALL_NTH)  // more rows than this: 4-column sub-panels (64 doubles of register image)
+#define STM_TALL_XWIDE (8 * STM_TALL_NTH) // more rows than this: 2-column sub-panels
+#define STM_PROG 64          // FrontNum::prog advances by this much per panel (2 per column group + 1, <= 16 groups)
 
 // Does panel p of this front take the tall-panel pipeline?  Planned on the host (number of launches) and re-evaluated
 // on the device from the same symbolic data, so both always agree.
@@ -63,14 +65,15 @@ static inline __host__ __device__ int stm_tall_panel(const FrontSym &s, int p, i
     if (g > s.fm_est) g = s.fm_est;
     return s.fm_est - g > tall_min;
 }
-// planned number of panel launches (sub-panels) for panel p: 1 (not tall), 4, or 8 when 4-column sub-panels may be needed
+// planned number of column groups for panel p: 1 (not tall), 4, or 8 / 16 when 4- / 2-column sub-panels may be needed
 static inline __host__ __device__ int stm_tall_launches(const FrontSym &s, int p, int tall_min)
 {
     if (!stm_tall_panel(s, p, tall_min)) return 1;
     int g = p * STM_NB;
     if (g > s.fp) g = s.fp;
     if (g > s.fm_est) g = s.fm_est;
-    return (s.fm_est - g > STM_TALL_WIDE) ? STM_NB / 4 : STM_NB / STM_SW;
+    const int rows = s.fm_est - g;
+    return (rows > STM_TALL_XWIDE) ? STM_NB / 2 : (rows > STM_TALL_WIDE) ? STM_NB / 4 : STM_NB / STM_SW;
 }
 
 // numeric, written by the kernels
@@ -82,7 +85,7 @@ struct FrontNum {
     int cm;                  // rows of the contribution block      (qr_cpack's return value)
     int rsize;               // entries of the packed R+H block     (qr_rhpack's return value)
     int hdr;                 // tall-panel pipeline: p+1 once the header (mode, pg1, tmax, sw) of panel p is published
-    int prog;                // ... 32*p + 2*(finished groups of panel p) + (1: first half of the next one); monotone
+    int prog;                // ... STM_PROG*p + 2*(finished groups of panel p) + (1: first half of the next one); monotone
     int perr;                // ... set when a bounded wait ran out (the factorization is reported as failed)
     int gcnt;                // arrival counter of the Gram slabs in k_upd_w (back to 0 after every panel)
     double flops;            // reference flop count of this front  (FLOP_COUNT, :1571)

@@ -248,7 +248,7 @@ void build_schedule(stmmqr_plan &P, std::vector<int> &tslot)
             for (int i = 0; i < L.n_all; i++) {
                 const FrontSym &s = P.fs[P.lists[L.all_off + i]];
                 long work = (long)s.fm_ub * s.fn;
-                int parts = (int)std::min(128L, std::max(1L, (work + 16383) / 16384));
+                int parts = (int)std::min(512L, std::max(1L, (work + 16383) / 16384));     // (two workgroups per CU on the top fronts)
                 P.lists.push_back(parts);
                 L.asm_maxparts = std::max(L.asm_maxparts, parts);
             }

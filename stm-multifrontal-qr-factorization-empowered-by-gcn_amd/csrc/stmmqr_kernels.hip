@@ -1182,7 +1182,7 @@ __device__ __forceinline__ void dev_tall_group(PanelShared &ps, const FrontSym &
     // ---- apply the reflectors of the groups before mine, as they become available ----
     int prev_done = 0;
     constexpr int HW = SWT / 2;                                // reflectors per published half group
-    constexpr int NGP = (HW * SWT) / 8;                        // exchange groups of eight V'C products
+    constexpr int NPV = HW * SWT, NGP = (NPV + 7) / 8;         // V'C products, in exchange groups of eight
     // (a group publishes twice: after the first half of its columns and at the end, so that the next group applies the
     //  first half of the reflectors while the second half is still being factorized)
     int seen = -1;
@@ -1191,7 +1191,7 @@ __device__ __forceinline__ void dev_tall_group(PanelShared &ps, const FrontSym &
     double ch_ls = 0, ch_fl = 0;
     for (int sp = 0; sp < b && !prev_done; sp++)
     for (int half = 0; half < 2; half++) {
-        if (!wait_progress(&num->prog, 32 * p + 2 * sp + 1 + half, seen)) { if (tid == 0) st_agent(&num->perr, 1); return; }
+        if (!wait_progress(&num->prog, STM_PROG * p + 2 * sp + 1 + half, seen)) { if (tid == 0) st_agent(&num->perr, 1); return; }
         TSTAMP(7);
         TL(2 + 3 * tl_h);
         const int pc0 = SWT * sp + half * (SWT / 2);
@@ -1232,7 +1232,7 @@ __device__ __forceinline__ void dev_tall_group(PanelShared &ps, const FrontSym &
         if (tid == 0) seen = ld_agent(&num->prog);             // for the next wait: in flight during the block below
         // exchange group 0: the strict upper triangle of V'V; groups 1..: V'C, eight products per group
         const int lane = tid & 63, wid = tid >> 6;
-        {
+        if constexpr (HW > 1) {
             double gv[8];
 #pragma unroll
             for (int e = 0; e < 8; e++) gv[e] = 0.0;
@@ -1254,10 +1254,12 @@ __device__ __forceinline__ void dev_tall_group(PanelShared &ps, const FrontSym &
             double pv[8];
 #pragma unroll
             for (int e = 0; e < 8; e++) {
-                const int q = (gi * 8 + e) / SWT, x = (gi * 8 + e) % SWT;
+                const int q = min((gi * 8 + e) / SWT, HW - 1), x = (gi * 8 + e) % SWT;
                 double acc = 0.0;
+                if (gi * 8 + e < NPV) {
 #pragma unroll
-                for (int r = 0; r < RPT; r++) acc += v[q][r] * a[r][x];
+                    for (int r = 0; r < RPT; r++) acc += v[q][r] * a[r][x];
+                }
                 pv[e] = acc;
             }
             const double rw = wave_reduce8(pv);
@@ -1266,7 +1268,8 @@ __device__ __forceinline__ void dev_tall_group(PanelShared &ps, const FrontSym &
         lds_barrier();
         // T (upper triangular, dlarft forward/columnwise): T(0:j,j) = -tau_j T(0:j,0:j) (V(:,0:j)' v_j)
         double Tq[HW][HW];
-        {
+        if constexpr (HW == 1) Tq[0][0] = tq[0];
+        else {
             const double rs = wave_sum_stride8((lane < (NTH / 64) * 8) ? ps.rsumB[0][lane] : 0.0);
             const double G8[8] = {lane_bcast<red8_lane(0)>(rs), lane_bcast<red8_lane(1)>(rs), lane_bcast<red8_lane(2)>(rs),
                                   lane_bcast<red8_lane(3)>(rs), lane_bcast<red8_lane(4)>(rs), lane_bcast<red8_lane(5)>(rs),
@@ -1300,9 +1303,11 @@ __device__ __forceinline__ void dev_tall_group(PanelShared &ps, const FrontSym &
                                   lane_bcast<red8_lane(6)>(rs), lane_bcast<red8_lane(7)>(rs)};
 #pragma unroll
             for (int e = 0; e < 8; e++) {
-                const int l = (gi * 8 + e) / SWT, x = (gi * 8 + e) % SWT;
+                if (gi * 8 + e < NPV) {
+                    const int l = min((gi * 8 + e) / SWT, HW - 1), x = (gi * 8 + e) % SWT;
 #pragma unroll
-                for (int q = l; q < HW; q++) Wq[q][x] += Tq[l][q] * P8[e];
+                    for (int q = l; q < HW; q++) Wq[q][x] += Tq[l][q] * P8[e];
+                }
             }
         }
 #pragma unroll
@@ -1354,7 +1359,7 @@ __device__ __forceinline__ void dev_tall_group(PanelShared &ps, const FrontSym &
     lds_barrier();                                             // ps.stair
     for (int j = 0; j < sw && !prev_done; j++) {
         const int jp = c0 + j, k = k1 + jp;
-        if (j == SWT / 2 && b + 1 < ns) publish_progress(&num->prog, 32 * p + 2 * b + 1);   // first half is in F
+        if (j == SWT / 2 && b + 1 < ns) publish_progress(&num->prog, STM_PROG * p + 2 * b + 1);   // first half is in F
         if (!done && g >= m) {
             // no rows left: remaining pivotal columns are dead, remaining columns are empty (:1444-1458)
             for (int kk = k + tid; kk < n; kk += NTH) {
@@ -1452,7 +1457,7 @@ __device__ __forceinline__ void dev_tall_group(PanelShared &ps, const FrontSym &
         if (done) st_agent(&pd->done_group, b);
     }
     if (!last) {
-        publish_progress(&num->prog, 32 * p + 2 * b + 2);
+        publish_progress(&num->prog, STM_PROG * p + 2 * b + 2);
         TL(30);
         return;
     }
@@ -1471,7 +1476,7 @@ __device__ __forceinline__ void dev_tall_group(PanelShared &ps, const FrontSym &
         num->flops_upd += 4.0 * (double)(n - k2) * (prev_done ? ls_before : ls_before + lensum);
     }
     if (defer_t) {
-        publish_progress(&num->prog, 32 * p + 2 * b + 2);
+        publish_progress(&num->prog, STM_PROG * p + 2 * b + 2);
         return;
     }
     if (tid < STM_NB) {
@@ -1493,7 +1498,7 @@ __device__ __forceinline__ void dev_tall_group(PanelShared &ps, const FrontSym &
     TL(31);
     // (when an earlier group ran out of rows the groups after mine are still storing their columns: the kernel
     //  boundary orders those stores before the trailing update)
-    publish_progress(&num->prog, 32 * p + 2 * b + 2);
+    publish_progress(&num->prog, STM_PROG * p + 2 * b + 2);
 #undef TSTAMP
 #undef TL
 #undef TLW
@@ -1595,7 +1600,7 @@ __global__ __launch_bounds__(NTP) void k_panel(DevCtx c, const int *__restrict__
             const int was_done = num->done;
             g1 = num->g;
             tmax = min(num->fm, max(St[k2 - 1], g1 + nbp));
-            w = (tmax - g1 > STM_TALL_WIDE) ? 4 : STM_SW;
+            w = (tmax - g1 > STM_TALL_XWIDE) ? 2 : (tmax - g1 > STM_TALL_WIDE) ? 4 : STM_SW;
             // mode 0: nothing to do or the whole panel is done below by this workgroup (it does not fit the register
             // image, or needs more groups than were launched: more rows than the full-rank estimate)
             mode = (was_done || tmax - g1 > STM_TALL_MAX || (nbp + w - 1) / w > nsub) ? 0 : 1;
@@ -1615,7 +1620,8 @@ __global__ __launch_bounds__(NTP) void k_panel(DevCtx c, const int *__restrict__
         if (mode == 1) {
             const int rows = tmax - g1;
 #define TALL_ARGS ps, s, num, pd, F, St, c.Tau + s.rp, c.Rdead + s.col1, p, b, g1, tmax, c.tol, c.ntol, T, dyn_lds, c.dbg, c.dbgbuf, Tkeep, defer_ok
-            if (w == 4) dev_tall_group<NTP, 8, 4>(TALL_ARGS);
+            if (w == 2) dev_tall_group<NTP, 16, 2>(TALL_ARGS);
+            else if (w == 4) dev_tall_group<NTP, 8, 4>(TALL_ARGS);
             else if (rows <= NTP) dev_tall_group<NTP, 1, 8>(TALL_ARGS);
             else if (rows <= 2 * NTP) dev_tall_group<NTP, 2, 8>(TALL_ARGS);
             else dev_tall_group<NTP, 4, 8>(TALL_ARGS);
@@ -1814,6 +1820,12 @@ __global__ __launch_bounds__(NT) void k_upd_c(DevCtx c, const int *__restrict__ 
     const int cb = blockIdx.x, sl = blockIdx.y;
     const int c0 = pd->pc0 + (cb0 + cb) * BN;
     if (nbp <= 0 || mp <= 0 || c0 >= s.fn || sl * SLAB >= mp) return;
+    // Very tall panels: one workgroup takes 2 or 4 slabs -- every workgroup of a column block sums the same nsl partial
+    // W (nsl x 8 KB: twice a slab of V and C at 32 slabs), so fewer, longer workgroups read less per updated row.
+    // (The rows of C are independent here: the arithmetic does not change.)
+    const int nsl_all = (mp + SLAB - 1) / SLAB;
+    const int spw = (nsl_all >= 32) ? 4 : (nsl_all >= 16) ? 2 : 1;
+    if (sl % spw) return;
     const int nc = min(BN, s.fn - c0);
     const long long ld = s.ld;
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, l15 = lane & 15, l4 = lane >> 4;
@@ -1852,7 +1864,7 @@ __global__ __launch_bounds__(NT) void k_upd_c(DevCtx c, const int *__restrict__ 
         for (int x = 0; x < 4; x++) Ws[l * WS + cg * 4 + x] = w2[x];
     }
     __syncthreads();
-    const int rend = min(mp, (sl + 1) * SLAB);
+    const int rend = min(mp, (sl + spw) * SLAB);
     for (int r0 = sl * SLAB; r0 < rend; r0 += RB) {
         const int i = r0 + lrow;
         upd_chunk_to_lds(ck, i, mp, nbp, nc, s_pd, g1, lrow, lcg, Vs, Cs);

@@ -104,6 +104,31 @@ struct OneFront {
     }
 };
 
+// device time of the kernels of the last seam call (hipEvents on the null stream), for the kernel micro-benchmarks
+double g_seam_ms = -1.0;
+struct SeamTimer {
+    hipEvent_t a = nullptr, b = nullptr;
+    SeamTimer()
+    {
+        g_seam_ms = -1.0;
+        if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) { a = b = nullptr; return; }
+        (void)hipEventRecord(a, nullptr);
+    }
+    void stop()
+    {
+        if (!a || !b) return;
+        float ms = 0;
+        if (hipEventRecord(b, nullptr) == hipSuccess && hipEventSynchronize(b) == hipSuccess &&
+            hipEventElapsedTime(&ms, a, b) == hipSuccess)
+            g_seam_ms = ms;
+    }
+    ~SeamTimer()
+    {
+        if (a) (void)hipEventDestroy(a);
+        if (b) (void)hipEventDestroy(b);
+    }
+};
+
 int lds_for(long m) { return (int)std::min(15360L, (((m + 63) & ~63L) | 1) * STM_NB + 64); }
 
 }  // namespace
@@ -111,6 +136,8 @@ int lds_for(long m) { return (int)std::min(15360L, (((m + 63) & ~63L) | 1) * STM
 extern "C" {
 
 void stmmqr_get_options(stmmqr_options *o);
+
+double stmmqr_last_seam_ms(void) { return g_seam_ms; }
 
 // ---------------------------------------------------------------------------------------------
 // qr_front (SparseQR.h:209-226 / SparseQR_factorize.c:1383-1618)
@@ -127,15 +154,27 @@ stm_long stmmqr_front(stm_long m, stm_long n, stm_long npiv, double tol, stm_lon
     stmmqr_get_options(&opt);
     const bool big = n >= opt.big_front_cols && m >= 64;
     int e = 0;
+    SeamTimer timer;
     if (!big) {
         e = stm_launch_front_wg(X.c, X.d_flist.p, 1, lds_for(m), nullptr);
     } else {
+        // as the plan does: a front of >= 3 row slabs takes the row-parallel update (and may leave T to it)
+        const int msl = (int)((m + 255) / 256);
+        const bool split = opt.split_update && msl >= 3;
+        Buf<double> d_Wp;
+        if (split && !d_Wp.alloc((size_t)((n + 31) / 32 + 1) * (size_t)msl * STM_NB * 32)) return -1;
         for (int p = 0; p < X.s.npanels && !e; p++) {
-            e = stm_launch_panel(X.c, X.d_flist.p, 1, p, stm_tall_launches(X.s, p, X.c.tall_min), 0, lds_for(m), nullptr);
             const int k2 = (int)std::min<long>(n, (long)(p + 1) * STM_NB);
-            if (!e) e = stm_launch_update(X.c, X.d_flist.p, 1, p, 0, (int)((n - k2 + 31) / 32), nullptr);
+            const int ncb = (int)((n - k2 + 31) / 32);
+            const int defer_ok = (split && ncb > 0) ? 1 : 0;
+            e = stm_launch_panel(X.c, X.d_flist.p, 1, p, stm_tall_launches(X.s, p, X.c.tall_min), defer_ok, lds_for(m), nullptr);
+            if (e || ncb <= 0) continue;
+            if (split) e = stm_launch_update_split(X.c, X.d_flist.p, 1, p, 0, ncb, msl, d_Wp.p, 1, nullptr);
+            else e = stm_launch_update(X.c, X.d_flist.p, 1, p, 0, ncb, nullptr);
         }
+        if (hipDeviceSynchronize() != hipSuccess) e = -1;          // (d_Wp is released at the end of this scope)
     }
+    timer.stop();
     if (e || hipDeviceSynchronize() != hipSuccess) return -1;
 #ifdef STMMQR_STAMPS
     if (X.c.dbg & 48) {
@@ -404,7 +443,8 @@ void qr_assemble(stm_long f, stm_long fm, int keepH, stm_long *Super, stm_long *
     if (sj0.empty()) sj0.push_back(0);
     Buf<FrontSym> d_fs; Buf<FrontNum> d_nm; Buf<double> d_F, d_C, d_Sx;
     Buf<int> d_child, d_rjrel, d_sjrel, d_sp, d_sj0, d_sleft, d_st, d_hii, d_cmap, d_cur, d_flist, d_parts;
-    std::vector<int> zero1(1, 0), parts(1, 4);
+    const int nparts = (int)std::min(512L, std::max(4L, ((long)fm * (long)fn + 16383) / 16384));    // (as the plan does)
+    std::vector<int> zero1(1, 0), parts(1, nparts);
     std::vector<int> hii_g(hii);       // S rows get LOCAL ids on the device; translate after download
     bool ok = d_fs.up(fs) && d_nm.up(fnum) && d_F.alloc((size_t)s.ld * (size_t)std::max<stm_long>(1, fn)) && d_C.up(Carena) &&
               d_Sx.up(sx) && d_child.up(child) && d_rjrel.up(rjrel) && d_sjrel.up(sjrel) && d_sp.up(sp32) &&
@@ -417,8 +457,10 @@ void qr_assemble(stm_long f, stm_long fm, int keepH, stm_long *Super, stm_long *
     c.fs = d_fs.p; c.fnum = d_nm.p; c.Farena = d_F.p; c.Carena = d_C.p; c.Sx = d_Sx.p; c.Sp = d_sp.p;
     c.Sjrel = d_sjrel.p; c.Sj0 = d_sj0.p; c.Sleft = d_sleft.p; c.Child = d_child.p; c.Rjrel = d_rjrel.p;
     c.Stair = d_st.p; c.Hii = d_hii.p; c.Cmap = d_cmap.p; c.Cursor = d_cur.p;
+    SeamTimer timer;
     if (stm_launch_setup(c, d_flist.p, 1, nullptr)) return;
-    if (stm_launch_assemble(c, d_flist.p, d_parts.p, 1, 4, nullptr)) return;
+    if (stm_launch_assemble(c, d_flist.p, d_parts.p, 1, nparts, nullptr)) return;
+    timer.stop();
     if (hipDeviceSynchronize() != hipSuccess) return;
     // results: F, Stair (advanced), Hii rows of f, Cmap of the LAST child (what the reference leaves behind)
     std::vector<double> Fd((size_t)s.ld * (size_t)std::max<stm_long>(1, fn));

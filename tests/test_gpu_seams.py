@@ -36,6 +36,8 @@ FRONTS = [(6, 4, 4), (5, 8, 3), (40, 30, 12), (64, 96, 32), (130, 70, 70), (266,
           (97, 33, 0), (33, 97, 97), (1, 5, 2), (700, 64, 64),
           # tall panels: the sub-panel pipeline (register-resident column groups, one launch per 8 columns)
           (1500, 96, 64), (2600, 80, 80), (900, 200, 40), (1100, 72, 72), (4200, 40, 40), (800, 1000, 900),
+          # more than 4096 rows: 2-column groups (16 rows per thread), 16 groups per panel; more than 8192: one workgroup
+          (6000, 48, 48), (8192, 40, 33), (8300, 36, 36),
           # rows run out in the middle of a sub-panel of a pipelined panel
           (1003, 1100, 900), (781, 900, 300), (1290, 1400, 64)]
 
@@ -65,7 +67,8 @@ def test_qr_front(pkg, oracle, m, n, npiv, bigcols, tall_min, stair):
 
 
 @pytest.mark.parametrize("late", [0, 1, 2, 3])
-@pytest.mark.parametrize("m,n,npiv", [(266, 422, 124), (781, 900, 300), (1290, 1400, 64), (1500, 96, 64), (33, 97, 97)])
+@pytest.mark.parametrize("m,n,npiv", [(266, 422, 124), (781, 900, 300), (1290, 1400, 64), (1500, 96, 64), (33, 97, 97),
+                                     (5000, 70, 64)])
 def test_pipeline_with_a_late_column_group(pkg, oracle, monkeypatch, late, m, n, npiv):
     """The column groups of a pipelined panel may start in any order and arbitrarily late (a launch with more
     workgroups than the GPU holds at once): STMMQR_DBG bit 11 delays group `late` by ~1 ms.  Fronts whose rows run out
@@ -157,3 +160,30 @@ def test_qr_rhpack(pkg, oracle, m, n, npiv):
     rso = oracle.lib.orc_rhpack(m, n, npiv, _ip(So), _dp(Fo), _dp(Ro), C.byref(rmo))
     assert (rs, rm) == (rso, rmo.value)
     np.testing.assert_array_equal(Rg, Ro[:rs])
+
+
+def test_micro_assembly_column_sums(pkg):
+    """The synthetic assembly of bench.py --workload micro at a small size: qr_assemble is an extend-COPY,
+    so every column of F must sum to the S entries plus the children's packed C entries that map to it; the seam reports
+    the device time of its kernels."""
+    import bench
+    P, CN = 4, 40
+    a, nbytes, (fm, fn) = bench.micro_assembly_input(seed=5, P=P, FN=96, FP=32, CN=CN, NS=12)
+    F, _ = pkg.qr_assemble(**a)
+    assert F.shape == (fm, fn)
+    expect = np.zeros(fn)
+    Sp, Sj, Sx, Fmap, Rp, Rj = a["Sp"], a["Sj"], a["Sx"], a["Fmap"], a["Rp"], a["Rj"]
+    for r in range(len(Sp) - 1):
+        for q in range(Sp[r], Sp[r + 1]):
+            expect[Fmap[Sj[q]]] += Sx[q]
+    for c in (0, 1):
+        cols = Fmap[Rj[Rp[c] + P:Rp[c + 1]]]
+        pos = 0
+        for k in range(CN):                                   # packed upper triangle: column k holds rows 0..k
+            expect[cols[k]] += a["Cblocks"][c][pos:pos + k + 1].sum()
+            pos += k + 1
+    assert np.allclose(F.sum(axis=0), expect, rtol=0, atol=1e-12 * max(1.0, np.abs(expect).max()))
+    assert np.count_nonzero(F) == len(Sx) + 2 * (CN * (CN + 1) // 2)
+    st = a["Stair"]
+    assert np.all(np.diff(st) >= 0) and st[-1] == fm
+    assert pkg.last_seam_ms() > 0.0
