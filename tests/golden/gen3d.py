@@ -10,9 +10,11 @@ tests on the GPU box to regenerate the VALUES (the symbolic analysis of the patt
 import numpy as np
 
 
-def gen3d(nx, ny, nz, seed, stencil27=True, dof=1):
+def gen3d(nx, ny, nz, seed, stencil27=True, dof=1, longrange=0):
     """CSC (Ap, Ai, Ax) of an unsymmetric-valued 7/27-point operator on an nx*ny*nz grid, `dof` unknowns per grid point
-    (every pair of neighbouring points couples all their unknowns: dof x dof blocks)."""
+    (every pair of neighbouring points couples all their unknowns: dof x dof blocks); longrange > 0 adds that many
+    random couplings per grid point to points anywhere in the grid (no small separators: the top fronts of the
+    frontal tree become a large fraction of n -- the structure of SURVEY.md 8(d)'s stand-in for 3D_51448_3D)."""
     rng = np.random.default_rng(seed)
     idx = np.arange(nx * ny * nz).reshape(nx, ny, nz)
     rows, cols = [], []
@@ -26,6 +28,14 @@ def gen3d(nx, ny, nz, seed, stencil27=True, dof=1):
                 zs = slice(max(0, -dz), nz - max(0, dz)); zt = slice(max(0, dz), nz - max(0, -dz))
                 rows.append(idx[xs, ys, zs].ravel()); cols.append(idx[xt, yt, zt].ravel())
     r = np.concatenate(rows); c = np.concatenate(cols)
+    if longrange > 0:
+        npts = idx.size
+        r2 = np.repeat(np.arange(npts), longrange)
+        c2 = rng.integers(0, npts, npts * longrange)
+        r = np.concatenate([r, r2]); c = np.concatenate([c, c2])
+        _, first = np.unique(c * npts + r, return_index=True)      # (a random coupling may repeat a stencil entry)
+        first.sort()
+        r, c = r[first], c[first]
     if dof > 1:
         a, b = np.meshgrid(np.arange(dof), np.arange(dof), indexing="ij")
         r = (r[:, None] * dof + a.ravel()[None, :]).ravel()
@@ -47,10 +57,15 @@ STANDINS = {
     "grid20_standin": (20, 20, 20, 0x58454E31, True, 2),
     # BASELINE configs[3] (sme3Dc.mtx, absent): 3 unknowns per grid point, ~81 nnz per row
     "sme3dc_standin": (24, 24, 25, 0x534D4533, True, 2, 3),
+    # the STRUCTURE of BASELINE configs[4] (3D_51448_3D.mtx, absent; SURVEY.md 8d: 7-point + random long-range couplings,
+    # 13 nnz per row) at 1/6.5 of its size: n = 8000, top front 0.4 n, 4.4e11 flops (the full size, n = 52 022, is
+    # ~1.2e14 flops and ~20 GB of factors: 47 minutes for the reference on one core)
+    "c5mini_standin": (20, 20, 20, 0x33445F35, False, 2, 1, 6),
 }
 
 
 def standin_matrix(name):
     nx, ny, nz, seed, s27, _ = STANDINS[name][:6]
     dof = STANDINS[name][6] if len(STANDINS[name]) > 6 else 1
-    return gen3d(nx, ny, nz, seed, s27, dof)
+    longrange = STANDINS[name][7] if len(STANDINS[name]) > 7 else 0
+    return gen3d(nx, ny, nz, seed, s27, dof, longrange)

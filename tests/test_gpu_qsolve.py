@@ -124,9 +124,11 @@ def test_blocked_qapply_equals_reflector_by_reflector(pkg, name, monkeypatch):
         plan.close()
 
 
-def test_solve_full_size_standin(pkg):
-    """BASELINE configs[2] size: residual of the device solve, factors never leave HBM."""
-    g = load_golden("xenon1_standin")
+@pytest.mark.parametrize("name", ["xenon1_standin", "c5mini_standin"])
+def test_solve_full_size_standin(pkg, name):
+    """BASELINE configs[2] size (and the configs[4] structure with a 7818-row top front: 2-column panel groups, T built
+    by the row-parallel update): residual of the device solve, factors never leave HBM."""
+    g = load_golden(name)
     S, plan = factorized_plan(pkg, g)
     try:
         Ap, Ai, Ax = g["in_Ap"], g["in_Ai"], g["in_Ax"]

@@ -13,7 +13,8 @@ PKG = "stm-multifrontal-qr-factorization-empowered-by-gcn_amd"
 
 
 @pytest.mark.parametrize("name,nranks", [(n, r) for n in ("epb1", "grid20_standin", "syn_rankdef_grid", "lns_3937") for r in (2, 4)] +
-                         [("sme3dc_standin", 4)])     # BASELINE configs[3]: the sme3Dc stand-in on 4 ranks
+                         [("sme3dc_standin", 4),      # BASELINE configs[3]: the sme3Dc stand-in on 4 ranks
+                          ("c5mini_standin", 8)])     # the structure of configs[4] (8 ranks) at n = 8000
 def test_sharded_equals_unsharded(name, nranks):
     pkg = importlib.import_module(PKG)
     sh = importlib.import_module(PKG + ".sharded")
