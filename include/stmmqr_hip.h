@@ -232,7 +232,7 @@ typedef struct stmmqr_options {
     int use_graph;          /* reserved (ignored): the level schedule is enqueued ahead of the device as it is     */
     int lookahead;          /* overlap panel p+1 with the rest of the trailing update of panel p (2 streams) */
     int split_update;       /* row-parallel (3-launch) trailing update for tall panels                      */
-    int tall_min_rows;      /* panels with more rows than this run as a pipeline of 8-column groups (plan time) */
+    int tall_min_rows;      /* panels with more rows than this run as a pipeline of 8-column groups (plan time; 0) */
 } stmmqr_options;
 void stmmqr_get_options(stmmqr_options *opt);
 void stmmqr_set_options(const stmmqr_options *opt);

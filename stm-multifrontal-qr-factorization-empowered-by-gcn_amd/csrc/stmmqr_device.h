@@ -49,7 +49,8 @@ struct PanelDesc {
 };
 
 #define STM_SW 8             // sub-panel width of the tall-panel pipeline (4 above STM_TALL_WIDE rows)
-#define STM_TALL_MIN 256     // default of stmmqr_options::tall_min_rows: panels with more (estimated) rows take the pipeline
+#define STM_TALL_MIN 0       // default of stmmqr_options::tall_min_rows: panels with more (estimated) rows take the pipeline
+                             // (0: every panel of a large front; the one-workgroup LDS panel is kept for the small-front kernel)
 #define STM_TALL_NTH 512     // threads of the panel kernel
 #define STM_TALL_MAX (16 * STM_TALL_NTH)  // rows a sub-panel can hold in registers (16 per thread)
 #define STM_TALL_WIDE (4 * STM_TALL_NTH)  // more rows than this: 4-column sub-panels (64 doubles of register image)

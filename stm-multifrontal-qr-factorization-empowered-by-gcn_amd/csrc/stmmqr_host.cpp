@@ -561,8 +561,8 @@ int run_schedule(stmmqr_plan &P, bool detail, int grp, bool first)
         if (detail || !g_opt.lookahead) {
             for (size_t p = 0; p < L.nbig_at.size(); p++) {
                 e = timed(t_front, [&]() -> int {
-                    // the split update may build T itself (its Gram block), see dev_tall_group
-                    const int defer_ok = (L.maxsl_at[p] > 0 && g_opt.split_update && L.maxcb_at[p] > 0) ? 1 : 0;
+                    // the trailing update (either form) builds T itself, see dev_tall_group
+                    const int defer_ok = (L.maxcb_at[p] > 0) ? 1 : 0;
                     LCHK(stm_launch_panel(c, big, L.nbig_at[p], (int)p, L.nsub_at[p], defer_ok, L.lds_big, st));
                     return 0;
                 });

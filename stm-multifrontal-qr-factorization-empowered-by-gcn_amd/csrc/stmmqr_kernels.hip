@@ -262,8 +262,14 @@ __device__ __forceinline__ void upd_chunk_to_lds(const UpdChunk &ck, int i, int 
 // v_mfma_f64_16x16x4_f64 operand maps (cdna_hip_programming.md 3): A[i=l&15][k=l>>4], B[k=l>>4][j=l&15],
 // D[i=(l>>4)+4r][j=l&15].
 // ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void dev_T_from_gram(double (*G)[STM_NB + 1], double (*T)[STM_NB + 1], const double *tau, int nc);
+
+// tau != nullptr: T was left to the update by the panel kernel (PanelDesc::t_deferred) -- G = V'V is accumulated beside
+// W1 (per 256-row slab, slabs added in order: bit-identical to the Gram block of k_upd_w) and T is built here by every
+// workgroup for itself (dev_T_from_gram); Tout / Tkeep (may be null) receive it from the caller's first column block.
 __device__ void dev_update_block(double *F, long long ld, int g1, int mp, int k1, int nbp, const int *diag,
-                                 const double *T, int c0, int nc, double *lds)
+                                 const double *T, int c0, int nc, double *lds, const double *tau = nullptr,
+                                 double *Tout = nullptr, double *Tkeep = nullptr)
 {
     if (nbp <= 0 || mp <= 0 || nc <= 0) return;
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
@@ -287,7 +293,8 @@ __device__ void dev_update_block(double *F, long long ld, int g1, int mp, int k1
     // W1 is accumulated per slab of 256 rows and the slabs are added in order -- exactly the association of the
     // row-parallel form (k_upd_w partials summed by k_upd_c), so that a front gets bit-identical results whichever of the
     // two its level happens to use
-    d4 acc = {0, 0, 0, 0}, tot = {0, 0, 0, 0};
+    const bool build_t = (tau != nullptr);
+    d4 acc = {0, 0, 0, 0}, tot = {0, 0, 0, 0}, gacc = {0, 0, 0, 0}, gtot = {0, 0, 0, 0};
     UpdChunk ck;
     upd_chunk_load(ck, Vg, Cg, ld, lrow, mp, nbp, nc, lcg);
     for (int r0 = 0; r0 < mp; r0 += RB) {
@@ -300,15 +307,36 @@ __device__ void dev_update_block(double *F, long long ld, int g1, int mp, int k1
             const double a = Vs[(16 * mi + l15) * VS + 4 * kk + l4];
             const double b = Cs[(16 * ni + l15) * VS + 4 * kk + l4];
             acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
+            if (build_t) {
+                const double bv = Vs[(16 * ni + l15) * VS + 4 * kk + l4];
+                gacc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, bv, gacc, 0, 0, 0);
+            }
         }
         if ((r0 + RB) % 256 == 0 || r0 + RB >= mp) {            // end of a 256-row slab (SLAB of the row-parallel form)
 #pragma unroll
-            for (int r = 0; r < 4; r++) { tot[r] += acc[r]; acc[r] = 0; }
+            for (int r = 0; r < 4; r++) { tot[r] += acc[r]; acc[r] = 0; gtot[r] += gacc[r]; gacc[r] = 0; }
         }
         __syncthreads();
     }
 #pragma unroll
     for (int r = 0; r < 4; r++) Ws[(16 * mi + l4 + 4 * r) * WS + 16 * ni + l15] = tot[r];
+    double *s_Tm = Cs;                       // T(q, l) at s_Tm[q * WS + l] when it is built here (the chunk images are free)
+    if (build_t) {
+        double (*Gm)[STM_NB + 1] = reinterpret_cast<double (*)[STM_NB + 1]>(Vs);
+        __shared__ double s_tau_u[STM_NB];
+#pragma unroll
+        for (int r = 0; r < 4; r++) Gm[16 * mi + l4 + 4 * r][16 * ni + l15] = gtot[r];
+        if (tid < STM_NB) s_tau_u[tid] = (tid < nbp) ? tau[tid] : 0.0;
+        __syncthreads();
+        dev_T_from_gram(Gm, reinterpret_cast<double (*)[STM_NB + 1]>(s_Tm), s_tau_u, nbp);
+        if (Tout || Tkeep)
+            for (int e = tid; e < STM_NB * STM_NB; e += blockDim.x) {
+                const int a = e % STM_NB, b = e / STM_NB;
+                const double tv = (a <= b && a < nbp && b < nbp) ? s_Tm[a * WS + b] : 0.0;
+                if (Tout) Tout[e] = tv;
+                if (Tkeep) Tkeep[e] = tv;
+            }
+    }
     __syncthreads();
 
     // ---- phase 2: W2 = T' W1 (T upper triangular) ----
@@ -316,7 +344,7 @@ __device__ void dev_update_block(double *F, long long ld, int g1, int mp, int k1
         const int l = tid & 31, cg = tid >> 5;          // 8 groups x 4 columns
         double w2[4] = {0, 0, 0, 0};
         for (int q = 0; q <= l; q++) {
-            const double tq = T[q + l * STM_NB];
+            const double tq = build_t ? s_Tm[q * WS + l] : T[q + l * STM_NB];
 #pragma unroll
             for (int x = 0; x < 4; x++) w2[x] += tq * Ws[q * WS + cg * 4 + x];
         }
@@ -1463,11 +1491,13 @@ __device__ __forceinline__ void dev_tall_group(PanelShared &ps, const FrontSym &
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // (the write-through column stores of every wave: acknowledged)
     __syncthreads();                                           // all stores of this workgroup are complete and visible
-    // T of a panel with >= 3 row slabs and trailing columns is left to the trailing update (k_upd_w: a Gram block per
-    // slab, the last slab to arrive builds T): the Gram pass over the whole panel leaves the critical path.  The rule
-    // depends on this front alone (such a front always takes the split update), so the results do not depend on which
-    // fronts share a level.
-    const int defer_t = (defer_ok && tlast - g1 >= 3 * 256 && k2 < n) ? 1 : 0;
+    // T of a panel with trailing columns is left to the trailing update: the row-parallel form builds it from a Gram
+    // block per slab (k_upd_w; the last slab to arrive runs the recurrence), the one-workgroup form from the Gram matrix
+    // it accumulates beside W (dev_update_block) -- same association, bit-identical T -- so the Gram pass over the
+    // whole panel (one CU filling rows x 32 columns: 6-11 us) and the recurrence leave the critical path.  The rule
+    // depends on this front alone (defer_ok: an update launch follows this panel launch; k2 < n: this front takes part
+    // in it), so the results do not depend on which fronts share a level.
+    const int defer_t = (defer_ok && k2 < n && tlast > g1) ? 1 : 0;   // (no live reflector: T = 0 is written here)
     if (tid == 0) {
         // (pd->mode stays 1: it belongs to the header, and a column group that starts late -- the finalising group is
         //  not always the last one -- must still find it there)
@@ -1647,8 +1677,18 @@ __global__ __launch_bounds__(NT) void k_update(DevCtx c, const int *__restrict__
     const PanelDesc *pd = &c.fnum[f].pd[p & 1];
     const int c0 = pd->pc0 + (cb0 + (int)blockIdx.x) * BN;
     if (c0 >= s.fn) return;
-    dev_update_block(c.Farena + s.foff, s.ld, pd->pg1, pd->pt - pd->pg1, pd->pk1, pd->pnb, pd->pdiag,
-                     c.Tws + (long long)(2 * c.tslot[f] + (p & 1)) * STM_NB * STM_NB, c0, min(BN, s.fn - c0), dyn_lds);
+    double *Tw = c.Tws + (long long)(2 * c.tslot[f] + (p & 1)) * STM_NB * STM_NB;
+    if (pd->t_deferred) {
+        // T was left to the update: every column-block workgroup builds it from its own Gram matrix; the first one
+        // stores it (T slot of the plan, kept T of the Q-apply)
+        const bool first = (cb0 + (int)blockIdx.x == 0);
+        dev_update_block(c.Farena + s.foff, s.ld, pd->pg1, pd->pt - pd->pg1, pd->pk1, pd->pnb, pd->pdiag, nullptr, c0,
+                         min(BN, s.fn - c0), dyn_lds, c.Tau + s.rp + pd->pk1, first ? Tw : nullptr,
+                         (first && c.Tall) ? c.Tall + (long long)(s.tpan + p) * STM_NB * STM_NB : nullptr);
+        return;
+    }
+    dev_update_block(c.Farena + s.foff, s.ld, pd->pg1, pd->pt - pd->pg1, pd->pk1, pd->pnb, pd->pdiag, Tw, c0,
+                     min(BN, s.fn - c0), dyn_lds);
 }
 
 // standalone T factor of the pending block reflector described by FrontNum (qr_larftb seam)

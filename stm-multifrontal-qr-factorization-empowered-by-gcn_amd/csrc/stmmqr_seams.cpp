@@ -166,7 +166,7 @@ stm_long stmmqr_front(stm_long m, stm_long n, stm_long npiv, double tol, stm_lon
         for (int p = 0; p < X.s.npanels && !e; p++) {
             const int k2 = (int)std::min<long>(n, (long)(p + 1) * STM_NB);
             const int ncb = (int)((n - k2 + 31) / 32);
-            const int defer_ok = (split && ncb > 0) ? 1 : 0;
+            const int defer_ok = (ncb > 0) ? 1 : 0;
             e = stm_launch_panel(X.c, X.d_flist.p, 1, p, stm_tall_launches(X.s, p, X.c.tall_min), defer_ok, lds_for(m), nullptr);
             if (e || ncb <= 0) continue;
             if (split) e = stm_launch_update_split(X.c, X.d_flist.p, 1, p, 0, ncb, msl, d_Wp.p, 1, nullptr);

@@ -58,11 +58,12 @@ def test_against_golden_and_oracle(pkg, oracle, name, bigcols):
         assert np.linalg.norm(G.Stack[:G.rh_total] - ref) <= 1e-10 * max(np.linalg.norm(ref), 1e-300)
 
 
-@pytest.mark.parametrize("name,tall_min", [(n, 0) for n in NAMES] +
+@pytest.mark.parametrize("name,tall_min", [(n, 256) for n in NAMES] +
                          [(n, t) for n in ("syn_grid3d", "syn_rankdef_grid", "bcsstk14", "grid20_standin") for t in (48, 1 << 30)])
 def test_panel_pipeline_threshold(pkg, oracle, name, tall_min):
-    """tall_min_rows = 0 sends every panel of a large front through the pipeline of 8-column groups (register-resident
-    column steps, inter-workgroup progress flags), 1<<30 none: integers, R rows and the factors must not care."""
+    """tall_min_rows = 0 (the default) sends every panel of a large front through the pipeline of 8-column groups
+    (register-resident column steps, inter-workgroup progress flags), 256 only the tall ones, 1<<30 none: integers, R rows
+    and the factors must not care."""
     if name not in NAMES:
         pytest.skip("fixture not present")
     g = load_golden(name)
@@ -70,7 +71,7 @@ def test_panel_pipeline_threshold(pkg, oracle, name, tall_min):
     try:
         S, G = gpu_run(pkg, g)
     finally:
-        pkg.set_options(tall_min_rows=256, big_front_cols=64)
+        pkg.set_options(tall_min_rows=0, big_front_cols=64)
     N = numeric_from_gpu(S, G)
     compare_integers(S, N, g)
     assert G.stats["flops"] == scalar(g, "flopcount")
@@ -92,7 +93,7 @@ def test_pipeline_late_group_whole_factorization(pkg, oracle, monkeypatch, name,
         S, G = gpu_run(pkg, g)
     finally:
         monkeypatch.delenv("STMMQR_DBG")
-        pkg.set_options(tall_min_rows=256, big_front_cols=64)
+        pkg.set_options(tall_min_rows=0, big_front_cols=64)
     N = numeric_from_gpu(S, G)
     compare_integers(S, N, g)
     assert G.stats["flops"] == scalar(g, "flopcount")
@@ -118,7 +119,7 @@ def test_pipeline_oversubscribed_and_chunked_launches(pkg, oracle, monkeypatch, 
         if chunk is not None:
             monkeypatch.delenv("STMMQR_DBG")
             monkeypatch.delenv("STMMQR_CHUNK")
-        pkg.set_options(tall_min_rows=256, big_front_cols=64)
+        pkg.set_options(tall_min_rows=0, big_front_cols=64)
     N = numeric_from_gpu(S, G)
     compare_integers(S, N, g)
     No = oracle.factorize(S, g["in_Ap"], g["in_Ai"], g["in_Ax"], scalar(g, "in_tol"), int(scalar(g, "in_ntol")))
@@ -153,7 +154,7 @@ def test_plan_reuse_across_rank_changes(pkg, oracle, tall_min):
     try:
         plan = pkg.HipQR(sym_dict(S))
     finally:
-        pkg.set_options(tall_min_rows=256, big_front_cols=64)
+        pkg.set_options(tall_min_rows=0, big_front_cols=64)
     rng = np.random.default_rng(9)
     tol, ntol = scalar(g, "in_tol"), int(scalar(g, "in_ntol"))
     ranks = []

@@ -54,7 +54,7 @@ def test_qr_front(pkg, oracle, m, n, npiv, bigcols, tall_min, stair):
     try:
         rg, Tg, Dg, flg = pkg.qr_front(m, n, npiv, -1.0, n, Fg, Sg)
     finally:
-        pkg.set_options(big_front_cols=64, tall_min_rows=256)
+        pkg.set_options(big_front_cols=64, tall_min_rows=0)
     ro, To, Do, flo = oracle.front(Fo, So, npiv, -1.0, n)
     assert rg == ro
     np.testing.assert_array_equal(Sg, So)
@@ -82,7 +82,7 @@ def test_pipeline_with_a_late_column_group(pkg, oracle, monkeypatch, late, m, n,
         rg, Tg, Dg, flg = pkg.qr_front(m, n, npiv, -1.0, n, Fg, Sg)
     finally:
         monkeypatch.delenv("STMMQR_DBG")
-        pkg.set_options(big_front_cols=64, tall_min_rows=256)
+        pkg.set_options(big_front_cols=64, tall_min_rows=0)
     ro, To, Do, flo = oracle.front(Fo, So, npiv, -1.0, n)
     assert rg == ro and flg == flo
     np.testing.assert_array_equal(Sg, So)
