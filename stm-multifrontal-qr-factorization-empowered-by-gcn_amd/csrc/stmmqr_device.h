@@ -26,7 +26,8 @@ struct FrontSym {
     int parent;              // parent front or -1
     int fm_est;              // rows of F if no pivot column dies (exact for full-rank fronts): launch planning only
     int tpan;                // index of this front's first panel in the kept-T array (DevCtx::Tall), panel p at tpan + p
-    int pad4;
+    int qbig;                // Q-apply on the resident factors: the rows of this front are split over workgroups, one launch
+                             // per panel (k_qbig_*), instead of one workgroup for the whole front (plan time)
 };
 
 // one pending block reflector (written by the panel kernel, read by the update kernel)
@@ -76,6 +77,14 @@ static inline __host__ __device__ int stm_tall_launches(const FrontSym &s, int p
     const int rows = s.fm_est - g;
     return (rows > STM_TALL_XWIDE) ? STM_NB / 2 : (rows > STM_TALL_WIDE) ? STM_NB / 4 : STM_NB / STM_SW;
 }
+
+// split Q-apply (k_qbig_*): one entry per large front of a tree level
+struct QbDesc {
+    int f;                   // front
+    int xoff, dqoff, wqoff;  // offsets of its slices of the level's x (doubles), reflector numbering (ints), slab partials
+    int nslab;               // row slabs of QB_ROWS rows (from fm_ub)
+    int pad;
+};
 
 // numeric, written by the kernels
 struct FrontNum {

@@ -145,9 +145,14 @@ struct stmmqr_plan {
     std::vector<FrontNum> h_fnum;
     // Q-apply / solve on the resident factors
     DevBuf<int> d_Rj, d_PLinv, d_Qfill, d_Wmap, d_err;
-    DevBuf<double> d_W, d_Xs, d_Io;
+    DevBuf<double> d_W, d_Xs, d_Io, d_Xf, d_Wq;
+    DevBuf<int> d_Dq;
+    DevBuf<QbDesc> d_qb;
+    struct QbLevel { int off = 0, n = 0, max_np = 0, max_nslab = 0, max_fm = 0; };
+    std::vector<QbLevel> level_qbig;               // descriptors (d_qb) of the fronts of each level that take the split Q-apply
     bool rowmap_ready = false;         // d_Wmap belongs to the factorization currently held
-    std::vector<int> level_lds_qa, level_lds_rs;   // dynamic LDS of k_qapply / k_rsolve per level of group 0
+    std::vector<int> level_lds_qa, level_lds_qa_all, level_lds_rs;   // dynamic LDS of k_qapply(_t) / k_rsolve per level of group 0
+                                                                     // (_all: the unblocked kernel takes the split fronts too)
     double last_tol = 0;
     long last_ntol = 0;
     stmmqr_stats stats = {};
@@ -390,6 +395,12 @@ int build_plan(stmmqr_plan &P, const stmmqr_symbolic_view &v)
         s.npanels = (int)((fn + STM_NB - 1) / STM_NB);
         s.tpan = (int)tpan_total;
         tpan_total += s.npanels;
+        {
+            // Q-apply: fronts with this many entries or more are split over workgroups (k_qbig_*); STMMQR_QBIG_MIN
+            // overrides the threshold (tests send small fronts through that path)
+            const long qbig_min = getenv("STMMQR_QBIG_MIN") ? atol(getenv("STMMQR_QBIG_MIN")) : (2L << 20);
+            s.qbig = (fm * fn >= qbig_min && fn >= 1) ? 1 : 0;
+        }
         s.parent = (int)parent[f];
         s.foff = foff;
         foff += (long long)s.ld * fn;
@@ -987,13 +998,39 @@ int ensure_rowmap(stmmqr_plan &P)
         // dynamic LDS per level: k_qapply holds fm doubles + fn ints, k_rsolve fp + (fn - fp) doubles
         const auto &LV = P.glevels[0];
         P.level_lds_qa.assign(LV.size(), 0);
+        P.level_lds_qa_all.assign(LV.size(), 0);
         P.level_lds_rs.assign(LV.size(), 0);
-        for (size_t l = 0; l < LV.size(); l++)
+        P.level_qbig.assign(LV.size(), stmmqr_plan::QbLevel());
+        std::vector<QbDesc> qb;
+        long xf = 1, dq = 1, wq = 1;
+        for (size_t l = 0; l < LV.size(); l++) {
+            long xo = 0, dqo = 0, wo = 0;
+            P.level_qbig[l].off = (int)qb.size();
             for (int q = 0; q < LV[l].n_all; q++) {
-                const FrontSym &s = P.fs[P.lists[LV[l].all_off + q]];
-                P.level_lds_qa[l] = std::max(P.level_lds_qa[l], (int)(((s.fm_ub + 1) & ~1) * 8 + s.fn * 4 + 16));
+                const int f = P.lists[LV[l].all_off + q];
+                const FrontSym &s = P.fs[f];
+                const int need = (int)(((s.fm_ub + 1) & ~1) * 8 + s.fn * 4 + 16);
+                P.level_lds_qa_all[l] = std::max(P.level_lds_qa_all[l], need);
+                if (s.qbig) {
+                    QbDesc d;
+                    d.f = f; d.xoff = (int)xo; d.dqoff = (int)dqo; d.wqoff = (int)wo; d.nslab = (s.fm_ub + 511) / 512; d.pad = 0;
+                    qb.push_back(d);
+                    xo += s.fm_ub; dqo += s.fn; wo += 2L * d.nslab * STM_NB;
+                    auto &Q = P.level_qbig[l];
+                    Q.n++; Q.max_np = std::max(Q.max_np, s.npanels); Q.max_nslab = std::max(Q.max_nslab, d.nslab);
+                    Q.max_fm = std::max(Q.max_fm, s.fm_ub);
+                } else
+                    P.level_lds_qa[l] = std::max(P.level_lds_qa[l], need);
                 P.level_lds_rs[l] = std::max(P.level_lds_rs[l], (int)((((s.fp + 1) & ~1) + (s.fn - s.fp) + 2) * 8 + s.fp * 4 + 16));
             }
+            xf = std::max(xf, xo); dq = std::max(dq, dqo); wq = std::max(wq, wo);
+        }
+        LCHK(P.d_Xf.alloc((size_t)xf));
+        LCHK(P.d_Dq.alloc((size_t)dq));
+        LCHK(P.d_Wq.alloc((size_t)wq));
+        if (qb.empty()) qb.push_back(QbDesc());
+        LCHK(P.d_qb.alloc(qb.size()));
+        HIPCHK(hipMemcpy(P.d_qb.p, qb.data(), qb.size() * sizeof(QbDesc), hipMemcpyHostToDevice));
     }
     for (int b : P.level_lds_qa)
         if (b > 131072) return fail(STMMQR_ERR_TOO_LARGE, "a front has more rows than the Q-apply kernel holds in LDS");
@@ -1020,8 +1057,16 @@ int run_qapply(stmmqr_plan &P, int method)
     // to rounding: used by the tests to cross-check the two)
     const bool blocked = c.Tall && !(c.dbg & 8192);
     auto launch = [&](size_t l, int m) -> int {
-        if (blocked) return stm_launch_qapply_t(c, L0 + LV[l].all_off, LV[l].n_all, m, P.d_W.p, P.level_lds_qa[l], P.stream);
-        return stm_launch_qapply(c, L0 + LV[l].all_off, LV[l].n_all, m, P.d_W.p, P.level_lds_qa[l], P.d_err.p, P.stream);
+        if (blocked) {
+            LCHK(stm_launch_qapply_t(c, L0 + LV[l].all_off, LV[l].n_all, m, P.d_W.p, P.level_lds_qa[l], P.stream));
+            // the large fronts of the level (independent of the others): rows split over workgroups, a launch per panel
+            const auto &Q = P.level_qbig[l];
+            LCHK(stm_launch_qapply_big(c, P.d_qb.p + Q.off, Q.n, Q.max_np, Q.max_nslab, Q.max_fm, m, P.d_W.p, P.d_Xf.p, P.d_Dq.p,
+                                       P.d_Wq.p, P.stream));
+            return 0;
+        }
+        if (P.level_lds_qa_all[l] > 131072) return fail(STMMQR_ERR_TOO_LARGE, "a front has more rows than the unblocked Q-apply kernel holds in LDS");
+        return stm_launch_qapply(c, L0 + LV[l].all_off, LV[l].n_all, m, P.d_W.p, P.level_lds_qa_all[l], P.d_err.p, P.stream);
     };
     if (method == 0) {
         for (size_t l = 0; l < LV.size(); l++) LCHK(launch(l, 0));

@@ -58,6 +58,8 @@ int stm_launch_rh_copy(const DevCtx &c, const int *flist, const int *nparts, int
 // Q-apply / triangular solve on the resident factors
 int stm_launch_qapply(const DevCtx &c, const int *flist, int nfr, int method, double *W, int lds_bytes, int *err, hipStream_t st);
 int stm_launch_qapply_t(const DevCtx &c, const int *flist, int nfr, int method, double *W, int lds_bytes, hipStream_t st);
+int stm_launch_qapply_big(const DevCtx &c, const QbDesc *qd, int nq, int max_npanels, int max_nslab, int max_fm, int method, double *W,
+                          double *Xf, int *Dq, double *Wq, hipStream_t st);
 int stm_launch_rsolve(const DevCtx &c, const int *flist, int nfr, const int *Rj, const double *W, double *X, int lds_bytes,
                       int *err, hipStream_t st);
 int stm_launch_perm(const double *in, const int *perm, double *out, int n, int scatter, hipStream_t st);

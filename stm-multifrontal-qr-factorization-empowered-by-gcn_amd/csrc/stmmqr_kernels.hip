@@ -2169,7 +2169,7 @@ __global__ __launch_bounds__(QA_NT) void k_qapply_t(DevCtx c, const int *__restr
     const int f = flist[blockIdx.x];
     const FrontSym s = c.fs[f];
     const int fm = c.fnum[f].fm;
-    if (fm <= 0 || s.fn <= 0) return;
+    if (fm <= 0 || s.fn <= 0 || s.qbig) return;         // (qbig: k_qbig_* below)
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int *St = c.Stair + s.rp;
     const double *Tau = c.Tau + s.rp;
@@ -2265,6 +2265,150 @@ __global__ __launch_bounds__(QA_NT) void k_qapply_t(DevCtx c, const int *__restr
 // y = the first rm rows of the front's slice of W (rm = live pivot columns), x of the non-pivotal columns comes from
 // the ancestors, a dead pivot column gets x = 0 (basic solution), the live pivot columns form an rm x rm upper triangle
 // whose row q is the q-th live column.
+// ------------------------------------------------------------------------------------------------
+// Q-apply for the large fronts (FrontSym::qbig): one workgroup streams a front's V at the fill rate of ONE CU
+// (~45 GB/s: 10 ms for a 7818 x 7818 front), so the rows of such a front are split over workgroups (QB_ROWS rows
+// each, one row per thread) and the panels become launches: launch k applies panel p_prev (x -= V y with y = T'w or
+// T w, w = the slab partials of the previous launch summed in slab order) and forms the slab partials of
+// w = V'x for panel p_next.  x lives in a device buffer Xf (gathered from / scattered to the work vector by
+// k_qbig_prep / k_qbig_finish), the reflector numbering in Dq.
+// ------------------------------------------------------------------------------------------------
+#define QB_ROWS QA_NT
+// All split fronts of a tree level advance together: blockIdx.y = index into the level's descriptor list
+// (QbDesc: front, offsets of its slices of Xf / Dq / Wq, number of row slabs), launch k handles the k-th panel of each.
+__global__ __launch_bounds__(QA_NT) void k_qbig_prep(DevCtx c, const QbDesc *__restrict__ qd, const double *W, double *Xf0, int *Dq0)
+{
+    __shared__ int s_scan[QA_NW];
+    const QbDesc d = qd[blockIdx.x];
+    const FrontSym s = c.fs[d.f];
+    const int fm = c.fnum[d.f].fm;
+    if (fm <= 0 || s.fn <= 0) return;
+    const int *Hi = c.Hii + s.hip;
+    double *Xf = Xf0 + d.xoff;
+    for (int i = threadIdx.x; i < fm; i += QA_NT) Xf[i] = W[Hi[i]];
+    qa_number_reflectors(s, fm, c.Stair + s.rp, c.Tau + s.rp, Dq0 + d.dqoff, s_scan);
+}
+__global__ __launch_bounds__(256) void k_qbig_finish(DevCtx c, const QbDesc *__restrict__ qd, double *W, const double *Xf0)
+{
+    const QbDesc d = qd[blockIdx.y];
+    const FrontSym s = c.fs[d.f];
+    const int fm = c.fnum[d.f].fm;
+    const int *Hi = c.Hii + s.hip;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < fm) W[Hi[i]] = Xf0[d.xoff + i];
+}
+__global__ __launch_bounds__(QA_NT) void k_qbig_step(DevCtx c, const QbDesc *__restrict__ qd, int k, int method, double *Xf0,
+                                                     const int *Dq0, double *Wq0)
+{
+    __shared__ int s_d[2][STM_NB], s_t[2][STM_NB];
+    __shared__ double s_part[QA_NW][STM_NB], s_w[STM_NB], s_y[STM_NB], s_T[STM_NB][STM_NB + 1];
+    const QbDesc qdd = qd[blockIdx.y];
+    const int f = qdd.f, nslab = qdd.nslab;
+    if ((int)blockIdx.x >= nslab) return;
+    const FrontSym s = c.fs[f];
+    const int fm = c.fnum[f].fm;
+    if (fm <= 0 || s.fn <= 0) return;
+    // launch k: apply the (k-1)-th panel of the order, form the partials of the k-th (Q'x: ascending, Q x: descending)
+    const int np = s.npanels;
+    if (k > np) return;
+    const int pp[2] = {(k >= 1) ? (method ? np - k : k - 1) : -1, (k < np) ? (method ? np - 1 - k : k) : -1};
+    double *Xf = Xf0 + qdd.xoff;
+    const int *Dq = Dq0 + qdd.dqoff;
+    double *Wq = Wq0 + qdd.wqoff;
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int *St = c.Stair + s.rp;
+    const double *F = c.Farena + s.foff;
+    const long long ld = s.ld;
+    const int i = blockIdx.x * QB_ROWS + tid, ic = min(i, fm - 1);
+    // round trip 1: the reflector descriptions of both panels
+    if (tid < 2 * STM_NB) {
+        const int w = tid >> 5, j = tid & 31, p = pp[w];
+        int d = -1, t = 0;
+        if (p >= 0 && p * STM_NB + j < s.fn) { d = Dq[p * STM_NB + j]; t = St[p * STM_NB + j]; }
+        s_d[w][j] = (d >= 0) ? d : STM_BIGROW;
+        s_t[w][j] = (d >= 0) ? t : 0;
+    }
+    double x = (i < fm) ? Xf[i] : 0.0;
+    __syncthreads();
+    bool on[2];
+#pragma unroll
+    for (int w = 0; w < 2; w++) {
+        int r0 = STM_BIGROW, r1 = 0;
+#pragma unroll
+        for (int j = 0; j < STM_NB; j++) {
+            r0 = min(r0, s_d[w][j]);
+            r1 = max(r1, max(s_t[w][j], (s_d[w][j] < STM_BIGROW) ? s_d[w][j] + 1 : 0));
+        }
+        on[w] = (pp[w] >= 0 && r0 < STM_BIGROW && (int)blockIdx.x * QB_ROWS < r1 && ((int)blockIdx.x + 1) * QB_ROWS > r0);   // (uniform)
+    }
+    // round trip 2: everything both phases read, requested together (the launch is a chain of memory round trips)
+    double v0[STM_NB] = {}, v1[STM_NB] = {}, treg[2] = {0, 0}, wsum = 0;
+    if (on[0]) {
+        const int nbp = min(STM_NB, s.fn - pp[0] * STM_NB);
+        const double *Vp = F + (long long)(pp[0] * STM_NB) * ld;
+#pragma unroll
+        for (int j = 0; j < STM_NB; j++) v0[j] = Vp[ic + (long long)min(j, nbp - 1) * ld];      // unconditional, masked below
+        const double *T = c.Tall + (long long)(s.tpan + pp[0]) * STM_NB * STM_NB;
+        treg[0] = T[tid]; treg[1] = T[tid + QA_NT];
+        if (tid < STM_NB) {
+            const double *wp = Wq + (long long)(pp[0] & 1) * nslab * STM_NB;
+            for (int q = 0; q < nslab; q++) wsum += wp[q * STM_NB + tid];                       // fixed order: deterministic
+        }
+    }
+    if (on[1]) {
+        const int nbp = min(STM_NB, s.fn - pp[1] * STM_NB);
+        const double *Vp = F + (long long)(pp[1] * STM_NB) * ld;
+#pragma unroll
+        for (int j = 0; j < STM_NB; j++) v1[j] = Vp[ic + (long long)min(j, nbp - 1) * ld];
+    }
+    if (on[0]) {
+        s_T[tid % STM_NB][tid / STM_NB] = treg[0];
+        s_T[(tid + QA_NT) % STM_NB][(tid + QA_NT) / STM_NB] = treg[1];
+        if (tid < STM_NB) s_w[tid] = wsum;
+        __syncthreads();
+        if (tid < STM_NB) {
+            double y = 0;
+            if (method == 0) { for (int q = 0; q <= tid; q++) y += s_T[q][tid] * s_w[q]; }
+            else { for (int q = tid; q < STM_NB; q++) y += s_T[tid][q] * s_w[q]; }
+            s_y[tid] = y;
+        }
+        __syncthreads();
+        double a = x;
+#pragma unroll
+        for (int j = 0; j < STM_NB; j++) {
+            const double v = (i > s_d[0][j] && i < s_t[0][j]) ? v0[j] : ((i == s_d[0][j]) ? 1.0 : 0.0);
+            a -= v * s_y[j];
+        }
+        if (i < fm && a != x) Xf[i] = a;
+        x = (i < fm) ? a : 0.0;
+    }
+    if (pp[1] >= 0) {
+        double acc[STM_NB];
+#pragma unroll
+        for (int j = 0; j < STM_NB; j++) {
+            const double v = (i < fm && i > s_d[1][j] && i < s_t[1][j]) ? v1[j] : ((i == s_d[1][j]) ? 1.0 : 0.0);
+            acc[j] = on[1] ? v * x : 0.0;
+        }
+        {
+            double part[8];
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+#pragma unroll
+                for (int xx = 0; xx < 8; xx++) part[xx] = acc[8 * q + xx];
+                const double rw = wave_reduce8(part);                             // lane l: total of value red8_idx(l)
+                if (lane < 8) s_part[wid][8 * q + red8_idx(lane)] = rw;
+            }
+        }
+        __syncthreads();
+        if (tid < STM_NB) {
+            double v = 0;
+#pragma unroll
+            for (int w = 0; w < QA_NW; w++) v += s_part[w][tid];
+            Wq[((long long)(pp[1] & 1) * nslab + blockIdx.x) * STM_NB + tid] = v;
+        }
+    }
+}
+
 #define RS_NT 1024               // the back substitution streams R through one workgroup: more loads in flight
 __global__ __launch_bounds__(RS_NT) void k_rsolve(DevCtx c, const int *__restrict__ flist, const int *__restrict__ Rj,
                                                   const double *W, double *X, int *err)
@@ -2469,6 +2613,17 @@ int stm_launch_qapply_t(const DevCtx &c, const int *flist, int nfr, int method, 
 {
     if (nfr <= 0) return 0;
     hipLaunchKernelGGL(k_qapply_t, dim3(nfr), dim3(QA_NT), (size_t)lds_bytes, st, c, flist, method, W);
+    return (int)hipGetLastError();
+}
+// the split fronts of one level: prep, max(npanels) + 1 steps, finish
+int stm_launch_qapply_big(const DevCtx &c, const QbDesc *qd, int nq, int max_npanels, int max_nslab, int max_fm, int method, double *W,
+                          double *Xf, int *Dq, double *Wq, hipStream_t st)
+{
+    if (nq <= 0 || max_npanels <= 0) return 0;
+    hipLaunchKernelGGL(k_qbig_prep, dim3(nq), dim3(QA_NT), 0, st, c, qd, (const double *)W, Xf, Dq);
+    for (int k = 0; k <= max_npanels; k++)
+        hipLaunchKernelGGL(k_qbig_step, dim3(max_nslab, nq), dim3(QA_NT), 0, st, c, qd, k, method, Xf, (const int *)Dq, Wq);
+    hipLaunchKernelGGL(k_qbig_finish, dim3((max_fm + 255) / 256, nq), dim3(256), 0, st, c, qd, W, (const double *)Xf);
     return (int)hipGetLastError();
 }
 int stm_launch_rsolve(const DevCtx &c, const int *flist, int nfr, const int *Rj, const double *W, double *X, int lds_bytes,

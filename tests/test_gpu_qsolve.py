@@ -142,3 +142,29 @@ def test_solve_full_size_standin(pkg, name):
         assert abs(np.linalg.norm(y) - np.linalg.norm(b)) <= 1e-12 * np.linalg.norm(b)
     finally:
         plan.close()
+
+
+@pytest.mark.parametrize("name", ["bcsstk14", "syn_rankdef_grid", "grid20_standin", "lns_3937"])
+def test_split_qapply_on_small_fronts(pkg, oracle, monkeypatch, name):
+    """STMMQR_QBIG_MIN = 1 (read when the plan is made) sends EVERY front through the split Q-apply of the large fronts
+    (rows over workgroups, one launch per panel, slab partials of V'x summed in slab order): same Q'X / Q X as the oracle
+    applies from the downloaded factors, and as the one-workgroup kernel."""
+    g = load_golden(name)
+    monkeypatch.setenv("STMMQR_QBIG_MIN", "1")
+    S, plan = factorized_plan(pkg, g)
+    monkeypatch.delenv("STMMQR_QBIG_MIN")
+    S2, plan2 = factorized_plan(pkg, g)
+    try:
+        N = numeric_from_gpu(S, plan.download())
+        X = np.random.default_rng(11).standard_normal((S.m, 2))
+        for method in (0, 1):
+            got = plan.qmult(method, X)
+            one = plan2.qmult(method, X)
+            for j in range(2):
+                ref = oracle.qmult(method, S, N, X[:, j])
+                assert np.linalg.norm(got[:, j] - ref) <= 1e-12 * np.linalg.norm(ref)
+            assert np.linalg.norm(got - one) <= 1e-12 * np.linalg.norm(one)
+        back = plan.qmult(1, plan.qmult(0, X))
+        assert np.linalg.norm(back - X) <= 1e-12 * np.linalg.norm(X)
+    finally:
+        plan.close(); plan2.close()
