@@ -78,6 +78,7 @@ static inline __host__ __device__ int stm_tall_launches(const FrontSym &s, int p
     return (rows > STM_TALL_XWIDE) ? STM_NB / 2 : (rows > STM_TALL_WIDE) ? STM_NB / 4 : STM_NB / STM_SW;
 }
 
+#define STM_QB_ROWS 512      // rows of a front per workgroup of the split Q-apply (k_qbig_step)
 // split Q-apply (k_qbig_*): one entry per large front of a tree level
 struct QbDesc {
     int f;                   // front

@@ -1013,7 +1013,7 @@ int ensure_rowmap(stmmqr_plan &P)
                 P.level_lds_qa_all[l] = std::max(P.level_lds_qa_all[l], need);
                 if (s.qbig) {
                     QbDesc d;
-                    d.f = f; d.xoff = (int)xo; d.dqoff = (int)dqo; d.wqoff = (int)wo; d.nslab = (s.fm_ub + 511) / 512; d.pad = 0;
+                    d.f = f; d.xoff = (int)xo; d.dqoff = (int)dqo; d.wqoff = (int)wo; d.nslab = (s.fm_ub + STM_QB_ROWS - 1) / STM_QB_ROWS; d.pad = 0;
                     qb.push_back(d);
                     xo += s.fm_ub; dqo += s.fn; wo += 2L * d.nslab * STM_NB;
                     auto &Q = P.level_qbig[l];

@@ -2273,7 +2273,7 @@ __global__ __launch_bounds__(QA_NT) void k_qapply_t(DevCtx c, const int *__restr
 // w = V'x for panel p_next.  x lives in a device buffer Xf (gathered from / scattered to the work vector by
 // k_qbig_prep / k_qbig_finish), the reflector numbering in Dq.
 // ------------------------------------------------------------------------------------------------
-#define QB_ROWS QA_NT
+#define QB_ROWS STM_QB_ROWS   // rows (= threads) of a step workgroup (128-row workgroups were measured: slower)
 // All split fronts of a tree level advance together: blockIdx.y = index into the level's descriptor list
 // (QbDesc: front, offsets of its slices of Xf / Dq / Wq, number of row slabs), launch k handles the k-th panel of each.
 __global__ __launch_bounds__(QA_NT) void k_qbig_prep(DevCtx c, const QbDesc *__restrict__ qd, const double *W, double *Xf0, int *Dq0)
@@ -2297,11 +2297,11 @@ __global__ __launch_bounds__(256) void k_qbig_finish(DevCtx c, const QbDesc *__r
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i < fm) W[Hi[i]] = Xf0[d.xoff + i];
 }
-__global__ __launch_bounds__(QA_NT) void k_qbig_step(DevCtx c, const QbDesc *__restrict__ qd, int k, int method, double *Xf0,
+__global__ __launch_bounds__(QB_ROWS) void k_qbig_step(DevCtx c, const QbDesc *__restrict__ qd, int k, int method, double *Xf0,
                                                      const int *Dq0, double *Wq0)
 {
     __shared__ int s_d[2][STM_NB], s_t[2][STM_NB];
-    __shared__ double s_part[QA_NW][STM_NB], s_w[STM_NB], s_y[STM_NB], s_T[STM_NB][STM_NB + 1];
+    __shared__ double s_part[QB_ROWS / 64][STM_NB], s_w[STM_NB], s_y[STM_NB], s_T[STM_NB][STM_NB + 1];
     const QbDesc qdd = qd[blockIdx.y];
     const int f = qdd.f, nslab = qdd.nslab;
     if ((int)blockIdx.x >= nslab) return;
@@ -2342,14 +2342,15 @@ __global__ __launch_bounds__(QA_NT) void k_qbig_step(DevCtx c, const QbDesc *__r
         on[w] = (pp[w] >= 0 && r0 < STM_BIGROW && (int)blockIdx.x * QB_ROWS < r1 && ((int)blockIdx.x + 1) * QB_ROWS > r0);   // (uniform)
     }
     // round trip 2: everything both phases read, requested together (the launch is a chain of memory round trips)
-    double v0[STM_NB] = {}, v1[STM_NB] = {}, treg[2] = {0, 0}, wsum = 0;
+    double v0[STM_NB] = {}, v1[STM_NB] = {}, treg[STM_NB * STM_NB / QB_ROWS], wsum = 0;
     if (on[0]) {
         const int nbp = min(STM_NB, s.fn - pp[0] * STM_NB);
         const double *Vp = F + (long long)(pp[0] * STM_NB) * ld;
 #pragma unroll
         for (int j = 0; j < STM_NB; j++) v0[j] = Vp[ic + (long long)min(j, nbp - 1) * ld];      // unconditional, masked below
         const double *T = c.Tall + (long long)(s.tpan + pp[0]) * STM_NB * STM_NB;
-        treg[0] = T[tid]; treg[1] = T[tid + QA_NT];
+#pragma unroll
+        for (int q = 0; q < STM_NB * STM_NB / QB_ROWS; q++) treg[q] = T[tid + QB_ROWS * q];
         if (tid < STM_NB) {
             const double *wp = Wq + (long long)(pp[0] & 1) * nslab * STM_NB;
             for (int q = 0; q < nslab; q++) wsum += wp[q * STM_NB + tid];                       // fixed order: deterministic
@@ -2362,8 +2363,8 @@ __global__ __launch_bounds__(QA_NT) void k_qbig_step(DevCtx c, const QbDesc *__r
         for (int j = 0; j < STM_NB; j++) v1[j] = Vp[ic + (long long)min(j, nbp - 1) * ld];
     }
     if (on[0]) {
-        s_T[tid % STM_NB][tid / STM_NB] = treg[0];
-        s_T[(tid + QA_NT) % STM_NB][(tid + QA_NT) / STM_NB] = treg[1];
+#pragma unroll
+        for (int q = 0; q < STM_NB * STM_NB / QB_ROWS; q++) s_T[(tid + QB_ROWS * q) % STM_NB][(tid + QB_ROWS * q) / STM_NB] = treg[q];
         if (tid < STM_NB) s_w[tid] = wsum;
         __syncthreads();
         if (tid < STM_NB) {
@@ -2403,7 +2404,7 @@ __global__ __launch_bounds__(QA_NT) void k_qbig_step(DevCtx c, const QbDesc *__r
         if (tid < STM_NB) {
             double v = 0;
 #pragma unroll
-            for (int w = 0; w < QA_NW; w++) v += s_part[w][tid];
+            for (int w = 0; w < QB_ROWS / 64; w++) v += s_part[w][tid];
             Wq[((long long)(pp[1] & 1) * nslab + blockIdx.x) * STM_NB + tid] = v;
         }
     }
@@ -2622,7 +2623,7 @@ int stm_launch_qapply_big(const DevCtx &c, const QbDesc *qd, int nq, int max_npa
     if (nq <= 0 || max_npanels <= 0) return 0;
     hipLaunchKernelGGL(k_qbig_prep, dim3(nq), dim3(QA_NT), 0, st, c, qd, (const double *)W, Xf, Dq);
     for (int k = 0; k <= max_npanels; k++)
-        hipLaunchKernelGGL(k_qbig_step, dim3(max_nslab, nq), dim3(QA_NT), 0, st, c, qd, k, method, Xf, (const int *)Dq, Wq);
+        hipLaunchKernelGGL(k_qbig_step, dim3(max_nslab, nq), dim3(QB_ROWS), 0, st, c, qd, k, method, Xf, (const int *)Dq, Wq);
     hipLaunchKernelGGL(k_qbig_finish, dim3((max_fm + 255) / 256, nq), dim3(256), 0, st, c, qd, W, (const double *)Xf);
     return (int)hipGetLastError();
 }
