@@ -13,6 +13,7 @@ cd /tmp && export TMPDIR=/tmp
 python3 $ROOT/bench.py --steps 5 --warmup 2 > $OUT/${TAG}_bench_xenon1_standin.json 2> $OUT/${TAG}_bench_xenon.err
 python3 $ROOT/bench.py --workload epb1 --steps 5 --warmup 2 > $OUT/${TAG}_bench_epb1.json 2> $OUT/${TAG}_bench_epb1.err
 python3 $ROOT/bench.py --workload sme3dc_standin --steps 5 --warmup 2 > $OUT/${TAG}_bench_sme3dc_standin.json 2> $OUT/${TAG}_bench_sme3dc.err
+python3 $ROOT/bench.py --workload c5mini_standin --steps 5 --warmup 2 > $OUT/${TAG}_bench_c5mini_standin.json 2> $OUT/${TAG}_bench_c5mini.err
 python3 $ROOT/bench.py --workload micro --steps 3 --warmup 1 > $OUT/${TAG}_bench_micro.json 2> $OUT/${TAG}_bench_micro.err
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_prof -o p -- python3 $ROOT/bench.py --steps 3 --warmup 1 --no-cpu > $OUT/${TAG}_prof.log 2>&1
 cp $OUT/${TAG}_prof/p_kernel_stats.csv $OUT/${TAG}_xenon1_standin_kernel_stats.csv
