@@ -148,7 +148,8 @@ struct stmmqr_plan {
     DevBuf<double> d_W, d_Xs, d_Io, d_Xf, d_Wq;
     DevBuf<int> d_Dq;
     DevBuf<QbDesc> d_qb;
-    struct QbLevel { int off = 0, n = 0, max_np = 0, max_nslab = 0, max_fm = 0; };
+    struct QbLevel { int off = 0, n = 0, max_np = 0, max_nslab = 0, max_fm = 0, max_rsteps = 0; };
+    DevBuf<int> d_Rm;                               // rows of R (live pivots) of the split fronts of a level (k_rbig_*)
     std::vector<QbLevel> level_qbig;               // descriptors (d_qb) of the fronts of each level that take the split Q-apply
     bool rowmap_ready = false;         // d_Wmap belongs to the factorization currently held
     std::vector<int> level_lds_qa, level_lds_qa_all, level_lds_rs;   // dynamic LDS of k_qapply(_t) / k_rsolve per level of group 0
@@ -1019,9 +1020,11 @@ int ensure_rowmap(stmmqr_plan &P)
                     auto &Q = P.level_qbig[l];
                     Q.n++; Q.max_np = std::max(Q.max_np, s.npanels); Q.max_nslab = std::max(Q.max_nslab, d.nslab);
                     Q.max_fm = std::max(Q.max_fm, s.fm_ub);
-                } else
+                    Q.max_rsteps = std::max(Q.max_rsteps, (std::min(s.fp, s.fm_ub) + 31) / 32);
+                } else {
                     P.level_lds_qa[l] = std::max(P.level_lds_qa[l], need);
-                P.level_lds_rs[l] = std::max(P.level_lds_rs[l], (int)((((s.fp + 1) & ~1) + (s.fn - s.fp) + 2) * 8 + s.fp * 4 + 16));
+                    P.level_lds_rs[l] = std::max(P.level_lds_rs[l], (int)((((s.fp + 1) & ~1) + (s.fn - s.fp) + 2) * 8 + s.fp * 4 + 16));
+                }
             }
             xf = std::max(xf, xo); dq = std::max(dq, dqo); wq = std::max(wq, wo);
         }
@@ -1030,6 +1033,7 @@ int ensure_rowmap(stmmqr_plan &P)
         LCHK(P.d_Wq.alloc((size_t)wq));
         if (qb.empty()) qb.push_back(QbDesc());
         LCHK(P.d_qb.alloc(qb.size()));
+        LCHK(P.d_Rm.alloc(qb.size()));
         HIPCHK(hipMemcpy(P.d_qb.p, qb.data(), qb.size() * sizeof(QbDesc), hipMemcpyHostToDevice));
     }
     for (int b : P.level_lds_qa)
@@ -1125,9 +1129,13 @@ int stmmqr_plan_solve(stmmqr_plan *plan, const double *B, stm_long ldb, double *
         HIPCHK(hipMemcpyAsync(P.d_Io.p, B + j * ldb, (size_t)m * sizeof(double), hipMemcpyHostToDevice, st));
         LCHK(stm_launch_perm(P.d_Io.p, P.d_PLinv.p, P.d_W.p, m, 1, st));
         LCHK(run_qapply(P, 0));
-        for (size_t l = LV.size(); l-- > 0;)
+        for (size_t l = LV.size(); l-- > 0;) {
             LCHK(stm_launch_rsolve(c, L0 + LV[l].all_off, LV[l].n_all, P.d_Rj.p, P.d_W.p, P.d_Xs.p, P.level_lds_rs[l],
                                    P.d_err.p, st));
+            const auto &Q = P.level_qbig[l];         // the large fronts of the level: rows split over workgroups
+            LCHK(stm_launch_rsolve_big(c, P.d_qb.p + Q.off, Q.n, Q.max_rsteps, Q.max_nslab, P.d_Rj.p, P.d_W.p, P.d_Xs.p, P.d_Xf.p,
+                                       P.d_Dq.p, P.d_Rm.p + Q.off, P.d_err.p, st));
+        }
         LCHK(stm_launch_perm(P.d_Xs.p, P.has_qfill ? P.d_Qfill.p : nullptr, P.d_Io.p, n, 1, st));   // X[Qfill[j]] = x[j]
         HIPCHK(hipMemcpyAsync(X + j * ldx, P.d_Io.p, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, st));
     }

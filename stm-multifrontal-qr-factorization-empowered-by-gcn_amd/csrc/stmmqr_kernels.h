@@ -60,6 +60,8 @@ int stm_launch_qapply(const DevCtx &c, const int *flist, int nfr, int method, do
 int stm_launch_qapply_t(const DevCtx &c, const int *flist, int nfr, int method, double *W, int lds_bytes, hipStream_t st);
 int stm_launch_qapply_big(const DevCtx &c, const QbDesc *qd, int nq, int max_npanels, int max_nslab, int max_fm, int method, double *W,
                           double *Xf, int *Dq, double *Wq, hipStream_t st);
+int stm_launch_rsolve_big(const DevCtx &c, const QbDesc *qd, int nq, int max_steps, int max_nslab, const int *Rj, const double *W,
+                          double *X, double *Acc, int *Lc, int *Rm, int *err, hipStream_t st);
 int stm_launch_rsolve(const DevCtx &c, const int *flist, int nfr, const int *Rj, const double *W, double *X, int lds_bytes,
                       int *err, hipStream_t st);
 int stm_launch_perm(const double *in, const int *perm, double *out, int n, int scatter, hipStream_t st);

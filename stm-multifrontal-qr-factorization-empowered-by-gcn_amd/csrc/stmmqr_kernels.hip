@@ -2420,7 +2420,7 @@ __global__ __launch_bounds__(RS_NT) void k_rsolve(DevCtx c, const int *__restric
     const FrontSym s = c.fs[f];
     const FrontNum nm = c.fnum[f];
     const int fp = s.fp, fn = s.fn, fm = nm.fm;
-    if (fp <= 0) return;
+    if (fp <= 0 || s.qbig) return;                      // (qbig: k_rbig_* below)
     const int tid = threadIdx.x;
     const int *St = c.Stair + s.rp;
     const int *Hi = c.Hii + s.hip;
@@ -2494,6 +2494,103 @@ __global__ __launch_bounds__(RS_NT) void k_rsolve(DevCtx c, const int *__restric
 }
 
 // scatter: out[perm[i]] = in[i]   gather: out[i] = in[perm[i]]   (perm == nullptr: identity)
+// ------------------------------------------------------------------------------------------------
+// Back substitution for the large fronts (FrontSym::qbig), rows split over workgroups as in k_qbig_*: prep (live pivot
+// columns -> Lc, rm), init (acc = y - R12 x_others, a row per thread), then one launch per block of 32 live columns
+// from the last to the first: every active workgroup solves the 32 x 32 triangle for itself (one wave, LDS) and updates
+// its rows above the block; workgroup 0 stores x.  All split fronts of a level advance together (blockIdx.y).
+// acc = the front's slice of Xf, Lc = its slice of Dq (the Q-apply has finished with both).
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(RS_NT) void k_rbig_prep(DevCtx c, const QbDesc *__restrict__ qd, double *X, int *Lc0, int *Rm, int *err)
+{
+    __shared__ int s_scan[RS_NT / 64];
+    const QbDesc d = qd[blockIdx.x];
+    const FrontSym s = c.fs[d.f];
+    const FrontNum nm = c.fnum[d.f];
+    const int fp = s.fp, fm = nm.fm, tid = threadIdx.x;
+    const int *St = c.Stair + s.rp;
+    int *lc = Lc0 + d.dqoff;
+    const int per = (fp + RS_NT - 1) / RS_NT;
+    const int k0 = min(fp, tid * per), k1 = min(fp, k0 + per);
+    int cnt = 0;
+    for (int k = k0; k < k1; k++) cnt += (St[k] != 0);
+    int total;
+    const int incl = qa_incl_scan<RS_NT / 64>(cnt, s_scan, &total);
+    int q = incl - cnt;
+    for (int k = k0; k < k1; k++) {
+        if (St[k] != 0 && q < fm) lc[q] = k;
+        else if (St[k] == 0) X[s.col1 + k] = 0.0;       // dead pivot column: basic solution
+        q += (St[k] != 0);
+    }
+    if (tid == 0) {
+        const int rm = min(total, fm);
+        Rm[blockIdx.x] = rm;
+        if (rm != nm.rank) atomicExch(err, 1);
+    }
+}
+__global__ __launch_bounds__(STM_QB_ROWS) void k_rbig_init(DevCtx c, const QbDesc *__restrict__ qd, const int *__restrict__ Rj,
+                                                           const double *W, const double *X, double *Acc0, const int *Rm)
+{
+    const QbDesc d = qd[blockIdx.y];
+    const FrontSym s = c.fs[d.f];
+    const int rm = Rm[blockIdx.y];
+    const int i = blockIdx.x * STM_QB_ROWS + threadIdx.x;
+    if (i >= rm) return;
+    const int *rj = Rj + s.rp;
+    const double *F = c.Farena + s.foff;
+    const long long ld = s.ld;
+    double a = W[c.Hii[s.hip + i]];
+    for (int k = s.fp; k < s.fn; k++) a -= F[i + (long long)k * ld] * X[rj[k]];   // (coalesced over the rows; X[rj[k]] uniform)
+    Acc0[d.xoff + i] = a;
+}
+__global__ __launch_bounds__(STM_QB_ROWS) void k_rbig_step(DevCtx c, const QbDesc *__restrict__ qd, int kstep, double *X, double *Acc0,
+                                                           const int *Lc0, const int *Rm)
+{
+    constexpr int QS_NB = 32;
+    __shared__ double s_tri[QS_NB][QS_NB + 1];
+    __shared__ double s_x[QS_NB];
+    const QbDesc d = qd[blockIdx.y];
+    const int rm = Rm[blockIdx.y];
+    const int nblk = (rm + QS_NB - 1) / QS_NB;
+    if (kstep >= nblk) return;
+    const int kb = (nblk - 1 - kstep) * QS_NB, nb = min(QS_NB, rm - kb);
+    const int sl = blockIdx.x, tid = threadIdx.x;
+    if (sl != 0 && sl * STM_QB_ROWS >= kb) return;      // no row above the block (workgroup 0 always runs: it stores x)
+    const FrontSym s = c.fs[d.f];
+    const double *F = c.Farena + s.foff;
+    const long long ld = s.ld;
+    const int *lc = Lc0 + d.dqoff;
+    double *acc = Acc0 + d.xoff;
+    // my row's entries of the block's columns: requested before the triangle is solved
+    const int i = sl * STM_QB_ROWS + tid;
+    double rv[QS_NB];
+#pragma unroll
+    for (int j = 0; j < QS_NB; j++) rv[j] = F[min(i, max(kb - 1, 0)) + (long long)lc[kb + min(j, nb - 1)] * ld];
+    double a = (i < kb) ? acc[i] : 0.0;
+    for (int e = tid; e < QS_NB * QS_NB; e += STM_QB_ROWS) {
+        const int ti = e % QS_NB, tj = e / QS_NB;
+        s_tri[ti][tj] = (ti < nb && tj < nb && ti <= tj) ? F[(kb + ti) + (long long)lc[kb + tj] * ld] : 0.0;
+    }
+    __syncthreads();
+    if (tid < 64) {
+        // lane r owns row r of the triangle (r < nb): x_j for j = nb-1 .. 0
+        double t = (tid < nb) ? acc[kb + tid] : 0.0;
+        for (int j = nb - 1; j >= 0; j--) {
+            const double aj = __shfl(t, j, 64);
+            const double xj = aj / s_tri[j][j];
+            if (tid < j) t -= s_tri[tid][j] * xj;
+            if (tid == j) s_x[j] = xj;
+        }
+    }
+    __syncthreads();
+    if (sl == 0 && tid < nb) X[s.col1 + lc[kb + tid]] = s_x[tid];
+    if (i < kb) {
+#pragma unroll
+        for (int j = 0; j < QS_NB; j++) a -= ((j < nb) ? rv[j] : 0.0) * s_x[min(j, nb - 1)];
+        acc[i] = a;
+    }
+}
+
 __global__ __launch_bounds__(256) void k_perm(const double *__restrict__ in, const int *__restrict__ perm, double *out, int n,
                                                int scatter)
 {
@@ -2632,6 +2729,17 @@ int stm_launch_rsolve(const DevCtx &c, const int *flist, int nfr, const int *Rj,
 {
     if (nfr <= 0) return 0;
     hipLaunchKernelGGL(k_rsolve, dim3(nfr), dim3(RS_NT), (size_t)lds_bytes, st, c, flist, Rj, W, X, err);
+    return (int)hipGetLastError();
+}
+// back substitution of the split fronts of one level: prep, init, max ceil(fp / 32) steps
+int stm_launch_rsolve_big(const DevCtx &c, const QbDesc *qd, int nq, int max_steps, int max_nslab, const int *Rj, const double *W,
+                          double *X, double *Acc, int *Lc, int *Rm, int *err, hipStream_t st)
+{
+    if (nq <= 0) return 0;
+    hipLaunchKernelGGL(k_rbig_prep, dim3(nq), dim3(RS_NT), 0, st, c, qd, X, Lc, Rm, err);
+    hipLaunchKernelGGL(k_rbig_init, dim3(max_nslab, nq), dim3(STM_QB_ROWS), 0, st, c, qd, Rj, W, (const double *)X, Acc, (const int *)Rm);
+    for (int k = 0; k < max_steps; k++)
+        hipLaunchKernelGGL(k_rbig_step, dim3(max_nslab, nq), dim3(STM_QB_ROWS), 0, st, c, qd, k, X, Acc, (const int *)Lc, (const int *)Rm);
     return (int)hipGetLastError();
 }
 int stm_launch_perm(const double *in, const int *perm, double *out, int n, int scatter, hipStream_t st)

@@ -166,5 +166,12 @@ def test_split_qapply_on_small_fronts(pkg, oracle, monkeypatch, name):
             assert np.linalg.norm(got - one) <= 1e-12 * np.linalg.norm(one)
         back = plan.qmult(1, plan.qmult(0, X))
         assert np.linalg.norm(back - X) <= 1e-12 * np.linalg.norm(X)
+        # ... and through the split back substitution (k_rbig_*): same solution as the one-workgroup kernels, which the
+        # other tests of this file pin to the oracle / the reference
+        B = np.random.default_rng(12).standard_normal((S.m, 2))
+        xs, x1 = plan.solve(B), plan2.solve(B)
+        tol = ILL_CONDITIONED.get(name, 1e-10)
+        assert np.linalg.norm(xs - x1) <= max(tol, 1e-10) * max(np.linalg.norm(x1), 1.0)
+        assert np.array_equal(xs == 0.0, x1 == 0.0)             # dead columns: exactly zero in both
     finally:
         plan.close(); plan2.close()
