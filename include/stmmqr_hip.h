@@ -225,14 +225,19 @@ double stmmqr_last_seam_ms(void);
 /* ================================================================================================
  * 3. Configuration / introspection
  * ================================================================================================ */
+/* Defaults: {32, 64, 0, 0, 0, 1, 0}.  Read when a plan is created (or a seam is called); the numerical results do not
+ * depend on them beyond rounding.
+ * Environment (diagnosis and tests only): STMMQR_DBG (bit mask, csrc/stmmqr_kernels.h), STMMQR_QBIG_MIN (entries of a
+ * front from which Q-apply / back substitution split its rows over workgroups; default 2097152, read at plan time),
+ * STMMQR_CHUNK (fronts per panel launch with STMMQR_DBG bit 9), STMMQR_DUMPLV (print the level lists). */
 typedef struct stmmqr_options {
-    int panel_width;        /* Householder panel width on device (<= 32); reference FCHUNK = 32          */
-    int big_front_cols;     /* fronts with fn >= this use the multi-workgroup panel/update path           */
+    int panel_width;        /* Householder panel width on device (<= 32); reference FCHUNK = 32                    */
+    int big_front_cols;     /* fronts with fn >= this use the multi-workgroup panel/update path                     */
     int verbose;
     int use_graph;          /* reserved (ignored): the level schedule is enqueued ahead of the device as it is     */
-    int lookahead;          /* overlap panel p+1 with the rest of the trailing update of panel p (2 streams) */
-    int split_update;       /* row-parallel (3-launch) trailing update for tall panels                      */
-    int tall_min_rows;      /* panels with more rows than this run as a pipeline of 8-column groups (plan time; 0) */
+    int lookahead;          /* overlap panel p+1 with the rest of the trailing update of panel p (2 streams; 0)     */
+    int split_update;       /* row-parallel (2-launch) trailing update for fronts of >= 3 row slabs (1)             */
+    int tall_min_rows;      /* panels with more rows than this run as a pipeline of column groups (plan time; 0)    */
 } stmmqr_options;
 void stmmqr_get_options(stmmqr_options *opt);
 void stmmqr_set_options(const stmmqr_options *opt);
