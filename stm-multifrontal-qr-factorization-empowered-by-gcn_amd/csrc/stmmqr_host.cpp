@@ -299,7 +299,10 @@ void build_schedule(stmmqr_plan &P, std::vector<int> &tslot)
                 }
                 L.nbig_at[p] = cnt;
                 L.maxcb_at[p] = mcb;
-                L.maxsl_at[p] = msl >= 3 ? msl : 0;          // row-parallel update only when it pays (>= 3 slabs)
+                // row-parallel update when it pays: >= 3 slabs, or so many column blocks in the launch that the one-workgroup
+                // form's redundant T (every column-block workgroup builds it) costs throughput (T is built once per front
+                // by k_upd_w).  Either form gives the same bits.
+                L.maxsl_at[p] = (msl >= 3 || (long)cnt * mcb >= 512) ? msl : 0;
                 P.wp_doubles = std::max(P.wp_doubles, (long long)cnt * (mcb + 1) * msl * (STM_NB * 32));   // (+1: Gram block)
             }
         }
