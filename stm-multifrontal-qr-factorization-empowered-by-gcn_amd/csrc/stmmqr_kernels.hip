@@ -2452,9 +2452,19 @@ __global__ __launch_bounds__(RS_NT) void k_rsolve(DevCtx c, const int *__restric
     if (rm != nm.rank && tid == 0) atomicExch(err, 1);  // (cannot happen: same rule as the factorization)
     // acc = y - R12 x_others : thread per row, columns streamed (coalesced over the rows)
     for (int i = tid; i < rm; i += RS_NT) {
-        double a = W[Hi[i]];
-        for (int k = fp; k < fn; k++) a -= F[i + (long long)k * ld] * xo[k - fp];
-        acc[i] = a;
+        double a0 = W[Hi[i]], a1 = 0, a2 = 0, a3 = 0;  // (four partial sums, 16 loads in flight: as k_rbig_init)
+        int k = fp;
+        for (; k + 16 <= fn; k += 16) {
+#pragma unroll
+            for (int u = 0; u < 16; u += 4) {
+                a0 -= F[i + (long long)(k + u) * ld] * xo[k + u - fp];
+                a1 -= F[i + (long long)(k + u + 1) * ld] * xo[k + u + 1 - fp];
+                a2 -= F[i + (long long)(k + u + 2) * ld] * xo[k + u + 2 - fp];
+                a3 -= F[i + (long long)(k + u + 3) * ld] * xo[k + u + 3 - fp];
+            }
+        }
+        for (; k < fn; k++) a0 -= F[i + (long long)k * ld] * xo[k - fp];
+        acc[i] = (a0 + a1) + (a2 + a3);
     }
     __syncthreads();
     // triangle: blocked back substitution over the compact list.  Per block of QS_NB live columns: the diagonal triangle
@@ -2539,9 +2549,21 @@ __global__ __launch_bounds__(STM_QB_ROWS) void k_rbig_init(DevCtx c, const QbDes
     const int *rj = Rj + s.rp;
     const double *F = c.Farena + s.foff;
     const long long ld = s.ld;
-    double a = W[c.Hii[s.hip + i]];
-    for (int k = s.fp; k < s.fn; k++) a -= F[i + (long long)k * ld] * X[rj[k]];   // (coalesced over the rows; X[rj[k]] uniform)
-    Acc0[d.xoff + i] = a;
+    // (coalesced over the rows; X[rj[k]] uniform; four partial sums and an unrolled body keep 16 loads in flight: the loop
+    //  is a chain of memory round trips otherwise)
+    double a0 = W[c.Hii[s.hip + i]], a1 = 0, a2 = 0, a3 = 0;
+    int k = s.fp;
+    for (; k + 16 <= s.fn; k += 16) {
+#pragma unroll
+        for (int u = 0; u < 16; u += 4) {
+            a0 -= F[i + (long long)(k + u) * ld] * X[rj[k + u]];
+            a1 -= F[i + (long long)(k + u + 1) * ld] * X[rj[k + u + 1]];
+            a2 -= F[i + (long long)(k + u + 2) * ld] * X[rj[k + u + 2]];
+            a3 -= F[i + (long long)(k + u + 3) * ld] * X[rj[k + u + 3]];
+        }
+    }
+    for (; k < s.fn; k++) a0 -= F[i + (long long)k * ld] * X[rj[k]];
+    Acc0[d.xoff + i] = (a0 + a1) + (a2 + a3);
 }
 __global__ __launch_bounds__(STM_QB_ROWS) void k_rbig_step(DevCtx c, const QbDesc *__restrict__ qd, int kstep, double *X, double *Acc0,
                                                            const int *Lc0, const int *Rm)
