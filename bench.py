@@ -361,7 +361,7 @@ def main():
                 out["f1_resident_factors"] = {"qmult_qtx_ms": (t1 - t0) * 1e3, "solve_ms": (t2 - t1) * 1e3, "residual": res}
         except Exception as e:  # rank-deficient inputs: the device solve refuses them
             out["f1_resident_factors"] = {"error": str(e)}
-        if not args.no_cpu:
+        if not args.no_cpu and world == 1:             # (the CPU baseline is reported at N = 1 only)
             cb = cpu_baseline(name, g)
             out["cpu_baseline"] = cb
         print(json.dumps(out))
