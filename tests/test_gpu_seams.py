@@ -187,3 +187,27 @@ def test_micro_assembly_column_sums(pkg):
     st = a["Stair"]
     assert np.all(np.diff(st) >= 0) and st[-1] == fm
     assert pkg.last_seam_ms() > 0.0
+
+
+def test_bench_micro_contract(pkg):
+    """bench.py --workload micro: one JSON line, every front factorized with the rank it must have, device
+    times reported by the seams, the synthetic assembly conserves its entries."""
+    import json
+    import subprocess
+    import sys
+    from pathlib import Path
+    root = Path(__file__).resolve().parent.parent
+    r = subprocess.run([sys.executable, str(root / "bench.py"), "--workload", "micro", "--no-cpu", "--steps", "1", "--warmup", "1"],
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "dtype", "config"):
+        assert k in d
+    assert len(d["fronts"]) == 10
+    for f in d["fronts"]:
+        assert f["rank"] == f["fp"] and f["device_ms"] > 0 and f["gflops"] > 0
+    assert d["assembly"]["entries_conserved"] and d["assembly"]["device_ms"] > 0
+    dense8k = [f for f in d["fronts"] if f["fm"] == 8192 and f["staircase"] == "dense"][0]
+    assert dense8k["gflops"] > 3000.0          # (the 2-column pipeline of the 4096..8192-row panels, not the one-workgroup fallback)
