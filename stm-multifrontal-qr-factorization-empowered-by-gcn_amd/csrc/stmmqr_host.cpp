@@ -151,6 +151,8 @@ struct stmmqr_plan {
     struct QbLevel { int off = 0, n = 0, max_np = 0, max_nslab = 0, max_fm = 0, max_rsteps = 0; };
     DevBuf<int> d_Rm;                               // rows of R (live pivots) of the split fronts of a level (k_rbig_*)
     std::vector<QbLevel> level_qbig;               // descriptors (d_qb) of the fronts of each level that take the split Q-apply
+    hipGraphExec_t graph_exec = nullptr;           // options.use_graph: the captured schedule of group 0
+    double graph_tol = 0; int graph_ntol = 0, graph_dbg = 0; long graph_nlaunch = 0;
     bool rowmap_ready = false;         // d_Wmap belongs to the factorization currently held
     std::vector<int> level_lds_qa, level_lds_qa_all, level_lds_rs;   // dynamic LDS of k_qapply(_t) / k_rsolve per level of group 0
                                                                      // (_all: the unblocked kernel takes the split fronts too)
@@ -178,6 +180,7 @@ struct stmmqr_plan {
             if (e) (void)hipEventDestroy(e);
         for (auto &e : evpool)
             if (e) (void)hipEventDestroy(e);
+        if (graph_exec) (void)hipGraphExecDestroy(graph_exec);
         if (stream) (void)hipStreamDestroy(stream);
         if (stream2) (void)hipStreamDestroy(stream2);
     }
@@ -781,7 +784,32 @@ int stmmqr_factorize_group(stmmqr_plan *plan, int group, int detail)
     if (!plan || !plan->begun) return fail(STMMQR_ERR_INVALID, "stmmqr_factorize_begin was not called");
     stmmqr_plan &P = *plan;
     HIPCHK(hipSetDevice(P.device));
-    int e = run_schedule(P, detail != 0, group, P.first_group);
+    int e = 0;
+    const bool graph_ok = g_opt.use_graph && !detail && !g_opt.lookahead && group == 0 && P.first_group && !getenv("STMMQR_DUMPLV");
+    if (graph_ok) {
+        // replay the level schedule of group 0 as a hipGraph (captured once per plan and per (tol, ntol, debug mask):
+        // these travel in the kernel arguments)
+        const DevCtx c = P.ctx();
+        if (!P.graph_exec || P.graph_tol != c.tol || P.graph_ntol != c.ntol || P.graph_dbg != c.dbg) {
+            if (P.graph_exec) { (void)hipGraphExecDestroy(P.graph_exec); P.graph_exec = nullptr; }
+            hipGraph_t gph = nullptr;
+            HIPCHK(hipStreamBeginCapture(P.stream, hipStreamCaptureModeThreadLocal));
+            e = run_schedule(P, false, 0, true);
+            const hipError_t ce = hipStreamEndCapture(P.stream, &gph);
+            if (e) { if (gph) (void)hipGraphDestroy(gph); return e; }
+            HIPCHK(ce);
+            HIPCHK(hipGraphInstantiate(&P.graph_exec, gph, nullptr, nullptr, 0));
+            (void)hipGraphDestroy(gph);
+            P.graph_tol = c.tol; P.graph_ntol = c.ntol; P.graph_dbg = c.dbg;
+        } else {
+            // (the statistics run_schedule accumulates on the host)
+            P.stats.nlaunch += P.graph_nlaunch;
+            P.stats.nlevels += (long)P.glevels[0].size();
+        }
+        if (!P.graph_nlaunch) P.graph_nlaunch = P.stats.nlaunch;
+        HIPCHK(hipGraphLaunch(P.graph_exec, P.stream));
+    } else
+        e = run_schedule(P, detail != 0, group, P.first_group);
     P.first_group = false;
     return e;
 }

@@ -182,6 +182,36 @@ def test_plan_reuse_across_rank_changes(pkg, oracle, tall_min):
     assert ranks[0] == ranks[2] < ranks[1] == ranks[3] == S.n
 
 
+@pytest.mark.parametrize("name", ["bcsstk14", "syn_rankdef_grid", "grid20_standin"])
+def test_graph_replay_equals_stream_launches(pkg, name):
+    """options.use_graph: the level schedule captured into a hipGraph (first call) and replayed (later calls, re-captured
+    when tol changes) gives bit-identical factors to the plain stream launches."""
+    g = load_golden(name)
+    S = Symbolic(g)
+    tol, ntol = scalar(g, "in_tol"), int(scalar(g, "in_ntol"))
+    ref_plan = pkg.HipQR(sym_dict(S))
+    ref_plan.factorize(g["in_Ax"], tol, ntol, g["in_Ap"], g["in_Ai"])
+    ref = ref_plan.download()
+    ref_plan.close()
+    pkg.set_options(use_graph=1)
+    try:
+        plan = pkg.HipQR(sym_dict(S))
+        try:
+            for it in range(3):
+                t = tol if it != 1 else -1.0                      # (second call: other tol -> new capture)
+                plan.factorize(g["in_Ax"], t, ntol, *((g["in_Ap"], g["in_Ai"]) if it == 0 else (None, None)))
+                G = plan.download()
+                if it != 1:
+                    assert G.rank == ref.rank and G.rh_total == ref.rh_total
+                    np.testing.assert_array_equal(G.HStair, ref.HStair)
+                    np.testing.assert_array_equal(G.HTau, ref.HTau)
+                    np.testing.assert_array_equal(G.Stack[:G.rh_total], ref.Stack[:ref.rh_total])
+        finally:
+            plan.close()
+    finally:
+        pkg.set_options(use_graph=0)
+
+
 def test_no_rank_detection_tol_negative(pkg, oracle):
     g = load_golden("syn_rankdef_grid")
     S = Symbolic(g)
