@@ -235,7 +235,8 @@ typedef struct stmmqr_options {
     int big_front_cols;     /* fronts with fn >= this use the multi-workgroup panel/update path                     */
     int verbose;
     int use_graph;          /* replay the level schedule as a hipGraph (captured per plan and tol); 0: no gain measured */
-    int lookahead;          /* overlap panel p+1 with the rest of the trailing update of panel p (2 streams; 0)     */
+    int panel_algo;         /* panel of the large fronts: 0 Gram-based (one reduction per panel; default), 1 the column
+                               pipeline of round 1 (one reduction per column), kept for cross-checks              */
     int split_update;       /* row-parallel (2-launch) trailing update for fronts of >= 3 row slabs (1)             */
     int tall_min_rows;      /* panels with more rows than this run as a pipeline of column groups (plan time; 0)    */
 } stmmqr_options;

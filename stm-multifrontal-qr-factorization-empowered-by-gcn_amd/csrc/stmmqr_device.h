@@ -42,7 +42,8 @@ struct PanelDesc {
     int nlive;               // live reflectors so far
     int sw;                  // sub-panel width of this panel: 8; 4 / 2 when the rows need 8 / 16 registers per thread and column
     int done_group;          // group that ran out of rows (g reached fm), -1 if none
-    int t_deferred;          // 1: the panel kernel left T to k_upd_w (Gram block + the last slab workgroup builds T)
+    int t_deferred;          // 1: the panel kernel left T to k_upd_w (Gram block + the last slab workgroup builds T);
+                             // 2: last panel of a front (no trailing update): T is built by k_cpack's extra workgroup
     int pad3;
     int sg[STM_NB / 2];      // first active row (g) at the start of sub-panel s
     int st[STM_NB / 2];      // one past the last row reached by the reflectors of sub-panel s
@@ -76,6 +77,15 @@ static inline __host__ __device__ int stm_tall_launches(const FrontSym &s, int p
     if (g > s.fm_est) g = s.fm_est;
     const int rows = s.fm_est - g;
     return (rows > STM_TALL_XWIDE) ? STM_NB / 2 : (rows > STM_TALL_WIDE) ? STM_NB / 4 : STM_NB / STM_SW;
+}
+
+// Gram-based panel (stmmqr_capanel.hip): rows of the panel below its pivot rows are cut into slabs of STM_CA_R rows, one
+// workgroup each.  The number of slab workgroups of a front is symbolic (every workgroup of a launch must agree on it).
+#define STM_CA_R 480
+static inline __host__ __device__ int stm_ca_slabs(const FrontSym &s)
+{
+    const int nb = (s.fm_ub - 1 + STM_CA_R - 1) / STM_CA_R;
+    return nb < 1 ? 1 : nb;
 }
 
 #define STM_QB_ROWS 512      // rows of a front per workgroup of the split Q-apply (k_qbig_step)

@@ -29,7 +29,7 @@
 namespace {
 
 thread_local std::string g_err;
-stmmqr_options g_opt = {STM_NB, 64, 0, 0, 0, 1, STM_TALL_MIN};
+stmmqr_options g_opt = {STM_NB, 64, 0, 0, 0, 1, STM_TALL_MIN};      // (panel_algo 0: Gram-based panel)
 size_t g_chunk[4] = {32, 5000, 4, 4};     // FCHUNK, SMALL, MINCHUNK, MINCHUNK_RATIO (SparseQR.h:16-19)
 
 // offsets inside the reference's sparse_common for the stock LP64 build; verified against the real header
@@ -101,6 +101,7 @@ struct Level {
     std::vector<int> nbig_at;            // big fronts with npanels > p
     std::vector<int> maxcb_at;           // max trailing column blocks at panel p
     std::vector<int> nsub_at;            // panel launches at p: 4 or 8 if any front takes the tall-panel pipeline
+    std::vector<int> nca_at;             // Gram-based panel: max slab workgroups (stm_ca_slabs) of the fronts active at p
     std::vector<int> maxsl_at;           // max 256-row slabs of the fronts still active at panel p (0: small)
 };
 
@@ -108,9 +109,8 @@ struct Level {
 
 struct stmmqr_plan {
     int device = 0;
-    hipStream_t stream = nullptr, stream2 = nullptr;   // stream2: look-ahead (rest of the trailing update)
+    hipStream_t stream = nullptr;
     hipEvent_t ev[8] = {};
-    std::vector<hipEvent_t> evpool;                    // ordering events of the look-ahead schedule
     long m = 0, n = 0, anz = 0, nf = 0, maxfn = 0, rjsize = 0, hisize = 0;
     int do_rank = 1;
     int tall_min = STM_TALL_MIN;                       // g_opt.tall_min_rows when the schedule was built
@@ -124,6 +124,7 @@ struct stmmqr_plan {
     int post_off = 0, rh_parts_off = 0, rh_maxparts = 1;
     long long farena = 0, carena = 0;
     int tslots = 1;
+    int gp_slabs = 1;                    // Gram-based panel: max slab workgroups of a front
     long long tpanels = 0;               // panels of all fronts: one kept T each (Q-apply on the resident factors)
     long long wp_doubles = 0;            // workspace of the row-parallel update (partial W blocks)
     bool pattern_set = false;
@@ -131,7 +132,7 @@ struct stmmqr_plan {
 
     DevBuf<FrontSym> d_fs;
     DevBuf<FrontNum> d_fnum;
-    DevBuf<double> d_F, d_C, d_T, d_Tall, d_Sx, d_Ax, d_Tau, d_RH, d_Wp, d_Wp2;
+    DevBuf<double> d_F, d_C, d_T, d_Gp, d_Tall, d_Sx, d_Ax, d_Tau, d_RH, d_Wp, d_Wp2;
     DevBuf<int> d_tslot, d_Sp, d_Sjrel, d_Sj0, d_Sleft, d_Child, d_Rjrel, d_Stair, d_Hii, d_Cmap, d_Cursor,
         d_Rhoff, d_lists, d_smap;
     DevBuf<long long> d_Rboff, d_total;
@@ -165,6 +166,7 @@ struct stmmqr_plan {
         DevCtx c;
         c.fs = d_fs.p; c.fnum = d_fnum.p; c.Farena = d_F.p; c.Carena = d_C.p; c.Tws = d_T.p; c.tslot = d_tslot.p;
         c.Tall = d_Tall.p;
+        c.Gp = d_Gp.p; c.gp_slabs = gp_slabs;
         c.Sx = d_Sx.p; c.Sp = d_Sp.p; c.Sjrel = d_Sjrel.p; c.Sj0 = d_Sj0.p; c.Sleft = d_Sleft.p;
         c.Child = d_Child.p; c.Rjrel = d_Rjrel.p; c.Stair = d_Stair.p; c.Tau = d_Tau.p; c.Hii = d_Hii.p;
         c.Rdead = d_Rdead.p; c.Cmap = d_Cmap.p; c.Cursor = d_Cursor.p; c.Rhoff = d_Rhoff.p; c.Rboff = d_Rboff.p;
@@ -178,11 +180,8 @@ struct stmmqr_plan {
     {
         for (auto &e : ev)
             if (e) (void)hipEventDestroy(e);
-        for (auto &e : evpool)
-            if (e) (void)hipEventDestroy(e);
         if (graph_exec) (void)hipGraphExecDestroy(graph_exec);
         if (stream) (void)hipStreamDestroy(stream);
-        if (stream2) (void)hipStreamDestroy(stream2);
     }
 };
 
@@ -202,6 +201,7 @@ int ensure_device(int device)
     static bool configured = false;
     if (!configured) {
         LCHK(stm_configure_kernels());
+        LCHK(stm_configure_capanel());
         configured = true;
     }
     return 0;
@@ -226,6 +226,7 @@ void build_schedule(stmmqr_plan &P, std::vector<int> &tslot)
     P.glevels.assign(ngroups, std::vector<Level>());
     P.lists.clear();
     P.tslots = 1;
+    P.gp_slabs = 1;
     P.wp_doubles = 0;
     for (int grp = 0; grp < ngroups; grp++) {
         std::vector<int> level(nf, -1);
@@ -288,6 +289,7 @@ void build_schedule(stmmqr_plan &P, std::vector<int> &tslot)
             L.maxcb_at.assign(maxp, 0);
             L.nsub_at.assign(maxp, 1);
             L.maxsl_at.assign(maxp, 0);
+            L.nca_at.assign(maxp, 1);
             for (int p = 0; p < maxp; p++) {
                 int cnt = 0, mcb = 0, msl = 0;
                 for (int f : big) {
@@ -298,6 +300,8 @@ void build_schedule(stmmqr_plan &P, std::vector<int> &tslot)
                         mcb = std::max(mcb, (s.fn - k2 + 31) / 32);
                         msl = std::max(msl, (s.fm_ub + 255) / 256);
                         L.nsub_at[p] = std::max(L.nsub_at[p], stm_tall_launches(s, p, P.tall_min));
+                        L.nca_at[p] = std::max(L.nca_at[p], stm_ca_slabs(s));
+                        P.gp_slabs = std::max(P.gp_slabs, stm_ca_slabs(s));
                     }
                 }
                 L.nbig_at[p] = cnt;
@@ -463,6 +467,7 @@ int build_plan(stmmqr_plan &P, const stmmqr_symbolic_view &v)
     LCHK(P.d_F.alloc((size_t)P.farena));
     LCHK(P.d_C.alloc((size_t)P.carena));
     LCHK(P.d_T.alloc((size_t)2 * P.tslots * STM_NB * STM_NB));
+    LCHK(P.d_Gp.alloc((size_t)P.tslots * (P.gp_slabs + 1) * STM_NB * STM_NB));
     LCHK(P.d_Tall.alloc((size_t)std::max(1LL, P.tpanels) * STM_NB * STM_NB));
     LCHK(P.d_Wp.alloc((size_t)P.wp_doubles));
     LCHK(P.d_Wp2.alloc((size_t)P.wp_doubles));
@@ -525,15 +530,6 @@ int run_schedule(stmmqr_plan &P, bool detail, int grp, bool first)
     const int *L0 = P.d_lists.p;
     long nlaunch = 0;
     float t_asm = 0, t_front = 0, t_upd = 0, t_cpk = 0;
-    size_t evnext = 0;
-    auto next_event = [&]() -> hipEvent_t {
-        if (evnext == P.evpool.size()) {
-            hipEvent_t e = nullptr;
-            if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return nullptr;
-            P.evpool.push_back(e);
-        }
-        return P.evpool[evnext++];
-    };
     // detail timing: bracket each category with events and accumulate (forces one sync per level)
     auto timed = [&](float &acc, auto &&fn) -> int {
         if (!detail) return fn();
@@ -576,66 +572,27 @@ int run_schedule(stmmqr_plan &P, bool detail, int grp, bool first)
             for (int q = 0; q < L.n_big; q++) fprintf(stderr, " %d", P.lists[L.all_off + L.n_small + q]);
             fprintf(stderr, "\n");
         }
-        if (detail || !g_opt.lookahead) {
-            for (size_t p = 0; p < L.nbig_at.size(); p++) {
-                e = timed(t_front, [&]() -> int {
-                    // the trailing update (either form) builds T itself, see dev_tall_group
-                    const int defer_ok = (L.maxcb_at[p] > 0) ? 1 : 0;
-                    LCHK(stm_launch_panel(c, big, L.nbig_at[p], (int)p, L.nsub_at[p], defer_ok, L.lds_big, st));
-                    return 0;
-                });
-                if (e) return e;
-                e = timed(t_upd, [&]() -> int {
-                    if (L.maxsl_at[p] > 0 && g_opt.split_update) {
-                        LCHK(stm_launch_update_split(c, big, L.nbig_at[p], (int)p, 0, L.maxcb_at[p], L.maxsl_at[p], P.d_Wp.p, 1, st));
-                        nlaunch += 1;
-                    } else
-                        LCHK(stm_launch_update(c, big, L.nbig_at[p], (int)p, 0, L.maxcb_at[p], st));
-                    return 0;
-                });
-                if (e) return e;
-                nlaunch += 2;
-            }
-        } else {
-            // look-ahead: the update of panel p is split into the column block the NEXT panel needs (stays on the
-            // main stream) and the rest, which runs on stream2 while panel p+1 is being factorized
-            if (!P.stream2) {
-                // look-ahead stream, created on first use: a few CUs are kept out of its mask so that the next panel's
-                // workgroup (one CU, ~150 KB of LDS) can start while the tail of the update fills the rest of the chip
-                uint32_t mask[8];
-                for (auto &w : mask) w = 0xffffffffu;
-                mask[0] &= ~0xffffu;
-                if (hipExtStreamCreateWithCUMask(&P.stream2, 8, mask) != hipSuccess) {
-                    (void)hipGetLastError();
-                    HIPCHK(hipStreamCreateWithFlags(&P.stream2, hipStreamNonBlocking));
-                }
-            }
-            hipStream_t s2 = P.stream2;
-            hipEvent_t prev_rest = nullptr;
-            for (size_t p = 0; p < L.nbig_at.size(); p++) {
-                LCHK(stm_launch_panel(c, big, L.nbig_at[p], (int)p, L.nsub_at[p], 0, L.lds_big, st));
-                hipEvent_t evp = next_event(), evr = next_event();
-                if (!evp || !evr) return fail(STMMQR_ERR_DEVICE, "hipEventCreate failed");
-                HIPCHK(hipEventRecord(evp, st));
-                if (prev_rest) HIPCHK(hipStreamWaitEvent(st, prev_rest, 0));      // same columns: keep the order
-                const bool split = L.maxsl_at[p] > 0 && g_opt.split_update;
-                if (split)
-                    LCHK(stm_launch_update_split(c, big, L.nbig_at[p], (int)p, 0, std::min(1, L.maxcb_at[p]), L.maxsl_at[p], P.d_Wp.p, 0, st));
+        for (size_t p = 0; p < L.nbig_at.size(); p++) {
+            e = timed(t_front, [&]() -> int {
+                // the trailing update (either form) builds T itself, see dev_tall_group / k_panel_ca
+                const int defer_ok = (L.maxcb_at[p] > 0) ? 1 : 0;
+                if (g_opt.panel_algo == 0)
+                    LCHK(stm_launch_panel_ca(c, big, L.nbig_at[p], (int)p, L.nca_at[p], defer_ok, st));
                 else
-                    LCHK(stm_launch_update(c, big, L.nbig_at[p], (int)p, 0, std::min(1, L.maxcb_at[p]), st));
-                if (L.maxcb_at[p] > 1) {
-                    HIPCHK(hipStreamWaitEvent(s2, evp, 0));
-                    if (split)
-                        LCHK(stm_launch_update_split(c, big, L.nbig_at[p], (int)p, 1, L.maxcb_at[p] - 1, L.maxsl_at[p], P.d_Wp2.p, 0, s2));
-                    else
-                        LCHK(stm_launch_update(c, big, L.nbig_at[p], (int)p, 1, L.maxcb_at[p] - 1, s2));
-                    HIPCHK(hipEventRecord(evr, s2));
-                    prev_rest = evr;
-                    nlaunch++;
-                }
-                nlaunch += 2;
-            }
-            if (prev_rest) HIPCHK(hipStreamWaitEvent(st, prev_rest, 0));
+                    LCHK(stm_launch_panel(c, big, L.nbig_at[p], (int)p, L.nsub_at[p], defer_ok, L.lds_big, st));
+                return 0;
+            });
+            if (e) return e;
+            e = timed(t_upd, [&]() -> int {
+                if (L.maxsl_at[p] > 0 && g_opt.split_update) {
+                    LCHK(stm_launch_update_split(c, big, L.nbig_at[p], (int)p, 0, L.maxcb_at[p], L.maxsl_at[p], P.d_Wp.p, 1, st));
+                    nlaunch += 1;
+                } else
+                    LCHK(stm_launch_update(c, big, L.nbig_at[p], (int)p, 0, L.maxcb_at[p], st));
+                return 0;
+            });
+            if (e) return e;
+            nlaunch += 2;
         }
         if (L.n_big > 0) {
             e = timed(t_cpk, [&]() -> int {
@@ -785,7 +742,7 @@ int stmmqr_factorize_group(stmmqr_plan *plan, int group, int detail)
     stmmqr_plan &P = *plan;
     HIPCHK(hipSetDevice(P.device));
     int e = 0;
-    const bool graph_ok = g_opt.use_graph && !detail && !g_opt.lookahead && group == 0 && P.first_group && !getenv("STMMQR_DUMPLV");
+    const bool graph_ok = g_opt.use_graph && !detail && group == 0 && P.first_group && !getenv("STMMQR_DUMPLV");
     if (graph_ok) {
         // replay the level schedule of group 0 as a hipGraph (captured once per plan and per (tol, ntol, debug mask):
         // these travel in the kernel arguments)
@@ -897,6 +854,7 @@ int stmmqr_plan_set_groups(stmmqr_plan *plan, const int *group)
     std::vector<int> tslot;
     build_schedule(P, tslot);
     LCHK(P.d_T.alloc((size_t)2 * P.tslots * STM_NB * STM_NB));
+    LCHK(P.d_Gp.alloc((size_t)P.tslots * (P.gp_slabs + 1) * STM_NB * STM_NB));
     LCHK(P.d_Wp.alloc((size_t)P.wp_doubles));
     LCHK(P.d_Wp2.alloc((size_t)P.wp_doubles));
     LCHK(P.d_tslot.upload(tslot, P.stream));

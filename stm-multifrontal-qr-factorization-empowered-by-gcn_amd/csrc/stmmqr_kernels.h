@@ -12,6 +12,8 @@ struct DevCtx {
     double *Tws;               // T factors of the large fronts in flight, [slots][NB*NB]
     const int *tslot;          // [nf] slot in Tws (large fronts only)
     double *Tall;              // [sum of npanels][NB*NB] T of EVERY panel, kept for the Q-apply (nullptr: not kept)
+    double *Gp;                // Gram-based panel: per T slot, gp_slabs partial Gram matrices + the M mailbox, NB*NB each
+    int gp_slabs;              // max slab workgroups of a front (stm_ca_slabs) over the plan
     const double *Sx;          // [anz] values of S = A(P,Q), row form
     const int *Sp;             // [m+1]
     const int *Sjrel;          // [anz] column of each S entry inside its front
@@ -46,6 +48,8 @@ int stm_launch_setup(const DevCtx &c, const int *flist, int nfr, hipStream_t st)
 int stm_launch_assemble(const DevCtx &c, const int *flist, const int *nparts, int nfr, int maxparts, hipStream_t st);
 int stm_launch_front_wg(const DevCtx &c, const int *flist, int nfr, int lds_doubles, hipStream_t st);
 int stm_launch_panel(const DevCtx &c, const int *flist, int nfr, int p, int nsub, int defer_ok, int lds_doubles, hipStream_t st);
+int stm_configure_capanel(void);
+int stm_launch_panel_ca(const DevCtx &c, const int *flist, int nfr, int p, int nw, int defer_ok, hipStream_t st);
 int stm_launch_update(const DevCtx &c, const int *flist, int nfr, int p, int cb0, int ncb, hipStream_t st);
 int stm_launch_update_split(const DevCtx &c, const int *flist, int nfr, int p, int cb0, int ncb, int maxsl, double *Wp,
                             int with_gram, hipStream_t st);

@@ -23,8 +23,7 @@
 #include "stmmqr_device.h"
 #include "stmmqr_kernels.h"
 #include "stmmqr_wave.h"
-
-typedef double d4 __attribute__((ext_vector_type(4)));
+#include "stmmqr_devutil.h"
 
 // small LDS working set of the panel routines, declared once per kernel and shared by every code path
 struct PanelShared {
@@ -1098,14 +1097,7 @@ __device__ __forceinline__ void dev_panel(PanelShared &ps, const FrontSym &s, Fr
 // panel height (<= STM_TALL_MAX rows).  The last group also builds T of the whole panel (dev_gram_T) and the
 // block-reflector description for the trailing update.
 // ------------------------------------------------------------------------------------------------
-// barrier that orders LDS traffic only: the column stores to F stay in flight (a full __syncthreads would wait for them)
-__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
-
-__device__ __forceinline__ int ld_agent(const int *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ void st_agent(int *p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ double ld_agent(const double *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ void st_agent(double *p, double v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ void st_agent(char *p, char v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+// (lds_barrier, ld_agent / st_agent: stmmqr_devutil.h)
 
 // whole workgroup: wait until *flag >= target (written by another workgroup of this launch), then acquire.
 // Returns false if the bounded spin ran out (never expected; the caller gives up on the panel).
@@ -1937,14 +1929,47 @@ __global__ __launch_bounds__(NT) void k_upd_c(DevCtx c, const int *__restrict__ 
     }
 }
 
-__global__ __launch_bounds__(NT) void k_cpack(DevCtx c, const int *__restrict__ flist,
-                                              const int *__restrict__ nparts_list)
+// T of the LAST panel of a front whose panel kernel left it pending (PanelDesc::t_deferred == 2: the Gram-based panel never
+// builds T, and no trailing update follows the last panel).  Only the Q-apply on the resident factors reads it (DevCtx::Tall).
+__device__ void dev_tlast(const DevCtx &c, int f, const FrontSym &s, FrontNum *num, double *scratch)
 {
+    __shared__ PanelShared ps;
+    const int p = s.npanels - 1;
+    if (p < 0) return;
+    const PanelDesc *pd = &num->pd[p & 1];
+    if (pd->t_deferred != 2 || pd->pnb <= 0) return;
+    const int tid = threadIdx.x;
+    if (tid < STM_NB) {
+        const int d = (tid < pd->pnb) ? pd->pdiag[tid] : STM_BIGROW;
+        ps.diag[tid] = d;
+        ps.tau[tid] = (d != STM_BIGROW) ? c.Tau[s.rp + pd->pk1 + tid] : 0.0;
+    }
+    __syncthreads();
+    double *Tout = c.Tws + (long long)(2 * c.tslot[f] + (p & 1)) * STM_NB * STM_NB;
+    dev_gram_T<NT>(c.Farena + s.foff + (long long)pd->pk1 * s.ld, s.ld, pd->pg1, pd->pt, pd->pnb, ps.diag, ps.tau, ps.G, ps.T, Tout,
+                   scratch);
+    if (c.Tall) {
+        double *Tkeep = c.Tall + (long long)(s.tpan + p) * STM_NB * STM_NB;
+        for (int e = tid; e < STM_NB * STM_NB; e += NT) {
+            const int a = e % STM_NB, b = e / STM_NB;
+            Tkeep[e] = (a < pd->pnb && b < pd->pnb && a <= b) ? ps.T[a][b] : 0.0;
+        }
+    }
+}
+
+__global__ __launch_bounds__(NT) void k_cpack(DevCtx c, const int *__restrict__ flist,
+                                              const int *__restrict__ nparts_list, int maxparts)
+{
+    extern __shared__ double dyn_lds[];
     const int fi = blockIdx.y;
-    const int nparts = nparts_list[fi];
-    if ((int)blockIdx.x >= nparts) return;
     const int f = flist[fi];
     const FrontSym s = c.fs[f];
+    if ((int)blockIdx.x == maxparts) {                         // the extra workgroup of every front: pending T of its last panel
+        dev_tlast(c, f, s, &c.fnum[f], dyn_lds);
+        return;
+    }
+    const int nparts = nparts_list[fi];
+    if ((int)blockIdx.x >= nparts) return;
     dev_cpack(c, s, &c.fnum[f], blockIdx.x, nparts);
 }
 
@@ -2702,7 +2727,8 @@ int stm_launch_larft(const DevCtx &c, int f, hipStream_t st)
 int stm_launch_cpack(const DevCtx &c, const int *flist, const int *nparts, int nfr, int maxparts, hipStream_t st)
 {
     if (nfr <= 0) return 0;
-    hipLaunchKernelGGL(k_cpack, dim3(maxparts, nfr), dim3(NT), 0, st, c, flist, nparts);
+    // (+1: the workgroup that builds a pending T of the last panel, dev_tlast; its Gram scratch is the dynamic LDS)
+    hipLaunchKernelGGL(k_cpack, dim3(maxparts + 1, nfr), dim3(NT), (size_t)(4 * 768) * sizeof(double), st, c, flist, nparts, maxparts);
     return (int)hipGetLastError();
 }
 int stm_launch_rh_count(const DevCtx &c, const int *flist, int nfr, hipStream_t st)

@@ -38,7 +38,7 @@ template <class T> struct Buf {
 bool device_ready()
 {
     static int state = 0;
-    if (state == 0) state = (stmmqr_device_count() > 0 && stm_configure_kernels() == 0) ? 1 : -1;
+    if (state == 0) state = (stmmqr_device_count() > 0 && stm_configure_kernels() == 0 && stm_configure_capanel() == 0) ? 1 : -1;
     return state == 1;
 }
 
@@ -48,7 +48,7 @@ struct OneFront {
     FrontNum nm{};
     Buf<FrontSym> d_fs;
     Buf<FrontNum> d_nm;
-    Buf<double> d_F, d_C, d_T, d_Tau, d_RH;
+    Buf<double> d_F, d_C, d_T, d_Gp, d_Tau, d_RH;
     Buf<int> d_St, d_tslot, d_flist, d_Rhoff, d_parts;
     Buf<long long> d_Rboff;
     Buf<unsigned long long> d_dbg;
@@ -73,7 +73,7 @@ struct OneFront {
         const long cn = n - s.fp, cm = std::min(m, cn);
         std::vector<int> zero1(1, 0);
         bool ok = d_F.up(Fd) && d_St.up(st32) && d_fs.up(&s, 1) && d_nm.up(&nm, 1) &&
-                  d_C.alloc((size_t)std::max(1L, cm * (cm + 1) / 2 + cm * (cn - cm))) && d_T.alloc(2 * STM_NB * STM_NB) &&
+                  d_C.alloc((size_t)std::max(1L, cm * (cm + 1) / 2 + cm * (cn - cm))) && d_T.alloc(2 * STM_NB * STM_NB) && d_Gp.alloc((size_t)(stm_ca_slabs(s) + 1) * STM_NB * STM_NB) &&
                   d_Tau.alloc((size_t)std::max(1L, n)) && d_Rdead.alloc((size_t)std::max(1L, n)) && d_tslot.up(zero1) &&
                   d_flist.up(zero1) && d_Rhoff.alloc((size_t)std::max(1L, n)) && d_Rboff.alloc(1) &&
                   d_RH.alloc((size_t)std::max(1L, m * n));
@@ -83,6 +83,7 @@ struct OneFront {
         (void)hipMemset(d_Rboff.p, 0, sizeof(long long));
         memset(&c, 0, sizeof c);
         c.fs = d_fs.p; c.fnum = d_nm.p; c.Farena = d_F.p; c.Carena = d_C.p; c.Tws = d_T.p; c.tslot = d_tslot.p;
+        c.Gp = d_Gp.p; c.gp_slabs = stm_ca_slabs(s);
         c.Stair = d_St.p; c.Tau = d_Tau.p; c.Rdead = d_Rdead.p; c.Rhoff = d_Rhoff.p; c.Rboff = d_Rboff.p;
         c.dbg = getenv("STMMQR_DBG") ? atoi(getenv("STMMQR_DBG")) : 0;
         { stmmqr_options o; stmmqr_get_options(&o); c.tall_min = o.tall_min_rows; }
@@ -167,7 +168,8 @@ stm_long stmmqr_front(stm_long m, stm_long n, stm_long npiv, double tol, stm_lon
             const int k2 = (int)std::min<long>(n, (long)(p + 1) * STM_NB);
             const int ncb = (int)((n - k2 + 31) / 32);
             const int defer_ok = (ncb > 0) ? 1 : 0;
-            e = stm_launch_panel(X.c, X.d_flist.p, 1, p, stm_tall_launches(X.s, p, X.c.tall_min), defer_ok, lds_for(m), nullptr);
+            if (opt.panel_algo == 0) e = stm_launch_panel_ca(X.c, X.d_flist.p, 1, p, stm_ca_slabs(X.s), defer_ok, nullptr);
+            else e = stm_launch_panel(X.c, X.d_flist.p, 1, p, stm_tall_launches(X.s, p, X.c.tall_min), defer_ok, lds_for(m), nullptr);
             if (e || ncb <= 0) continue;
             if (split) e = stm_launch_update_split(X.c, X.d_flist.p, 1, p, 0, ncb, msl, d_Wp.p, 1, nullptr);
             else e = stm_launch_update(X.c, X.d_flist.p, 1, p, 0, ncb, nullptr);
@@ -187,8 +189,10 @@ stm_long stmmqr_front(stm_long m, stm_long n, stm_long npiv, double tol, stm_lon
         if (X.c.dbg & 32) {
             std::vector<unsigned long long> tl(1024);
             (void)hipMemcpy(tl.data(), X.c.dbgbuf, 1024 * sizeof(unsigned long long), hipMemcpyDeviceToHost);
-            const unsigned long long t0 = tl[16];
-            for (int b = 0; b < 8 && tl[16 + 64 * b]; b++) {
+            unsigned long long t0 = ~0ull;
+            for (int b = 0; b < 8; b++) if (tl[16 + 64 * b] && tl[16 + 64 * b] < t0) t0 = tl[16 + 64 * b];
+            for (int b = 0; b < 8; b++) {
+                if (!tl[16 + 64 * b]) continue;
                 fprintf(stderr, "[timeline panel 1, group %d, us]", b);
                 for (int i = 0; i < 48; i++)
                     if (tl[16 + 64 * b + i]) fprintf(stderr, " %d:%.2f", i, 0.01 * (double)(long long)(tl[16 + 64 * b + i] - t0));
