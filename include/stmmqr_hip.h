@@ -137,7 +137,7 @@ typedef struct stmmqr_stats {
     double flops;              /* the reference's FLOP_COUNT formula (SparseQR_factorize.c:1571)          */
     double ms_total;           /* upload-excluded device time: gather S .. pack R+H                        */
     double ms_assemble;        /* front_setup + assemble kernels                                            */
-    double ms_front;           /* panel + trailing-update kernels                                           */
+    double ms_front;           /* panel + trailing-update + small-front kernels (detail runs)              */
     double ms_pack;            /* R+H count / scan / copy kernels                                           */
     double ms_h2d, ms_d2h;     /* PCIe transfers of A values in, packed factors out                         */
     double ms_host;            /* host-side planning + hpinv                                                */
@@ -147,6 +147,11 @@ typedef struct stmmqr_stats {
     double ms_update;          /* time of the MFMA trailing-update launches only                            */
     stm_long nlaunch;          /* kernel launches in the timed region                                       */
     stm_long nlevels;
+    /* detail runs only (stats->nlaunch == -1 on entry): HIP-event pairs around every launch of a category, recorded on
+       the plan's stream without any synchronisation (the schedule runs as in an untimed call)                       */
+    double ms_panel;           /* panel kernels of the large fronts (k_panel / k_panel_ca)                          */
+    double ms_small;           /* k_front_wg: whole small fronts                                                    */
+    stm_long npanel_launch, nupdate_launch;   /* event pairs behind ms_panel / ms_update (one per level step)       */
 } stmmqr_stats;
 
 typedef struct stmmqr_plan stmmqr_plan;     /* device-resident symbolic plan + arenas; reusable across calls */
@@ -235,8 +240,9 @@ typedef struct stmmqr_options {
     int big_front_cols;     /* fronts with fn >= this use the multi-workgroup panel/update path                     */
     int verbose;
     int use_graph;          /* replay the level schedule as a hipGraph (captured per plan and tol); 0: no gain measured */
-    int panel_algo;         /* panel of the large fronts: 0 Gram-based (one reduction per panel; default), 1 the column
-                               pipeline of round 1 (one reduction per column), kept for cross-checks              */
+    int panel_algo;         /* panel of the large fronts: 1 the column pipeline (one workgroup reduction per column),
+                               2 the Gram-based panel (one Gram matrix per panel, any height), 0 (default) by panel
+                               height: Gram-based above 2048 rows, where the pipeline's register groups narrow      */
     int split_update;       /* row-parallel (2-launch) trailing update for fronts of >= 3 row slabs (1)             */
     int tall_min_rows;      /* panels with more rows than this run as a pipeline of column groups (plan time; 0)    */
 } stmmqr_options;

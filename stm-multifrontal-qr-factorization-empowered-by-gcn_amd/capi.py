@@ -39,7 +39,8 @@ class SymbolicView(C.Structure):
 class Stats(C.Structure):
     _fields_ = [(k, C.c_double) for k in ["flops", "ms_total", "ms_assemble", "ms_front", "ms_pack", "ms_h2d", "ms_d2h",
                                           "ms_host", "bytes_assemble", "bytes_pack", "flops_update", "ms_update"]] + \
-               [("nlaunch", C.c_long), ("nlevels", C.c_long)]
+               [("nlaunch", C.c_long), ("nlevels", C.c_long), ("ms_panel", C.c_double), ("ms_small", C.c_double),
+                ("npanel_launch", C.c_long), ("nupdate_launch", C.c_long)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}

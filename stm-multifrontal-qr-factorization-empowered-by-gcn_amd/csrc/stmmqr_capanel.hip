@@ -148,7 +148,7 @@ __global__ __launch_bounds__(CA_NT) void k_panel_ca(DevCtx c, const int *__restr
     __shared__ int s_ok;
     const int f = flist[blockIdx.x];
     const FrontSym s = c.fs[f];
-    if (p >= s.npanels) return;
+    if (p >= s.npanels || !stm_use_ca(s, p, c.panel_algo)) return;
     const int w = blockIdx.y;
     const int nwf = stm_ca_slabs(s);                    // symbolic: every workgroup of the launch agrees
     if (w >= nwf) return;
@@ -212,8 +212,10 @@ __global__ __launch_bounds__(CA_NT) void k_panel_ca(DevCtx c, const int *__restr
         double v[STM_NB];
 #pragma unroll
         for (int x = 0; x < STM_NB; x++) v[x] = F[(long long)(k1 + min(x, nbp - 1)) * ld + rbase + i];
+        if (tid < STM_CA_R) {                           // (the image has STM_CA_R rows per column; rows >= nr are zero)
 #pragma unroll
-        for (int x = 0; x < STM_NB; x++) S[x * CA_LD + tid] = (x < nbp && tid < nr) ? v[x] : 0.0;
+            for (int x = 0; x < STM_NB; x++) S[x * CA_LD + tid] = (x < nbp && tid < nr) ? v[x] : 0.0;
+        }
     }
     for (int e = tid; e < STM_NB * STM_NB; e += CA_NT) {
         const int i = e >> 5, x = e & 31;

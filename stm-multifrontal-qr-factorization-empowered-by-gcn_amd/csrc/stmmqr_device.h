@@ -68,6 +68,22 @@ static inline __host__ __device__ int stm_tall_panel(const FrontSym &s, int p, i
     if (g > s.fm_est) g = s.fm_est;
     return s.fm_est - g > tall_min;
 }
+// estimated rows of panel p (exact for full-rank fronts)
+static inline __host__ __device__ int stm_panel_rows_est(const FrontSym &s, int p)
+{
+    int g = p * STM_NB;
+    if (g > s.fp) g = s.fp;
+    if (g > s.fm_est) g = s.fm_est;
+    return s.fm_est - g;
+}
+// Which panel kernel factorizes panel p of this front?  A property of the front alone (symbolic), never of the fronts that
+// happen to share its level: the two kernels round differently and sharded == unsharded must stay bit-identical.
+// algo = stmmqr_options::panel_algo: 1 column pipeline, 2 Gram-based, 0 Gram-based above STM_TALL_WIDE rows.
+#define STM_CA_MIN_ROWS (4 * 512)
+static inline __host__ __device__ int stm_use_ca(const FrontSym &s, int p, int algo)
+{
+    return algo == 2 || (algo == 0 && stm_panel_rows_est(s, p) > STM_CA_MIN_ROWS);
+}
 // planned number of column groups for panel p: 1 (not tall), 4, or 8 / 16 when 4- / 2-column sub-panels may be needed
 static inline __host__ __device__ int stm_tall_launches(const FrontSym &s, int p, int tall_min)
 {

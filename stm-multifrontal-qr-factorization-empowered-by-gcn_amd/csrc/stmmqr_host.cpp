@@ -29,7 +29,7 @@
 namespace {
 
 thread_local std::string g_err;
-stmmqr_options g_opt = {STM_NB, 64, 0, 0, 0, 1, STM_TALL_MIN};      // (panel_algo 0: Gram-based panel)
+stmmqr_options g_opt = {STM_NB, 64, 0, 0, 0, 1, STM_TALL_MIN};      // (panel_algo 0: by panel height)
 size_t g_chunk[4] = {32, 5000, 4, 4};     // FCHUNK, SMALL, MINCHUNK, MINCHUNK_RATIO (SparseQR.h:16-19)
 
 // offsets inside the reference's sparse_common for the stock LP64 build; verified against the real header
@@ -101,6 +101,7 @@ struct Level {
     std::vector<int> nbig_at;            // big fronts with npanels > p
     std::vector<int> maxcb_at;           // max trailing column blocks at panel p
     std::vector<int> nsub_at;            // panel launches at p: 4 or 8 if any front takes the tall-panel pipeline
+    std::vector<int> nca_use, npipe_use; // fronts active at p that take the Gram-based / the pipeline panel kernel
     std::vector<int> nca_at;             // Gram-based panel: max slab workgroups (stm_ca_slabs) of the fronts active at p
     std::vector<int> maxsl_at;           // max 256-row slabs of the fronts still active at panel p (0: small)
 };
@@ -111,8 +112,14 @@ struct stmmqr_plan {
     int device = 0;
     hipStream_t stream = nullptr;
     hipEvent_t ev[8] = {};
+    // detail timing: one event pair per launch category and level step, recorded on the plan's stream WITHOUT any
+    // synchronisation (the schedule runs exactly as in the timed region); the pairs are read after the final sync
+    struct EvPair { hipEvent_t a, b; int cat; };
+    std::vector<EvPair> evpairs;
+    size_t evused = 0;
     long m = 0, n = 0, anz = 0, nf = 0, maxfn = 0, rjsize = 0, hisize = 0;
     int do_rank = 1;
+    int plan_algo = 0;                                 // g_opt.panel_algo when the schedule was built
     int tall_min = STM_TALL_MIN;                       // g_opt.tall_min_rows when the schedule was built
     std::vector<long> Sp, Sj, Qfill, PLinv, Sleft, Child, Childp, Super, Rp, Rj, Post, Hip, Fm;
     bool has_qfill = false;
@@ -166,7 +173,7 @@ struct stmmqr_plan {
         DevCtx c;
         c.fs = d_fs.p; c.fnum = d_fnum.p; c.Farena = d_F.p; c.Carena = d_C.p; c.Tws = d_T.p; c.tslot = d_tslot.p;
         c.Tall = d_Tall.p;
-        c.Gp = d_Gp.p; c.gp_slabs = gp_slabs;
+        c.Gp = d_Gp.p; c.gp_slabs = gp_slabs; c.panel_algo = plan_algo;
         c.Sx = d_Sx.p; c.Sp = d_Sp.p; c.Sjrel = d_Sjrel.p; c.Sj0 = d_Sj0.p; c.Sleft = d_Sleft.p;
         c.Child = d_Child.p; c.Rjrel = d_Rjrel.p; c.Stair = d_Stair.p; c.Tau = d_Tau.p; c.Hii = d_Hii.p;
         c.Rdead = d_Rdead.p; c.Cmap = d_Cmap.p; c.Cursor = d_Cursor.p; c.Rhoff = d_Rhoff.p; c.Rboff = d_Rboff.p;
@@ -180,6 +187,7 @@ struct stmmqr_plan {
     {
         for (auto &e : ev)
             if (e) (void)hipEventDestroy(e);
+        for (auto &q : evpairs) { if (q.a) (void)hipEventDestroy(q.a); if (q.b) (void)hipEventDestroy(q.b); }
         if (graph_exec) (void)hipGraphExecDestroy(graph_exec);
         if (stream) (void)hipStreamDestroy(stream);
     }
@@ -215,6 +223,7 @@ int ensure_device(int device)
 void build_schedule(stmmqr_plan &P, std::vector<int> &tslot)
 {
     P.tall_min = g_opt.tall_min_rows;
+    P.plan_algo = g_opt.panel_algo;
     const long nf = P.nf;
     int ngroups = 1;
     for (long f = 0; f < nf; f++) ngroups = std::max(ngroups, P.group[f] + 1);
@@ -290,6 +299,8 @@ void build_schedule(stmmqr_plan &P, std::vector<int> &tslot)
             L.nsub_at.assign(maxp, 1);
             L.maxsl_at.assign(maxp, 0);
             L.nca_at.assign(maxp, 1);
+            L.nca_use.assign(maxp, 0);
+            L.npipe_use.assign(maxp, 0);
             for (int p = 0; p < maxp; p++) {
                 int cnt = 0, mcb = 0, msl = 0;
                 for (int f : big) {
@@ -301,6 +312,7 @@ void build_schedule(stmmqr_plan &P, std::vector<int> &tslot)
                         msl = std::max(msl, (s.fm_ub + 255) / 256);
                         L.nsub_at[p] = std::max(L.nsub_at[p], stm_tall_launches(s, p, P.tall_min));
                         L.nca_at[p] = std::max(L.nca_at[p], stm_ca_slabs(s));
+                        (stm_use_ca(s, p, g_opt.panel_algo) ? L.nca_use[p] : L.npipe_use[p])++;
                         P.gp_slabs = std::max(P.gp_slabs, stm_ca_slabs(s));
                     }
                 }
@@ -529,20 +541,25 @@ int run_schedule(stmmqr_plan &P, bool detail, int grp, bool first)
     const DevCtx c = P.ctx();
     const int *L0 = P.d_lists.p;
     long nlaunch = 0;
-    float t_asm = 0, t_front = 0, t_upd = 0, t_cpk = 0;
-    // detail timing: bracket each category with events and accumulate (forces one sync per level)
-    auto timed = [&](float &acc, auto &&fn) -> int {
+    // detail timing: bracket each category with an event pair from the pool; no host synchronisation here
+    enum { CAT_ASM = 0, CAT_SMALL = 1, CAT_PANEL = 2, CAT_UPD = 3, CAT_CPK = 4 };
+    auto timed = [&](int cat, auto &&fn) -> int {
         if (!detail) return fn();
-        HIPCHK(hipEventRecord(P.ev[2], st));
+        if (P.evused == P.evpairs.size()) {
+            stmmqr_plan::EvPair q = {nullptr, nullptr, 0};
+            HIPCHK(hipEventCreate(&q.a));
+            HIPCHK(hipEventCreate(&q.b));
+            P.evpairs.push_back(q);
+        }
+        stmmqr_plan::EvPair &q = P.evpairs[P.evused++];
+        q.cat = cat;
+        HIPCHK(hipEventRecord(q.a, st));
         int e = fn();
         if (e) return e;
-        HIPCHK(hipEventRecord(P.ev[3], st));
-        HIPCHK(hipEventSynchronize(P.ev[3]));
-        float ms = 0;
-        HIPCHK(hipEventElapsedTime(&ms, P.ev[2], P.ev[3]));
-        acc += ms;
+        HIPCHK(hipEventRecord(q.b, st));
         return 0;
     };
+    const int t_asm = CAT_ASM, t_front = CAT_SMALL, t_panel = CAT_PANEL, t_upd = CAT_UPD, t_cpk = CAT_CPK;
 
     if (first) {
         HIPCHK(hipMemsetAsync(P.d_F.p, 0, (size_t)P.farena * sizeof(double), st));
@@ -573,12 +590,14 @@ int run_schedule(stmmqr_plan &P, bool detail, int grp, bool first)
             fprintf(stderr, "\n");
         }
         for (size_t p = 0; p < L.nbig_at.size(); p++) {
-            e = timed(t_front, [&]() -> int {
+            e = timed(t_panel, [&]() -> int {
                 // the trailing update (either form) builds T itself, see dev_tall_group / k_panel_ca
                 const int defer_ok = (L.maxcb_at[p] > 0) ? 1 : 0;
-                if (g_opt.panel_algo == 0)
+                // which kernel takes a panel is a property of the front (stm_use_ca); a level step with both kinds gets
+                // both launches (each kernel skips the other's fronts)
+                if (L.nca_use[p])
                     LCHK(stm_launch_panel_ca(c, big, L.nbig_at[p], (int)p, L.nca_at[p], defer_ok, st));
-                else
+                if (L.npipe_use[p])
                     LCHK(stm_launch_panel(c, big, L.nbig_at[p], (int)p, L.nsub_at[p], defer_ok, L.lds_big, st));
                 return 0;
             });
@@ -603,10 +622,6 @@ int run_schedule(stmmqr_plan &P, bool detail, int grp, bool first)
             nlaunch++;
         }
     }
-    P.stats.ms_assemble += t_asm;
-    P.stats.ms_front += t_front + t_upd;
-    P.stats.ms_update += t_upd;
-    P.stats.ms_pack += t_cpk;
     P.stats.nlaunch += nlaunch;
     P.stats.nlevels += (long)P.glevels[grp].size();
     return 0;
@@ -722,6 +737,7 @@ int stmmqr_factorize_begin(stmmqr_plan *plan, const stm_long *Ap, const stm_long
     P.stats.ms_host = host_ms_plan;
     P.factored = false;
     P.rowmap_ready = false;
+    P.evused = 0;
     P.begun = true;
     P.first_group = true;
     if (!P.do_rank) tol = -1;                                  // SparseQR_factorize.c:285-289
@@ -786,6 +802,18 @@ int stmmqr_factorize_finish(stmmqr_plan *plan, stmmqr_stats *stats)
     HIPCHK(hipEventElapsedTime(&ms, P.ev[0], P.ev[1])); P.stats.ms_h2d = ms;
     HIPCHK(hipEventElapsedTime(&ms, P.ev[1], P.ev[5])); P.stats.ms_total = ms;
     HIPCHK(hipEventElapsedTime(&ms, P.ev[4], P.ev[5])); P.stats.ms_pack += ms;
+    for (size_t q = 0; q < P.evused; q++) {
+        float t = 0;
+        HIPCHK(hipEventElapsedTime(&t, P.evpairs[q].a, P.evpairs[q].b));
+        switch (P.evpairs[q].cat) {
+            case 0: P.stats.ms_assemble += t; break;
+            case 1: P.stats.ms_front += t; P.stats.ms_small += t; break;
+            case 2: P.stats.ms_front += t; P.stats.ms_panel += t; P.stats.npanel_launch++; break;
+            case 3: P.stats.ms_front += t; P.stats.ms_update += t; P.stats.nupdate_launch++; break;
+            default: P.stats.ms_pack += t; break;
+        }
+    }
+    P.evused = 0;
 
     // per-front numeric summary (small): flops, ranks
     P.h_fnum.resize((size_t)std::max(1L, P.nf));

@@ -86,7 +86,7 @@ struct OneFront {
         c.Gp = d_Gp.p; c.gp_slabs = stm_ca_slabs(s);
         c.Stair = d_St.p; c.Tau = d_Tau.p; c.Rdead = d_Rdead.p; c.Rhoff = d_Rhoff.p; c.Rboff = d_Rboff.p;
         c.dbg = getenv("STMMQR_DBG") ? atoi(getenv("STMMQR_DBG")) : 0;
-        { stmmqr_options o; stmmqr_get_options(&o); c.tall_min = o.tall_min_rows; }
+        { stmmqr_options o; stmmqr_get_options(&o); c.tall_min = o.tall_min_rows; c.panel_algo = o.panel_algo; }
 #ifdef STMMQR_STAMPS
         if (!d_dbg.alloc(1024)) return false;
         (void)hipMemset(d_dbg.p, 0, 1024 * sizeof(unsigned long long));
@@ -168,7 +168,7 @@ stm_long stmmqr_front(stm_long m, stm_long n, stm_long npiv, double tol, stm_lon
             const int k2 = (int)std::min<long>(n, (long)(p + 1) * STM_NB);
             const int ncb = (int)((n - k2 + 31) / 32);
             const int defer_ok = (ncb > 0) ? 1 : 0;
-            if (opt.panel_algo == 0) e = stm_launch_panel_ca(X.c, X.d_flist.p, 1, p, stm_ca_slabs(X.s), defer_ok, nullptr);
+            if (stm_use_ca(X.s, p, opt.panel_algo)) e = stm_launch_panel_ca(X.c, X.d_flist.p, 1, p, stm_ca_slabs(X.s), defer_ok, nullptr);
             else e = stm_launch_panel(X.c, X.d_flist.p, 1, p, stm_tall_launches(X.s, p, X.c.tall_min), defer_ok, lds_for(m), nullptr);
             if (e || ncb <= 0) continue;
             if (split) e = stm_launch_update_split(X.c, X.d_flist.p, 1, p, 0, ncb, msl, d_Wp.p, 1, nullptr);

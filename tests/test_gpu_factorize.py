@@ -58,6 +58,34 @@ def test_against_golden_and_oracle(pkg, oracle, name, bigcols):
         assert np.linalg.norm(G.Stack[:G.rh_total] - ref) <= 1e-10 * max(np.linalg.norm(ref), 1e-300)
 
 
+@pytest.mark.parametrize("name", NAMES)
+@pytest.mark.parametrize("late", [None, 0, 1])
+def test_gram_panel_everywhere(pkg, oracle, monkeypatch, name, late):
+    """panel_algo = 2: every panel of every large front (fn >= 16 here) takes the Gram-based panel kernel (k_panel_ca: one
+    Gram matrix per panel, downdated in the column loop, refreshed when a column has lost too much of its norm; the default
+    uses it above 2048 rows only).  late: slab workgroup `late` of every panel starts ~1 ms late (the chain's owner is
+    the last workgroup to arrive: the result must not depend on who that is)."""
+    g = load_golden(name)
+    pkg.set_options(panel_algo=2, big_front_cols=16)
+    if late is not None:
+        monkeypatch.setenv("STMMQR_DBG", str(2048 + (late << 20)))
+    try:
+        S, G = gpu_run(pkg, g)
+    finally:
+        if late is not None:
+            monkeypatch.delenv("STMMQR_DBG")
+        pkg.set_options(panel_algo=0, big_front_cols=64)
+    N = numeric_from_gpu(S, G)
+    compare_integers(S, N, g)
+    assert G.stats["flops"] == scalar(g, "flopcount")
+    got, ref = rrow_sig_all(S, N), g["num_rrow_sig"]
+    ftol = ILL_CONDITIONED.get(name, 1e-10)
+    scale = np.max(ref[:, 1], initial=1e-300) if name in ILL_CONDITIONED else np.maximum(ref[:, 1:2], 1e-300)
+    assert np.max(np.abs(got - ref) / scale, initial=0.0) <= ftol
+    No = oracle.factorize(S, g["in_Ap"], g["in_Ai"], g["in_Ax"], scalar(g, "in_tol"), int(scalar(g, "in_ntol")))
+    compare_numeric(oracle, S, G, No, g, ftol=1e-10, name=name)
+
+
 @pytest.mark.parametrize("name,tall_min", [(n, 256) for n in NAMES] +
                          [(n, t) for n in ("syn_grid3d", "syn_rankdef_grid", "bcsstk14", "grid20_standin") for t in (48, 1 << 30)])
 def test_panel_pipeline_threshold(pkg, oracle, name, tall_min):

@@ -66,6 +66,32 @@ def test_qr_front(pkg, oracle, m, n, npiv, bigcols, tall_min, stair):
     assert np.linalg.norm(Fg - Fo) <= 1e-11 * scale
 
 
+@pytest.mark.parametrize("m,n,npiv", FRONTS + [(12000, 64, 64), (20000, 40, 33)])
+@pytest.mark.parametrize("stair", ["ramp", "full", "steps"])
+@pytest.mark.parametrize("late", [None, 2])
+def test_qr_front_gram_panel(pkg, oracle, monkeypatch, m, n, npiv, stair, late):
+    """panel_algo = 2: the Gram-based panel (k_panel_ca) for every panel of the front, any height (row slabs of 480 rows, one
+    workgroup each; no 8192-row limit).  late = 2: slab workgroup 2 starts ~1 ms late and therefore owns the chain."""
+    F0, St0 = make_front(m, n, 1234 + m + n, stair)
+    Fg, Sg = F0.copy(order="F"), St0.copy()
+    Fo, So = F0.copy(order="F"), St0.copy()
+    pkg.set_options(big_front_cols=8, panel_algo=2)
+    if late is not None:
+        monkeypatch.setenv("STMMQR_DBG", str(2048 + (late << 20)))
+    try:
+        rg, Tg, Dg, flg = pkg.qr_front(m, n, npiv, -1.0, n, Fg, Sg)
+    finally:
+        if late is not None:
+            monkeypatch.delenv("STMMQR_DBG")
+        pkg.set_options(big_front_cols=64, panel_algo=0)
+    ro, To, Do, flo = oracle.front(Fo, So, npiv, -1.0, n)
+    assert rg == ro and flg == flo
+    np.testing.assert_array_equal(Sg, So)
+    np.testing.assert_array_equal(Dg, Do)
+    assert np.linalg.norm(Tg - To) <= 1e-11 * max(np.linalg.norm(To), 1)
+    assert np.linalg.norm(Fg - Fo) <= 1e-11 * np.linalg.norm(Fo)
+
+
 @pytest.mark.parametrize("late", [0, 1, 2, 3])
 @pytest.mark.parametrize("m,n,npiv", [(266, 422, 124), (781, 900, 300), (1290, 1400, 64), (1500, 96, 64), (33, 97, 97),
                                      (5000, 70, 64)])
@@ -96,14 +122,14 @@ def test_qr_front_dead_columns(pkg, oracle, m):
     F0, St0 = make_front(m, n, 77, "full")
     F0[:, 7] = F0[:, 3]; F0[:, 21] = 2 * F0[:, 20] - F0[:, 19]; F0[:, 33] = 0
     tol = 1e-9
-    for bigcols in (128, 8):
+    for bigcols, algo in ((128, 0), (8, 1), (8, 2)):
         Fg, Sg = F0.copy(order="F"), St0.copy()
         Fo, So = F0.copy(order="F"), St0.copy()
-        pkg.set_options(big_front_cols=bigcols)
+        pkg.set_options(big_front_cols=bigcols, panel_algo=algo)
         try:
             rg, Tg, Dg, _ = pkg.qr_front(m, n, npiv, tol, npiv, Fg, Sg)
         finally:
-            pkg.set_options(big_front_cols=64)
+            pkg.set_options(big_front_cols=64, panel_algo=0)
         ro, To, Do, _ = oracle.front(Fo, So, npiv, tol, npiv)
         assert rg == ro == npiv - 3
         np.testing.assert_array_equal(Dg, Do)
