@@ -9,8 +9,10 @@ are already resident in HBM when the timed region starts; the factors stay in HB
 reported separately in DESIGN.md, never in `value`).  Flops are the reference's own count
 (SparseQR_factorize.c:1571), verified equal to the reference's on the same matrix.
 
-N > 1: one process per GPU (torch.distributed, backend nccl = RCCL), every rank factorizes its own matrix
-(independent objects, no data-path collective): "weak" scaling, value = all ranks' flops / max-over-ranks time.
+N > 1: `--gpus N` starts N ranks itself (one process per GPU, torch.distributed, backend nccl = RCCL) unless a launcher
+already did; default mode "sharded": ONE matrix, subtrees on the ranks, contribution blocks up a tree of joins with
+point-to-point messages, value = the matrix's flops / max-over-ranks time (strong scaling; the flop share of the
+critical path is printed).  `--mode replicas`: every rank its own matrix (weak scaling).
 
 Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` and `cpu_baseline` objects.
 """
@@ -35,13 +37,63 @@ PEAK_FP64_MFMA_TFLOPS = 78.6      # MI355X dense fp64 matrix peak (SURVEY.md 8d;
 PEAK_HBM_GBS = 8000.0             # MI355X_MICROARCH.md: 8.0 TB/s spec (6.3 TB/s measured copy)
 
 
-def cpu_baseline(name, g, budget_s=20.0):
-    """The REAL reference (oracle/_ref/refdump, built by oracle/Makefile) timed on this host, 1 core (SPQR_grain = 1,
-    STMMQR/README.md:71-72), MKL sequential; falls back to the CPU restatement (kind "port") when the reference
-    build is not present.  Bounded sample: repetitions sized to ~budget_s seconds of CPU work."""
+ORDERING_NAMES = {5: "AMD", 2: "COLAMD", 7: "default (COLAMD: qrtest without an ordering argument)", 11: "METIS", 6: "NESDIS"}
+FETCH_CORRECTION = 1.0 / 0.545    # gfx950 FETCH_SIZE under-reports streaming reads by one half (MI355X_MICROARCH.md, HBM);
+                                  # calibrated on this code's own 8-byte-per-lane streams: k_rh_copy / k_cpack read exactly
+                                  # what they write, rocprofv3 reports FETCH = 0.54-0.55 x WRITE (profiles/r01_i_pmc_summary.txt)
+
+
+def host_cores():
+    """cores this process may really use: the affinity mask, cut by the cgroup CPU quota when there is one"""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            t = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if t[0] != "max":
+                    n = min(n, max(1, int(int(t[0]) / int(t[1]))))
+            else:
+                q = int(t[0]); per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+                if q > 0:
+                    n = min(n, max(1, q // per))
+        except Exception:
+            pass
+    return n
+
+
+def _refdump_run(refdump, mtx, ordering, reps, threads, timeout):
+    """one refdump process: `reps` qr_factorize runs of the compiled reference, best time; threads = MKL threads
+    (the reference's second parallel mode, BLAS-internal threading, STMMQR/README.md:94; SPQR_grain = 1 so that the TPSM
+    pool -- which deadlocks on small pools, SURVEY.md 3.3 -- stays out of it)"""
+    env = dict(os.environ, MKL_NUM_THREADS=str(threads), OMP_NUM_THREADS=str(threads),
+               MKL_THREADING_LAYER="SEQUENTIAL" if threads == 1 else "GNU", MKL_DYNAMIC="FALSE")
+    print(f"[bench] cpu baseline: reference on {threads} core(s), {reps} run(s) ...", file=sys.stderr, flush=True)
+    try:
+        out = subprocess.run([str(refdump), str(mtx), ordering, "1", "d", "-", str(reps)], capture_output=True, text=True, env=env,
+                             timeout=timeout).stdout
+    except subprocess.TimeoutExpired:
+        print(f"[bench] cpu baseline: the {threads}-core leg exceeded {timeout:.0f} s and was dropped", file=sys.stderr, flush=True)
+        return None
+    res = {}
+    for line in out.splitlines():
+        if line.startswith("REF factorize seconds"):
+            res["seconds"] = float(line.split(":")[1].split()[0])
+        elif line.startswith("nf ="):
+            res["flops"] = float(line.split("flops =")[1].split()[0])
+        elif line.startswith("REF qmult(QTX) seconds"):
+            t = line.replace(":", " ").split()
+            res["qmult_qtx_seconds"] = float(t[3]); res["solve_seconds"] = float(t[6])
+    return res if "seconds" in res and "flops" in res else None
+
+
+def cpu_baseline(name, g, budget_s=30.0):
+    """The REAL reference (oracle/_ref/refdump, built by oracle/Makefile) timed on this host in two legs -- 1 core
+    (SPQR_grain = 1, MKL sequential: STMMQR/README.md:71-72) and all cores (MKL threads = nproc) --, best of `reps` runs each,
+    reps sized so that both legs together stay within ~budget_s seconds of CPU work.  `value` is the faster leg.
+    Falls back to the CPU restatement (kind "port") when the reference build is not present."""
     refdump = ROOT / "oracle" / "_ref" / "refdump"
-    flops = float(g["flopcount"][0])
     ref_s = float(g["fac_seconds"][0])                 # seconds in the build container: sizing hint only
+    nproc = host_cores()
     if refdump.exists():
         try:
             with tempfile.TemporaryDirectory() as td:
@@ -56,27 +108,23 @@ def cpu_baseline(name, g, budget_s=20.0):
                 with open(mtx, "w") as f:
                     f.write("%%MatrixMarket matrix coordinate real general\n%d %d %d\n" % (m, n, len(Ax)))
                     np.savetxt(f, np.c_[Ai + 1, cols + 1, Ax], fmt="%d %d %.17g")
-                reps = int(max(1, min(50, budget_s / max(ref_s * 1.5, 1e-3))))
-                env = dict(os.environ, MKL_THREADING_LAYER="SEQUENTIAL", MKL_NUM_THREADS="1")
+                reps = int(max(1, min(3, budget_s / 2 / max(ref_s * 1.3, 1e-3))))
                 ordering = str(int(g["ordering"][0])) if "ordering" in g else "-1"
                 omap = {"5": "0", "2": "1", "11": "2", "6": "3"}      # QR_ORDERING_* -> refdump selector
-                out = subprocess.run([str(refdump), str(mtx), omap.get(ordering, "-1"), "1", "d", "-", str(reps)],
-                                     capture_output=True, text=True, env=env, timeout=600).stdout
-                for line in out.splitlines():
-                    if line.startswith("REF factorize seconds"):
-                        sec = float(line.split(":")[1].split()[0])
-                        rfl = [l for l in out.splitlines() if l.startswith("nf =")][0]
-                        rflops = float(rfl.split("flops =")[1].split()[0])
-                        cb = {"value": rflops / sec * 1e-9, "unit": "GFLOP/s", "cores": 1, "kind": "reference",
-                              "sample": f"{name}: best of {reps} qr_factorize runs of the compiled reference "
-                                        f"(SPQR_grain=1, MKL sequential), {sec * 1e3:.2f} ms each",
-                              "seconds": sec}
-                        for l2 in out.splitlines():
-                            if l2.startswith("REF qmult(QTX) seconds"):
-                                t = l2.replace(":", " ").split()
-                                cb["qmult_qtx_seconds"] = float(t[3])
-                                cb["solve_seconds"] = float(t[6])
-                        return cb
+                legs = []
+                for threads in ([1, nproc] if nproc > 1 else [1]):
+                    r = _refdump_run(refdump, mtx, omap.get(ordering, "-1"), reps, threads, timeout=max(60.0, 6 * reps * ref_s))
+                    if r:
+                        legs.append({"cores": threads, "value": r["flops"] / r["seconds"] * 1e-9, "unit": "GFLOP/s",
+                                     "seconds": r["seconds"], "best_of": reps,
+                                     **({k: r[k] for k in ("qmult_qtx_seconds", "solve_seconds") if k in r})})
+                if legs:
+                    best = max(legs, key=lambda l: l["value"])
+                    return {"value": best["value"], "unit": "GFLOP/s", "cores": best["cores"], "kind": "reference",
+                            "sample": f"{name}: qr_factorize of the compiled reference on this host, best of {reps} per leg; "
+                                      f"legs: " + "; ".join(f"{l['cores']} core(s) {l['seconds'] * 1e3:.1f} ms" for l in legs) +
+                                      " (SPQR_grain=1; 1 core = MKL sequential, all cores = MKL_NUM_THREADS=nproc)",
+                            "seconds": best["seconds"], "legs": legs, "host_cores": nproc}
         except Exception as e:  # fall through to the port
             print(f"[bench] reference baseline failed: {e}", file=sys.stderr)
     from stmmqr_testlib import Oracle, Symbolic, scalar
@@ -197,18 +245,37 @@ def run_micro(pkg, args):
     return 0
 
 
+DEFAULT_WORKLOAD = {1: "xenon1_colamd_standin", 2: "xenon1_standin", 4: "sme3dc_standin", 8: "c5mini_standin"}
+
+
+def spawn_ranks(args):
+    """--gpus N without a launcher: start the N ranks ourselves (torch.distributed.run, one process per GPU) BEFORE
+    anything in this process touches the GPU, relay their output, exit with their code."""
+    import socket
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), str(Path(__file__).resolve())] + sys.argv[1:]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--workload", default="xenon1_standin")
+    ap.add_argument("--workload", default=None,
+                    help="fixture name or 'micro'; default by --gpus: 1 the xenon1 stand-in in the driver's default (COLAMD) "
+                         "ordering, 2 the METIS-ordered xenon1 stand-in, 4 the sme3Dc stand-in, 8 the configs[4] structure")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--big-front-cols", type=int, default=None)
-    ap.add_argument("--mode", choices=["replicas", "sharded"], default="replicas",
-                    help="N>1: replicas = every rank factorizes its own matrix (weak scaling, default); "
-                         "sharded = ONE matrix, subtrees on the ranks, contribution blocks to rank 0 over RCCL (strong)")
+    ap.add_argument("--panel-algo", type=int, default=None)
+    ap.add_argument("--mode", choices=["replicas", "sharded"], default=None,
+                    help="N>1: sharded (default) = ONE matrix, subtrees on the ranks, contribution blocks up a tree of joins "
+                         "over RCCL point-to-point (strong scaling); replicas = every rank factorizes its own matrix (weak)")
     args = ap.parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(args))
 
     import torch
     rank = int(os.environ.get("RANK", "0"))
@@ -220,11 +287,17 @@ def main():
         dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local))
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
+    if args.mode is None:
+        args.mode = "sharded" if world > 1 else "replicas"
+    if args.workload is None:
+        args.workload = DEFAULT_WORKLOAD.get(world, "xenon1_standin")
 
     from stmmqr_testlib import Symbolic, load_golden, scalar
     pkg = importlib.import_module(PKG)
     if args.big_front_cols:
         pkg.set_options(big_front_cols=args.big_front_cols)
+    if args.panel_algo is not None:
+        pkg.set_options(panel_algo=args.panel_algo)
     name = args.workload
     if name == "micro":
         return run_micro(pkg, args)
@@ -246,10 +319,12 @@ def main():
 
     st = None
     sharded = args.mode == "sharded" and world > 1
+    crit = None
     if sharded:
         sh = importlib.import_module(PKG + ".sharded")
         comm = sh.Comm(dist, dev)
         owner, phase = sh.partition(sym, world)
+        crit = sh.critical_path_flops(sym, owner, phase, world)
 
         def step():
             return sh.factorize_sharded(plan, sym, None, tol, ntol, comm, owner=owner, phase=phase,
@@ -278,73 +353,89 @@ def main():
     flops = scalar(g, "flopcount")
     assert total_flops == (flops if (sharded or world == 1) else world * flops), (total_flops, flops)
 
-    # one extra, un-timed step with per-category HIP events (forces a sync per level: not part of `value`)
+    # One extra, un-timed factorization with an event pair around every launch of a category (panel / update / assembly /
+    # pack), recorded on the plan's stream with NO synchronisation in between: the schedule runs exactly as in the timed
+    # region, and the pairs give each kernel family's own time (kernel-only: what rocprofv3 --kernel-trace --stats sums).
     if sharded:
         plan.set_groups(np.zeros(S.nf, np.int32))
     det = plan.factorize(None, tol, ntol, device_ptr=Ax.data_ptr(), detail=True)
     if rank == 0:
         value = total_flops * args.steps / wall * 1e-9
-        # Roofline of the dominant kernel.  Times are HIP-event sums on the plan's stream from the detail pass (one event
-        # pair per launch category and level).  Algorithmic work: the reference's flop count (FLOP_COUNT, :1571) splits
-        # into the dlarfb flops handed to the trailing update (4 * rows * cols * reflectors per panel) and the rest,
-        # which the panel kernels do (dlarfg + in-panel dlarf + T).
-        upd_tf = det["flops_update"] / max(det["ms_update"], 1e-9) * 1e-9 if det["ms_update"] > 0 else 0.0
+        # Algorithmic work: the reference's flop count (FLOP_COUNT, :1571) splits into the dlarfb flops handed to the
+        # trailing update (4 * rows * cols * reflectors per panel: stats.flops_update) and the rest, which the panel kernels
+        # do (dlarfg + in-panel dlarf + T).  Update bytes: 2 reads + 1 write of every trailing entry per panel = 24 B per
+        # (row, col); flops_update counts 4 flops per (live column, row below its diagonal, trailing col), i.e. <= 4*32 per
+        # (row, col): a lower bound on the bytes.
+        ms_panel, ms_upd = max(det["ms_panel"] + det["ms_small"], 1e-9), max(det["ms_update"], 1e-9)
         panel_flops = max(flops - det["flops_update"], 0.0)
-        panel_tf = panel_flops / max(det["ms_front"], 1e-9) * 1e-9
-        # trailing update: 2 reads + 1 write of the trailing block per panel = 24 B per (row, col); flops_update counts
-        # 4 flops per (live column, row below its diagonal, trailing col), i.e. <= 4*32 per (row, col): a lower bound
+        panel_tf = panel_flops / ms_panel * 1e-9
+        upd_tf = det["flops_update"] / ms_upd * 1e-9
         upd_bytes = det["flops_update"] * 24.0 / (4.0 * 32.0)
-        upd_gbs = upd_bytes / max(det["ms_update"], 1e-9) * 1e-6
-        pmc = {}
-        for cand in sorted((ROOT / "profiles").glob("r*_pmc_fetch_write_per_kernel.json")):
-            pmc_file = cand
+        upd_gbs = upd_bytes / ms_upd * 1e-6
+        pmc, pmc_file = {}, None
+        for cand in sorted((ROOT / "profiles").glob(f"r*_{name}_pmc_fetch_write_per_kernel.json")) or \
+                sorted((ROOT / "profiles").glob("r*_pmc_fetch_write_per_kernel.json")):
             try:
-                pmc = json.loads(cand.read_text())
+                pmc, pmc_file = json.loads(cand.read_text()), cand
             except Exception:
-                pmc = {}
+                pass
+        pmc_ok = bool(pmc) and pmc_file is not None and (name in pmc_file.name or (name == "xenon1_standin" and "standin" not in pmc_file.name.replace("_pmc", "")))
 
         def pmc_traffic(kernels):
-            """HBM bytes per launch from the committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (KB units)."""
+            """HBM bytes per launch from the committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (KB units; separate
+            passes; FETCH_SIZE corrected for the gfx950 half-counting, see FETCH_CORRECTION)"""
             tot, calls = 0.0, 0
             for k in kernels:
                 e = pmc.get(k, {})
                 if "FETCH_SIZE" in e and "WRITE_SIZE" in e:
-                    tot += (e["FETCH_SIZE"]["sum_kb"] + e["WRITE_SIZE"]["sum_kb"]) * 1024.0
+                    tot += (e["FETCH_SIZE"]["sum_kb"] * FETCH_CORRECTION + e["WRITE_SIZE"]["sum_kb"]) * 1024.0
                     calls += e["FETCH_SIZE"]["calls"]
-            return (tot / calls) if calls and "standin" in name else None
+            return (tot / calls) if calls and pmc_ok else None
 
-        if det["ms_front"] >= det["ms_update"]:
-            roof = {"bound": "mfma", "kernel": "k_panel (+ k_front_wg): Householder panels, fp64 vector/MFMA rate",
-                    "achieved": panel_tf, "peak": PEAK_FP64_MFMA_TFLOPS, "unit": "TFLOP/s",
-                    "frac": panel_tf / PEAK_FP64_MFMA_TFLOPS, "traffic": pmc_traffic(["k_panel"]),
-                    "note": "latency-bound: one workgroup reduction per Householder column (DESIGN.md 4)"}
-        else:
-            roof = {"bound": "hbm", "kernel": "k_upd_w + k_upd_c (dlarfb on v_mfma_f64_16x16x4_f64)", "achieved": upd_gbs,
-                    "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": upd_gbs / PEAK_HBM_GBS,
-                    "traffic": pmc_traffic(["k_upd_w", "k_upd_c"])}
+        npl, nul = max(det["npanel_launch"], 1), max(det["nupdate_launch"], 1)
+        panel_obj = {"bound": "mfma", "kernel": "k_panel / k_panel_ca (+ k_front_wg): Householder panels; fp64 vector = matrix peak on gfx950",
+                     "achieved": panel_tf, "peak": PEAK_FP64_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": panel_tf / PEAK_FP64_MFMA_TFLOPS,
+                     "ms": ms_panel, "launch_groups": det["npanel_launch"], "avg_us_per_level_step": ms_panel / npl * 1e3,
+                     "traffic": pmc_traffic(["k_panel", "k_panel_ca"]),
+                     "note": "latency-bound: a serial chain of Householder columns (DESIGN.md 4-5)"}
+        upd_obj = {"bound": "hbm", "kernel": "k_upd_w + k_upd_c / k_update (dlarfb on v_mfma_f64_16x16x4_f64)", "achieved": upd_gbs,
+                   "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": upd_gbs / PEAK_HBM_GBS, "ms": ms_upd,
+                   "launch_groups": det["nupdate_launch"], "avg_us_per_level_step": ms_upd / nul * 1e3,
+                   "mfma_tflops": upd_tf, "mfma_frac": upd_tf / PEAK_FP64_MFMA_TFLOPS,
+                   "traffic": pmc_traffic(["k_upd_w", "k_upd_c", "k_update"])}
+        roof = dict(panel_obj if ms_panel >= ms_upd else upd_obj)
+        roof["dominant_by"] = "HIP-event pairs around every launch of the family, no syncs in between (detail pass)"
+        roof["panel_kernels"] = panel_obj
+        roof["update_kernels"] = upd_obj
+        roof["traffic_source"] = (str(pmc_file.relative_to(ROOT)) + f"; FETCH_SIZE x {FETCH_CORRECTION:.3f} (gfx950 half-counting, "
+                                  "calibrated on k_rh_copy / k_cpack)") if pmc_ok else None
         roof["whole_factorization"] = {"bound": "mfma", "achieved": flops / max(det["ms_total"], 1e-9) * 1e-9,
                                        "peak": PEAK_FP64_MFMA_TFLOPS, "unit": "TFLOP/s",
                                        "frac": flops / max(det["ms_total"], 1e-9) * 1e-9 / PEAK_FP64_MFMA_TFLOPS}
-        roof["update_kernels"] = {"bound": "hbm", "kernel": "k_upd_w + k_upd_c", "achieved": upd_gbs, "peak": PEAK_HBM_GBS,
-                                  "unit": "GB/s", "frac": upd_gbs / PEAK_HBM_GBS, "tflops": upd_tf,
-                                  "traffic": pmc_traffic(["k_upd_w", "k_upd_c"]),
-                                  "traffic_source": str(pmc_file.relative_to(ROOT)) if pmc else None}
         roof["assembly"] = {"bound": "hbm", "achieved": det["bytes_assemble"] / max(det["ms_assemble"], 1e-9) * 1e-6,
                             "peak": PEAK_HBM_GBS, "unit": "GB/s",
                             "frac": det["bytes_assemble"] / max(det["ms_assemble"], 1e-9) * 1e-6 / PEAK_HBM_GBS}
-        roof["ms"] = {k: det[k] for k in ("ms_total", "ms_assemble", "ms_front", "ms_update", "ms_pack")}
+        roof["ms"] = {k: det[k] for k in ("ms_total", "ms_assemble", "ms_panel", "ms_small", "ms_update", "ms_pack")}
+        oname = ORDERING_NAMES.get(int(g["ordering"][0]), str(int(g["ordering"][0]))) if "ordering" in g else "unknown"
+        standin_of = {"xenon1": "xenon1.mtx", "sme3dc": "sme3Dc.mtx", "c5": "3D_51448_3D.mtx (structure only, n = 8000)"}
+        sof = next((v for k, v in standin_of.items() if name.startswith(k)), None)
+        wl = (f"{name}: m={S.m} n={S.n} nnz={S.anz} fronts={S.nf} flops/step={flops:.4g}, ordering {oname}" +
+              (f" (stand-in for {sof}, absent from the reference checkout)" if "standin" in name and sof else ""))
         out = {
             "metric": "numerical-factorization GFLOP/s", "value": value, "unit": "GFLOP/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": wall / args.steps * 1e3,
             "higher_is_better": True, "scaling": "strong" if sharded else "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": f"{name}: m={S.m} n={S.n} nnz={S.anz} fronts={S.nf} "
-                                   f"flops/step={flops:.4g} (stand-in for xenon1.mtx, absent from the reference checkout)"
-                       if "standin" in name else f"{name}: m={S.m} n={S.n} nnz={S.anz} fronts={S.nf} flops/step={flops:.4g}",
-                       "inputs": "values resident in HBM, factors left in HBM", "parallelism": (f"subtree-sharded x{world}" if sharded else f"replica x{world}"),
+            "config": {"workload": wl,
+                       "inputs": "values resident in HBM, factors left in HBM",
+                       "parallelism": (f"subtree-sharded x{world}: tree of joins, contribution blocks device-to-device over RCCL "
+                                       f"point-to-point" if sharded else f"replica x{world}"),
                        "device_ms_per_step": dev_ms / args.steps, "launches_per_step": st["nlaunch"],
                        "levels": st["nlevels"]},
             "roofline": roof,
         }
+        if crit is not None:
+            out["config"]["critical_path_flop_share"] = crit[0] / max(crit[1], 1.0)
+            out["config"]["strong_scaling_bound"] = crit[1] / max(crit[0], 1.0)
         # SURVEY 8 (f1), outside the timed region: Q'b and the least-squares solve on the factors still resident in HBM
         # (wall time including the copies of the vectors), with the residual the reference's driver prints
         try:

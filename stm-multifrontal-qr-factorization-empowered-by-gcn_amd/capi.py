@@ -241,6 +241,19 @@ class HipQR:
                "stmmqr_plan_export_front")
         return info, Cb[:info["csize"]], rows[:info["cm"]]
 
+    def export_front_dev(self, f, dev_ptr: int, info=None):
+        """packed C of front f copied device-to-device into the buffer at dev_ptr (>= csize doubles); returns the row ids
+        (host int64).  The contribution block never crosses PCIe (multi-GPU: it is then sent by RCCL from that buffer)."""
+        info = info or self.front_info(f)
+        rows = np.zeros(max(info["cm"], 1), I64)
+        _check(lib.stmmqr_plan_export_front(self._h, int(f), C.c_void_p(dev_ptr), _ip(rows), 1), "stmmqr_plan_export_front")
+        return rows[:info["cm"]]
+
+    def import_front_dev(self, f, fm, rank, cm, dev_ptr: int, rows):
+        rows = np.ascontiguousarray(rows, I64)
+        _check(lib.stmmqr_plan_import_front(self._h, int(f), int(fm), int(rank), int(cm), C.c_void_p(dev_ptr), _ip(rows), 1),
+               "stmmqr_plan_import_front")
+
     def import_front(self, f, fm, rank, cm, Cb, rows):
         Cb = np.ascontiguousarray(Cb, np.float64); rows = np.ascontiguousarray(rows, I64)
         _check(lib.stmmqr_plan_import_front(self._h, int(f), int(fm), int(rank), int(cm), Cb.ctypes.data_as(C.c_void_p),

@@ -54,6 +54,9 @@ def gen3d(nx, ny, nz, seed, stencil27=True, dof=1, longrange=0):
 STANDINS = {
     # name: (nx, ny, nz, seed, 27-point?, ordering for the reference run: 2 = METIS)
     "xenon1_standin": (36, 36, 38, 0x58454E31, True, 2),
+    # the same matrix with the driver's DEFAULT ordering (qrtest without an ordering argument = COLAMD, qrtest.c:155-169):
+    # the ordering BASELINE.md's published totals were measured with
+    "xenon1_colamd_standin": (36, 36, 38, 0x58454E31, True, -1),
     "grid20_standin": (20, 20, 20, 0x58454E31, True, 2),
     # BASELINE configs[3] (sme3Dc.mtx, absent): 3 unknowns per grid point, ~81 nnz per row
     "sme3dc_standin": (24, 24, 25, 0x534D4533, True, 2, 3),

@@ -28,23 +28,29 @@ def test_sharded_equals_unsharded(name, nranks):
     plans, shards, flops = [], [], 0.0
     for r in range(nranks):
         p = pkg.HipQR(sym)
-        group = np.full(S.nf, -1, np.int32)
-        group[(owner == r) & (phase == 0)] = 0
-        if r == 0:
-            group[phase == 1] = 1
-        p.set_groups(group)
+        p.set_groups(np.where(owner == r, phase, -1).astype(np.int32))
         p.begin(g["in_Ax"], tol, ntol, g["in_Ap"], g["in_Ai"])
-        p.run_group(0)
         plans.append(p)
     nmoved = 0
-    for c, _par in sh.cross_edges(sym, owner, phase):
-        if owner[c] != 0:
-            info, Cb, rows = plans[owner[c]].export_front(c)
-            plans[0].import_front(c, info["fm"], info["rank"], info["cm"], Cb, rows)
-            nmoved += 1
+    for k in range(int(phase.max()) + 1):
+        # the tree of joins: before phase k every contribution block that enters it from another "rank" moves (device
+        # to device: export into a device buffer, import from it)
+        if k > 0:
+            import ctypes
+            hip = ctypes.CDLL("libamdhip64.so")
+            for c, par in sh.cross_edges(sym, owner, phase, k):
+                info = plans[owner[c]].front_info(c)
+                buf = ctypes.c_void_p()
+                assert hip.hipMalloc(ctypes.byref(buf), ctypes.c_size_t(8 * max(info["csize"], 1))) == 0
+                rows = plans[owner[c]].export_front_dev(c, buf.value, info)
+                assert hip.hipDeviceSynchronize() == 0
+                plans[owner[par]].import_front_dev(c, info["fm"], info["rank"], info["cm"], buf.value, rows)
+                assert hip.hipFree(buf) == 0
+                nmoved += 1
+        for r in range(nranks):
+            if np.any((owner == r) & (phase == k)):
+                plans[r].run_group(k)
     assert nmoved >= 1 or not phase.any()      # a forest with enough roots needs no exchange at all
-    if phase.any():
-        plans[0].run_group(1)
     for r, p in enumerate(plans):
         st = p.finish()
         flops += st["flops"]
