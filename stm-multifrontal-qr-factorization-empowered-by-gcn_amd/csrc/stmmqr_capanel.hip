@@ -148,7 +148,7 @@ __global__ __launch_bounds__(CA_NT) void k_panel_ca(DevCtx c, const int *__restr
     __shared__ int s_ok;
     const int f = flist[blockIdx.x];
     const FrontSym s = c.fs[f];
-    if (p >= s.npanels || !stm_use_ca(s, p, c.panel_algo)) return;
+    if (p >= s.npanels || !stm_use_ca(s, p, c.panel_algo, c.ca_min_rows)) return;
     const int w = blockIdx.y;
     const int nwf = stm_ca_slabs(s);                    // symbolic: every workgroup of the launch agrees
     if (w >= nwf) return;

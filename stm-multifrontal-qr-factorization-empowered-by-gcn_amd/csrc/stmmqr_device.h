@@ -79,10 +79,11 @@ static inline __host__ __device__ int stm_panel_rows_est(const FrontSym &s, int 
 // Which panel kernel factorizes panel p of this front?  A property of the front alone (symbolic), never of the fronts that
 // happen to share its level: the two kernels round differently and sharded == unsharded must stay bit-identical.
 // algo = stmmqr_options::panel_algo: 1 column pipeline, 2 Gram-based, 0 Gram-based above STM_TALL_WIDE rows.
-#define STM_CA_MIN_ROWS (4 * 512)
-static inline __host__ __device__ int stm_use_ca(const FrontSym &s, int p, int algo)
+#define STM_CA_MIN_ROWS (8 * 512)      // (= STM_TALL_XWIDE: above it the pipeline drops to 2-column groups, above 8192 rows to one workgroup;
+                                       //  measured: up to 4096 rows the pipeline is the faster one)
+static inline __host__ __device__ int stm_use_ca(const FrontSym &s, int p, int algo, int min_rows = STM_CA_MIN_ROWS)
 {
-    return algo == 2 || (algo == 0 && stm_panel_rows_est(s, p) > STM_CA_MIN_ROWS);
+    return algo == 2 || (algo == 0 && stm_panel_rows_est(s, p) > min_rows);
 }
 // planned number of column groups for panel p: 1 (not tall), 4, or 8 / 16 when 4- / 2-column sub-panels may be needed
 static inline __host__ __device__ int stm_tall_launches(const FrontSym &s, int p, int tall_min)

@@ -119,6 +119,7 @@ struct stmmqr_plan {
     size_t evused = 0;
     long m = 0, n = 0, anz = 0, nf = 0, maxfn = 0, rjsize = 0, hisize = 0;
     int do_rank = 1;
+    int ca_min = STM_CA_MIN_ROWS;                      // (env STMMQR_CA_MIN at plan time: experiments)
     int plan_algo = 0;                                 // g_opt.panel_algo when the schedule was built
     int tall_min = STM_TALL_MIN;                       // g_opt.tall_min_rows when the schedule was built
     std::vector<long> Sp, Sj, Qfill, PLinv, Sleft, Child, Childp, Super, Rp, Rj, Post, Hip, Fm;
@@ -173,7 +174,7 @@ struct stmmqr_plan {
         DevCtx c;
         c.fs = d_fs.p; c.fnum = d_fnum.p; c.Farena = d_F.p; c.Carena = d_C.p; c.Tws = d_T.p; c.tslot = d_tslot.p;
         c.Tall = d_Tall.p;
-        c.Gp = d_Gp.p; c.gp_slabs = gp_slabs; c.panel_algo = plan_algo;
+        c.Gp = d_Gp.p; c.gp_slabs = gp_slabs; c.panel_algo = plan_algo; c.ca_min_rows = ca_min;
         c.Sx = d_Sx.p; c.Sp = d_Sp.p; c.Sjrel = d_Sjrel.p; c.Sj0 = d_Sj0.p; c.Sleft = d_Sleft.p;
         c.Child = d_Child.p; c.Rjrel = d_Rjrel.p; c.Stair = d_Stair.p; c.Tau = d_Tau.p; c.Hii = d_Hii.p;
         c.Rdead = d_Rdead.p; c.Cmap = d_Cmap.p; c.Cursor = d_Cursor.p; c.Rhoff = d_Rhoff.p; c.Rboff = d_Rboff.p;
@@ -224,6 +225,7 @@ void build_schedule(stmmqr_plan &P, std::vector<int> &tslot)
 {
     P.tall_min = g_opt.tall_min_rows;
     P.plan_algo = g_opt.panel_algo;
+    P.ca_min = getenv("STMMQR_CA_MIN") ? atoi(getenv("STMMQR_CA_MIN")) : STM_CA_MIN_ROWS;
     const long nf = P.nf;
     int ngroups = 1;
     for (long f = 0; f < nf; f++) ngroups = std::max(ngroups, P.group[f] + 1);
@@ -312,7 +314,7 @@ void build_schedule(stmmqr_plan &P, std::vector<int> &tslot)
                         msl = std::max(msl, (s.fm_ub + 255) / 256);
                         L.nsub_at[p] = std::max(L.nsub_at[p], stm_tall_launches(s, p, P.tall_min));
                         L.nca_at[p] = std::max(L.nca_at[p], stm_ca_slabs(s));
-                        (stm_use_ca(s, p, g_opt.panel_algo) ? L.nca_use[p] : L.npipe_use[p])++;
+                        (stm_use_ca(s, p, g_opt.panel_algo, P.ca_min) ? L.nca_use[p] : L.npipe_use[p])++;
                         P.gp_slabs = std::max(P.gp_slabs, stm_ca_slabs(s));
                     }
                 }

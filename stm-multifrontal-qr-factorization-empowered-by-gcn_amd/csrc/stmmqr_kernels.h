@@ -15,6 +15,7 @@ struct DevCtx {
     double *Gp;                // Gram-based panel: per T slot, gp_slabs partial Gram matrices + the M mailbox, NB*NB each
     int gp_slabs;              // max slab workgroups of a front (stm_ca_slabs) over the plan
     int panel_algo;            // stmmqr_options::panel_algo (stm_use_ca)
+    int ca_min_rows;           // ... panels with more estimated rows take the Gram-based kernel (panel_algo 0)
     const double *Sx;          // [anz] values of S = A(P,Q), row form
     const int *Sp;             // [m+1]
     const int *Sjrel;          // [anz] column of each S entry inside its front

@@ -1601,7 +1601,7 @@ __global__ __launch_bounds__(NTP) void k_panel(DevCtx c, const int *__restrict__
     __shared__ PanelShared ps;
     const int f = flist[blockIdx.x];
     const FrontSym s = c.fs[f];
-    if (p >= s.npanels || stm_use_ca(s, p, c.panel_algo)) return;      // (the Gram-based panel kernel takes those)
+    if (p >= s.npanels || stm_use_ca(s, p, c.panel_algo, c.ca_min_rows)) return;      // (the Gram-based panel kernel takes those)
     FrontNum *num = &c.fnum[f];
     double *F = c.Farena + s.foff;
     double *T = c.Tws + (long long)(2 * c.tslot[f] + (p & 1)) * STM_NB * STM_NB;

@@ -86,7 +86,7 @@ struct OneFront {
         c.Gp = d_Gp.p; c.gp_slabs = stm_ca_slabs(s);
         c.Stair = d_St.p; c.Tau = d_Tau.p; c.Rdead = d_Rdead.p; c.Rhoff = d_Rhoff.p; c.Rboff = d_Rboff.p;
         c.dbg = getenv("STMMQR_DBG") ? atoi(getenv("STMMQR_DBG")) : 0;
-        { stmmqr_options o; stmmqr_get_options(&o); c.tall_min = o.tall_min_rows; c.panel_algo = o.panel_algo; }
+        { stmmqr_options o; stmmqr_get_options(&o); c.tall_min = o.tall_min_rows; c.panel_algo = o.panel_algo; c.ca_min_rows = STM_CA_MIN_ROWS; }
 #ifdef STMMQR_STAMPS
         if (!d_dbg.alloc(1024)) return false;
         (void)hipMemset(d_dbg.p, 0, 1024 * sizeof(unsigned long long));
