@@ -249,6 +249,7 @@ typedef struct stmmqr_options {
 void stmmqr_get_options(stmmqr_options *opt);
 void stmmqr_set_options(const stmmqr_options *opt);
 
+void stmmqr_shutdown(void);                           /* optional end-of-use call for dlopen()ing hosts: device sync  */
 int stmmqr_device_count(void);                        /* number of visible HIP devices (0 = none)          */
 const char *stmmqr_device_name(int device);           /* gcnArchName, e.g. "gfx950:sramecc+:xnack-"        */
 const char *stmmqr_last_error(void);                  /* thread-local message of the last failure          */

@@ -39,6 +39,7 @@
 #endif
 
 static FILE *g_out = NULL;
+static void *g_hiplib = NULL;
 static double g_fac_seconds = 0;
 static double g_flops = 0;
 
@@ -78,6 +79,7 @@ qr_numeric *qr_factorize(sparse_csc **Ahandle, Long freeA, double tol, Long ntol
          * (SparseQR, QR_qmult, QR_solve, SparseQR_free) stays the compiled reference */
         void *h = dlopen(getenv("REFDUMP_HIPLIB"), RTLD_NOW | RTLD_LOCAL);
         if (!h) { fprintf(stderr, "refdump: cannot load %s: %s\n", getenv("REFDUMP_HIPLIB"), dlerror()); exit(2); }
+        g_hiplib = h;
         real = (factorize_fn)dlsym(h, "qr_factorize");
         printf("seam routed to %s\n", getenv("REFDUMP_HIPLIB"));
     }
@@ -298,11 +300,11 @@ int main(int argc, char **argv)
     SparseQR_free(&QR, cc);
     SparseCore_free_sparse(&A, cc);
     SparseCore_finish(cc);
-    if (getenv("REFDUMP_HIPLIB")) {
-        /* the HIP runtime was pulled in through dlopen: skip its exit-time teardown (it can stall at process exit
-         * when the library is unloaded after main) */
-        fflush(stdout); fflush(stderr);
-        _exit(0);
+    if (getenv("REFDUMP_HIPLIB") && g_hiplib) {
+        /* the drop-in library offers an explicit end-of-use call (include/stmmqr_hip.h: stmmqr_shutdown); a host program
+         * that dlopen()ed it calls that before it returns from main, then exits normally */
+        void (*shut)(void) = (void (*)(void))dlsym(g_hiplib, "stmmqr_shutdown");
+        if (shut && !getenv("REFDUMP_NO_SHUTDOWN")) shut();
     }
     return 0;
 }

@@ -6,4 +6,5 @@ path (same names and argument meaning as STMMQR/include/SparseQR.h) on numpy arr
 code and no CPU fallback: importing :mod:`capi` raises if the HIP library has not been built.
 """
 from .capi import (HipQR, QRNumeric, StmmqrError, device_count, device_name, get_options, last_seam_ms, lib,  # noqa: F401
-                   lib_path, qr_assemble, qr_cpack, qr_factorize, qr_fcsize, qr_front, qr_larftb, qr_rhpack, set_options)
+                   lib_path, qr_assemble, qr_cpack, qr_factorize, qr_fcsize, qr_front, qr_fsize, qr_hpinv, qr_larftb, qr_rhpack,
+                   qr_stranspose2, set_options)

@@ -350,6 +350,71 @@ def qr_rhpack(m, n, npiv, Stair, F):
     return int(rs), int(rm.value), R[:rs]
 
 
+class SparseCsc(C.Structure):
+    """sparse_csc (STMMQR/include/SparseCore.h:514-556), the fields the seams read"""
+    _fields_ = [("nrow", C.c_size_t), ("ncol", C.c_size_t), ("nzmax", C.c_size_t), ("p", C.c_void_p), ("i", C.c_void_p),
+                ("nz", C.c_void_p), ("x", C.c_void_p), ("z", C.c_void_p), ("stype", C.c_int), ("itype", C.c_int),
+                ("xtype", C.c_int), ("dtype", C.c_int), ("sorted", C.c_int), ("packed", C.c_int)]
+
+
+class QrSymbolicC(C.Structure):
+    """qr_symbolic (SparseQR_struct.h:26-137), field order of include/stmmqr_hip.h"""
+    _fields_ = [("m", C.c_long), ("n", C.c_long), ("anz", C.c_long)] + \
+               [(k, c_long_p) for k in ("Sp", "Sj", "Qfill", "PLinv", "Sleft")] + [("nf", C.c_long), ("maxfn", C.c_long)] + \
+               [(k, c_long_p) for k in ("Parent", "Child", "Childp", "Super", "Rp", "Rj", "Post")] + \
+               [(k, C.c_long) for k in ("rjsize", "do_rank_detection", "maxstack", "hisize", "keepH")] + [("Hip", c_long_p)] + \
+               [("ntasks", C.c_long), ("ns", C.c_long)] + \
+               [(k, c_long_p) for k in ("TaskChildp", "TaskChild", "TaskStack", "TaskFront", "TaskFrontp", "On_stack",
+                                        "Stack_maxstack", "Fm", "Cm")]
+
+
+class QrNumericC(C.Structure):
+    """qr_numeric (SparseQR_struct.h:145-209)"""
+    _fields_ = [("Rblock", C.c_void_p), ("Stacks", C.c_void_p), ("Stack_size", c_long_p)] + \
+               [(k, C.c_long) for k in ("hisize", "n", "m", "nf", "ntasks", "ns", "maxstack")] + [("Rdead", C.c_char_p)] + \
+               [(k, C.c_long) for k in ("rank", "rank1", "maxfrank")] + [("norm_E_fro", C.c_double)] + \
+               [("keepH", C.c_long), ("rjsize", C.c_long), ("HStair", c_long_p), ("HTau", c_double_p)] + \
+               [(k, c_long_p) for k in ("Hii", "HPinv", "Hm", "Hr")] + [("maxfm", C.c_long)]
+
+
+def qr_fsize(f, Super, Rp, Rj, Sleft, Child, Childp, Cm, Fmap, Stair):
+    """qr_fsize (SparseQR.h:159-176 / SparseQR_factorize.c:1066-1145): Fmap and Stair are written; returns fm"""
+    a = [np.ascontiguousarray(x, I64) for x in (Super, Rp, Rj, Sleft, Child, Childp, Cm)]
+    assert Fmap.dtype == I64 and Stair.dtype == I64
+    lib.qr_fsize.restype = C.c_long
+    return int(lib.qr_fsize(C.c_long(int(f)), *[_ip(x) for x in a], _ip(Fmap), _ip(Stair)))
+
+
+def qr_stranspose2(m, n, Ap, Ai, Ax, Qfill, Sp, PLinv):
+    """qr_stranspose2 (SparseQR_factorize.c:755-785): returns Sx, the values of S = A(P,Q) in row form"""
+    Ap = np.ascontiguousarray(Ap, I64); Ai = np.ascontiguousarray(Ai, I64); Ax = np.ascontiguousarray(Ax, np.float64)
+    Sp = np.ascontiguousarray(Sp, I64); PLinv = np.ascontiguousarray(PLinv, I64)
+    Qf = None if Qfill is None else np.ascontiguousarray(Qfill, I64)
+    A = SparseCsc(m, n, Ax.size, Ap.ctypes.data, Ai.ctypes.data, None, Ax.ctypes.data, None, 0, 2, 1, 0, 1, 1)
+    Sx = np.zeros(max(Ax.size, 1)); W = np.zeros(max(m, 1), I64)
+    lib.qr_stranspose2.restype = None
+    lib.qr_stranspose2(C.byref(A), _ip(Qf), _ip(Sp), _ip(PLinv), _dp(Sx), _ip(W))
+    return Sx[:Ax.size]
+
+
+def qr_hpinv(sym: dict, Hm, Hr, Hii):
+    """qr_hpinv (SparseQR_factorize.c:991-1060): Hii is rewritten in place; returns (HPinv, maxfm)"""
+    keep = {k: np.ascontiguousarray(sym[k], I64) for k in ("Sleft", "Super", "Rp", "Hip", "PLinv")}
+    S = QrSymbolicC()
+    S.m, S.n, S.nf = int(sym["m"]), int(sym["n"]), int(sym["nf"])
+    for k, a in keep.items():
+        setattr(S, k, _ip(a))
+    Hm = np.ascontiguousarray(Hm, I64); Hr = np.ascontiguousarray(Hr, I64)
+    assert Hii.dtype == I64 and Hii.flags.c_contiguous
+    HPinv = np.zeros(max(S.m, 1), I64); W = np.zeros(max(S.m, 1), I64)
+    N = QrNumericC()
+    N.m, N.n, N.nf = S.m, S.n, S.nf
+    N.Hm, N.Hr, N.Hii, N.HPinv = _ip(Hm), _ip(Hr), _ip(Hii), _ip(HPinv)
+    lib.qr_hpinv.restype = None
+    lib.qr_hpinv(C.byref(S), C.byref(N), _ip(W))
+    return HPinv[:S.m], int(N.maxfm)
+
+
 def qr_assemble(f, fm, Super, Rp, Rj, Sp, Sj, Sleft, Child, Childp, Sx, Fmap, Cm, Cblocks: dict, Hr, Stair, Hii, Hip):
     """qr_assemble (SparseQR.h:178-200).  Cblocks: {child: packed C array}.  Returns (F, Cmap); Stair/Hii in place."""
     nf = len(Rp) - 1

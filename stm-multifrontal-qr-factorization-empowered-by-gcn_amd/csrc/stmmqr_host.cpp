@@ -149,6 +149,8 @@ struct stmmqr_plan {
 
     // results of the last factorization
     bool factored = false, begun = false, first_group = true;
+    bool panel_wait_failed = false;      // a bounded inter-workgroup wait of a panel kernel ran out in the last factorization
+    bool serial_panels = false;          // recovery: every panel by ONE workgroup (no inter-workgroup waits at all)
     long long rh_total = 0;
     long rank = 0;
     std::vector<FrontNum> h_fnum;
@@ -174,12 +176,13 @@ struct stmmqr_plan {
         DevCtx c;
         c.fs = d_fs.p; c.fnum = d_fnum.p; c.Farena = d_F.p; c.Carena = d_C.p; c.Tws = d_T.p; c.tslot = d_tslot.p;
         c.Tall = d_Tall.p;
-        c.Gp = d_Gp.p; c.gp_slabs = gp_slabs; c.panel_algo = plan_algo; c.ca_min_rows = ca_min;
+        c.Gp = d_Gp.p; c.gp_slabs = gp_slabs; c.panel_algo = serial_panels ? 1 : plan_algo; c.ca_min_rows = ca_min;
         c.Sx = d_Sx.p; c.Sp = d_Sp.p; c.Sjrel = d_Sjrel.p; c.Sj0 = d_Sj0.p; c.Sleft = d_Sleft.p;
         c.Child = d_Child.p; c.Rjrel = d_Rjrel.p; c.Stair = d_Stair.p; c.Tau = d_Tau.p; c.Hii = d_Hii.p;
         c.Rdead = d_Rdead.p; c.Cmap = d_Cmap.p; c.Cursor = d_Cursor.p; c.Rhoff = d_Rhoff.p; c.Rboff = d_Rboff.p;
         c.tol = last_tol; c.ntol = (int)last_ntol;
         c.dbg = getenv("STMMQR_DBG") ? atoi(getenv("STMMQR_DBG")) : 0;
+        if (serial_panels) c.dbg = (c.dbg & ~(2048 | 4096)) | 256;   // the one-workgroup LDS / in-place panel for every panel
         c.tall_min = tall_min;
         c.dbgbuf = d_dbg.p;
         return c;
@@ -597,9 +600,9 @@ int run_schedule(stmmqr_plan &P, bool detail, int grp, bool first)
                 const int defer_ok = (L.maxcb_at[p] > 0) ? 1 : 0;
                 // which kernel takes a panel is a property of the front (stm_use_ca); a level step with both kinds gets
                 // both launches (each kernel skips the other's fronts)
-                if (L.nca_use[p])
+                if (L.nca_use[p] && !P.serial_panels)
                     LCHK(stm_launch_panel_ca(c, big, L.nbig_at[p], (int)p, L.nca_at[p], defer_ok, st));
-                if (L.npipe_use[p])
+                if (L.npipe_use[p] || P.serial_panels)
                     LCHK(stm_launch_panel(c, big, L.nbig_at[p], (int)p, L.nsub_at[p], defer_ok, L.lds_big, st));
                 return 0;
             });
@@ -664,6 +667,15 @@ void stmmqr_set_options(const stmmqr_options *o)
 }
 void stmmqr_set_common_layout(const stm_common_layout *l) { if (l) g_layout = *l; }
 void stmmqr_get_common_layout(stm_common_layout *l) { if (l) *l = g_layout; }
+
+/* End of use (optional): waits for the device and releases what the library holds process-wide.  A host program that
+ * dlopen()s the library calls it before returning from main; the library has no static object whose destructor calls
+ * into the HIP runtime, so nothing else happens at exit / dlclose. */
+void stmmqr_shutdown(void)
+{
+    int cnt = 0;
+    if (hipGetDeviceCount(&cnt) == hipSuccess && cnt > 0) (void)hipDeviceSynchronize();
+}
 
 int stmmqr_device_count(void)
 {
@@ -830,7 +842,10 @@ int stmmqr_factorize_finish(stmmqr_plan *plan, stmmqr_stats *stats)
         flops += nm.flops;
         fl_upd += nm.flops_upd;
         rank += nm.rank;
-        if (nm.perr) return fail(STMMQR_ERR_DEVICE, "a panel workgroup gave up waiting for its neighbours (device shared with another job?)");
+        if (nm.perr) {
+            P.panel_wait_failed = true;
+            return fail(STMMQR_ERR_DEVICE, "a panel workgroup gave up waiting for its neighbours (device shared with another job?)");
+        }
         const double cn = s.fn - s.fp, cm = nm.cm;
         const double csize = cm * (cm + 1) / 2 + cm * (cn - cm);
         bytes_asm += 8.0 * ((double)nm.fm * s.fn) + 8.0 * csize;   // F first write + child C read (as a child)
@@ -860,12 +875,27 @@ int stmmqr_factorize_finish(stmmqr_plan *plan, stmmqr_stats *stats)
 int stmmqr_factorize_device(stmmqr_plan *plan, const stm_long *Ap, const stm_long *Ai, const double *Ax,
                             int ax_on_device, double tol, stm_long ntol, stmmqr_stats *stats)
 {
-    int e = stmmqr_factorize_begin(plan, Ap, Ai, Ax, ax_on_device, tol, ntol);
-    if (e) return e;
+    if (!plan) return fail(STMMQR_ERR_INVALID, "null plan");
     const bool detail = g_opt.verbose >= 2 || (stats && stats->nlaunch == -1);
-    for (int g = 0; g < (int)plan->glevels.size() && !e; g++) e = stmmqr_factorize_group(plan, g, detail);
-    if (e) return e;
-    return stmmqr_factorize_finish(plan, stats);
+    // The multi-workgroup panel kernels wait for each other inside a launch (bounded).  Should such a wait ever run out
+    // (the workgroups of a launch are not guaranteed to run together: a GPU shared with another job), the factorization is
+    // not lost: it is run once more with every panel factorized by ONE workgroup (dev_panel: no inter-workgroup wait
+    // anywhere), slower but independent of co-residency.
+    for (int attempt = 0; attempt < 2; attempt++) {
+        plan->serial_panels = (attempt == 1);
+        plan->panel_wait_failed = false;
+        int e = stmmqr_factorize_begin(plan, Ap, Ai, Ax, ax_on_device, tol, ntol);
+        for (int g = 0; g < (int)plan->glevels.size() && !e; g++) e = stmmqr_factorize_group(plan, g, detail);
+        if (!e) e = stmmqr_factorize_finish(plan, stats);
+        const bool retry = e && plan->panel_wait_failed && attempt == 0;
+        plan->serial_panels = false;
+        if (!retry) return e;
+        if (g_opt.verbose) fprintf(stderr, "[stmmqr_hip] a panel wait ran out: factorizing again with one-workgroup panels\n");
+        if (stats && detail) stats->nlaunch = -1;
+        Ap = nullptr; Ai = nullptr;                  // (the pattern is set)
+        if (!ax_on_device) continue;                 // host values are uploaded again by begin
+    }
+    return fail(STMMQR_ERR_DEVICE, "panel kernels failed twice");
 }
 
 // ---- multi-GPU support: regroup the fronts, move contribution blocks in and out of a plan --------------

@@ -41,6 +41,7 @@ struct DevCtx {
                                //  8192 reflector-by-reflector Q-apply instead of the blocked one,
                                //  512 panel launches in chunks of env STMMQR_CHUNK fronts (default 1),
                                //  2048 column group (dbg >> 20) & 7 of every pipelined panel starts late (tests)
+                               //  4096 every column group but the first gives up waiting at once (tests: recovery)
 };
 
 int stm_configure_kernels(void);

@@ -1612,6 +1612,10 @@ __global__ __launch_bounds__(NTP) void k_panel(DevCtx c, const int *__restrict__
     if ((c.dbg & 2048) && b == ((c.dbg >> 20) & 7)) {          // tests: column group (dbg >> 20) & 7 starts ~1 ms late
         for (int it = 0; it < 4000; it++) __builtin_amdgcn_s_sleep(100);
     }
+    if ((c.dbg & 4096) && b > 0) {                              // tests: every column group but the first gives up at once
+        if (threadIdx.x == 0) st_agent(&num->perr, 1);
+        return;
+    }
     bool tall = stm_tall_panel(s, p, c.tall_min) && !(c.dbg & 256);
     if (!tall && b > 0) return;
     if (tall) {

@@ -129,6 +129,28 @@ def test_pipeline_late_group_whole_factorization(pkg, oracle, monkeypatch, name,
     compare_numeric(oracle, S, G, No, g, ftol=1e-10, name=name)
 
 
+@pytest.mark.parametrize("name", ["epb1", "syn_rankdef_grid", "grid20_standin"])
+def test_panel_wait_timeout_is_recovered(pkg, oracle, monkeypatch, name):
+    """STMMQR_DBG bit 12: every column group of the panel pipeline but the first gives up at once, as if its bounded wait
+    had run out.  The factorization must not be lost: the library runs it again with one-workgroup panels (no
+    inter-workgroup waits) and returns a correct result."""
+    if name not in golden_names(True):
+        pytest.skip("fixture not present")
+    g = load_golden(name)
+    pkg.set_options(tall_min_rows=0, big_front_cols=16)
+    monkeypatch.setenv("STMMQR_DBG", "4096")
+    try:
+        S, G = gpu_run(pkg, g)
+    finally:
+        monkeypatch.delenv("STMMQR_DBG")
+        pkg.set_options(tall_min_rows=0, big_front_cols=64)
+    N = numeric_from_gpu(S, G)
+    compare_integers(S, N, g)
+    assert G.stats["flops"] == scalar(g, "flopcount")
+    No = oracle.factorize(S, g["in_Ap"], g["in_Ai"], g["in_Ax"], scalar(g, "in_tol"), int(scalar(g, "in_ntol")))
+    compare_numeric(oracle, S, G, No, g, ftol=1e-10, name=name)
+
+
 @pytest.mark.parametrize("chunk", [None, 3, 40])
 def test_pipeline_oversubscribed_and_chunked_launches(pkg, oracle, monkeypatch, chunk):
     """epb1 with every panel pipelined has a level of 97 large fronts = 388 workgroups in one launch, more than the GPU

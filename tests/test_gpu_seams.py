@@ -237,3 +237,76 @@ def test_bench_micro_contract(pkg):
     assert d["assembly"]["entries_conserved"] and d["assembly"]["device_ms"] > 0
     dense8k = [f for f in d["fronts"] if f["fm"] == 8192 and f["staircase"] == "dense"][0]
     assert dense8k["gflops"] > 3000.0          # (the 2-column pipeline of the 4096..8192-row panels, not the one-workgroup fallback)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# qr_stranspose2 / qr_fsize / qr_assemble / qr_hpinv, seam by seam against the oracle's functions on the fronts of real
+# fixtures: the oracle factorization is walked front by front (tests/oracle_plan.py) and every front's inputs -- the
+# children's packed C blocks, Cm, Hr, Hii as the ORACLE left them -- go through the HIP seam: everything must be identical
+# (integers, and F entry by entry: the assembly is an extend-COPY).
+# ---------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("name", ["syn_grid3d", "syn_rankdef_grid", "syn_star", "bcsstk14", "epb1", "lns_3937"])
+def test_front_seams_on_real_fronts(pkg, oracle, name):
+    import ctypes as C
+    from oracle_plan import OraclePlan
+    from stmmqr_testlib import Symbolic, _dp, _ip, c_double_p, golden_names, load_golden, scalar
+    if name not in golden_names():
+        pytest.skip("fixture not present")
+    g = load_golden(name)
+    S = Symbolic(g)
+    # qr_stranspose2: exact gather
+    Sx_g = pkg.qr_stranspose2(S.m, S.n, g["in_Ap"], g["in_Ai"], g["in_Ax"], S.arr.get("Qfill"), S.Sp, S.PLinv)
+    P = OraclePlan(S, oracle)
+    P.begin(g["in_Ax"], scalar(g, "in_tol"), int(scalar(g, "in_ntol")), g["in_Ap"], g["in_Ai"])
+    np.testing.assert_array_equal(Sx_g, P.Sx[:S.anz])
+    L = oracle.lib
+    checked = 0
+    orig = L.orc_assemble
+
+    for f in S.Post[:S.nf]:
+        f = int(f)
+        fn = int(S.Rp[f + 1] - S.Rp[f])
+        # ---- qr_fsize on the oracle's state before this front ----
+        Fmap_o, Fmap_g = P.Fmap.copy(), P.Fmap.copy()
+        St_o = np.zeros(max(fn, 1), I64); St_g = np.zeros(max(fn, 1), I64)
+        fm_o = L.orc_fsize(f, _ip(S.Super), _ip(S.Rp), _ip(S.Rj), _ip(S.Sleft), _ip(S.Child), _ip(S.Childp), _ip(P.Cm), _ip(Fmap_o), _ip(St_o))
+        fm_g = pkg.qr_fsize(f, S.Super, S.Rp, S.Rj, S.Sleft, S.Child, S.Childp, P.Cm, Fmap_g, St_g)
+        assert fm_g == fm_o
+        np.testing.assert_array_equal(St_g[:fn], St_o[:fn])
+        np.testing.assert_array_equal(Fmap_g[S.Rj[S.Rp[f]:S.Rp[f + 1]]], Fmap_o[S.Rj[S.Rp[f]:S.Rp[f + 1]]])
+        # ---- qr_assemble: same inputs to both ----
+        kids = [int(S.Child[q]) for q in range(S.Childp[f], S.Childp[f + 1])]
+        if fm_o * fn > 0 and (checked < 40 or fn >= 64):
+            Fo = np.zeros(max(fm_o * fn, 1)); Cmap_o = np.zeros(max(S.maxfn, 1), I64)
+            Hii_o, Hii_g = P.Hii.copy(), P.Hii.copy()
+            So, Sg = St_o.copy(), St_o.copy()
+            ptrs = (c_double_p * (S.nf + 1))()
+            for c in kids:
+                ptrs[c] = _dp(P.Cblk[c])
+            orig(f, fm_o, _ip(S.Super), _ip(S.Rp), _ip(S.Rj), _ip(S.Sp), _ip(S.Sj), _ip(S.Sleft), _ip(S.Child), _ip(S.Childp),
+                 _dp(P.Sx), _ip(Fmap_o), _ip(P.Cm), ptrs, _ip(P.Hr), _ip(So), _ip(Hii_o), _ip(S.Hip), _dp(Fo), _ip(Cmap_o))
+            Fg, Cmap_g = pkg.qr_assemble(f, fm_o, S.Super, S.Rp, S.Rj, S.Sp, S.Sj, S.Sleft, S.Child, S.Childp, P.Sx, Fmap_o,
+                                         P.Cm, {c: P.Cblk[c] for c in kids}, P.Hr, Sg, Hii_g, S.Hip)
+            np.testing.assert_array_equal(Fg, Fo[:fm_o * fn].reshape((fn, fm_o)).T)
+            np.testing.assert_array_equal(Sg[:fn], So[:fn])
+            a = int(S.Hip[f])
+            np.testing.assert_array_equal(Hii_g[a:a + fm_o], Hii_o[a:a + fm_o])
+            # Cmap is scratch that each child overwrites: what is left is the LAST child's row map
+            if kids:
+                cm = int(P.Cm[kids[-1]])
+                np.testing.assert_array_equal(Cmap_g[:cm], Cmap_o[:cm])
+            checked += 1
+        P.group[:] = -1
+        P.group[f] = 0
+        P.run_group(0)                          # the oracle factorizes the front: state for the parents
+    assert checked >= 1
+    # ---- qr_hpinv on the oracle's final Hii / Hm / Hr ----
+    sym = {**S.sc, **{k: v for k, v in S.arr.items() if v is not None}}
+    No = oracle.factorize(S, g["in_Ap"], g["in_Ai"], g["in_Ax"], scalar(g, "in_tol"), int(scalar(g, "in_ntol")))
+    Hii_g = P.Hii.copy()
+    HPinv_g, maxfm_g = pkg.qr_hpinv(sym, P.Hm, P.Hr, Hii_g)
+    np.testing.assert_array_equal(HPinv_g, No.HPinv[:S.m])
+    assert maxfm_g == No.c.maxfm
+    for f in range(S.nf):
+        a = int(S.Hip[f])
+        np.testing.assert_array_equal(Hii_g[a:a + No.Hm[f]], No.Hii[a:a + No.Hm[f]])
