@@ -105,6 +105,8 @@ static inline __host__ __device__ int stm_ca_slabs(const FrontSym &s)
     return nb < 1 ? 1 : nb;
 }
 
+#define STM_UPD_SLAB 256     // rows of a workgroup tile of the row-parallel trailing update (k_upd_w / k_upd_c); W is accumulated
+                             // per slab and the slabs are added in order in BOTH update forms (bit-identical results)
 #define STM_QB_ROWS 512      // rows of a front per workgroup of the split Q-apply (k_qbig_step)
 // split Q-apply (k_qbig_*): one entry per large front of a tree level
 struct QbDesc {

@@ -15,3 +15,23 @@ __device__ __forceinline__ void st_agent(int *p, int v) { __hip_atomic_store(p, 
 __device__ __forceinline__ double ld_agent(const double *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void st_agent(double *p, double v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void st_agent(char *p, char v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+// dlarfg scalars from alpha and ss = |x|^2 > 0 without the library sqrt / divisions (700 cycles a column on
+// the critical path of every panel): v_rsq_f64 / v_rcp_f64 seeds + Newton steps, results within an ulp or two of the
+// correctly rounded ones.  beta = -sign(alpha) sqrt(alpha^2 + ss), tau = (beta - alpha) / beta, scal = 1 / (alpha - beta).
+__device__ __forceinline__ void stm_larfg_scalars(double alpha, double ss, double &beta, double &tau, double &scal)
+{
+    const double total = alpha * alpha + ss;
+    double r = __builtin_amdgcn_rsq(total);
+    r = r * (1.5 - 0.5 * total * r * r);
+    r = r * (1.5 - 0.5 * total * r * r);
+    double sq = total * r;
+    sq = sq + 0.5 * r * (total - sq * sq);
+    beta = -copysign(sq, alpha);
+    const double den = alpha - beta;                    // = copysign(|alpha| + sq, alpha): no cancellation
+    double ri = __builtin_amdgcn_rcp(den);
+    ri = ri * (2.0 - den * ri);
+    ri = ri * (2.0 - den * ri);
+    scal = ri;
+    tau = (beta - alpha) * (-copysign(r, alpha));       // 1 / beta = -sign(alpha) r
+}

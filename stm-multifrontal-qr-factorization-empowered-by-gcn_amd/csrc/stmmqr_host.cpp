@@ -314,7 +314,7 @@ void build_schedule(stmmqr_plan &P, std::vector<int> &tslot)
                         cnt++;
                         const int k2 = std::min(s.fn, (p + 1) * STM_NB);
                         mcb = std::max(mcb, (s.fn - k2 + 31) / 32);
-                        msl = std::max(msl, (s.fm_ub + 255) / 256);
+                        msl = std::max(msl, (s.fm_ub + STM_UPD_SLAB - 1) / STM_UPD_SLAB);
                         L.nsub_at[p] = std::max(L.nsub_at[p], stm_tall_launches(s, p, P.tall_min));
                         L.nca_at[p] = std::max(L.nca_at[p], stm_ca_slabs(s));
                         (stm_use_ca(s, p, g_opt.panel_algo, P.ca_min) ? L.nca_use[p] : L.npipe_use[p])++;

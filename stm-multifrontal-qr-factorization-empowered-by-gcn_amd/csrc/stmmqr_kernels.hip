@@ -311,7 +311,7 @@ __device__ void dev_update_block(double *F, long long ld, int g1, int mp, int k1
                 gacc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, bv, gacc, 0, 0, 0);
             }
         }
-        if ((r0 + RB) % 256 == 0 || r0 + RB >= mp) {            // end of a 256-row slab (SLAB of the row-parallel form)
+        if ((r0 + RB) % STM_UPD_SLAB == 0 || r0 + RB >= mp) {   // end of a slab (SLAB of the row-parallel form)
 #pragma unroll
             for (int r = 0; r < 4; r++) { tot[r] += acc[r]; acc[r] = 0; gtot[r] += gacc[r]; gacc[r] = 0; }
         }
@@ -703,11 +703,7 @@ __device__ __forceinline__ void dev_subpanel_reg(PanelShared &ps, double *F, lon
             const double alpha = ps.top[par][0];
             const double ss = sum[0];
             double tau = 0, beta = alpha, scal = 0;
-            if (ss != 0.0) {                            // (no active row below the diagonal gives ss == 0 exactly)
-                beta = -copysign(sqrt(alpha * alpha + ss), alpha);
-                tau = (beta - alpha) / beta;
-                scal = 1.0 / (alpha - beta);
-            }
+            if (ss != 0.0) stm_larfg_scalars(alpha, ss, beta, tau, scal);   // (no active row below the diagonal: ss == 0 exactly)
             const bool dead = (k < ntol) && (fabs(beta) <= tol);
             if (dead) {
                 // zero the column from the diagonal down, no reflector, g does not advance (:1495-1544)
@@ -925,11 +921,7 @@ __device__ __forceinline__ void dev_panel(PanelShared &ps, const FrontSym &s, Fr
             }
             const double ss = part[0];
             double tau = 0, beta = alpha, scal = 0;
-            if (len > 1 && ss != 0.0) {
-                beta = -copysign(sqrt(alpha * alpha + ss), alpha);   // |x|^2 is unscaled anyway: no hypot
-                tau = (beta - alpha) / beta;
-                scal = 1.0 / (alpha - beta);
-            }
+            if (len > 1 && ss != 0.0) stm_larfg_scalars(alpha, ss, beta, tau, scal);   // (|x|^2 is unscaled anyway: no hypot)
             const bool dead = (k < ntol) && (fabs(beta) <= tol);
             if (dead) {
                 // zero the column from the diagonal down, no reflector, g does not advance (:1495-1544)
@@ -1174,7 +1166,9 @@ __device__ __forceinline__ void dev_tall_group(PanelShared &ps, const FrontSym &
     const bool tl_on = (dbg & 32) && dbgbuf && p == 1 && tid == 0;
 #define TL(idx) do { if (tl_on) dbgbuf[16 + 64 * b + (idx)] = wall_clock64(); } while (0)
 #define TLW(idx) do { if ((dbg & 32) && p == 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); TL(idx); } while (0)
+#define TCY(idx) do { if (tl_on && j == 4) dbgbuf[16 + 64 * b + 48 + (idx)] = clock64(); } while (0)
 #else
+#define TCY(idx) do { } while (0)
 #define TSTAMP(idx) do { } while (0)
 #define TL(idx) do { } while (0)
 #define TLW(idx) do { } while (0)
@@ -1372,14 +1366,26 @@ __device__ __forceinline__ void dev_tall_group(PanelShared &ps, const FrontSym &
     int tlast = (b == 0) ? g1 : ch_pt;
     const int nl_before = (b == 0) ? 0 : ch_nl;
     const double ls_before = (b == 0) ? 0.0 : ch_ls;
-    double lensum = 0;
+    long long iflops = 0, ilen = 0;                            // the reference's flop count: integers, exact in fp64
     const int gs = g;
     const int ntol = min(ntol_global - s.col1, npiv);
-    double flops = 0;
+    // HStair / HTau / pdiag / Rdead of my columns [j0, j1): from LDS to global memory, write-through, before a publish
+    auto flush_cols = [&](int j0, int j1) {
+        lds_barrier();
+        if (tid >= j0 && tid < j1) {
+            const int kk = k1 + c0 + tid;
+            st_agent(&St[kk], ps.st_out[tid]); st_agent(&Tau[kk], ps.tau[tid]); st_agent(&pd->pdiag[c0 + tid], ps.diag[tid]);
+            if (ps.dead[tid]) st_agent(&Rdead[kk], (char)1);
+        }
+    };
+    int flushed = 0, jdone = SWT;
     lds_barrier();                                             // ps.stair
     for (int j = 0; j < sw && !prev_done; j++) {
         const int jp = c0 + j, k = k1 + jp;
-        if (j == SWT / 2 && b + 1 < ns) publish_progress(&num->prog, STM_PROG * p + 2 * b + 1);   // first half is in F
+        if (j == SWT / 2 && b + 1 < ns) {
+            flush_cols(0, min(j, jdone)); flushed = j;
+            publish_progress(&num->prog, STM_PROG * p + 2 * b + 1);   // first half is in F
+        }
         if (!done && g >= m) {
             // no rows left: remaining pivotal columns are dead, remaining columns are empty (:1444-1458)
             for (int kk = k + tid; kk < n; kk += NTH) {
@@ -1389,10 +1395,12 @@ __device__ __forceinline__ void dev_tall_group(PanelShared &ps, const FrontSym &
             }
             for (int jj = jp + tid; jj < STM_NB; jj += NTH) st_agent(&pd->pdiag[jj], STM_BIGROW);
             done = 1;
+            jdone = j;
         }
         if (!done) {
             // Straight-line column step: the dead-column and tau == 0 cases are folded into the scalars (a branch
             // around the update would make the compiler copy the whole register image at the join).
+            TCY(0);
             const int t = max(g + 1, ps.stair[j]);
             double part[8], sum[8];
 #pragma unroll
@@ -1410,17 +1418,21 @@ __device__ __forceinline__ void dev_tall_group(PanelShared &ps, const FrontSym &
 #pragma unroll
                 for (int x = 0; x < SWT; x++) ps.top[tpar][x] = a[0][x];
             }
+            TCY(1);
             block_reduce8<NTH>(ps, par, part, sum);
+            TCY(2);
             const double alpha = ps.top[tpar][0];
             const double ss = sum[0];
             // dlarfg; ss == 0 (no active row below the diagonal, or all of them zero) gives H = I
-            const double bb = -copysign(sqrt(alpha * alpha + ss), alpha);
+            double bb, tau0, scal0;
+            stm_larfg_scalars(alpha, ss, bb, tau0, scal0);
             const bool ident = (ss == 0.0);
             const double beta = ident ? alpha : bb;
             const bool dead = (k < ntol) && (fabs(beta) <= tol);    // (:1495-1544) column zeroed, g does not advance
             const bool upd = !ident && !dead;
-            const double tau = upd ? (bb - alpha) / bb : 0.0;
-            const double scal = upd ? 1.0 / (alpha - bb) : 0.0;
+            const double tau = upd ? tau0 : 0.0;
+            const double scal = upd ? scal0 : 0.0;
+            TCY(3);
             double w[8];
 #pragma unroll
             for (int x = 1; x < SWT; x++) w[x] = tau * (ps.top[tpar][x] + scal * sum[x]);     // 0 unless upd
@@ -1438,18 +1450,18 @@ __device__ __forceinline__ void dev_tall_group(PanelShared &ps, const FrontSym &
                 for (int x = 1; x < SWT; x++) a[0][x] -= w[x];
                 a[0][0] = dead ? 0.0 : beta;
             }
-            if (tid == 0) {
-                st_agent(&St[k], dead ? 0 : t); st_agent(&Tau[k], tau); st_agent(&pd->pdiag[jp], dead ? STM_BIGROW : g);
-                if (dead) st_agent(&Rdead[k], (char)1);
+            if (tid == 0) {          // (flushed to global memory before each publish: flush_cols below)
+                ps.st_out[j] = dead ? 0 : t; ps.tau[j] = tau; ps.diag[j] = dead ? STM_BIGROW : g; ps.dead[j] = dead ? 1 : 0;
             }
             if (!dead) {
-                flops += (double)(t - g) * (3.0 + 4.0 * (double)(n - k - 1));
-                lensum += (double)(t - g);
+                iflops += (long long)(t - g) * (3 + 4 * (long long)(n - k - 1));
+                ilen += (t - g);
                 nlive += (tau != 0.0);
                 tlast = t;
                 g++;
             }
             if (k == npiv - 1) rank = g;                       // (:1604-1608) also taken on a dead last pivot
+            TCY(4);
         }
         // ---- retire register column 0 to F and rotate ----
         {
@@ -1463,9 +1475,12 @@ __device__ __forceinline__ void dev_tall_group(PanelShared &ps, const FrontSym &
                 a[r][SWT - 1] = 0.0;
             }
         }
+        TCY(5);
         TL(20 + j);
     }
     TSTAMP(9);
+    const double flops = (double)iflops, lensum = (double)ilen;
+    if (!prev_done) flush_cols(min(flushed, jdone), min(sw, jdone));
     // ---- sub-panel bookkeeping; the last sub-panel (or the group after one that ran out of rows) finalises ----
     const bool last = prev_done || b == ns - 1;
     const int nl_total = nl_before + nlive;
@@ -1524,6 +1539,7 @@ __device__ __forceinline__ void dev_tall_group(PanelShared &ps, const FrontSym &
 #undef TSTAMP
 #undef TL
 #undef TLW
+#undef TCY
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1716,7 +1732,7 @@ __global__ __launch_bounds__(NT) void k_larft(DevCtx c, int f)
 //   k_upd_c : W2 = T' sum_slabs W1 ;  C(slab, cb) -= V(slab) W2     grid (cb, slab, front)
 // SLAB rows per slab; the summation order over slabs is fixed (deterministic results).
 // ------------------------------------------------------------------------------------------------
-#define SLAB 256
+#define SLAB STM_UPD_SLAB
 
 __global__ __launch_bounds__(NT) void k_upd_w(DevCtx c, const int *__restrict__ flist, int p, int cb0, double *Wp,
                                               int maxcb, int maxsl)

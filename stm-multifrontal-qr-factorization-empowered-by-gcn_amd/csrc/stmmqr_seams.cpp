@@ -160,7 +160,7 @@ stm_long stmmqr_front(stm_long m, stm_long n, stm_long npiv, double tol, stm_lon
         e = stm_launch_front_wg(X.c, X.d_flist.p, 1, lds_for(m), nullptr);
     } else {
         // as the plan does: a front of >= 3 row slabs takes the row-parallel update (and may leave T to it)
-        const int msl = (int)((m + 255) / 256);
+        const int msl = (int)((m + STM_UPD_SLAB - 1) / STM_UPD_SLAB);
         const bool split = opt.split_update && msl >= 3;
         Buf<double> d_Wp;
         if (split && !d_Wp.alloc((size_t)((n + 31) / 32 + 1) * (size_t)msl * STM_NB * 32)) return -1;
@@ -194,7 +194,7 @@ stm_long stmmqr_front(stm_long m, stm_long n, stm_long npiv, double tol, stm_lon
             for (int b = 0; b < 8; b++) {
                 if (!tl[16 + 64 * b]) continue;
                 fprintf(stderr, "[timeline panel 1, group %d, us]", b);
-                for (int i = 0; i < 48; i++)
+                for (int i = 0; i < 64; i++)
                     if (tl[16 + 64 * b + i]) fprintf(stderr, " %d:%.2f", i, 0.01 * (double)(long long)(tl[16 + 64 * b + i] - t0));
                 fprintf(stderr, "\n");
             }

@@ -341,8 +341,10 @@ def csc_matvec(m, Ap, Ai, Ax, x):
     return y
 
 
-def aqr_probe_error(orc: Oracle, S: Symbolic, N: Numeric, Ap, Ai, Ax, nprobe=4, seed=7):
-    """max over random x of ||A*E*x - Q*(R*x)|| / (||A||_F ||x||)   (SURVEY.md 8d parity metric)."""
+def aqr_probe_error(orc: Oracle, S: Symbolic, N: Numeric, Ap, Ai, Ax, nprobe=4, seed=7, live_only=False):
+    """max over random x of ||A*E*x - Q*(R*x)|| / (||A||_F ||x||)   (SURVEY.md 8d parity metric).
+    live_only: x is zero on the dead pivot columns (Rdead) -- on a rank-deficient factorization A E = Q R holds on the
+    live columns to working accuracy (a dead column is dropped, it generates no reflector), on the dead ones only to tol."""
     rng = np.random.default_rng(seed)
     m, n = S.m, S.n
     q = S.Qfill if S.Qfill is not None else np.arange(n)
@@ -350,6 +352,8 @@ def aqr_probe_error(orc: Oracle, S: Symbolic, N: Numeric, Ap, Ai, Ax, nprobe=4, 
     worst = 0.0
     for _ in range(nprobe):
         x = rng.standard_normal(n)
+        if live_only:
+            x[np.asarray(N.Rdead[:n]) != 0] = 0.0
         xa = np.zeros(n)
         xa[q] = x                      # (A E) x = A (E x)
         y1 = csc_matvec(m, Ap, Ai, Ax, xa)
