@@ -249,6 +249,17 @@ typedef struct stmmqr_options {
 void stmmqr_get_options(stmmqr_options *opt);
 void stmmqr_set_options(const stmmqr_options *opt);
 
+/* ---- the driver's Matrix Market reader ------------------------------------------------------------
+ * SparseCore_read_matrix (STMMQR/src/core/SparseCore_read_write.c:982) as test/qrtest.c:112 calls it (prefer = 1): a
+ * coordinate file (real / integer / pattern; general / symmetric / hermitian / skew-symmetric, or without a banner) is
+ * returned as an UNSYMMETRIC CSC with both triangles, duplicates summed, columns sorted, explicit zeros kept.
+ * Ap (ncol+1), Ai, Ax are malloc'ed: release with stmmqr_free.  Returns 0 or a negative STMMQR_ERR_* code
+ * (stmmqr_mm_last_error() has the text); dense ("array") and complex files are refused as the driver refuses them. */
+int stmmqr_read_matrix_market(const char *path, stm_long *nrow, stm_long *ncol, stm_long *nnz, stm_long **Ap,
+                              stm_long **Ai, double **Ax);
+const char *stmmqr_mm_last_error(void);
+void stmmqr_free(void *p);
+
 void stmmqr_shutdown(void);                           /* optional end-of-use call for dlopen()ing hosts: device sync  */
 int stmmqr_device_count(void);                        /* number of visible HIP devices (0 = none)          */
 const char *stmmqr_device_name(int device);           /* gcnArchName, e.g. "gfx950:sramecc+:xnack-"        */

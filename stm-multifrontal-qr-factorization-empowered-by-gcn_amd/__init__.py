@@ -7,4 +7,4 @@ code and no CPU fallback: importing :mod:`capi` raises if the HIP library has no
 """
 from .capi import (HipQR, QRNumeric, StmmqrError, device_count, device_name, get_options, last_seam_ms, lib,  # noqa: F401
                    lib_path, qr_assemble, qr_cpack, qr_factorize, qr_fcsize, qr_front, qr_fsize, qr_hpinv, qr_larftb, qr_rhpack,
-                   qr_stranspose2, set_options)
+                   qr_stranspose2, read_matrix_market, set_options)

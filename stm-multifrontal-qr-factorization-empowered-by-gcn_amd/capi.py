@@ -377,6 +377,26 @@ class QrNumericC(C.Structure):
                [(k, c_long_p) for k in ("Hii", "HPinv", "Hm", "Hr")] + [("maxfm", C.c_long)]
 
 
+def read_matrix_market(path):
+    """The driver's Matrix Market reader (SparseCore_read_matrix with prefer = 1, qrtest.c:112): (m, n, Ap, Ai, Ax) of the
+    unsymmetric CSC with both triangles."""
+    m, n, nz = C.c_long(0), C.c_long(0), C.c_long(0)
+    pp, pi, px = c_long_p(), c_long_p(), c_double_p()
+    lib.stmmqr_mm_last_error.restype = C.c_char_p
+    rc = lib.stmmqr_read_matrix_market(str(path).encode(), C.byref(m), C.byref(n), C.byref(nz), C.byref(pp), C.byref(pi), C.byref(px))
+    if rc != 0:
+        raise StmmqrError(f"stmmqr_read_matrix_market({path}): {lib.stmmqr_mm_last_error().decode()}")
+    try:
+        Ap = np.ctypeslib.as_array(pp, shape=(n.value + 1,)).copy()
+        Ai = np.ctypeslib.as_array(pi, shape=(max(nz.value, 1),))[:nz.value].copy()
+        Ax = np.ctypeslib.as_array(px, shape=(max(nz.value, 1),))[:nz.value].copy()
+    finally:
+        lib.stmmqr_free.argtypes = [C.c_void_p]
+        for q in (pp, pi, px):
+            lib.stmmqr_free(C.cast(q, C.c_void_p))
+    return m.value, n.value, Ap, Ai, Ax
+
+
 def qr_fsize(f, Super, Rp, Rj, Sleft, Child, Childp, Cm, Fmap, Stair):
     """qr_fsize (SparseQR.h:159-176 / SparseQR_factorize.c:1066-1145): Fmap and Stair are written; returns fm"""
     a = [np.ascontiguousarray(x, I64) for x in (Super, Rp, Rj, Sleft, Child, Childp, Cm)]

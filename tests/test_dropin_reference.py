@@ -44,3 +44,37 @@ def test_reference_driver_on_hip_factorization(tmp_path, name):
     if scalar(g, "QR_rank") == scalar(g, "A_n"):
         assert bwd < 1e-13
         assert res <= max(10 * ref_res, 1e-9)
+
+
+DRIVER = ROOT / "stm-multifrontal-qr-factorization-empowered-by-gcn_amd" / "stmmqr_qrtest"
+REFLIB = ROOT / "oracle" / "_ref" / "libstmmqr_ref.so"
+
+
+@pytest.mark.parametrize("name,ordering", [("bcsstk14", None), ("epb1", None), ("epb1", "1"), ("syn_grid3d", "0")])
+def test_qrtest_compatible_driver(tmp_path, name, ordering):
+    """stmmqr_qrtest <matrix.mtx> <graph_id> [ordering] (csrc/stmmqr_qrtest.cpp): the reference driver's arguments, printed
+    lines and Results/QR_Time.txt record (STMMQR/test/qrtest.c:65-217), with this repository's Matrix Market reader and
+    numeric factorization; the reference library named with --reflib provides the symbolic analysis around the seam."""
+    if not DRIVER.exists() or not REFLIB.exists():
+        pytest.skip("driver or reference library not built")
+    from stmmqr_testlib import load_golden, scalar
+    g = load_golden(name)
+    mtx = tmp_path / "a.mtx"
+    write_mtx(mtx, g)
+    (tmp_path / "Results").mkdir()
+    args = [str(DRIVER), str(mtx), "42"] + ([ordering] if ordering is not None else []) + [f"--reflib={REFLIB}"]
+    env = dict(os.environ, MKL_THREADING_LAYER="SEQUENTIAL")
+    out = subprocess.run(args, capture_output=True, text=True, env=env, timeout=180, cwd=tmp_path)
+    assert out.returncode == 0, out.stdout + out.stderr
+    m, n, nnz = int(g["A_m"][0]), int(g["A_n"][0]), len(g["A_x"])
+    assert "Matrix %6d-by-%-6d nnz: %6d" % (m, n, nnz) in out.stdout
+    assert re.search(r"SparseQR TOTAL time: [0-9.]+", out.stdout)
+    res = float(re.search(r"res =\s*([0-9.eE+-]+)", out.stdout).group(1))
+    rec = (tmp_path / "Results" / "QR_Time.txt").read_text().split()
+    assert rec[0] == "42" and len(rec) == 5 and float(rec[4]) == res
+    assert float(rec[2]) > 0                                        # Fac_time of the interposed factorization
+    if ordering is None and scalar(g, "QR_rank") == scalar(g, "A_n"):
+        assert res <= max(10 * scalar(g, "res"), 1e-9)               # the reference's own run of the same driver flow
+    # without a reference library the driver says what is missing and stops
+    out2 = subprocess.run([str(DRIVER), str(mtx), "1"], capture_output=True, text=True, env=env, timeout=60, cwd=tmp_path)
+    assert out2.returncode == 2 and "no reference library" in out2.stderr
