@@ -216,6 +216,14 @@ int stmmqr_factorize_arrays(const stmmqr_symbolic_view *sym, const stm_long *Ap,
  *                      block R1 of SparseQR() is not part of the plan: it stays with the caller. */
 int stmmqr_plan_qmult(stmmqr_plan *plan, int method, double *X, stm_long ldx, stm_long nrhs);
 int stmmqr_plan_solve(stmmqr_plan *plan, const double *B, stm_long ldb, double *X, stm_long ldx, stm_long nrhs);
+/*   stmmqr_plan_qmult also takes the methods QR_XQT (2: X <- X Q') and QR_XQ (3: X <- X Q) of qr_panel (SparseQR.c:1591-1700,
+ *                      2040-2075): X is then k x m with ldx >= k and `nrhs` = k.  All vectors cross PCIe in one transfer.
+ *   stmmqr_plan_rsolve replaces QR_solve for all four systems (SparseQR_definitions.h:27-30; SparseQR.c:2118-2216,
+ *                      qr_rsolve :2218-2517, qr_private_rtsolve :2522): 0 QR_RX_EQUALS_B  X = R\B, 1 QR_RETX_EQUALS_B
+ *                      X = E(R\B) -- B is m x nrhs in R's row order (what QR_QTX returns), X n x nrhs --, 2 QR_RTX_EQUALS_B
+ *                      X = R'\B, 3 QR_RTX_EQUALS_ETB  X = R'\(E'B) -- B n x nrhs, X m x nrhs (zero beyond the rank). */
+int stmmqr_plan_rsolve(stmmqr_plan *plan, int system, const double *B, stm_long ldb, double *X, stm_long ldx,
+                       stm_long nrhs);
 
 /* dense single-front kernels on host buffers (inner seams without the cc argument) */
 stm_long stmmqr_front(stm_long m, stm_long n, stm_long npiv, double tol, stm_long ntol, double *F,

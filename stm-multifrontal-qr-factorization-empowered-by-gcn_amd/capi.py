@@ -89,6 +89,9 @@ lib.qr_assemble.restype = None
 lib.qr_assemble.argtypes = [C.c_long, C.c_long, C.c_int] + [c_long_p] * 8 + [c_double_p, c_long_p, c_long_p,
                                                                              C.POINTER(c_double_p), c_long_p, c_long_p,
                                                                              c_long_p, c_long_p, c_double_p, c_long_p]
+lib.stmmqr_plan_rsolve.argtypes = [C.c_void_p, C.c_int, c_double_p, C.c_long, c_double_p, C.c_long, C.c_long]
+lib.stmmqr_read_matrix_market.argtypes = [C.c_char_p, c_long_p, c_long_p, c_long_p, C.POINTER(c_long_p), C.POINTER(c_long_p), C.POINTER(c_double_p)]
+lib.qr_fsize.argtypes = [C.c_long] + [c_long_p] * 9
 lib.stmmqr_factorize_begin.argtypes = [C.c_void_p, c_long_p, c_long_p, C.c_void_p, C.c_int, C.c_double, C.c_long]
 lib.stmmqr_factorize_group.argtypes = [C.c_void_p, C.c_int, C.c_int]
 lib.stmmqr_factorize_finish.argtypes = [C.c_void_p, C.POINTER(Stats)]
@@ -260,12 +263,27 @@ class HipQR:
                                             _ip(rows), 0), "stmmqr_plan_import_front")
 
     def qmult(self, method: int, X: np.ndarray) -> np.ndarray:
-        """QR_qmult (SparseQR.h:403-409) on the resident factors: method 0 = QR_QTX (Q'X), 1 = QR_QX (Q X).
-        X: m or m x nrhs; returns a new array (row order of the reference: Q'X in R's row order)."""
+        """QR_qmult (SparseQR.h:403-409) on the resident factors: method 0 = QR_QTX (Q'X), 1 = QR_QX (Q X) with X m or
+        m x nrhs; 2 = QR_XQT (X Q'), 3 = QR_XQ (X Q) with X k x m.  Returns a new array (orders as in the reference: Q'X
+        and X Q in the permuted order of the factorization)."""
         m = self.sym["m"]
-        Xf = np.array(X, dtype=np.float64, order="F", copy=True).reshape(m, -1, order="F")
-        _check(lib.stmmqr_plan_qmult(self._h, int(method), _dp(Xf), m, Xf.shape[1]), "stmmqr_plan_qmult")
+        if method <= 1:
+            Xf = np.array(X, dtype=np.float64, order="F", copy=True).reshape(m, -1, order="F")
+            _check(lib.stmmqr_plan_qmult(self._h, int(method), _dp(Xf), m, Xf.shape[1]), "stmmqr_plan_qmult")
+            return Xf.reshape(np.shape(X), order="F")
+        Xf = np.array(X, dtype=np.float64, order="F", copy=True).reshape(-1, m, order="F")
+        _check(lib.stmmqr_plan_qmult(self._h, int(method), _dp(Xf), Xf.shape[0], Xf.shape[0]), "stmmqr_plan_qmult")
         return Xf.reshape(np.shape(X), order="F")
+
+    def rsolve(self, system: int, B: np.ndarray) -> np.ndarray:
+        """QR_solve (SparseQR.h:411-417): system 0 RX=B, 1 RE'X=B (B m x nrhs in R's row order, X n x nrhs), 2 R'X=B,
+        3 R'X=E'B (B n x nrhs, X m x nrhs)."""
+        m, n = self.sym["m"], self.sym["n"]
+        br, xr = (m, n) if system <= 1 else (n, m)
+        Bf = np.array(B, dtype=np.float64, order="F", copy=True).reshape(br, -1, order="F")
+        X = np.zeros((xr, Bf.shape[1]), order="F")
+        _check(lib.stmmqr_plan_rsolve(self._h, int(system), _dp(Bf), br, _dp(X), xr, Bf.shape[1]), "stmmqr_plan_rsolve")
+        return X[:, 0] if np.ndim(B) == 1 else X
 
     def solve(self, B: np.ndarray) -> np.ndarray:
         """QR_solve(QR_RETX_EQUALS_B) (SparseQR.h:411-417): X = E R^-1 (Q'B)(1:n), least-squares solution; rank == n only."""

@@ -156,7 +156,9 @@ struct stmmqr_plan {
     std::vector<FrontNum> h_fnum;
     // Q-apply / solve on the resident factors
     DevBuf<int> d_Rj, d_PLinv, d_Qfill, d_Wmap, d_err;
-    DevBuf<double> d_W, d_Xs, d_Io, d_Xf, d_Wq;
+    DevBuf<double> d_W, d_Xs, d_Io, d_Xf, d_Wq, d_Xall, d_Yall, d_U, d_Xr;
+    DevBuf<int> d_rowbase;                          // rows of R above each front (R rows are numbered front by front)
+    std::vector<int> level_lds_rt;                  // dynamic LDS of k_rtsolve per level
     DevBuf<int> d_Dq;
     DevBuf<QbDesc> d_qb;
     struct QbLevel { int off = 0, n = 0, max_np = 0, max_nslab = 0, max_fm = 0, max_rsteps = 0; };
@@ -1025,6 +1027,12 @@ int ensure_rowmap(stmmqr_plan &P)
         for (long i = fm - 1; i >= rm + cm; i--) W[Hi[i]] = (int)--row2;
     }
     LCHK(P.d_Wmap.upload(W, st));
+    {
+        std::vector<int> rb((size_t)std::max(1L, nf), 0);
+        long run = 0;
+        for (long f = 0; f < nf; f++) { rb[f] = (int)run; run += P.h_fnum[f].rank; }
+        LCHK(P.d_rowbase.upload(rb, st));
+    }
     HIPCHK(hipStreamSynchronize(st));
     if (!P.d_Rj.p) {
         std::vector<int> t((size_t)std::max(1L, P.rjsize));
@@ -1050,6 +1058,7 @@ int ensure_rowmap(stmmqr_plan &P)
         P.level_lds_qa.assign(LV.size(), 0);
         P.level_lds_qa_all.assign(LV.size(), 0);
         P.level_lds_rs.assign(LV.size(), 0);
+        P.level_lds_rt.assign(LV.size(), 0);
         P.level_qbig.assign(LV.size(), stmmqr_plan::QbLevel());
         std::vector<QbDesc> qb;
         long xf = 1, dq = 1, wq = 1;
@@ -1060,6 +1069,7 @@ int ensure_rowmap(stmmqr_plan &P)
                 const int f = P.lists[LV[l].all_off + q];
                 const FrontSym &s = P.fs[f];
                 const int need = (int)(((s.fm_ub + 1) & ~1) * 8 + s.fn * 4 + 16);
+                P.level_lds_rt[l] = std::max(P.level_lds_rt[l], (int)((((s.fn + 1) & ~1) + ((std::min(s.fp, std::max(s.fm_ub, 1)) + 2) & ~1)) * 8 + s.fp * 4 + 32));
                 P.level_lds_qa_all[l] = std::max(P.level_lds_qa_all[l], need);
                 if (s.qbig) {
                     QbDesc d;
@@ -1130,37 +1140,141 @@ int run_qapply(stmmqr_plan &P, int method)
 }
 }  // namespace
 
-// X (m x nrhs, column-major, ldx >= m, host) <- Q' X (method 0 = QR_QTX) or Q X (method 1 = QR_QX), in place.
-// Row order as in the reference: Q'X is returned in the permuted order of the factorization (HPinv), Q X takes it.
-int stmmqr_plan_qmult(stmmqr_plan *plan, int method, double *X, stm_long ldx, stm_long nrhs)
+namespace {
+// host matrix (rows x cols, leading dimension ld) <-> contiguous device matrix (rows x cols), one transfer each way
+int upload_cols(stmmqr_plan &P, DevBuf<double> &d, const double *H, long ld, long rows, long cols)
+{
+    if ((size_t)(rows * cols) > d.n) LCHK(d.alloc((size_t)std::max(1L, rows * cols)));
+    if (rows > 0 && cols > 0)
+        HIPCHK(hipMemcpy2DAsync(d.p, (size_t)rows * sizeof(double), H, (size_t)ld * sizeof(double), (size_t)rows * sizeof(double),
+                                (size_t)cols, hipMemcpyHostToDevice, P.stream));
+    return 0;
+}
+int download_cols(stmmqr_plan &P, const DevBuf<double> &d, double *H, long ld, long rows, long cols)
+{
+    if (rows > 0 && cols > 0)
+        HIPCHK(hipMemcpy2DAsync(H, (size_t)ld * sizeof(double), d.p, (size_t)rows * sizeof(double), (size_t)rows * sizeof(double),
+                                (size_t)cols, hipMemcpyDeviceToHost, P.stream));
+    HIPCHK(hipStreamSynchronize(P.stream));
+    return 0;
+}
+// one vector through Q' (method 0) or Q (method 1): in / out are device vectors of length m in the reference's row order
+int qapply_vector(stmmqr_plan &P, int method, const double *in, double *out)
+{
+    hipStream_t st = P.stream;
+    const int m = (int)P.m;
+    if (method == 0) {
+        LCHK(stm_launch_perm(in, P.d_PLinv.p, P.d_W.p, m, 1, st));                     // W[PLinv[i]] = x[i]
+        LCHK(run_qapply(P, 0));
+        LCHK(stm_launch_perm(P.d_W.p, P.d_Wmap.p, out, m, 1, st));                     // out[Wmap[r]] = W[r]
+    } else {
+        LCHK(stm_launch_perm(in, P.d_Wmap.p, P.d_W.p, m, 0, st));                      // W[r] = x[Wmap[r]]
+        LCHK(run_qapply(P, 1));
+        LCHK(stm_launch_perm(P.d_W.p, P.d_PLinv.p, out, m, 0, st));                    // out[i] = W[PLinv[i]]
+    }
+    return 0;
+}
+// back substitution R x = y on the device work vector W (internal row order) -> d_Xs (R's column order)
+int rsolve_vector(stmmqr_plan &P)
+{
+    DevCtx c = P.ctx();
+    const int *L0 = P.d_lists.p;
+    const auto &LV = P.glevels[0];
+    hipStream_t st = P.stream;
+    for (size_t l = LV.size(); l-- > 0;) {
+        LCHK(stm_launch_rsolve(c, L0 + LV[l].all_off, LV[l].n_all, P.d_Rj.p, P.d_W.p, P.d_Xs.p, P.level_lds_rs[l], P.d_err.p, st));
+        const auto &Q = P.level_qbig[l];         // the large fronts of the level: rows split over workgroups
+        LCHK(stm_launch_rsolve_big(c, P.d_qb.p + Q.off, Q.n, Q.max_rsteps, Q.max_nslab, P.d_Rj.p, P.d_W.p, P.d_Xs.p, P.d_Xf.p,
+                                   P.d_Dq.p, P.d_Rm.p + Q.off, P.d_err.p, st));
+    }
+    return 0;
+}
+}  // namespace
+
+// QR_qmult (STMMQR/include/SparseQR.h:403-409, SparseQR.c:1815-2116) on the resident factors, in place:
+//   method 0 QR_QTX: X (m x k, ldx >= m) <- Q' X      method 1 QR_QX: X <- Q X
+//   method 2 QR_XQT: X (k x m, ldx >= k) <- X Q'      method 3 QR_XQ: X <- X Q
+// Row (methods 0, 1) / column (2, 3) order as in the reference: Q'X and X Q come out in the permuted order of the
+// factorization (HPinv), Q X and X Q' take it.  All vectors cross PCIe in ONE transfer each way.
+int stmmqr_plan_qmult(stmmqr_plan *plan, int method, double *X, stm_long ldx, stm_long k)
 {
     if (!plan || !plan->factored) return fail(STMMQR_ERR_INVALID, "no factorization held by the plan");
-    if (!X || ldx < plan->m || nrhs < 0 || (method != 0 && method != 1)) return fail(STMMQR_ERR_INVALID, "bad qmult arguments");
+    if (!X || k < 0 || method < 0 || method > 3 || ldx < ((method <= 1) ? plan->m : k))
+        return fail(STMMQR_ERR_INVALID, "bad qmult arguments");
     stmmqr_plan &P = *plan;
     HIPCHK(hipSetDevice(P.device));
     LCHK(ensure_rowmap(P));
-    hipStream_t st = P.stream;
-    const int m = (int)P.m;
-    for (stm_long j = 0; j < nrhs; j++) {
-        double *xj = X + j * ldx;
-        HIPCHK(hipMemcpyAsync(P.d_Io.p, xj, (size_t)m * sizeof(double), hipMemcpyHostToDevice, st));
-        if (method == 0) {
-            LCHK(stm_launch_perm(P.d_Io.p, P.d_PLinv.p, P.d_W.p, m, 1, st));               // W[PLinv[i]] = x[i]
-            LCHK(run_qapply(P, 0));
-            LCHK(stm_launch_perm(P.d_W.p, P.d_Wmap.p, P.d_Io.p, m, 1, st));                // out[Wmap[r]] = W[r]
-        } else {
-            LCHK(stm_launch_perm(P.d_Io.p, P.d_Wmap.p, P.d_W.p, m, 0, st));                // W[r] = x[Wmap[r]]
-            LCHK(run_qapply(P, 1));
-            LCHK(stm_launch_perm(P.d_W.p, P.d_PLinv.p, P.d_Io.p, m, 0, st));               // out[i] = W[PLinv[i]]
-        }
-        HIPCHK(hipMemcpyAsync(xj, P.d_Io.p, (size_t)m * sizeof(double), hipMemcpyDeviceToHost, st));
+    const long m = P.m;
+    if (k == 0 || m == 0) return 0;
+    if (method <= 1) {
+        LCHK(upload_cols(P, P.d_Xall, X, ldx, m, k));
+        for (stm_long j = 0; j < k; j++) LCHK(qapply_vector(P, method, P.d_Xall.p + j * m, P.d_Xall.p + j * m));
+        return download_cols(P, P.d_Xall, X, ldx, m, k);
     }
-    HIPCHK(hipStreamSynchronize(st));
+    // X Q' = (Q X')' and X Q = (Q' X')': the rows of X are the vectors (SparseQR.c:2040-2075: the same permutation pattern)
+    std::vector<double> T((size_t)m * (size_t)k);
+    for (stm_long r = 0; r < k; r++)
+        for (long i = 0; i < m; i++) T[(size_t)r * m + i] = X[r + (size_t)i * ldx];
+    LCHK(upload_cols(P, P.d_Xall, T.data(), m, m, k));
+    const int vm = (method == 2) ? 1 : 0;
+    for (stm_long r = 0; r < k; r++) LCHK(qapply_vector(P, vm, P.d_Xall.p + r * m, P.d_Xall.p + r * m));
+    LCHK(download_cols(P, P.d_Xall, T.data(), m, m, k));
+    for (stm_long r = 0; r < k; r++)
+        for (long i = 0; i < m; i++) X[r + (size_t)i * ldx] = T[(size_t)r * m + i];
     return 0;
 }
 
-// X (n x nrhs, ldx >= n) = E * R^{-1} * (Q' B)(1:n)  for B (m x nrhs, ldb >= m): QR_solve(QR_RETX_EQUALS_B) of the reference
-// (the least-squares solution; the driver's residual check, qrtest.c:11-53); dead columns get x = 0 (basic solution).
+// QR_solve (STMMQR/include/SparseQR.h:411-417, SparseQR.c:2118-2216) on the resident factors:
+//   system 0 QR_RX_EQUALS_B   : X (n x nrhs) = R \ B            B (m x nrhs) in R's row order (what QR_QTX returns)
+//   system 1 QR_RETX_EQUALS_B : X = E (R \ B)
+//   system 2 QR_RTX_EQUALS_B  : X (m x nrhs) = R' \ B           B (n x nrhs), rows of X beyond the rank are zero
+//   system 3 QR_RTX_EQUALS_ETB: X = R' \ (E' B)
+// Dead pivot columns: x = 0 (systems 0, 1: the basic solution of qr_rsolve) / no equation (2, 3: the squeezed R).
+int stmmqr_plan_rsolve(stmmqr_plan *plan, int system, const double *B, stm_long ldb, double *X, stm_long ldx, stm_long nrhs)
+{
+    if (!plan || !plan->factored) return fail(STMMQR_ERR_INVALID, "no factorization held by the plan");
+    if (system < 0 || system > 3 || !B || !X || nrhs < 0) return fail(STMMQR_ERR_INVALID, "bad solve arguments");
+    stmmqr_plan &P = *plan;
+    const long m = P.m, n = P.n;
+    const long brows = (system <= 1) ? m : n, xrows = (system <= 1) ? n : m;
+    if (ldb < brows || ldx < xrows) return fail(STMMQR_ERR_INVALID, "bad leading dimension");
+    HIPCHK(hipSetDevice(P.device));
+    LCHK(ensure_rowmap(P));
+    hipStream_t st = P.stream;
+    if (nrhs == 0) return 0;
+    HIPCHK(hipMemsetAsync(P.d_err.p, 0, sizeof(int), st));
+    LCHK(upload_cols(P, P.d_Xall, B, ldb, brows, nrhs));
+    if ((size_t)(xrows * nrhs) > P.d_Yall.n) LCHK(P.d_Yall.alloc((size_t)std::max(1L, xrows * nrhs)));
+    if (system <= 1) {
+        for (stm_long j = 0; j < nrhs; j++) {
+            LCHK(stm_launch_perm(P.d_Xall.p + j * m, P.d_Wmap.p, P.d_W.p, (int)m, 0, st));          // W[r] = b[Wmap[r]]
+            LCHK(rsolve_vector(P));
+            LCHK(stm_launch_perm(P.d_Xs.p, (system == 1 && P.has_qfill) ? P.d_Qfill.p : nullptr, P.d_Yall.p + j * n, (int)n, 1, st));
+        }
+    } else {
+        DevCtx c = P.ctx();
+        const int *L0 = P.d_lists.p;
+        const auto &LV = P.glevels[0];
+        if (!P.d_U.p) { LCHK(P.d_U.alloc((size_t)std::max(1L, P.rjsize))); LCHK(P.d_Xr.alloc((size_t)std::max(1L, m))); }
+        for (int need : P.level_lds_rt)
+            if (need > 131072) return fail(STMMQR_ERR_TOO_LARGE, "a front is too wide for the one-workgroup R' solve");
+        for (stm_long j = 0; j < nrhs; j++) {
+            // b in R's column order: E'B gathers through Qfill
+            LCHK(stm_launch_perm(P.d_Xall.p + j * n, (system == 3 && P.has_qfill) ? P.d_Qfill.p : nullptr, P.d_Xs.p, (int)n, 0, st));
+            HIPCHK(hipMemsetAsync(P.d_Xr.p, 0, (size_t)std::max(1L, m) * sizeof(double), st));
+            for (size_t l = 0; l < LV.size(); l++)
+                LCHK(stm_launch_rtsolve(c, L0 + LV[l].all_off, LV[l].n_all, P.d_Xs.p, P.d_U.p, P.d_Xr.p, P.d_rowbase.p,
+                                        P.level_lds_rt[l], st));
+            HIPCHK(hipMemcpyAsync(P.d_Yall.p + j * m, P.d_Xr.p, (size_t)m * sizeof(double), hipMemcpyDeviceToDevice, st));
+        }
+    }
+    LCHK(download_cols(P, P.d_Yall, X, ldx, xrows, nrhs));
+    return check_device_err(P, "internal: live pivot count of a front differs from its rank");
+}
+
+// X (n x nrhs, ldx >= n) = E * R^{-1} * (Q' B)(1:n)  for B (m x nrhs, ldb >= m): QR_qmult(QR_QTX) followed by
+// QR_solve(QR_RETX_EQUALS_B), the driver's least-squares solve (qrtest.c:11-53), without the trip to the host in between;
+// dead columns get x = 0 (basic solution).
 int stmmqr_plan_solve(stmmqr_plan *plan, const double *B, stm_long ldb, double *X, stm_long ldx, stm_long nrhs)
 {
     if (!plan || !plan->factored) return fail(STMMQR_ERR_INVALID, "no factorization held by the plan");
@@ -1169,27 +1283,19 @@ int stmmqr_plan_solve(stmmqr_plan *plan, const double *B, stm_long ldb, double *
     HIPCHK(hipSetDevice(P.device));
     LCHK(ensure_rowmap(P));
     hipStream_t st = P.stream;
-    const int m = (int)P.m, n = (int)P.n;
-    DevCtx c = P.ctx();
-    const int *L0 = P.d_lists.p;
-    const auto &LV = P.glevels[0];
+    const long m = P.m, n = P.n;
+    if (nrhs == 0) return 0;
     HIPCHK(hipMemsetAsync(P.d_err.p, 0, sizeof(int), st));
+    LCHK(upload_cols(P, P.d_Xall, B, ldb, m, nrhs));
+    if ((size_t)(n * nrhs) > P.d_Yall.n) LCHK(P.d_Yall.alloc((size_t)std::max(1L, n * nrhs)));
     for (stm_long j = 0; j < nrhs; j++) {
-        HIPCHK(hipMemcpyAsync(P.d_Io.p, B + j * ldb, (size_t)m * sizeof(double), hipMemcpyHostToDevice, st));
-        LCHK(stm_launch_perm(P.d_Io.p, P.d_PLinv.p, P.d_W.p, m, 1, st));
+        LCHK(stm_launch_perm(P.d_Xall.p + j * m, P.d_PLinv.p, P.d_W.p, (int)m, 1, st));
         LCHK(run_qapply(P, 0));
-        for (size_t l = LV.size(); l-- > 0;) {
-            LCHK(stm_launch_rsolve(c, L0 + LV[l].all_off, LV[l].n_all, P.d_Rj.p, P.d_W.p, P.d_Xs.p, P.level_lds_rs[l],
-                                   P.d_err.p, st));
-            const auto &Q = P.level_qbig[l];         // the large fronts of the level: rows split over workgroups
-            LCHK(stm_launch_rsolve_big(c, P.d_qb.p + Q.off, Q.n, Q.max_rsteps, Q.max_nslab, P.d_Rj.p, P.d_W.p, P.d_Xs.p, P.d_Xf.p,
-                                       P.d_Dq.p, P.d_Rm.p + Q.off, P.d_err.p, st));
-        }
-        LCHK(stm_launch_perm(P.d_Xs.p, P.has_qfill ? P.d_Qfill.p : nullptr, P.d_Io.p, n, 1, st));   // X[Qfill[j]] = x[j]
-        HIPCHK(hipMemcpyAsync(X + j * ldx, P.d_Io.p, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, st));
+        LCHK(rsolve_vector(P));
+        LCHK(stm_launch_perm(P.d_Xs.p, P.has_qfill ? P.d_Qfill.p : nullptr, P.d_Yall.p + j * n, (int)n, 1, st));   // X[Qfill[j]] = x[j]
     }
-    LCHK(check_device_err(P, "internal: live pivot count of a front differs from its rank"));
-    return 0;
+    LCHK(download_cols(P, P.d_Yall, X, ldx, n, nrhs));
+    return check_device_err(P, "internal: live pivot count of a front differs from its rank");
 }
 
 int stmmqr_plan_download(stmmqr_plan *plan, double *Stack, stm_long *Rblock_off, char *Rdead, stm_long *HStair,

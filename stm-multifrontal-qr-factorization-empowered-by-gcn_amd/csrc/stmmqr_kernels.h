@@ -71,4 +71,6 @@ int stm_launch_rsolve_big(const DevCtx &c, const QbDesc *qd, int nq, int max_ste
                           double *X, double *Acc, int *Lc, int *Rm, int *err, hipStream_t st);
 int stm_launch_rsolve(const DevCtx &c, const int *flist, int nfr, const int *Rj, const double *W, double *X, int lds_bytes,
                       int *err, hipStream_t st);
+int stm_launch_rtsolve(const DevCtx &c, const int *flist, int nfr, const double *Bp, double *U, double *Xr, const int *rowbase,
+                       int lds_bytes, hipStream_t st);
 int stm_launch_perm(const double *in, const int *perm, double *out, int n, int scatter, hipStream_t st);

@@ -2548,6 +2548,104 @@ __global__ __launch_bounds__(RS_NT) void k_rsolve(DevCtx c, const int *__restric
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// R' x = b (qr_private_rtsolve, reference SparseQR.c:2522-2700), fronts leaves -> root, one workgroup per front.
+// Every front carries a vector u over its fn columns: b minus the contributions of the rows solved so far.  A front
+// starts with u = b on its pivotal columns and 0 elsewhere, ADDS its children's pass vectors (their u on the columns they
+// hand up, mapped through Rjrel -- the assembly's column map, children in order: deterministic, no atomics), solves its
+// triangle R11' x = u(pivots) forwards over the live pivot columns, and passes u(non-pivotal) - R12' x up.
+//   Bp: b in R's column order (length n); U: the pass vectors, slot Rp[f] + k (rjsize); Xr: x in R's global row order
+//   (rowbase[f] = rows of R above front f's).  Dead pivot columns have no equation (the squeezed R of the reference).
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(RS_NT) void k_rtsolve(DevCtx c, const int *__restrict__ flist, const double *__restrict__ Bp,
+                                                   double *U, double *Xr, const int *__restrict__ rowbase)
+{
+    extern __shared__ double dyn_lds[];
+    __shared__ int s_scan[RS_NT / 64];
+    const int f = flist[blockIdx.x];
+    const FrontSym s = c.fs[f];
+    const FrontNum nm = c.fnum[f];
+    const int fp = s.fp, fn = s.fn, fm = nm.fm;
+    const int tid = threadIdx.x;
+    const int *St = c.Stair + s.rp;
+    const double *F = c.Farena + s.foff;
+    const long long ld = s.ld;
+    double *u = dyn_lds;                                // [fn]
+    double *x = u + ((fn + 1) & ~1);                    // [min(fp, fm)] the front's rows of x
+    int *lc = (int *)(x + ((min(fp, max(fm, 1)) + 2) & ~1));   // [fp] live pivot columns, compact
+    int rm;
+    {
+        const int per = (fp + RS_NT - 1) / RS_NT;
+        const int k0 = min(fp, tid * per), k1 = min(fp, k0 + per);
+        int cnt = 0;
+        for (int k = k0; k < k1; k++) cnt += (St[k] != 0);
+        int total;
+        const int incl = qa_incl_scan<RS_NT / 64>(cnt, s_scan, &total);
+        int q = incl - cnt;
+        for (int k = k0; k < k1; k++) {
+            if (St[k] != 0 && q < fm) lc[q] = k;
+            q += (St[k] != 0);
+        }
+        rm = min(total, fm);
+    }
+    for (int k = tid; k < fn; k += RS_NT) u[k] = (k < fp) ? Bp[s.col1 + k] : 0.0;
+    __syncthreads();
+    for (int q = s.child0; q < s.child1; q++) {
+        const int ch = c.Child[q];
+        const FrontSym cs = c.fs[ch];
+        const int pc = cs.rp + cs.fp, cn = cs.fn - cs.fp;
+        for (int cj = tid; cj < cn; cj += RS_NT) u[c.Rjrel[pc + cj]] += U[pc + cj];     // (distinct targets within a child)
+        __syncthreads();
+    }
+    // forward substitution over the live pivot columns in blocks of 32: (a) the block's right-hand sides lose the rows
+    // solved before (32 columns x 32 row lanes per pass), (b) one wave solves the 32 x 32 lower triangle R' in LDS
+    constexpr int QS_NB = 32;
+    __shared__ double s_tri[QS_NB][QS_NB + 1];
+    __shared__ double s_rhs[QS_NB];
+    const int lane32 = tid & 31, grp = tid >> 5;                          // 32 groups of 32 lanes
+    for (int kb = 0; kb < rm; kb += QS_NB) {
+        const int nb = min(QS_NB, rm - kb);
+        {
+            const int j = grp;                                            // column of the block
+            double a = 0;
+            if (j < nb) {
+                const double *col = F + (long long)lc[kb + j] * ld;
+                for (int r = lane32; r < kb; r += 32) a += col[r] * x[r];
+            }
+#pragma unroll
+            for (int o = 16; o > 0; o >>= 1) a += __shfl_xor(a, o, 64);
+            if (lane32 == 0 && j < nb) s_rhs[j] = u[lc[kb + j]] - a;
+        }
+        for (int e = tid; e < QS_NB * QS_NB; e += RS_NT) {
+            const int i = e % QS_NB, j = e / QS_NB;                       // R(kb + i, column j of the block), i <= j
+            s_tri[i][j] = (i < nb && j < nb && i <= j) ? F[(kb + i) + (long long)lc[kb + j] * ld] : 0.0;
+        }
+        __syncthreads();
+        if (tid < 64) {
+            // lane j owns equation j: x_j = (rhs_j - sum_{i<j} R(i,j) x_i) / R(j,j)
+            const int j = tid;
+            double a = (j < nb) ? s_rhs[j] : 0.0;
+            for (int i = 0; i < nb; i++) {
+                const double ai = __shfl(a, i, 64);
+                const double xi = ai / s_tri[i][i];
+                if (j > i && j < nb) a -= s_tri[i][j] * xi;
+                if (j == i) x[kb + i] = xi;
+            }
+        }
+        __syncthreads();
+    }
+    // pass up: u(non-pivotal) -= R12' x ; a thread per column, the front's rows of R streamed
+    for (int k = fp + tid; k < fn; k += RS_NT) {
+        const double *col = F + (long long)k * ld;
+        double a0 = 0, a1 = 0, a2 = 0, a3 = 0;
+        int r = 0;
+        for (; r + 4 <= rm; r += 4) { a0 += col[r] * x[r]; a1 += col[r + 1] * x[r + 1]; a2 += col[r + 2] * x[r + 2]; a3 += col[r + 3] * x[r + 3]; }
+        for (; r < rm; r++) a0 += col[r] * x[r];
+        U[s.rp + k] = u[k] - ((a0 + a1) + (a2 + a3));
+    }
+    for (int r = tid; r < rm; r += RS_NT) Xr[rowbase[f] + r] = x[r];
+}
+
 // scatter: out[perm[i]] = in[i]   gather: out[i] = in[perm[i]]   (perm == nullptr: identity)
 // ------------------------------------------------------------------------------------------------
 // Back substitution for the large fronts (FrontSym::qbig), rows split over workgroups as in k_qbig_*: prep (live pivot
@@ -2810,6 +2908,13 @@ int stm_launch_rsolve_big(const DevCtx &c, const QbDesc *qd, int nq, int max_ste
         hipLaunchKernelGGL(k_rbig_step, dim3(max_nslab, nq), dim3(STM_QB_ROWS), 0, st, c, qd, k, X, Acc, (const int *)Lc, (const int *)Rm);
     return (int)hipGetLastError();
 }
+int stm_launch_rtsolve(const DevCtx &c, const int *flist, int nfr, const double *Bp, double *U, double *Xr, const int *rowbase,
+                       int lds_bytes, hipStream_t st)
+{
+    if (nfr <= 0) return 0;
+    hipLaunchKernelGGL(k_rtsolve, dim3(nfr), dim3(RS_NT), (size_t)lds_bytes, st, c, flist, Bp, U, Xr, rowbase);
+    return (int)hipGetLastError();
+}
 int stm_launch_perm(const double *in, const int *perm, double *out, int n, int scatter, hipStream_t st)
 {
     if (n <= 0) return 0;
@@ -2826,5 +2931,6 @@ int stm_configure_kernels(void)
     CK(hipFuncSetAttribute((const void *)k_qapply, hipFuncAttributeMaxDynamicSharedMemorySize, 131072));
     CK(hipFuncSetAttribute((const void *)k_qapply_t, hipFuncAttributeMaxDynamicSharedMemorySize, 131072));
     CK(hipFuncSetAttribute((const void *)k_rsolve, hipFuncAttributeMaxDynamicSharedMemorySize, 131072));
+    CK(hipFuncSetAttribute((const void *)k_rtsolve, hipFuncAttributeMaxDynamicSharedMemorySize, 131072));
     return 0;
 }

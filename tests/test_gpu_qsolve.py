@@ -175,3 +175,55 @@ def test_split_qapply_on_small_fronts(pkg, oracle, monkeypatch, name):
         assert np.array_equal(xs == 0.0, x1 == 0.0)             # dead columns: exactly zero in both
     finally:
         plan.close(); plan2.close()
+
+
+@pytest.mark.parametrize("name", NAMES)
+def test_all_qmult_methods_and_solve_systems(pkg, oracle, name):
+    """The rest of QR_qmult / QR_solve (SparseQR.c:1591-1700, 2040-2216, 2522): X Q', X Q as the transposes of Q X, Q' X;
+    R X = B and R E' X = B against the oracle's qr_rsolve; R' X = B and R' X = E' B through the adjoint identity
+    x' (R z) = b' z on random z (R has full row rank, so that pins x), rows of X beyond the rank exactly zero."""
+    g = load_golden(name)
+    S, plan = factorized_plan(pkg, g)
+    try:
+        N = numeric_from_gpu(S, plan.download())
+        rng = np.random.default_rng(23)
+        m, n, rank = S.m, S.n, int(N.c.rank)
+        # ---- X Q' and X Q ----
+        X = rng.standard_normal((3, m))
+        XQt = plan.qmult(2, X)
+        XQ = plan.qmult(3, X)
+        for r in range(3):
+            ref = oracle.qmult(1, S, N, X[r])                      # (X Q')(r,:) = (Q X(r,:)')'
+            assert np.linalg.norm(XQt[r] - ref) <= 1e-12 * max(np.linalg.norm(ref), 1e-300)
+            ref = oracle.qmult(0, S, N, X[r])
+            assert np.linalg.norm(XQ[r] - ref) <= 1e-12 * max(np.linalg.norm(ref), 1e-300)
+        # ---- R X = B, R E' X = B ----
+        Y = rng.standard_normal((m, 2))
+        X0 = plan.rsolve(0, Y)
+        X1 = plan.rsolve(1, Y)
+        q = S.Qfill if S.Qfill is not None else np.arange(n)
+        for j in range(2):
+            xo = oracle.rsolve(S, N, Y[:, j])                       # qr_rsolve restated: R \\ y in R's column order, dead columns 0
+            scale = max(np.linalg.norm(xo), 1e-300)
+            tolr = 1e-9 if name not in ILL_CONDITIONED else 1e-5
+            assert np.linalg.norm(X0[:, j] - xo) <= tolr * scale
+            assert np.linalg.norm(X1[q, j] - xo) <= tolr * scale     # with E: X(Qfill(j)) = x(j)
+        # ---- R' X = B, R' X = E' B ----
+        B = rng.standard_normal((n, 2))
+        X2 = plan.rsolve(2, B)
+        X3 = plan.rsolve(3, B)
+        dead = np.asarray(N.Rdead[:n]) != 0
+        for j in range(2):
+            assert not np.any(X2[rank:, j]) and not np.any(X3[rank:, j])
+            for _ in range(4):
+                z = rng.standard_normal(n)
+                z[dead] = 0.0                                       # (a dead column has no equation in the squeezed R)
+                Rz = oracle.rmult(S, N, z)                          # rank rows, then zeros
+                lhs2, lhs3 = float(X2[:rank, j] @ Rz[:rank]), float(X3[:rank, j] @ Rz[:rank])
+                rhs2, rhs3 = float(B[:, j] @ z), float(B[q, j] @ z)
+                sc = np.linalg.norm(B[:, j]) * np.linalg.norm(z) + abs(rhs2)
+                tolt = 1e-9 if name not in ILL_CONDITIONED else 1e-4
+                assert abs(lhs2 - rhs2) <= tolt * max(sc, np.linalg.norm(X2[:, j]) * np.linalg.norm(Rz))
+                assert abs(lhs3 - rhs3) <= tolt * max(sc, np.linalg.norm(X3[:, j]) * np.linalg.norm(Rz))
+    finally:
+        plan.close()
