@@ -64,7 +64,7 @@ __device__ __forceinline__ double rdlane(double v, int src)
 
 // G <- S'S over the nr rows of the slab image (rows >= nr are zero).  Waves 0..3 / 4..7 take the two halves of the rows,
 // one 16 x 16 tile each; the second half lands in cs.M (scratch: M is not live here) and is added.  Ends with a barrier.
-__device__ __forceinline__ void ca_gram(CaShared &cs, const double *S, int nr)
+__device__ __forceinline__ void ca_gram(CaShared &cs, const double *S, int nr, double sg)
 {
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, l15 = lane & 15, l4 = lane >> 4;
     const int ti = (wid >> 1) & 1, tj = wid & 1, h = wid >> 2;
@@ -73,7 +73,7 @@ __device__ __forceinline__ void ca_gram(CaShared &cs, const double *S, int nr)
     d4 acc = {0, 0, 0, 0};
     const double *Sa = S + (16 * ti + l15) * CA_LD + l4, *Sb = S + (16 * tj + l15) * CA_LD + l4;
 #pragma unroll 4
-    for (int kk = ka; kk < kb; kk++) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(Sa[4 * kk], Sb[4 * kk], acc, 0, 0, 0);
+    for (int kk = ka; kk < kb; kk++) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(Sa[4 * kk] * sg, Sb[4 * kk], acc, 0, 0, 0);   // (one operand carries the magnitude guard)
     double (*dst)[STM_NB + 1] = h ? cs.M : cs.G;
 #pragma unroll
     for (int r = 0; r < 4; r++) dst[16 * ti + l4 + 4 * r][16 * tj + l15] = acc[r];
@@ -203,6 +203,7 @@ __global__ __launch_bounds__(CA_NT) void k_panel_ca(DevCtx c, const int *__restr
     const int nwact = max(1, (nB + STM_CA_R - 1) / STM_CA_R);
     const int rbase = g1 + nt + w * STM_CA_R;           // first row of my slab
     const int nr = max(0, min(STM_CA_R, nB - w * STM_CA_R));
+    const double sg = c.sig ? c.sig[0] : 1.0, isg = c.sig ? c.sig[1] : 1.0;     // magnitude guard: G and every dot carry ONE factor sg
     const int slot = c.tslot[f];
     double *Gp = c.Gp + (long long)slot * (c.gp_slabs + 1) * (STM_NB * STM_NB);    // partial Gram matrices, then the M mailbox
 
@@ -227,7 +228,7 @@ __global__ __launch_bounds__(CA_NT) void k_panel_ca(DevCtx c, const int *__restr
     TL(1);
 
     // ---- round 0: Gram matrix; with several slabs: exchange, the last arriver owns the chain ----
-    if (nr > 0) ca_gram(cs, S, nr);
+    if (nr > 0) ca_gram(cs, S, nr, sg);
     TL(2);
     bool owner = true;
     if (nwf > 1) {
@@ -261,7 +262,7 @@ __global__ __launch_bounds__(CA_NT) void k_panel_ca(DevCtx c, const int *__restr
             ca_apply(cs, S, nr);
             TL(5 + 2 * round);
             if (final) break;
-            ca_gram(cs, S, nr);
+            ca_gram(cs, S, nr, sg);
             ca_publish_block(cs.G, Gp + (long long)w * (STM_NB * STM_NB));
             if (tid == 0) __hip_atomic_fetch_add(&num->gcnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             round++;
@@ -286,7 +287,7 @@ __global__ __launch_bounds__(CA_NT) void k_panel_ca(DevCtx c, const int *__restr
     }
     if (tid < STM_NB) {
         double a2 = 0;
-        for (int i = 0; i < nt; i++) a2 += cs.At[i][tid] * cs.At[i][tid];
+        for (int i = 0; i < nt; i++) a2 += (cs.At[i][tid] * sg) * cs.At[i][tid];
         cs.gref[tid] = cs.G[tid][tid] + a2;
         cs.tau[tid] = 0; cs.diag[tid] = STM_BIGROW; cs.st_out[tid] = 0; cs.dead[tid] = 0;
     }
@@ -305,7 +306,7 @@ __global__ __launch_bounds__(CA_NT) void k_panel_ca(DevCtx c, const int *__restr
         if (tx == 1) { cs.colN[0][i0] = at0; cs.colN[0][i1] = at1; }
         if (i0 == 0) { cs.rowA[0][tx] = at0; cs.gj[0][tx] = gq0; }
         const double c0 = cs.At[i0][0], c1 = cs.At[i1][0];
-        cs.part[0][ig][tx] = ((i0 > 0) ? at0 * c0 : 0.0) + at1 * c1;
+        cs.part[0][ig][tx] = ((i0 > 0) ? (at0 * sg) * c0 : 0.0) + (at1 * sg) * c1;
     }
     const int stairx = cs.stair[tx];
     __syncthreads();
@@ -341,7 +342,7 @@ __global__ __launch_bounds__(CA_NT) void k_panel_ca(DevCtx c, const int *__restr
         const double ssr = dj + gjj;
         const bool unresolved = (ssr <= 0.0) && !(dj == 0.0 && gjj == 0.0);
         const double ss = fmax(ssr, 0.0);
-        const double total = alpha * alpha + ss;
+        const double total = alpha * (alpha * sg) + ss;                      // (one factor sg, as ss and gref)
         TC(42);
         if (j != jref && nB > 0 && (unresolved || grefj > CA_K * total)) {
             // ---- REFRESH: G has lost too much of column j: B <- B M, M <- I, G <- B'B from the real rows ----
@@ -355,7 +356,7 @@ __global__ __launch_bounds__(CA_NT) void k_panel_ca(DevCtx c, const int *__restr
                 round++;
                 if (nr > 0) {
                     ca_apply(cs, S, nr);
-                    ca_gram(cs, S, nr);
+                    ca_gram(cs, S, nr, sg);
                     ca_publish_block(cs.G, Gp + (long long)w * (STM_NB * STM_NB));
                 }
                 const int others = nwact - (nr > 0 ? 1 : 0);
@@ -369,7 +370,7 @@ __global__ __launch_bounds__(CA_NT) void k_panel_ca(DevCtx c, const int *__restr
                 __syncthreads();
             } else {
                 ca_apply(cs, S, nr);
-                ca_gram(cs, S, nr);
+                ca_gram(cs, S, nr, sg);
             }
             // back to registers: the fresh G, M = I; republish what the retried step reads (row j of G, column j of M)
             gq0 = cs.G[i0][tx]; gq1 = cs.G[i1][tx];
@@ -379,7 +380,7 @@ __global__ __launch_bounds__(CA_NT) void k_panel_ca(DevCtx c, const int *__restr
             if (tx == j) { cs.mjv[par][i0] = m0; cs.mjv[par][i1] = m1; }
             if (tid < STM_NB) {
                 double a2 = 0;
-                for (int i = gi; i < nt; i++) a2 += cs.At[i][tid] * cs.At[i][tid];
+                for (int i = gi; i < nt; i++) a2 += (cs.At[i][tid] * sg) * cs.At[i][tid];
                 cs.gref[tid] = cs.G[tid][tid] + a2;
             }
             __syncthreads();
@@ -390,24 +391,16 @@ __global__ __launch_bounds__(CA_NT) void k_panel_ca(DevCtx c, const int *__restr
         // ---- dlarfg; ss == 0 (no row below the diagonal, or all of them zero) gives H = I.
         //      sqrt / reciprocals by v_rsq_f64 / v_rcp_f64 + Newton steps (the library forms cost 700 cycles per column)
         const bool ident = (ss == 0.0);
-        double r = __builtin_amdgcn_rsq(total);                              // ~1/sqrt(total)
-        r = r * (1.5 - 0.5 * total * r * r);
-        r = r * (1.5 - 0.5 * total * r * r);
-        double sq = total * r;
-        sq = sq + 0.5 * r * (total - sq * sq);                                // sqrt(total), correctly rounded but for rare ties
-        const double bb = -copysign(sq, alpha);
+        double bb, tau0, scal0, scals0;
+        stm_larfg_guarded(alpha, ss, sg, isg, bb, tau0, scal0, scals0);
         const double beta = ident ? alpha : bb;
         const bool dead = (k < ntol) && (fabs(beta) <= tol);                 // (:1495-1544) column zeroed, g does not advance
         const bool upd = !ident && !dead;
-        const double den = alpha - bb;                                       // = copysign(|alpha| + sq, alpha): no cancellation
-        double ri = __builtin_amdgcn_rcp(den);
-        ri = ri * (2.0 - den * ri);
-        ri = ri * (2.0 - den * ri);
-        const double scal = upd ? ri : 0.0;                                  // 1 / (alpha - beta)
-        const double tau = upd ? (bb - alpha) * (-copysign(r, alpha)) : 0.0; // (beta - alpha) / beta,  1/beta = -sign(alpha) r
+        const double scal = upd ? scal0 : 0.0, scals = upd ? scals0 : 0.0;   // 1 / (alpha - beta), and the same over sg
+        const double tau = upd ? tau0 : 0.0;
         TC(43);
         const bool on = upd && tx > j && tx < nbp;
-        const double cwx = on ? tau * (rowx + scal * (d + gjx)) : 0.0;        // tau v'a_x
+        const double cwx = on ? tau * (rowx + scals * (d + gjx)) : 0.0;       // tau v'a_x
         const double ccx = cwx * scal;
         const double cwn = rdlane(cwx, jn & 31);                             // (lane jn; 0 when jn == nbp: `on` is false there)
         const double ccA = rdlane(ccx, 2 * wid), ccB = rdlane(ccx, 2 * wid + 1);          // cc[i0]: my row group is 2 wid + half
@@ -429,7 +422,7 @@ __global__ __launch_bounds__(CA_NT) void k_panel_ca(DevCtx c, const int *__restr
         m0 = isj ? (upd ? m0 * scal : 0.0) : m0;                              // b_j <- b_j scal; dead / identity: zero column
         m1 = isj ? (upd ? m1 * scal : 0.0) : m1;
         const int gin = dead ? gi : gi + 1;
-        cs.part[np][ig][tx] = ((i0 > gin) ? at0 * bn0 : 0.0) + ((i1 > gin) ? at1 * bn1 : 0.0);
+        cs.part[np][ig][tx] = ((i0 > gin) ? (at0 * sg) * bn0 : 0.0) + ((i1 > gin) ? (at1 * sg) * bn1 : 0.0);
         if (tx == jn) { cs.colA[np][i0] = at0; cs.colA[np][i1] = at1; cs.mjv[np][i0] = m0; cs.mjv[np][i1] = m1; }
         if (tx == jn + 1) { cs.colN[np][i0] = at0; cs.colN[np][i1] = at1; }
         if (i0 == gin) cs.rowA[np][tx] = at0;

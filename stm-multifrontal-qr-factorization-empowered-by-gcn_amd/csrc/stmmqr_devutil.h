@@ -35,3 +35,18 @@ __device__ __forceinline__ void stm_larfg_scalars(double alpha, double ss, doubl
     scal = ri;
     tau = (beta - alpha) * (-copysign(r, alpha));       // 1 / beta = -sign(alpha) r
 }
+
+// The same with the magnitude guard of LAPACK's dlarfg / dnrm2 folded in as ONE power-of-two factor for the whole
+// factorization: sg = 2^-e when the largest |entry| of A is 2^e beyond 2^+-300, else 1 (DevCtx::sig, computed on the device
+// from A's values).  The callers accumulate their sums with ONE operand scaled,  ss1 = sum (sg x) x,  dots1 = sum (sg x) c,
+// which keeps every product representable for entries up to 1e+-160 and beyond (orthogonal transformations keep the entries
+// of a front below sqrt(m) max|A|).  Returned: beta, tau and scal = 1/(alpha - beta) in true units, and scals = scal / sg
+// so that  scal * (sum x c) = scals * dots1.  With sg = 1 every multiplication here is exact: the same bits as the unguarded form.
+__device__ __forceinline__ void stm_larfg_guarded(double alpha, double ss1, double sg, double isg, double &beta, double &tau,
+                                                  double &scal, double &scals)
+{
+    double bs;
+    stm_larfg_scalars(alpha * sg, ss1 * sg, bs, tau, scals);
+    beta = bs * isg;
+    scal = scals * sg;
+}

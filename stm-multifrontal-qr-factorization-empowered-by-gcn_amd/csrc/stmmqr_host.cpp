@@ -144,7 +144,8 @@ struct stmmqr_plan {
     DevBuf<int> d_tslot, d_Sp, d_Sjrel, d_Sj0, d_Sleft, d_Child, d_Rjrel, d_Stair, d_Hii, d_Cmap, d_Cursor,
         d_Rhoff, d_lists, d_smap;
     DevBuf<long long> d_Rboff, d_total;
-    DevBuf<unsigned long long> d_dbg;
+    DevBuf<unsigned long long> d_dbg, d_amax;
+    DevBuf<double> d_sig;                           // {sg, 1/sg}: magnitude guard of the panel kernels
     DevBuf<char> d_Rdead;
 
     // results of the last factorization
@@ -178,7 +179,7 @@ struct stmmqr_plan {
         DevCtx c;
         c.fs = d_fs.p; c.fnum = d_fnum.p; c.Farena = d_F.p; c.Carena = d_C.p; c.Tws = d_T.p; c.tslot = d_tslot.p;
         c.Tall = d_Tall.p;
-        c.Gp = d_Gp.p; c.gp_slabs = gp_slabs; c.panel_algo = serial_panels ? 1 : plan_algo; c.ca_min_rows = ca_min;
+        c.Gp = d_Gp.p; c.gp_slabs = gp_slabs; c.sig = d_sig.p; c.panel_algo = serial_panels ? 1 : plan_algo; c.ca_min_rows = ca_min;
         c.Sx = d_Sx.p; c.Sp = d_Sp.p; c.Sjrel = d_Sjrel.p; c.Sj0 = d_Sj0.p; c.Sleft = d_Sleft.p;
         c.Child = d_Child.p; c.Rjrel = d_Rjrel.p; c.Stair = d_Stair.p; c.Tau = d_Tau.p; c.Hii = d_Hii.p;
         c.Rdead = d_Rdead.p; c.Cmap = d_Cmap.p; c.Cursor = d_Cursor.p; c.Rhoff = d_Rhoff.p; c.Rboff = d_Rboff.p;
@@ -509,6 +510,8 @@ int build_plan(stmmqr_plan &P, const stmmqr_symbolic_view &v)
     LCHK(P.d_Rboff.alloc((size_t)std::max(1L, nf)));
     LCHK(P.d_total.alloc(1));
     LCHK(P.d_dbg.alloc(16));
+    LCHK(P.d_amax.alloc(1));
+    LCHK(P.d_sig.alloc(2));
     HIPCHK(hipMemsetAsync(P.d_dbg.p, 0, 16 * sizeof(unsigned long long), st));
     LCHK(P.d_Rdead.alloc((size_t)std::max(1L, n)));
     LCHK(P.d_lists.upload(P.lists, st));
@@ -572,8 +575,9 @@ int run_schedule(stmmqr_plan &P, bool detail, int grp, bool first)
         HIPCHK(hipMemsetAsync(P.d_F.p, 0, (size_t)P.farena * sizeof(double), st));
         HIPCHK(hipMemsetAsync(P.d_Rdead.p, 0, (size_t)std::max(1L, P.n), st));
         HIPCHK(hipMemsetAsync(P.d_fnum.p, 0, (size_t)std::max(1L, P.nf) * sizeof(FrontNum), st));
+        LCHK(stm_launch_sigma(P.d_Ax.p, (int)P.anz, P.d_amax.p, P.d_sig.p, st));
         LCHK(stm_launch_gather_sx(P.d_Ax.p, P.d_smap.p, P.d_Sx.p, (int)P.anz, st));
-        nlaunch += 4;
+        nlaunch += 6;
     }
     if (grp < 0 || grp >= (int)P.glevels.size()) return fail(STMMQR_ERR_INVALID, "no such front group");
     for (const Level &L : P.glevels[grp]) {

@@ -14,6 +14,7 @@ struct DevCtx {
     double *Tall;              // [sum of npanels][NB*NB] T of EVERY panel, kept for the Q-apply (nullptr: not kept)
     double *Gp;                // Gram-based panel: per T slot, gp_slabs partial Gram matrices + the M mailbox, NB*NB each
     int gp_slabs;              // max slab workgroups of a front (stm_ca_slabs) over the plan
+    const double *sig;         // {sg, 1/sg}: the power-of-two magnitude guard of the panel kernels (stm_larfg_guarded)
     int panel_algo;            // stmmqr_options::panel_algo (stm_use_ca)
     int ca_min_rows;           // ... panels with more estimated rows take the Gram-based kernel (panel_algo 0)
     const double *Sx;          // [anz] values of S = A(P,Q), row form
@@ -46,6 +47,7 @@ struct DevCtx {
 
 int stm_configure_kernels(void);
 int stm_update_lds_bytes(void);
+int stm_launch_sigma(const double *Ax, int anz, unsigned long long *amaxbits, double *sig, hipStream_t st);
 int stm_launch_gather_sx(const double *Ax, const int *smap, double *Sx, int anz, hipStream_t st);
 int stm_launch_setup(const DevCtx &c, const int *flist, int nfr, hipStream_t st);
 int stm_launch_assemble(const DevCtx &c, const int *flist, const int *nparts, int nfr, int maxparts, hipStream_t st);

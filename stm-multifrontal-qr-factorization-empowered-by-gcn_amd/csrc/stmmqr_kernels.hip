@@ -94,6 +94,32 @@ __device__ __forceinline__ int block_incl_scan(int v, int *s_scan, int *total)
 }
 
 // ------------------------------------------------------------------------------------------------
+// magnitude guard: sig = {sg, 1/sg}, sg = 2^-e when max|A| = 2^e lies beyond 2^+-300 (so that the sums of squares of the
+// panel kernels stay representable: stm_larfg_guarded), else 1.  No host involvement: the values may be device resident.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_amax(const double *__restrict__ Ax, int anz, unsigned long long *amaxbits)
+{
+    double mx = 0;
+    for (int s = blockIdx.x * 256 + threadIdx.x; s < anz; s += gridDim.x * 256) {
+        const double a = fabs(Ax[s]);
+        if (a > mx && a <= 1.7976931348623157e308) mx = a;                  // (infinities / NaNs are not a scale)
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mx = fmax(mx, __shfl_xor(mx, o, 64));
+    if ((threadIdx.x & 63) == 0 && mx > 0) atomicMax(amaxbits, (unsigned long long)__double_as_longlong(mx));   // (order of positive doubles = order of their bits)
+}
+__global__ void k_sigma(const unsigned long long *amaxbits, double *sig)
+{
+    const double amax = __longlong_as_double((long long)*amaxbits);
+    double sg = 1.0;
+    if (amax > 0) {
+        const int e = ilogb(amax);
+        if (e > 300 || e < -300) sg = ldexp(1.0, -e);
+    }
+    sig[0] = sg; sig[1] = 1.0 / sg;
+}
+
+// ------------------------------------------------------------------------------------------------
 // qr_stranspose2: Sx[s] = Ax[smap[s]]   (smap is symbolic: planner, from Ap/Ai/Qfill/PLinv/Sp)
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_gather_sx(const double *__restrict__ Ax, const int *__restrict__ smap,
@@ -644,7 +670,7 @@ template <int NTH, int RPT, int SWT>
 __device__ __forceinline__ void dev_subpanel_reg(PanelShared &ps, double *F, long long ld, int *St, double *Tau, char *Rdead,
                                                  int k1, int j0, int sw, int nbp, int gs, int tmax, int m, int n, int npiv,
                                                  int ntol, double tol, int &g, int &rank, double &flops, double &lensum, int &nlive,
-                                                 int &tlast, int &done, int &ncols_done, double *lds, long long pst)
+                                                 int &tlast, int &done, int &ncols_done, double *lds, long long pst, double sg, double isg)
 {
     constexpr int NWV = NTH / 64;
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
@@ -682,7 +708,7 @@ __device__ __forceinline__ void dev_subpanel_reg(PanelShared &ps, double *F, lon
 #pragma unroll
             for (int r = 0; r < RPT; r++) {
                 const int i = gs + tid + NTH * r;
-                const double xv = (i > g && i < t) ? a[r][0] : 0.0;
+                const double xv = (i > g && i < t) ? a[r][0] * sg : 0.0;    // (one operand carries the magnitude guard)
 #pragma unroll
                 for (int x = 0; x < SWT; x++) part[x] += xv * a[r][x];      // (part[SWT..7] stay zero)
             }
@@ -702,8 +728,8 @@ __device__ __forceinline__ void dev_subpanel_reg(PanelShared &ps, double *F, lon
             sum[6] = lane_bcast<red8_lane(6)>(rb); sum[7] = lane_bcast<red8_lane(7)>(rb);
             const double alpha = ps.top[par][0];
             const double ss = sum[0];
-            double tau = 0, beta = alpha, scal = 0;
-            if (ss != 0.0) stm_larfg_scalars(alpha, ss, beta, tau, scal);   // (no active row below the diagonal: ss == 0 exactly)
+            double tau = 0, beta = alpha, scal = 0, scals = 0;
+            if (ss != 0.0) stm_larfg_guarded(alpha, ss, sg, isg, beta, tau, scal, scals);   // (no active row below the diagonal: ss == 0 exactly)
             const bool dead = (k < ntol) && (fabs(beta) <= tol);
             if (dead) {
                 // zero the column from the diagonal down, no reflector, g does not advance (:1495-1544)
@@ -720,7 +746,7 @@ __device__ __forceinline__ void dev_subpanel_reg(PanelShared &ps, double *F, lon
                     nlive++;
                     double w[8];
 #pragma unroll
-                    for (int x = 1; x < SWT; x++) w[x] = tau * (ps.top[par][x] + scal * sum[x]);
+                    for (int x = 1; x < SWT; x++) w[x] = tau * (ps.top[par][x] + scals * sum[x]);
 #pragma unroll
                     for (int r = 0; r < RPT; r++) {
                         const int i = gs + tid + NTH * r;
@@ -770,7 +796,7 @@ __device__ __forceinline__ void dev_subpanel_reg(PanelShared &ps, double *F, lon
 template <int NTH, bool INPLACE>
 __device__ __forceinline__ void dev_panel(PanelShared &ps, const FrontSym &s, FrontNum *num, double *F, int *St, double *Tau, char *Rdead,
                           int p, double tol, int ntol_global, double *Tout, double *lds, int lds_doubles, int dbg = 0,
-                          unsigned long long *dbgbuf = nullptr, double *Tkeep = nullptr)
+                          unsigned long long *dbgbuf = nullptr, double *Tkeep = nullptr, const double *sigp = nullptr)
 {
     constexpr int NWV = NTH / 64;
     double *s_red = ps.red;
@@ -794,6 +820,7 @@ __device__ __forceinline__ void dev_panel(PanelShared &ps, const FrontSym &s, Fr
     }
     const int ntol = min(ntol_global - s.col1, npiv);
     const int g1 = g;
+    const double sg = sigp ? sigp[0] : 1.0, isg = sigp ? sigp[1] : 1.0;      // magnitude guard (stm_larfg_guarded)
     if (tid == 0) ps.nextss_col = -1;
     if (tid < nbp) ps.stair[tid] = St[k1 + tid];       // the panel's staircase, once (a global load per column
     __syncthreads();                                   //  step would sit on the critical path)
@@ -857,16 +884,16 @@ __device__ __forceinline__ void dev_panel(PanelShared &ps, const FrontSym &s, Fr
             // ---- register-resident column loop; leaves the finished sub-panel in the LDS image ----
             if (ms <= NTH)
                 dev_subpanel_reg<NTH, 1, 8>(ps, F, ld, St, Tau, Rdead, k1, j0, sw, nbp, gs, tmax, m, n, npiv, ntol, tol, g, rank,
-                                         flops, lensum, nlive, tlast, done, ncols_done, lds, pst);
+                                         flops, lensum, nlive, tlast, done, ncols_done, lds, pst, sg, isg);
             else if (ms <= 2 * NTH)
                 dev_subpanel_reg<NTH, 2, 8>(ps, F, ld, St, Tau, Rdead, k1, j0, sw, nbp, gs, tmax, m, n, npiv, ntol, tol, g, rank,
-                                         flops, lensum, nlive, tlast, done, ncols_done, lds, pst);
+                                         flops, lensum, nlive, tlast, done, ncols_done, lds, pst, sg, isg);
             else if (ms <= 4 * NTH)
                 dev_subpanel_reg<NTH, 4, 8>(ps, F, ld, St, Tau, Rdead, k1, j0, sw, nbp, gs, tmax, m, n, npiv, ntol, tol, g, rank,
-                                         flops, lensum, nlive, tlast, done, ncols_done, lds, pst);
+                                         flops, lensum, nlive, tlast, done, ncols_done, lds, pst, sg, isg);
             else
                 dev_subpanel_reg<NTH, 8, 4>(ps, F, ld, St, Tau, Rdead, k1, j0, sw, nbp, gs, tmax, m, n, npiv, ntol, tol, g, rank,
-                                         flops, lensum, nlive, tlast, done, ncols_done, lds, pst);
+                                         flops, lensum, nlive, tlast, done, ncols_done, lds, pst, sg, isg);
         } else {
         __syncthreads();
         STAMP(0);
@@ -902,8 +929,8 @@ __device__ __forceinline__ void dev_panel(PanelShared &ps, const FrontSym &s, Fr
                 for (int x = 1; x < 8; x++)
                     if (x <= nrest) top[x] = col[x * pst];      // F(g, k+x)
                 for (int i = 1 + tid; i < len; i += NTH) {
-                    const double xv = col[i];
-                    part[0] += xv * xv;
+                    const double x0 = col[i], xv = x0 * sg;         // (one operand carries the magnitude guard)
+                    part[0] += xv * x0;
 #pragma unroll
                     for (int x = 1; x < 8; x++)
                         if (x <= nrest) part[x] += xv * col[i + x * pst];
@@ -916,12 +943,12 @@ __device__ __forceinline__ void dev_panel(PanelShared &ps, const FrontSym &s, Fr
                 __syncthreads();                        // every wave has read alpha / nextss before anyone writes
             } else {
                 double ss0 = 0;
-                for (int i = 1 + tid; i < len; i += NTH) { const double xv = col[i]; ss0 += xv * xv; }
+                for (int i = 1 + tid; i < len; i += NTH) { const double xv = col[i]; ss0 += (xv * sg) * xv; }
                 part[0] = block_sum<NTH>(ss0, s_red);
             }
             const double ss = part[0];
-            double tau = 0, beta = alpha, scal = 0;
-            if (len > 1 && ss != 0.0) stm_larfg_scalars(alpha, ss, beta, tau, scal);   // (|x|^2 is unscaled anyway: no hypot)
+            double tau = 0, beta = alpha, scal = 0, scals = 0;
+            if (len > 1 && ss != 0.0) stm_larfg_guarded(alpha, ss, sg, isg, beta, tau, scal, scals);
             const bool dead = (k < ntol) && (fabs(beta) <= tol);
             if (dead) {
                 // zero the column from the diagonal down, no reflector, g does not advance (:1495-1544)
@@ -942,7 +969,7 @@ __device__ __forceinline__ void dev_panel(PanelShared &ps, const FrontSym &s, Fr
                     nlive++;
                     double w[8];
 #pragma unroll
-                    for (int x = 1; x < 8; x++) w[x] = tau * (top[x] + scal * part[x]);
+                    for (int x = 1; x < 8; x++) w[x] = tau * (top[x] + scals * part[x]);
                     for (int i = 1 + tid; i < len; i += NTH) {
                         const double v = col[i] * scal;
                         col[i] = v;
@@ -991,7 +1018,7 @@ __device__ __forceinline__ void dev_panel(PanelShared &ps, const FrontSym &s, Fr
                             for (int i = 1 + lane; i < max(len, lenn); i += 64) {
                                 double cv = cc[i];
                                 if (i < len) { cv -= w * col[i]; cc[i] = cv; }
-                                if (i >= 2 && i < lenn) sq += cv * cv;
+                                if (i >= 2 && i < lenn) sq += (cv * sg) * cv;
                             }
                             sq = wave_sum(sq);
                             if (lane == 0) { ps.nextss = sq; ps.nextss_col = jj; }
@@ -1147,7 +1174,8 @@ template <int NTH, int RPT, int SWT>
 __device__ __forceinline__ void dev_tall_group(PanelShared &ps, const FrontSym &s, FrontNum *num, PanelDesc *pd, double *F,
                                                int *St, double *Tau, char *Rdead, int p, int b, int g1, int tmax,
                                                double tol, int ntol_global, double *Tout, double *lds, int dbg = 0,
-                                               unsigned long long *dbgbuf = nullptr, double *Tkeep = nullptr, int defer_ok = 0)
+                                               unsigned long long *dbgbuf = nullptr, double *Tkeep = nullptr, int defer_ok = 0,
+                                               const double *sigp = nullptr)
 {
     const int tid = threadIdx.x;
     const int m = num->fm, n = s.fn, npiv = s.fp;              // (fm is fixed before the panel kernels run)
@@ -1369,6 +1397,7 @@ __device__ __forceinline__ void dev_tall_group(PanelShared &ps, const FrontSym &
     long long iflops = 0, ilen = 0;                            // the reference's flop count: integers, exact in fp64
     const int gs = g;
     const int ntol = min(ntol_global - s.col1, npiv);
+    const double sg = sigp ? sigp[0] : 1.0, isg = sigp ? sigp[1] : 1.0;      // magnitude guard (stm_larfg_guarded)
     // HStair / HTau / pdiag / Rdead of my columns [j0, j1): from LDS to global memory, write-through, before a publish
     auto flush_cols = [&](int j0, int j1) {
         lds_barrier();
@@ -1408,7 +1437,7 @@ __device__ __forceinline__ void dev_tall_group(PanelShared &ps, const FrontSym &
 #pragma unroll
             for (int r = 0; r < RPT; r++) {
                 const int i = rb + tid + NTH * r;
-                const double xv = (i > g && i < t) ? a[r][0] : 0.0;
+                const double xv = (i > g && i < t) ? a[r][0] * sg : 0.0;   // (one operand carries the magnitude guard)
 #pragma unroll
                 for (int x = 0; x < SWT; x++) part[x] += xv * a[r][x];
             }
@@ -1424,18 +1453,18 @@ __device__ __forceinline__ void dev_tall_group(PanelShared &ps, const FrontSym &
             const double alpha = ps.top[tpar][0];
             const double ss = sum[0];
             // dlarfg; ss == 0 (no active row below the diagonal, or all of them zero) gives H = I
-            double bb, tau0, scal0;
-            stm_larfg_scalars(alpha, ss, bb, tau0, scal0);
+            double bb, tau0, scal0, scals0;
+            stm_larfg_guarded(alpha, ss, sg, isg, bb, tau0, scal0, scals0);
             const bool ident = (ss == 0.0);
             const double beta = ident ? alpha : bb;
             const bool dead = (k < ntol) && (fabs(beta) <= tol);    // (:1495-1544) column zeroed, g does not advance
             const bool upd = !ident && !dead;
             const double tau = upd ? tau0 : 0.0;
-            const double scal = upd ? scal0 : 0.0;
+            const double scal = upd ? scal0 : 0.0, scals = upd ? scals0 : 0.0;
             TCY(3);
             double w[8];
 #pragma unroll
-            for (int x = 1; x < SWT; x++) w[x] = tau * (ps.top[tpar][x] + scal * sum[x]);     // 0 unless upd
+            for (int x = 1; x < SWT; x++) w[x] = tau * (ps.top[tpar][x] + scals * sum[x]);    // 0 unless upd
 #pragma unroll
             for (int r = 0; r < RPT; r++) {
                 const int i = rb + tid + NTH * r;
@@ -1592,10 +1621,10 @@ __global__ __launch_bounds__(NT) void k_front_wg(DevCtx c, const int *__restrict
     for (int p = 0; p < s.npanels; p++) {
         if ((c.dbg & 64) || panel_rows(s, num, c.Stair + s.rp, p) > lds_doubles - 65)
             dev_panel<NT, true>(ps, s, num, F, c.Stair + s.rp, c.Tau + s.rp, c.Rdead + s.col1, p, c.tol, c.ntol, s_Tw,
-                                dyn_lds, lds_doubles, c.dbg, nullptr, Tkeep(p));
+                                dyn_lds, lds_doubles, c.dbg, nullptr, Tkeep(p), c.sig);
         else
             dev_panel<NT, false>(ps, s, num, F, c.Stair + s.rp, c.Tau + s.rp, c.Rdead + s.col1, p, c.tol, c.ntol, s_Tw,
-                                 dyn_lds, lds_doubles, c.dbg, nullptr, Tkeep(p));
+                                 dyn_lds, lds_doubles, c.dbg, nullptr, Tkeep(p), c.sig);
         const int k2 = min(s.fn, (p + 1) * STM_NB);
         const int ncb = (s.fn - k2 + BN - 1) / BN;
         const PanelDesc *pd = &num->pd[p & 1];
@@ -1661,7 +1690,7 @@ __global__ __launch_bounds__(NTP) void k_panel(DevCtx c, const int *__restrict__
         }
         if (mode == 1) {
             const int rows = tmax - g1;
-#define TALL_ARGS ps, s, num, pd, F, St, c.Tau + s.rp, c.Rdead + s.col1, p, b, g1, tmax, c.tol, c.ntol, T, dyn_lds, c.dbg, c.dbgbuf, Tkeep, defer_ok
+#define TALL_ARGS ps, s, num, pd, F, St, c.Tau + s.rp, c.Rdead + s.col1, p, b, g1, tmax, c.tol, c.ntol, T, dyn_lds, c.dbg, c.dbgbuf, Tkeep, defer_ok, c.sig
             if (w == 2) dev_tall_group<NTP, 16, 2>(TALL_ARGS);
             else if (w == 4) dev_tall_group<NTP, 8, 4>(TALL_ARGS);
             else if (rows <= NTP) dev_tall_group<NTP, 1, 8>(TALL_ARGS);
@@ -1673,10 +1702,10 @@ __global__ __launch_bounds__(NTP) void k_panel(DevCtx c, const int *__restrict__
     }
     if ((c.dbg & 64) || panel_rows(s, num, St, p) > lds_doubles - 65)
         dev_panel<NTP, true>(ps, s, num, F, St, c.Tau + s.rp, c.Rdead + s.col1, p, c.tol, c.ntol, T, dyn_lds,
-                             lds_doubles, c.dbg, c.dbgbuf, Tkeep);
+                             lds_doubles, c.dbg, c.dbgbuf, Tkeep, c.sig);
     else
         dev_panel<NTP, false>(ps, s, num, F, St, c.Tau + s.rp, c.Rdead + s.col1, p, c.tol, c.ntol, T, dyn_lds,
-                              lds_doubles, c.dbg, c.dbgbuf, Tkeep);
+                              lds_doubles, c.dbg, c.dbgbuf, Tkeep, c.sig);
     if (threadIdx.x == 0) { pd->mode = 0; pd->t_deferred = 0; }
 }
 
@@ -2771,6 +2800,17 @@ __global__ __launch_bounds__(256) void k_perm(const double *__restrict__ in, con
 // ------------------------------------------------------------------------------------------------
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) return (int)e_; } while (0)
 
+int stm_launch_sigma(const double *Ax, int anz, unsigned long long *amaxbits, double *sig, hipStream_t st)
+{
+    CK(hipMemsetAsync(amaxbits, 0, sizeof(unsigned long long), st));
+    if (anz > 0) {
+        int grid = (anz + 255) / 256;
+        if (grid > 1024) grid = 1024;
+        hipLaunchKernelGGL(k_amax, dim3(grid), dim3(256), 0, st, Ax, anz, amaxbits);
+    }
+    hipLaunchKernelGGL(k_sigma, dim3(1), dim3(1), 0, st, (const unsigned long long *)amaxbits, sig);
+    return (int)hipGetLastError();
+}
 int stm_launch_gather_sx(const double *Ax, const int *smap, double *Sx, int anz, hipStream_t st)
 {
     if (anz <= 0) return 0;

@@ -8,6 +8,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <cmath>
 #include <cstdlib>
 #include <cstring>
 #include <string>
@@ -48,7 +49,7 @@ struct OneFront {
     FrontNum nm{};
     Buf<FrontSym> d_fs;
     Buf<FrontNum> d_nm;
-    Buf<double> d_F, d_C, d_T, d_Gp, d_Tau, d_RH;
+    Buf<double> d_F, d_C, d_T, d_Gp, d_Tau, d_RH, d_sig;
     Buf<int> d_St, d_tslot, d_flist, d_Rhoff, d_parts;
     Buf<long long> d_Rboff;
     Buf<unsigned long long> d_dbg;
@@ -84,6 +85,16 @@ struct OneFront {
         memset(&c, 0, sizeof c);
         c.fs = d_fs.p; c.fnum = d_nm.p; c.Farena = d_F.p; c.Carena = d_C.p; c.Tws = d_T.p; c.tslot = d_tslot.p;
         c.Gp = d_Gp.p; c.gp_slabs = stm_ca_slabs(s);
+        {
+            // magnitude guard of the panel kernels from the front's own entries (the full path takes it from A's values)
+            double amax = 0;
+            for (double v : Fd) { const double a = std::fabs(v); if (a > amax && std::isfinite(a)) amax = a; }
+            double sg = 1.0;
+            if (amax > 0) { const int e = std::ilogb(amax); if (e > 300 || e < -300) sg = std::ldexp(1.0, -e); }
+            std::vector<double> sv = {sg, 1.0 / sg};
+            if (!d_sig.up(sv)) return false;
+            c.sig = d_sig.p;
+        }
         c.Stair = d_St.p; c.Tau = d_Tau.p; c.Rdead = d_Rdead.p; c.Rhoff = d_Rhoff.p; c.Rboff = d_Rboff.p;
         c.dbg = getenv("STMMQR_DBG") ? atoi(getenv("STMMQR_DBG")) : 0;
         { stmmqr_options o; stmmqr_get_options(&o); c.tall_min = o.tall_min_rows; c.panel_algo = o.panel_algo; c.ca_min_rows = STM_CA_MIN_ROWS; }

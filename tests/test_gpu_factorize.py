@@ -294,3 +294,31 @@ def test_full_size_standin(pkg, oracle, name):
     x = np.random.default_rng(3).standard_normal(S.m)
     y = oracle.qmult(1, S, N, oracle.qmult(0, S, N, x))          # Q Q' x = x
     assert np.linalg.norm(y - x) <= 1e-12 * np.linalg.norm(x)
+
+
+@pytest.mark.parametrize("name", ["syn_grid3d", "epb1", "syn_rankdef_grid"])
+@pytest.mark.parametrize("scale", [2.0 ** 520, 2.0 ** -530])
+def test_badly_scaled_matrix(pkg, oracle, name, scale):
+    """The whole path on A * 2^+-5xx (entries around 1e+-157): the magnitude guard of the panel kernels is one power of two
+    taken from max|A| on the device; integer outputs, Tau and the scaled factors must match the oracle (which restates
+    LAPACK's scaled dlarfg / dnrm2).  A power-of-two scale leaves every rounding unchanged: R comes out exactly scaled."""
+    g = load_golden(name)
+    S = Symbolic(g)
+    Ax = g["in_Ax"] * scale
+    tol = scalar(g, "in_tol") * scale if scalar(g, "in_tol") > 0 else scalar(g, "in_tol")
+    ntol = int(scalar(g, "in_ntol"))
+    G = pkg.qr_factorize(sym_dict(S), g["in_Ap"], g["in_Ai"], Ax, tol, ntol)
+    G1 = pkg.qr_factorize(sym_dict(S), g["in_Ap"], g["in_Ai"], g["in_Ax"], scalar(g, "in_tol"), ntol)
+    assert np.all(np.isfinite(G.Stack[:G.rh_total])) and np.all(np.isfinite(G.HTau))
+    assert (G.rank, G.rh_total) == (G1.rank, G1.rh_total)
+    np.testing.assert_array_equal(G.HStair, G1.HStair)
+    np.testing.assert_array_equal(G.Rdead, G1.Rdead)
+    np.testing.assert_array_equal(G.HTau, G1.HTau)                       # bit for bit: the scale is a power of two
+    # every entry of the packed R+H is either a Householder entry (scale free: identical) or an R entry (exactly scaled)
+    a, b = G.Stack[:G.rh_total], G1.Stack[:G1.rh_total]
+    assert np.all((a == b) | (a == b * scale))
+    assert np.any(a == b * scale) and (name == "syn_rankdef_grid" or np.any((a == b) & (b != 0)))
+    # integers against the oracle on the scaled input (its dlarfg / dnrm2 restate LAPACK's scaled forms)
+    from parity import numeric_as_ref
+    No = oracle.factorize(S, g["in_Ap"], g["in_Ai"], Ax, tol, ntol)
+    compare_integers(S, numeric_from_gpu(S, G), numeric_as_ref(S, No))

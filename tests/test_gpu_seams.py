@@ -310,3 +310,30 @@ def test_front_seams_on_real_fronts(pkg, oracle, name):
     for f in range(S.nf):
         a = int(S.Hip[f])
         np.testing.assert_array_equal(Hii_g[a:a + No.Hm[f]], No.Hii[a:a + No.Hm[f]])
+
+
+@pytest.mark.parametrize("scale", [1e160, 1e-160, 3e-200])
+@pytest.mark.parametrize("m,n,npiv,bigcols,algo", [(40, 30, 12, 128, 0), (380, 380, 380, 128, 0), (700, 64, 64, 8, 1),
+                                                  (1500, 96, 64, 8, 1), (1500, 96, 64, 8, 2), (900, 200, 40, 8, 2)])
+def test_qr_front_extreme_magnitudes(pkg, oracle, m, n, npiv, bigcols, algo, scale):
+    """Entries around 1e+-160: the sums of squares of an unguarded dlarfg overflow / underflow there (LAPACK's dlarfg
+    rescales, the oracle restates that: orc_larfg, SparseQR_factorize.c:1309-1326).  The panel kernels carry ONE power-of-two
+    factor for the whole factorization in their sums (stm_larfg_guarded): V and Tau must match the oracle as at scale 1,
+    R up to the scale.  All panel paths: one-workgroup LDS panel, column pipeline, Gram-based."""
+    F0, St0 = make_front(m, n, 991 + m + n, "steps")
+    F0 *= scale
+    Fg, Sg = F0.copy(order="F"), St0.copy()
+    Fo, So = F0.copy(order="F"), St0.copy()
+    pkg.set_options(big_front_cols=bigcols, panel_algo=algo)
+    try:
+        rg, Tg, Dg, flg = pkg.qr_front(m, n, npiv, -1.0, n, Fg, Sg)
+    finally:
+        pkg.set_options(big_front_cols=64, panel_algo=0)
+    ro, To, Do, flo = oracle.front(Fo, So, npiv, -1.0, n)
+    assert rg == ro and flg == flo
+    np.testing.assert_array_equal(Sg, So)
+    assert np.all(np.isfinite(Fg)) and np.all(np.isfinite(Tg))
+    assert np.linalg.norm(Tg - To) <= 1e-11 * max(np.linalg.norm(To), 1)
+    # V is scale free, R carries the scale: compare entry by entry relative to the column's largest entry
+    colmax = np.maximum(np.abs(Fo).max(axis=0), np.finfo(float).tiny)
+    assert np.max(np.abs(Fg / colmax - Fo / colmax)) <= 1e-10
