@@ -270,6 +270,8 @@ def main():
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--big-front-cols", type=int, default=None)
     ap.add_argument("--panel-algo", type=int, default=None)
+    ap.add_argument("--lookahead", type=int, default=None)
+    ap.add_argument("--tall-min", type=int, default=None)
     ap.add_argument("--mode", choices=["replicas", "sharded"], default=None,
                     help="N>1: sharded (default) = ONE matrix, subtrees on the ranks, contribution blocks up a tree of joins "
                          "over RCCL point-to-point (strong scaling); replicas = every rank factorizes its own matrix (weak)")
@@ -298,6 +300,10 @@ def main():
         pkg.set_options(big_front_cols=args.big_front_cols)
     if args.panel_algo is not None:
         pkg.set_options(panel_algo=args.panel_algo)
+    if args.lookahead is not None:
+        pkg.set_options(lookahead=args.lookahead)
+    if args.tall_min is not None:
+        pkg.set_options(tall_min_rows=args.tall_min)
     name = args.workload
     if name == "micro":
         return run_micro(pkg, args)
@@ -395,12 +401,12 @@ def main():
         npl, nul = max(det["npanel_launch"], 1), max(det["nupdate_launch"], 1)
         panel_obj = {"bound": "mfma", "kernel": "k_panel / k_panel_ca (+ k_front_wg): Householder panels; fp64 vector = matrix peak on gfx950",
                      "achieved": panel_tf, "peak": PEAK_FP64_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": panel_tf / PEAK_FP64_MFMA_TFLOPS,
-                     "ms": ms_panel, "launch_groups": det["npanel_launch"], "avg_us_per_level_step": ms_panel / npl * 1e3,
+                     "ms": ms_panel, "launch_groups": det["npanel_launch"], "avg_us_per_step": ms_panel / npl * 1e3,
                      "traffic": pmc_traffic(["k_panel", "k_panel_ca"]),
                      "note": "latency-bound: a serial chain of Householder columns (DESIGN.md 4-5)"}
         upd_obj = {"bound": "hbm", "kernel": "k_upd_w + k_upd_c / k_update (dlarfb on v_mfma_f64_16x16x4_f64)", "achieved": upd_gbs,
                    "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": upd_gbs / PEAK_HBM_GBS, "ms": ms_upd,
-                   "launch_groups": det["nupdate_launch"], "avg_us_per_level_step": ms_upd / nul * 1e3,
+                   "launch_groups": det["nupdate_launch"], "avg_us_per_step": ms_upd / nul * 1e3,
                    "mfma_tflops": upd_tf, "mfma_frac": upd_tf / PEAK_FP64_MFMA_TFLOPS,
                    "traffic": pmc_traffic(["k_upd_w", "k_upd_c", "k_update"])}
         roof = dict(panel_obj if ms_panel >= ms_upd else upd_obj)
@@ -430,7 +436,7 @@ def main():
                        "parallelism": (f"subtree-sharded x{world}: tree of joins, contribution blocks device-to-device over RCCL "
                                        f"point-to-point" if sharded else f"replica x{world}"),
                        "device_ms_per_step": dev_ms / args.steps, "launches_per_step": st["nlaunch"],
-                       "levels": st["nlevels"]},
+                       "levels": st["nlevels"], "timeline_steps": st["nsteps"]},
             "roofline": roof,
         }
         if crit is not None:

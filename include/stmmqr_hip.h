@@ -151,7 +151,8 @@ typedef struct stmmqr_stats {
        the plan's stream without any synchronisation (the schedule runs as in an untimed call)                       */
     double ms_panel;           /* panel kernels of the large fronts (k_panel / k_panel_ca)                          */
     double ms_small;           /* k_front_wg: whole small fronts                                                    */
-    stm_long npanel_launch, nupdate_launch;   /* event pairs behind ms_panel / ms_update (one per level step)       */
+    stm_long npanel_launch, nupdate_launch;   /* event pairs behind ms_panel / ms_update (one per timeline step)    */
+    stm_long nsteps;           /* steps of the factorization timeline (a big front advances one panel per step)     */
 } stmmqr_stats;
 
 typedef struct stmmqr_plan stmmqr_plan;     /* device-resident symbolic plan + arenas; reusable across calls */
@@ -238,11 +239,11 @@ double stmmqr_last_seam_ms(void);
 /* ================================================================================================
  * 3. Configuration / introspection
  * ================================================================================================ */
-/* Defaults: {32, 64, 0, 0, 0, 1, 0}.  Read when a plan is created (or a seam is called); the numerical results do not
+/* Defaults: {32, 64, 0, 0, 0, 1, 0, 1}.  Read when a plan is created (or a seam is called); the numerical results do not
  * depend on them beyond rounding.
  * Environment (diagnosis and tests only): STMMQR_DBG (bit mask, csrc/stmmqr_kernels.h), STMMQR_QBIG_MIN (entries of a
  * front from which Q-apply / back substitution split its rows over workgroups; default 2097152, read at plan time),
- * STMMQR_CHUNK (fronts per panel launch with STMMQR_DBG bit 9), STMMQR_DUMPLV (print the level lists). */
+ * STMMQR_CHUNK (fronts per panel launch with STMMQR_DBG bit 9). */
 typedef struct stmmqr_options {
     int panel_width;        /* Householder panel width on device (<= 32); reference FCHUNK = 32                    */
     int big_front_cols;     /* fronts with fn >= this use the multi-workgroup panel/update path                     */
@@ -253,6 +254,9 @@ typedef struct stmmqr_options {
                                height: Gram-based above 2048 rows, where the pipeline's register groups narrow      */
     int split_update;       /* row-parallel (2-launch) trailing update for fronts of >= 3 row slabs (1)             */
     int tall_min_rows;      /* panels with more rows than this run as a pipeline of column groups (plan time; 0)    */
+    int lookahead;          /* 1 (default): the trailing update beyond the next panel's columns, the packing of finished
+                               fronts and the assembly of the next ones run on a second stream beside the panel chain;
+                               0: one stream, serial order.  Same bits either way.                                  */
 } stmmqr_options;
 void stmmqr_get_options(stmmqr_options *opt);
 void stmmqr_set_options(const stmmqr_options *opt);
@@ -269,6 +273,11 @@ const char *stmmqr_mm_last_error(void);
 void stmmqr_free(void *p);
 
 void stmmqr_shutdown(void);                           /* optional end-of-use call for dlopen()ing hosts: device sync  */
+/* Device buffers for hosts without HIP bindings of their own (FFI callers of stmmqr_export_front_dev /
+ * stmmqr_import_front_dev, device-resident A values): allocated by the HIP runtime THIS library is bound to, on the
+ * current device.  0 or a negative STMMQR_ERR_* code. */
+int stmmqr_device_alloc(size_t bytes, void **ptr);
+int stmmqr_device_free(void *ptr);
 int stmmqr_device_count(void);                        /* number of visible HIP devices (0 = none)          */
 const char *stmmqr_device_name(int device);           /* gcnArchName, e.g. "gfx950:sramecc+:xnack-"        */
 const char *stmmqr_last_error(void);                  /* thread-local message of the last failure          */

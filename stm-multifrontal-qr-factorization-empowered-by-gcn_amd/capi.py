@@ -40,7 +40,7 @@ class Stats(C.Structure):
     _fields_ = [(k, C.c_double) for k in ["flops", "ms_total", "ms_assemble", "ms_front", "ms_pack", "ms_h2d", "ms_d2h",
                                           "ms_host", "bytes_assemble", "bytes_pack", "flops_update", "ms_update"]] + \
                [("nlaunch", C.c_long), ("nlevels", C.c_long), ("ms_panel", C.c_double), ("ms_small", C.c_double),
-                ("npanel_launch", C.c_long), ("nupdate_launch", C.c_long)]
+                ("npanel_launch", C.c_long), ("nupdate_launch", C.c_long), ("nsteps", C.c_long)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}
@@ -48,7 +48,8 @@ class Stats(C.Structure):
 
 class Options(C.Structure):
     _fields_ = [("panel_width", C.c_int), ("big_front_cols", C.c_int), ("verbose", C.c_int), ("use_graph", C.c_int),
-                ("panel_algo", C.c_int), ("split_update", C.c_int), ("tall_min_rows", C.c_int)]
+                ("panel_algo", C.c_int), ("split_update", C.c_int), ("tall_min_rows", C.c_int),
+                ("lookahead", C.c_int)]
 
 
 def _ip(a):
@@ -121,6 +122,21 @@ def get_options() -> dict:
     o = Options()
     lib.stmmqr_get_options(C.byref(o))
     return {k: getattr(o, k) for k, _ in o._fields_}
+
+
+lib.stmmqr_device_alloc.argtypes = [C.c_size_t, C.POINTER(C.c_void_p)]
+lib.stmmqr_device_free.argtypes = [C.c_void_p]
+
+
+def device_alloc(nbytes: int) -> int:
+    """Device buffer from the HIP runtime the library is bound to (current device); release with device_free."""
+    p = C.c_void_p()
+    _check(lib.stmmqr_device_alloc(nbytes, C.byref(p)), "stmmqr_device_alloc")
+    return p.value
+
+
+def device_free(ptr: int):
+    _check(lib.stmmqr_device_free(ptr), "stmmqr_device_free")
 
 
 def set_options(**kw):

@@ -141,8 +141,11 @@ __device__ __forceinline__ void ca_publish_block(const double (*src)[STM_NB + 1]
     __syncthreads();
 }
 
-__global__ __launch_bounds__(CA_NT) void k_panel_ca(DevCtx c, const int *__restrict__ flist, int p, int defer_ok)
+__global__ __launch_bounds__(CA_NT) void k_panel_ca(DevCtx c, const int *__restrict__ flist, const int *__restrict__ plist, int defer_ok)
 {
+    const int p = plist[blockIdx.x];                            // every front of a step is at its own panel
+    __builtin_amdgcn_s_setprio(3);                              // (the panel chain is the critical path: ahead of the update waves
+                                                                //  of the side stream that share the CU)
     extern __shared__ double S[];                       // slab image [STM_NB][CA_LD]
     __shared__ CaShared cs;
     __shared__ int s_ok;
@@ -280,7 +283,7 @@ __global__ __launch_bounds__(CA_NT) void k_panel_ca(DevCtx c, const int *__restr
         for (int e = tid; e < STM_NB * STM_NB; e += CA_NT) {
             double acc = 0;
             if (nB > 0)                                  // (no bottom rows: nobody published anything, G = 0)
-                for (int q = 0; q < nwact; q++) acc += Gp[(long long)q * (STM_NB * STM_NB) + e];
+                acc = stm_ordered_sum<false>(Gp + e, STM_NB * STM_NB, nwact);
             cs.G[e >> 5][e & 31] = acc;
         }
         __syncthreads();
@@ -363,9 +366,7 @@ __global__ __launch_bounds__(CA_NT) void k_panel_ca(DevCtx c, const int *__restr
                 if (!ca_wait_ge(&num->gcnt, others, &s_ok)) { if (tid == 0) st_agent(&num->perr, 1); return; }
                 if (tid == 0) st_agent(&num->gcnt, 0);
                 for (int e = tid; e < STM_NB * STM_NB; e += CA_NT) {
-                    double acc = 0;
-                    for (int q = 0; q < nwact; q++) acc += ld_agent(&Gp[(long long)q * (STM_NB * STM_NB) + e]);
-                    cs.G[e >> 5][e & 31] = acc;
+                    cs.G[e >> 5][e & 31] = stm_ordered_sum<true>(Gp + e, STM_NB * STM_NB, nwact);
                 }
                 __syncthreads();
             } else {
@@ -519,7 +520,7 @@ int stm_configure_capanel(void)
     return (int)hipFuncSetAttribute((const void *)k_panel_ca, hipFuncAttributeMaxDynamicSharedMemorySize, stm_ca_lds_bytes());
 }
 
-int stm_launch_panel_ca(const DevCtx &c, const int *flist, int nfr, int p, int nw, int defer_ok, hipStream_t st)
+int stm_launch_panel_ca(const DevCtx &c, const int *flist, const int *plist, int nfr, int nw, int defer_ok, hipStream_t st)
 {
     if (nfr <= 0) return 0;
     if (nw < 1) nw = 1;
@@ -528,7 +529,7 @@ int stm_launch_panel_ca(const DevCtx &c, const int *flist, int nfr, int p, int n
     int K = 240 / nw;
     if (K < 1) K = 1;
     for (int i = 0; i < nfr; i += K)
-        hipLaunchKernelGGL(k_panel_ca, dim3(nfr - i < K ? nfr - i : K, nw), dim3(CA_NT), (size_t)stm_ca_lds_bytes(), st, c, flist + i, p,
+        hipLaunchKernelGGL(k_panel_ca, dim3(nfr - i < K ? nfr - i : K, nw), dim3(CA_NT), (size_t)stm_ca_lds_bytes(), st, c, flist + i, plist + i,
                            defer_ok);
     return (int)hipGetLastError();
 }

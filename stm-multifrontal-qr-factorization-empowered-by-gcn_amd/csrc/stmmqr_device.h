@@ -96,6 +96,14 @@ static inline __host__ __device__ int stm_tall_launches(const FrontSym &s, int p
     return (rows > STM_TALL_XWIDE) ? STM_NB / 2 : (rows > STM_TALL_WIDE) ? STM_NB / 4 : STM_NB / STM_SW;
 }
 
+// dynamic LDS (doubles) of the one-workgroup panel of this front: the padded rows of a whole panel, capped at 128 KiB
+#define STM_LDS_CAP_DOUBLES 16384
+static inline __host__ __device__ int stm_front_lds(const FrontSym &s)
+{
+    const long need = (long)(((s.fm_ub + 63) & ~63) | 1) * STM_NB + 64;
+    return need < STM_LDS_CAP_DOUBLES ? (int)need : STM_LDS_CAP_DOUBLES;
+}
+
 // Gram-based panel (stmmqr_capanel.hip): rows of the panel below its pivot rows are cut into slabs of STM_CA_R rows, one
 // workgroup each.  The number of slab workgroups of a front is symbolic (every workgroup of a launch must agree on it).
 #define STM_CA_R 480
@@ -107,6 +115,16 @@ static inline __host__ __device__ int stm_ca_slabs(const FrontSym &s)
 
 #define STM_UPD_SLAB 256     // rows of a workgroup tile of the row-parallel trailing update (k_upd_w / k_upd_c); W is accumulated
                              // per slab and the slabs are added in order in BOTH update forms (bit-identical results)
+// the row-parallel trailing update's workspace slice of a front at panel p: (ncb + 1) column-block slots (trailing
+// blocks + the Gram block) of nsl slabs of NB x 32 partial sums; both counts are symbolic (host sizing = device indexing)
+static inline __host__ __device__ int stm_upd_ncb(const FrontSym &s, int p)
+{
+    int k2 = (p + 1) * STM_NB;
+    if (k2 > s.fn) k2 = s.fn;
+    return (s.fn - k2 + 31) / 32;
+}
+static inline __host__ __device__ int stm_upd_nsl(const FrontSym &s) { return (s.fm_ub + STM_UPD_SLAB - 1) / STM_UPD_SLAB; }
+
 #define STM_QB_ROWS 512      // rows of a front per workgroup of the split Q-apply (k_qbig_step)
 // split Q-apply (k_qbig_*): one entry per large front of a tree level
 struct QbDesc {

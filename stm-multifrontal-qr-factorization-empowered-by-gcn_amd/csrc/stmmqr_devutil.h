@@ -50,3 +50,24 @@ __device__ __forceinline__ void stm_larfg_guarded(double alpha, double ss1, doub
     beta = bs * isg;
     scal = scals * sg;
 }
+
+// Sum of n doubles, p[0], p[stride], ..., in THAT order (fixed association: deterministic partial-sum reductions), with the
+// loads of eight terms in flight together -- a plain loop waits for every load before the next add, ~0.7 us per term from L2.
+// (Padding a short batch with +0.0 is exact: a sum that starts at +0.0 never is -0.0.)
+template <bool AGENT>
+__device__ __forceinline__ double stm_ordered_sum(const double *p, long long stride, int n)
+{
+    double v = 0;
+    for (int q = 0; q < n; q += 8) {
+        double t[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            const double *a = p + (long long)min(q + u, n - 1) * stride;
+            const double x = AGENT ? ld_agent(a) : *a;
+            t[u] = (q + u < n) ? x : 0.0;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; u++) v += t[u];
+    }
+    return v;
+}

@@ -20,6 +20,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <mutex>
 #include <vector>
 
 #include "../../include/stmmqr_hip.h"
@@ -29,7 +30,7 @@
 namespace {
 
 thread_local std::string g_err;
-stmmqr_options g_opt = {STM_NB, 64, 0, 0, 0, 1, STM_TALL_MIN};      // (panel_algo 0: by panel height)
+stmmqr_options g_opt = {STM_NB, 64, 0, 0, 0, 1, STM_TALL_MIN, 1};      // (panel_algo 0: by panel height)
 size_t g_chunk[4] = {32, 5000, 4, 4};     // FCHUNK, SMALL, MINCHUNK, MINCHUNK_RATIO (SparseQR.h:16-19)
 
 // offsets inside the reference's sparse_common for the stock LP64 build; verified against the real header
@@ -92,18 +93,24 @@ template <class T> struct DevBuf {
     ~DevBuf() { release(); }
 };
 
-struct Level {
+struct Level {                           // tree level of a group: what the solve / Q-apply kernels walk (f1)
     int all_off = 0, n_all = 0;          // every front of the level (small first, then big by npanels desc)
     int n_small = 0, n_big = 0;
-    int asm_parts_off = 0, asm_maxparts = 1;
-    int cpk_parts_off = 0, cpk_maxparts = 1;
-    int lds_small = 0, lds_big = 0;      // dynamic LDS (doubles) for the panel staging
-    std::vector<int> nbig_at;            // big fronts with npanels > p
-    std::vector<int> maxcb_at;           // max trailing column blocks at panel p
-    std::vector<int> nsub_at;            // panel launches at p: 4 or 8 if any front takes the tall-panel pipeline
-    std::vector<int> nca_use, npipe_use; // fronts active at p that take the Gram-based / the pipeline panel kernel
-    std::vector<int> nca_at;             // Gram-based panel: max slab workgroups (stm_ca_slabs) of the fronts active at p
-    std::vector<int> maxsl_at;           // max 256-row slabs of the fronts still active at panel p (0: small)
+};
+
+// One step of the factorization timeline.  Every front starts at the step after the last of its children has finished
+// (a small front takes one step, a big one a step per panel), so a front deep in a short branch does not wait for the
+// tallest front of its tree level: at every step the launches cover all the big fronts that are in flight, each at its
+// own panel.  Everything here is symbolic (lists built once per plan).
+struct Step {
+    int start_off = 0, n_start = 0, n_small = 0;      // fronts starting here (small first): set up + assembled
+    int asm_parts_off = 0, asm_maxparts = 1, lds_small = 0;
+    int act_off = 0, plist_off = 0, n_act = 0;        // big fronts in flight + the panel each is at
+    int wp_off = 0;                                   // (index into d_wlists) their slices of the update workspace
+    int nsub = 1, nca = 1, nca_use = 0, npipe_use = 0, maxcb = 0, maxsl = 0, split = 0;
+    int lds_big = 0;       // dynamic LDS of the panel launch when every front may take the one-workgroup panel (recovery, tests)
+    int lds_plan = 0;      // ... when only the fronts planned for it do (the pipeline groups need the update's LDS only)
+    int cpk_off = 0, cpk_parts_off = 0, n_cpk = 0, cpk_maxparts = 1;   // big fronts whose last panel runs here
 };
 
 }  // namespace
@@ -111,10 +118,13 @@ struct Level {
 struct stmmqr_plan {
     int device = 0;
     hipStream_t stream = nullptr;
+    // look-ahead: the panel chain runs on `stream` (high priority), everything that does not feed the next panel on `side`
+    hipStream_t side = nullptr;                               // (the device's shared side stream: side_stream_for)
+    std::vector<hipEvent_t> ev_main, ev_prep, ev_side;        // one of each per timeline step (no timing)
     hipEvent_t ev[8] = {};
     // detail timing: one event pair per launch category and level step, recorded on the plan's stream WITHOUT any
     // synchronisation (the schedule runs exactly as in the timed region); the pairs are read after the final sync
-    struct EvPair { hipEvent_t a, b; int cat; };
+    struct EvPair { hipEvent_t a, b; int cat, step; };
     std::vector<EvPair> evpairs;
     size_t evused = 0;
     long m = 0, n = 0, anz = 0, nf = 0, maxfn = 0, rjsize = 0, hisize = 0;
@@ -126,6 +136,8 @@ struct stmmqr_plan {
     bool has_qfill = false;
     std::vector<FrontSym> fs;
     std::vector<std::vector<Level>> glevels;   // [group][level]
+    std::vector<std::vector<Step>> gsteps;     // [group][step]
+    std::vector<long long> wlists;             // host copy of d_wlists
     std::vector<int> group;                    // per front: phase on this device, -1 = elsewhere
     int own_off = 0, n_own = 0;
     std::vector<int> lists;              // host copy of d_lists
@@ -143,6 +155,7 @@ struct stmmqr_plan {
     DevBuf<double> d_F, d_C, d_T, d_Gp, d_Tall, d_Sx, d_Ax, d_Tau, d_RH, d_Wp, d_Wp2;
     DevBuf<int> d_tslot, d_Sp, d_Sjrel, d_Sj0, d_Sleft, d_Child, d_Rjrel, d_Stair, d_Hii, d_Cmap, d_Cursor,
         d_Rhoff, d_lists, d_smap;
+    DevBuf<long long> d_wlists;
     DevBuf<long long> d_Rboff, d_total;
     DevBuf<unsigned long long> d_dbg, d_amax;
     DevBuf<double> d_sig;                           // {sg, 1/sg}: magnitude guard of the panel kernels
@@ -196,14 +209,67 @@ struct stmmqr_plan {
             if (e) (void)hipEventDestroy(e);
         for (auto &q : evpairs) { if (q.a) (void)hipEventDestroy(q.a); if (q.b) (void)hipEventDestroy(q.b); }
         if (graph_exec) (void)hipGraphExecDestroy(graph_exec);
+        for (auto *v : {&ev_main, &ev_prep, &ev_side})
+            for (auto &e : *v)
+                if (e) (void)hipEventDestroy(e);
         if (stream) (void)hipStreamDestroy(stream);
     }
 };
 
 namespace {
 
-const int LDS_CAP_DOUBLES = 16384;        // 128 KiB of dynamic LDS for the staged (sub-)panel, k_panel
+const int LDS_CAP_DOUBLES = STM_LDS_CAP_DOUBLES;   // 128 KiB of dynamic LDS for the staged (sub-)panel, k_panel
 const int LDS_CAP_SMALL = 15360;          // 120 KiB in k_front_wg (it carries 8 KiB more static LDS)
+
+// The side stream of the look-ahead schedule: ONE per device and process, created at the first look-ahead factorization
+// and kept (a CU-masked stream owns a hardware queue; creating one per plan exhausted them).  Its CU mask leaves
+// STMMQR_SIDE_RESERVE compute units (default 32; the mask bits interleave over the 8 XCDs, so 4 per XCD) to the plan
+// streams: the workgroups of a panel kernel need most of a CU's LDS and would otherwise wait until the side stream's
+// update grid has drained.  Plans of one device that factorize at the same time share it (still ordered by events).
+std::mutex g_side_mu;
+hipStream_t g_side[64] = {};
+bool g_side_tried[64] = {};
+
+// (registered with atexit at the first creation, i.e. after the HIP runtime registered its own handlers: it runs before
+//  them; stmmqr_shutdown() calls it too)
+void destroy_side_streams()
+{
+    std::lock_guard<std::mutex> lock(g_side_mu);
+    for (int d = 0; d < 64; d++) {
+        if (g_side[d]) {
+            if (hipSetDevice(d) == hipSuccess) { (void)hipStreamSynchronize(g_side[d]); (void)hipStreamDestroy(g_side[d]); }
+            g_side[d] = nullptr;
+        }
+        g_side_tried[d] = false;
+    }
+}
+
+hipStream_t side_stream_for(int device)
+{
+    hipStream_t *side = g_side;
+    bool *tried = g_side_tried;
+    static bool registered = false;
+    if (device < 0 || device >= 64) return nullptr;
+    std::lock_guard<std::mutex> lock(g_side_mu);
+    if (tried[device]) return side[device];
+    tried[device] = true;
+    if (!registered) { registered = true; atexit(destroy_side_streams); }
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) != hipSuccess) return nullptr;
+    const int ncu = prop.multiProcessorCount;
+    int reserve = getenv("STMMQR_SIDE_RESERVE") ? atoi(getenv("STMMQR_SIDE_RESERVE")) : 32;
+    if (reserve < 0) reserve = 0;
+    if (reserve > ncu / 2) reserve = ncu / 2;
+    hipStream_t q = nullptr;
+    if (reserve > 0) {
+        std::vector<uint32_t> mask((size_t)(ncu + 31) / 32, 0u);
+        for (int i = reserve; i < ncu; i++) mask[(size_t)i >> 5] |= 1u << (i & 31);
+        if (hipExtStreamCreateWithCUMask(&q, (uint32_t)mask.size(), mask.data()) != hipSuccess) q = nullptr;
+    }
+    if (!q && hipStreamCreateWithFlags(&q, hipStreamNonBlocking) != hipSuccess) q = nullptr;
+    side[device] = q;
+    return q;
+}
 
 int ensure_device(int device)
 {
@@ -239,22 +305,51 @@ void build_schedule(stmmqr_plan &P, std::vector<int> &tslot)
         const FrontSym &s = P.fs[f];
         return s.fn >= g_opt.big_front_cols && s.fm_ub >= 64;
     };
+    const int sched_policy = getenv("STMMQR_SCHED") ? atoi(getenv("STMMQR_SCHED")) : 0;
+    const bool sched_level = sched_policy == 1;
     tslot.assign(std::max(1L, nf), 0);
     P.glevels.assign(ngroups, std::vector<Level>());
+    P.gsteps.assign(ngroups, std::vector<Step>());
     P.lists.clear();
+    P.wlists.clear();
     P.tslots = 1;
     P.gp_slabs = 1;
     P.wp_doubles = 0;
     for (int grp = 0; grp < ngroups; grp++) {
-        std::vector<int> level(nf, -1);
-        int nlev = 0;
+        // ---- tree levels (leaves = 0, counted inside the group): the order of the solves and of Q ----
+        std::vector<int> level(nf, -1), start(nf, 0), end(nf, 0);
+        int nlev = 0, nstep = 0;
         for (long kf = 0; kf < nf; kf++) {
             const long f = P.Post[kf];
             if (P.group[f] != grp) continue;
-            int lv = 0;
-            for (long q = P.Childp[f]; q < P.Childp[f + 1]; q++) lv = std::max(lv, level[P.Child[q]] + 1);
+            int lv = 0, t0 = 0;
+            for (long q = P.Childp[f]; q < P.Childp[f + 1]; q++) {
+                const long ch = P.Child[q];
+                if (P.group[ch] != grp) continue;              // (earlier phase or imported: already there)
+                lv = std::max(lv, level[ch] + 1);
+                t0 = std::max(t0, end[ch]);
+            }
             level[f] = lv;
             nlev = std::max(nlev, lv + 1);
+            start[f] = t0;
+            end[f] = t0 + (is_big((int)f) ? P.fs[f].npanels : 1);
+            nstep = std::max(nstep, end[f]);
+        }
+        if (sched_level) {
+            // the level-synchronous schedule: every front of a tree level starts when the level below has finished
+            std::vector<int> lvl_end(nlev + 1, 0);
+            for (int lv = 0; lv < nlev; lv++) {
+                int e1 = lvl_end[lv];
+                for (long kf = 0; kf < nf; kf++) {
+                    const long f = P.Post[kf];
+                    if (P.group[f] != grp || level[f] != lv) continue;
+                    start[f] = lvl_end[lv];
+                    end[f] = start[f] + (is_big((int)f) ? P.fs[f].npanels : 1);
+                    e1 = std::max(e1, end[f]);
+                }
+                lvl_end[lv + 1] = e1;
+            }
+            nstep = lvl_end[nlev];
         }
         std::vector<std::vector<int>> byl(nlev);
         for (long kf = 0; kf < nf; kf++)
@@ -270,69 +365,168 @@ void build_schedule(stmmqr_plan &P, std::vector<int> &tslot)
             L.n_small = (int)small.size(); L.n_big = (int)big.size(); L.n_all = L.n_small + L.n_big;
             P.lists.insert(P.lists.end(), small.begin(), small.end());
             P.lists.insert(P.lists.end(), big.begin(), big.end());
-            L.asm_parts_off = (int)P.lists.size();
-            L.asm_maxparts = 1;
-            for (int i = 0; i < L.n_all; i++) {
-                const FrontSym &s = P.fs[P.lists[L.all_off + i]];
-                long work = (long)s.fm_ub * s.fn;
-                int parts = (int)std::min(512L, std::max(1L, (work + 16383) / 16384));     // (two workgroups per CU on the top fronts)
-                P.lists.push_back(parts);
-                L.asm_maxparts = std::max(L.asm_maxparts, parts);
+        }
+        // ---- the step timeline ----
+        // panel_at[t] = the (big front, panel) pairs of step t; small_at[t] = the small fronts factorized at step t.
+        // Policies (STMMQR_SCHED, experiments): 1 level-synchronous, 2 as soon as possible (above), default the envelope
+        // rule: every step runs the fronts on the longest remaining path (counted in panels up to the root); any other
+        // front that is ready or in flight rides along if its panel is no taller than theirs -- a launch lasts as long
+        // as its tallest panel and is configured for it (LDS, column groups), so shorter panels are free while a taller
+        // one would make the step of the critical fronts longer.  The minimum number of steps, the cheapest envelope.
+        std::vector<std::vector<std::pair<int, int>>> panel_at;
+        std::vector<std::vector<int>> small_at;
+        if (sched_policy != 0) {
+            panel_at.assign(nstep, {});
+            small_at.assign(nstep, {});
+            for (long kf = 0; kf < nf; kf++) {
+                const int f = (int)P.Post[kf];
+                if (P.group[f] != grp) continue;
+                if (!is_big(f)) { small_at[start[f]].push_back(f); continue; }
+                for (int q = 0; q < P.fs[f].npanels; q++) panel_at[start[f] + q].push_back({f, q});
             }
-            L.cpk_parts_off = (int)P.lists.size();
-            L.cpk_maxparts = 1;
-            for (int i = 0; i < L.n_big; i++) {
-                const FrontSym &s = P.fs[big[i]];
-                long cn = s.fn - s.fp;
-                long work = cn * std::min((long)s.fm_ub, cn);
-                int parts = (int)std::min(64L, std::max(1L, (work + 16383) / 16384));
-                P.lists.push_back(parts);
-                L.cpk_maxparts = std::max(L.cpk_maxparts, parts);
+        } else {
+            std::vector<int> parent_in(nf, -1), pend(nf, 0), tails(nf, 0);
+            for (long f = 0; f < nf; f++) {
+                if (P.group[f] != grp) continue;
+                for (long q = P.Childp[f]; q < P.Childp[f + 1]; q++)
+                    if (P.group[P.Child[q]] == grp) { parent_in[P.Child[q]] = (int)f; pend[f]++; }
             }
-            int maxp = 0;
-            long maxfm_small = 0, maxfm_big = 0;
-            for (int f : small) maxfm_small = std::max(maxfm_small, (long)P.fs[f].fm_ub);
-            for (size_t i = 0; i < big.size(); i++) {
-                maxp = std::max(maxp, P.fs[big[i]].npanels);
-                maxfm_big = std::max(maxfm_big, (long)P.fs[big[i]].fm_ub);
-                tslot[big[i]] = (int)i;
+            for (long kf = nf; kf-- > 0;) {
+                const long f = P.Post[kf];
+                if (P.group[f] != grp) continue;
+                tails[f] = (is_big((int)f) ? P.fs[f].npanels : 1) + (parent_in[f] >= 0 ? tails[parent_in[f]] : 0);
             }
-            P.tslots = std::max(P.tslots, (int)big.size());
-            // (rows padded as dev_panel pads them, so that a whole panel fits whenever the cap allows: the sub-panel width
-            //  of a front -- and with it the rounding -- must not depend on which other fronts share its level)
-            L.lds_small = (int)std::min((long)LDS_CAP_SMALL, (((maxfm_small + 63) & ~63L) | 1) * STM_NB + 64);
-            L.lds_big = (int)std::min((long)LDS_CAP_DOUBLES, (((maxfm_big + 63) & ~63L) | 1) * STM_NB + 64);
-            L.nbig_at.assign(maxp, 0);
-            L.maxcb_at.assign(maxp, 0);
-            L.nsub_at.assign(maxp, 1);
-            L.maxsl_at.assign(maxp, 0);
-            L.nca_at.assign(maxp, 1);
-            L.nca_use.assign(maxp, 0);
-            L.npipe_use.assign(maxp, 0);
-            for (int p = 0; p < maxp; p++) {
-                int cnt = 0, mcb = 0, msl = 0;
-                for (int f : big) {
-                    const FrontSym &s = P.fs[f];
-                    if (s.npanels > p) {
-                        cnt++;
-                        const int k2 = std::min(s.fn, (p + 1) * STM_NB);
-                        mcb = std::max(mcb, (s.fn - k2 + 31) / 32);
-                        msl = std::max(msl, (s.fm_ub + STM_UPD_SLAB - 1) / STM_UPD_SLAB);
-                        L.nsub_at[p] = std::max(L.nsub_at[p], stm_tall_launches(s, p, P.tall_min));
-                        L.nca_at[p] = std::max(L.nca_at[p], stm_ca_slabs(s));
-                        (stm_use_ca(s, p, g_opt.panel_algo, P.ca_min) ? L.nca_use[p] : L.npipe_use[p])++;
-                        P.gp_slabs = std::max(P.gp_slabs, stm_ca_slabs(s));
-                    }
+            std::vector<int> ready;
+            for (long kf = 0; kf < nf; kf++)
+                if (P.group[P.Post[kf]] == grp && pend[P.Post[kf]] == 0) ready.push_back((int)P.Post[kf]);
+            const double ride = getenv("STMMQR_RIDE") ? atof(getenv("STMMQR_RIDE")) : 1.0;
+            struct Fly { int f, p; };
+            std::vector<Fly> fly;                                 // big fronts ready or in flight, with their next panel
+            while (!ready.empty() || !fly.empty()) {
+                std::vector<int> newly, smalls;
+                for (int f : ready) {
+                    if (is_big(f)) fly.push_back({f, 0});
+                    else smalls.push_back(f);
                 }
-                L.nbig_at[p] = cnt;
-                L.maxcb_at[p] = mcb;
-                // row-parallel update when it pays: >= 3 slabs, or so many column blocks in the launch that the one-workgroup
-                // form's redundant T (every column-block workgroup builds it) costs throughput (T is built once per front
-                // by k_upd_w).  Either form gives the same bits.
-                L.maxsl_at[p] = (msl >= 3 || (long)cnt * mcb >= 512) ? msl : 0;
-                P.wp_doubles = std::max(P.wp_doubles, (long long)cnt * (mcb + 1) * msl * (STM_NB * 32));   // (+1: Gram block)
+                panel_at.push_back({});
+                small_at.push_back(smalls);
+                auto finish = [&](int f) {
+                    const int pf = parent_in[f];
+                    if (pf >= 0 && --pend[pf] == 0) newly.push_back(pf);
+                };
+                if (!fly.empty()) {
+                    auto rem = [&](const Fly &e) { return tails[e.f] - e.p; };
+                    auto rows = [&](const Fly &e) { return stm_panel_rows_est(P.fs[e.f], e.p); };
+                    int rl = 0, env = 0;
+                    for (const Fly &e : fly) rl = std::max(rl, rem(e));
+                    for (const Fly &e : fly)
+                        if (rem(e) == rl) env = std::max(env, rows(e));
+                    std::vector<Fly> keep;
+                    for (Fly &e : fly) {
+                        if (rem(e) == rl || rows(e) <= ride * env) {
+                            panel_at.back().push_back({e.f, e.p});
+                            if (++e.p >= P.fs[e.f].npanels) { finish(e.f); continue; }
+                        }
+                        keep.push_back(e);
+                    }
+                    fly.swap(keep);
+                }
+                for (int f : smalls) finish(f);
+                ready.swap(newly);
+            }
+            nstep = (int)panel_at.size();
+        }
+        std::vector<std::vector<int>> starting(nstep), ending(nstep);
+        std::vector<int> pan_now(nf, 0);                          // the panel a front in flight is at, per step
+        for (int t = 0; t < nstep; t++) {
+            for (int f : small_at[t]) starting[t].push_back(f);
+            for (const auto &fp : panel_at[t]) {
+                if (fp.second == 0) starting[t].push_back(fp.first);
+                if (fp.second == P.fs[fp.first].npanels - 1) ending[t].push_back(fp.first);
             }
         }
+        std::vector<Step> &SV = P.gsteps[grp];
+        SV.assign(nstep, Step());
+        std::vector<int> active, freeslots;                   // big fronts in flight; released T / Gram slots
+        int nslots = 0;
+        for (int t = 0; t < nstep; t++) {
+            Step &S = SV[t];
+            std::vector<int> small, big;
+            for (int f : starting[t]) (is_big(f) ? big : small).push_back(f);
+            S.start_off = (int)P.lists.size();
+            S.n_small = (int)small.size(); S.n_start = (int)(small.size() + big.size());
+            P.lists.insert(P.lists.end(), small.begin(), small.end());
+            P.lists.insert(P.lists.end(), big.begin(), big.end());
+            S.asm_parts_off = (int)P.lists.size();
+            long maxfm_small = 0;
+            for (int i = 0; i < S.n_start; i++) {
+                const FrontSym &s = P.fs[P.lists[S.start_off + i]];
+                const long work = (long)s.fm_ub * s.fn;
+                const int parts = (int)std::min(512L, std::max(1L, (work + 16383) / 16384));     // (two workgroups per CU on the top fronts)
+                P.lists.push_back(parts);
+                S.asm_maxparts = std::max(S.asm_maxparts, parts);
+                if (i < S.n_small) maxfm_small = std::max(maxfm_small, (long)s.fm_ub);
+            }
+            // (rows padded as dev_panel pads them, so that a whole panel fits whenever the cap allows: the sub-panel width
+            //  of a front -- and with it the rounding -- must not depend on which other fronts share its step)
+            S.lds_small = (int)std::min((long)LDS_CAP_SMALL, (((maxfm_small + 63) & ~63L) | 1) * STM_NB + 64);
+            // T / Gram-partial slots: a slot is held from the step a front starts to the step it ends
+            for (int f : big) {
+                if (!freeslots.empty()) { tslot[f] = freeslots.back(); freeslots.pop_back(); }
+                else tslot[f] = nslots++;
+            }
+            active.clear();
+            for (const auto &fp : panel_at[t]) { active.push_back(fp.first); pan_now[fp.first] = fp.second; }
+            // heaviest update first (the order inside a launch does not change any result)
+            auto work_at = [&](int f) { return (long)stm_upd_ncb(P.fs[f], pan_now[f]) * stm_upd_nsl(P.fs[f]); };
+            std::stable_sort(active.begin(), active.end(), [&](int a, int b) { return work_at(a) > work_at(b); });
+            S.act_off = (int)P.lists.size();
+            S.n_act = (int)active.size();
+            P.lists.insert(P.lists.end(), active.begin(), active.end());
+            S.plist_off = (int)P.lists.size();
+            for (int f : active) P.lists.push_back(pan_now[f]);
+            S.wp_off = (int)P.wlists.size();
+            long long wp = 0, ncbsum = 0;
+            long maxfm_big = 0;
+            for (int f : active) {
+                const FrontSym &s = P.fs[f];
+                const int p = pan_now[f];
+                const int ncb = stm_upd_ncb(s, p), nsl = stm_upd_nsl(s);
+                P.wlists.push_back(wp);
+                wp += (long long)(ncb + 1) * nsl * (STM_NB * 32);                         // (+1: Gram block)
+                ncbsum += ncb;
+                S.maxcb = std::max(S.maxcb, ncb);
+                S.maxsl = std::max(S.maxsl, nsl);
+                S.nsub = std::max(S.nsub, stm_tall_launches(s, p, P.tall_min));
+                S.nca = std::max(S.nca, stm_ca_slabs(s));
+                (stm_use_ca(s, p, g_opt.panel_algo, P.ca_min) ? S.nca_use : S.npipe_use)++;
+                P.gp_slabs = std::max(P.gp_slabs, stm_ca_slabs(s));
+                maxfm_big = std::max(maxfm_big, (long)s.fm_ub);
+                if (!stm_tall_panel(s, p, P.tall_min) && !stm_use_ca(s, p, g_opt.panel_algo, P.ca_min))
+                    S.lds_plan = std::max(S.lds_plan, stm_front_lds(s));
+            }
+            S.lds_big = (int)std::min((long)LDS_CAP_DOUBLES, (((maxfm_big + 63) & ~63L) | 1) * STM_NB + 64);
+            // row-parallel update when it pays: >= 3 slabs, or so many column blocks in the launch that the one-workgroup
+            // form's redundant T (every column-block workgroup builds it) costs throughput (T is built once per front
+            // by k_upd_w).  Either form gives the same bits.
+            S.split = (S.maxsl >= 3 || ncbsum >= 512) ? 1 : 0;
+            P.wp_doubles = std::max(P.wp_doubles, wp);
+            // fronts at their last panel: packed at the end of the step, slot released for the next
+            S.cpk_off = (int)P.lists.size();
+            S.n_cpk = (int)ending[t].size();
+            P.lists.insert(P.lists.end(), ending[t].begin(), ending[t].end());
+            S.cpk_parts_off = (int)P.lists.size();
+            for (int f : ending[t]) {
+                const FrontSym &s = P.fs[f];
+                const long cn = s.fn - s.fp;
+                const long work = cn * std::min((long)s.fm_ub, cn);
+                const int parts = (int)std::min(64L, std::max(1L, (work + 16383) / 16384));
+                P.lists.push_back(parts);
+                S.cpk_maxparts = std::max(S.cpk_maxparts, parts);
+                freeslots.push_back(tslot[f]);
+            }
+        }
+        P.tslots = std::max(P.tslots, nslots);
     }
     // fronts factorized on this device, in Post order, + their R+H copy parts; then ALL fronts in Post order
     P.own_off = (int)P.lists.size();
@@ -351,6 +545,7 @@ void build_schedule(stmmqr_plan &P, std::vector<int> &tslot)
     P.post_off = (int)P.lists.size();
     for (long kf = 0; kf < nf; kf++) P.lists.push_back((int)P.Post[kf]);
     if (P.lists.empty()) P.lists.push_back(0);
+    if (P.wlists.empty()) P.wlists.push_back(0);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -515,6 +710,7 @@ int build_plan(stmmqr_plan &P, const stmmqr_symbolic_view &v)
     HIPCHK(hipMemsetAsync(P.d_dbg.p, 0, 16 * sizeof(unsigned long long), st));
     LCHK(P.d_Rdead.alloc((size_t)std::max(1L, n)));
     LCHK(P.d_lists.upload(P.lists, st));
+    LCHK(P.d_wlists.upload(P.wlists, st));
     HIPCHK(hipStreamSynchronize(st));
     return 0;
 }
@@ -553,16 +749,18 @@ int run_schedule(stmmqr_plan &P, bool detail, int grp, bool first)
     long nlaunch = 0;
     // detail timing: bracket each category with an event pair from the pool; no host synchronisation here
     enum { CAT_ASM = 0, CAT_SMALL = 1, CAT_PANEL = 2, CAT_UPD = 3, CAT_CPK = 4 };
+    int cur_step = 0;
     auto timed = [&](int cat, auto &&fn) -> int {
         if (!detail) return fn();
         if (P.evused == P.evpairs.size()) {
-            stmmqr_plan::EvPair q = {nullptr, nullptr, 0};
+            stmmqr_plan::EvPair q = {nullptr, nullptr, 0, 0};
             HIPCHK(hipEventCreate(&q.a));
             HIPCHK(hipEventCreate(&q.b));
             P.evpairs.push_back(q);
         }
         stmmqr_plan::EvPair &q = P.evpairs[P.evused++];
         q.cat = cat;
+        q.step = cur_step;
         HIPCHK(hipEventRecord(q.a, st));
         int e = fn();
         if (e) return e;
@@ -579,62 +777,159 @@ int run_schedule(stmmqr_plan &P, bool detail, int grp, bool first)
         LCHK(stm_launch_gather_sx(P.d_Ax.p, P.d_smap.p, P.d_Sx.p, (int)P.anz, st));
         nlaunch += 6;
     }
-    if (grp < 0 || grp >= (int)P.glevels.size()) return fail(STMMQR_ERR_INVALID, "no such front group");
-    for (const Level &L : P.glevels[grp]) {
-        const int *all = L0 + L.all_off;
-        int e = timed(t_asm, [&]() -> int {
-            LCHK(stm_launch_setup(c, all, L.n_all, st));
-            LCHK(stm_launch_assemble(c, all, L0 + L.asm_parts_off, L.n_all, L.asm_maxparts, st));
-            return 0;
-        });
-        if (e) return e;
-        nlaunch += 2;
-        e = timed(t_front, [&]() -> int {
-            if (L.n_small > 0) { LCHK(stm_launch_front_wg(c, all, L.n_small, L.lds_small, st)); nlaunch++; }
-            return 0;
-        });
-        if (e) return e;
-        const int *big = all + L.n_small;
-        if (getenv("STMMQR_DUMPLV")) {
-            fprintf(stderr, "[level] nbig %d:", L.n_big);
-            for (int q = 0; q < L.n_big; q++) fprintf(stderr, " %d", P.lists[L.all_off + L.n_small + q]);
-            fprintf(stderr, "\n");
-        }
-        for (size_t p = 0; p < L.nbig_at.size(); p++) {
-            e = timed(t_panel, [&]() -> int {
-                // the trailing update (either form) builds T itself, see dev_tall_group / k_panel_ca
-                const int defer_ok = (L.maxcb_at[p] > 0) ? 1 : 0;
-                // which kernel takes a panel is a property of the front (stm_use_ca); a level step with both kinds gets
-                // both launches (each kernel skips the other's fronts)
-                if (L.nca_use[p] && !P.serial_panels)
-                    LCHK(stm_launch_panel_ca(c, big, L.nbig_at[p], (int)p, L.nca_at[p], defer_ok, st));
-                if (L.npipe_use[p] || P.serial_panels)
-                    LCHK(stm_launch_panel(c, big, L.nbig_at[p], (int)p, L.nsub_at[p], defer_ok, L.lds_big, st));
-                return 0;
-            });
-            if (e) return e;
-            e = timed(t_upd, [&]() -> int {
-                if (L.maxsl_at[p] > 0 && g_opt.split_update) {
-                    LCHK(stm_launch_update_split(c, big, L.nbig_at[p], (int)p, 0, L.maxcb_at[p], L.maxsl_at[p], P.d_Wp.p, 1, st));
-                    nlaunch += 1;
-                } else
-                    LCHK(stm_launch_update(c, big, L.nbig_at[p], (int)p, 0, L.maxcb_at[p], st));
+    if (grp < 0 || grp >= (int)P.gsteps.size()) return fail(STMMQR_ERR_INVALID, "no such front group");
+    const std::vector<Step> &SV = P.gsteps[grp];
+    // prep(t): set up + assemble the fronts that start at step t, factorize the small ones among them (whole, one launch)
+    auto prep = [&](const Step &S, hipStream_t q) -> int {
+        const int *starting = L0 + S.start_off;
+        if (S.n_start > 0) {
+            int e = timed(t_asm, [&]() -> int {
+                LCHK(stm_launch_setup(c, starting, S.n_start, q));
+                LCHK(stm_launch_assemble(c, starting, L0 + S.asm_parts_off, S.n_start, S.asm_maxparts, q));
                 return 0;
             });
             if (e) return e;
             nlaunch += 2;
         }
-        if (L.n_big > 0) {
-            e = timed(t_cpk, [&]() -> int {
-                LCHK(stm_launch_cpack(c, big, L0 + L.cpk_parts_off, L.n_big, L.cpk_maxparts, st));
+        if (S.n_small > 0) {
+            int e = timed(t_front, [&]() -> int {
+                LCHK(stm_launch_front_wg(c, starting, S.n_small, S.lds_small, q));
                 return 0;
             });
             if (e) return e;
             nlaunch++;
         }
+        return 0;
+    };
+    // which kernel takes a panel is a property of the front (stm_use_ca); a step with both kinds gets both launches (each
+    // kernel skips the other's fronts).  A front with trailing columns leaves T to its update (dev_tall_group /
+    // k_panel_ca), one at its last panel to k_cpack.
+    auto panels = [&](const Step &S) -> int {
+        const int *act = L0 + S.act_off, *pl = L0 + S.plist_off;
+        return timed(t_panel, [&]() -> int {
+            if (S.nca_use && !P.serial_panels) { LCHK(stm_launch_panel_ca(c, act, pl, S.n_act, S.nca, 1, st)); nlaunch++; }
+            if (S.npipe_use || P.serial_panels) {
+                const int lds = (P.serial_panels || (c.dbg & (64 | 256))) ? S.lds_big : S.lds_plan;
+                LCHK(stm_launch_panel(c, act, pl, S.n_act, S.nsub, 1, lds, st));
+                nlaunch++;
+            }
+            return 0;
+        });
+    };
+    // trailing update of the column blocks [cb0, cb0 + ncb) of every front in flight (block 0 = the columns of its next
+    // panel); gram: the T factors the panel kernels left to the update are built in this launch (row-parallel form; the
+    // one-workgroup form builds T in every workgroup)
+    auto update = [&](const Step &S, int cb0, int ncb, bool gram, double *Wp, hipStream_t q) -> int {
+        const bool split = S.split && g_opt.split_update;
+        if (ncb <= 0 && !(gram && split)) return 0;
+        const int *act = L0 + S.act_off, *pl = L0 + S.plist_off;
+        return timed(t_upd, [&]() -> int {
+            if (split) {
+                LCHK(stm_launch_update_split(c, act, pl, S.n_act, cb0, ncb, S.maxsl, Wp, P.d_wlists.p + S.wp_off, gram ? 1 : 0, q));
+                nlaunch += 2;
+            } else {
+                LCHK(stm_launch_update(c, act, pl, S.n_act, cb0, ncb, q));
+                nlaunch++;
+            }
+            return 0;
+        });
+    };
+    auto post = [&](const Step &S, hipStream_t q) -> int {
+        if (S.n_cpk <= 0) return 0;
+        nlaunch++;
+        return timed(t_cpk, [&]() -> int {
+            LCHK(stm_launch_cpack(c, L0 + S.cpk_off, L0 + S.cpk_parts_off, S.n_cpk, S.cpk_maxparts, q));
+            return 0;
+        });
+    };
+    bool la = g_opt.lookahead && !detail && !P.serial_panels && SV.size() > 1;
+    if (la) P.side = side_stream_for(P.device);
+    la = la && P.side;
+    if (!la) {
+        for (const Step &S : SV) {
+            cur_step = (int)(&S - SV.data());
+            int e = prep(S, st);
+            if (!e && S.n_act > 0) e = panels(S);
+            if (!e && S.n_act > 0 && S.maxcb > 0) e = update(S, 0, S.maxcb, true, P.d_Wp.p, st);
+            if (!e) e = post(S, st);
+            if (e) return e;
+        }
+    } else {
+        // Look-ahead of depth one.  The chain  panel(t) -> update of block 0 (the next panel's columns) -> panel(t+1)
+        // stays on the plan's stream; the rest of the update of step t, the packing of the fronts that ended at t and the
+        // preparation of those that start at t+1 run beside it on the side stream:
+        //   main:  [wait prep(t)]  panel(t)  T(t)  record main(t)  [wait side(t-1)]  update block 0
+        //   side:  wait main(t)    pack(t)   prep(t+1)  record prep(t+1)   update blocks 1..  record side(t)
+        // (side(t) needs the panel and its T only, not block 0: the side stream runs its updates back to back while the
+        //  main stream alternates block 0 and the next panel.)  Every kernel does exactly what it does in the serial
+        // order (same bits).
+        const size_t ns = SV.size();
+        for (auto *v : {&P.ev_main, &P.ev_prep, &P.ev_side})
+            while (v->size() < ns + 1) {
+                hipEvent_t ev = nullptr;
+                HIPCHK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+                v->push_back(ev);
+            }
+        hipStream_t sd = P.side;
+        // a step goes to the side stream when the update beyond block 0 is worth two cross-stream hand-offs (~25 us):
+        // STMMQR_LA_MIN tiles of 256 x 32 (default 2500)
+        const long la_min = getenv("STMMQR_LA_MIN") ? atol(getenv("STMMQR_LA_MIN")) : 2500;
+        // ... and when the panel workgroups of the step fit the compute units the side stream leaves alone (a wide step
+        // fills the GPU with panel workgroups by itself): STMMQR_LA_MAXPWG (default 48)
+        const long la_maxpwg = getenv("STMMQR_LA_MAXPWG") ? atol(getenv("STMMQR_LA_MAXPWG")) : 48;
+        auto worth_it = [&](const Step &S) -> bool {
+            long tiles = 0, pwg = 0;
+            for (int i = 0; i < S.n_act; i++) {
+                const FrontSym &fsym = P.fs[P.lists[S.act_off + i]];
+                const int p = P.lists[S.plist_off + i];
+                const int ncb = stm_upd_ncb(fsym, p);
+                if (ncb > 1) tiles += (long)(ncb - 1) * ((stm_panel_rows_est(fsym, p) + STM_UPD_SLAB - 1) / STM_UPD_SLAB);   // (expected rows, not the bound)
+                pwg += stm_use_ca(fsym, p, P.plan_algo, P.ca_min) ? stm_ca_slabs(fsym) : stm_tall_launches(fsym, p, P.tall_min);
+            }
+            return tiles >= la_min && pwg <= la_maxpwg;
+        };
+        long side_ev = -1;                                     // last side event the main stream has not waited for
+        bool prep_on_side = false;                             // prep(t) was issued on the side stream during step t-1
+        int e = 0;
+        for (size_t t = 0; t < ns; t++) {
+            const Step &S = SV[t];
+            if (prep_on_side) HIPCHK(hipStreamWaitEvent(st, P.ev_prep[t], 0));
+            else {
+                // (what a starting front assembles may have been packed on the side stream)
+                if (S.n_start > 0 && side_ev >= 0) { HIPCHK(hipStreamWaitEvent(st, P.ev_side[side_ev], 0)); side_ev = -1; }
+                if ((e = prep(S, st))) return e;
+            }
+            prep_on_side = false;
+            if (S.n_act > 0 && (e = panels(S))) return e;
+            const bool offload = S.n_act > 0 && S.maxcb > 1 && worth_it(S);
+            if (!offload) {
+                if (S.n_act > 0 && S.maxcb > 0) {
+                    if (side_ev >= 0) { HIPCHK(hipStreamWaitEvent(st, P.ev_side[side_ev], 0)); side_ev = -1; }
+                    if ((e = update(S, 0, S.maxcb, true, P.d_Wp.p, st))) return e;
+                }
+                if ((e = post(S, st))) return e;
+                continue;
+            }
+            if ((e = update(S, 0, 0, true, P.d_Wp.p, st))) return e;                                   // T
+            HIPCHK(hipEventRecord(P.ev_main[t], st));
+            if (side_ev >= 0) { HIPCHK(hipStreamWaitEvent(st, P.ev_side[side_ev], 0)); side_ev = -1; }
+            if ((e = update(S, 0, 1, false, P.d_Wp.p, st))) return e;                                  // block 0
+            HIPCHK(hipStreamWaitEvent(sd, P.ev_main[t], 0));
+            if ((e = post(S, sd))) return e;
+            if (t + 1 < ns && SV[t + 1].n_start > 0) {
+                if ((e = prep(SV[t + 1], sd))) return e;
+                HIPCHK(hipEventRecord(P.ev_prep[t + 1], sd));
+                prep_on_side = true;
+            }
+            if ((e = update(S, 1, S.maxcb - 1, false, P.d_Wp2.p, sd))) return e;
+            HIPCHK(hipEventRecord(P.ev_side[t], sd));
+            side_ev = (long)t;
+        }
+        if (side_ev >= 0) HIPCHK(hipStreamWaitEvent(st, P.ev_side[side_ev], 0));   // join: the caller continues on `stream`
     }
     P.stats.nlaunch += nlaunch;
     P.stats.nlevels += (long)P.glevels[grp].size();
+    P.stats.nsteps += (long)P.gsteps[grp].size();
     return 0;
 }
 
@@ -677,10 +972,29 @@ void stmmqr_get_common_layout(stm_common_layout *l) { if (l) *l = g_layout; }
 /* End of use (optional): waits for the device and releases what the library holds process-wide.  A host program that
  * dlopen()s the library calls it before returning from main; the library has no static object whose destructor calls
  * into the HIP runtime, so nothing else happens at exit / dlclose. */
+int stmmqr_device_alloc(size_t bytes, void **ptr)
+{
+    if (!ptr) return fail(STMMQR_ERR_INVALID, "null argument");
+    *ptr = nullptr;
+    if (hipMalloc(ptr, bytes ? bytes : 1) != hipSuccess) return fail(STMMQR_ERR_OUT_OF_MEMORY, "hipMalloc failed");
+    return 0;
+}
+int stmmqr_device_free(void *ptr)
+{
+    if (ptr && hipFree(ptr) != hipSuccess) return fail(STMMQR_ERR_DEVICE, "hipFree failed");
+    return 0;
+}
+
 void stmmqr_shutdown(void)
 {
     int cnt = 0;
-    if (hipGetDeviceCount(&cnt) == hipSuccess && cnt > 0) (void)hipDeviceSynchronize();
+    if (hipGetDeviceCount(&cnt) == hipSuccess && cnt > 0) {
+        (void)hipDeviceSynchronize();
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        destroy_side_streams();
+        (void)hipSetDevice(dev);
+    }
 }
 
 int stmmqr_device_count(void)
@@ -716,7 +1030,9 @@ stmmqr_plan *stmmqr_plan_create(const stmmqr_symbolic_view *sym, int device, int
     }
     if (!st) {
         (void)hipGetDevice(&P->device);
-        if (hipStreamCreateWithFlags(&P->stream, hipStreamNonBlocking) != hipSuccess)
+        int prio_lo = 0, prio_hi = 0;
+        (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
+        if (hipStreamCreateWithPriority(&P->stream, hipStreamNonBlocking, prio_hi) != hipSuccess)
             st = fail(STMMQR_ERR_DEVICE, "hipStreamCreate failed");
         for (auto &e : P->ev)
             if (!st && hipEventCreate(&e) != hipSuccess) st = fail(STMMQR_ERR_DEVICE, "hipEventCreate failed");
@@ -798,6 +1114,7 @@ int stmmqr_factorize_group(stmmqr_plan *plan, int group, int detail)
             // (the statistics run_schedule accumulates on the host)
             P.stats.nlaunch += P.graph_nlaunch;
             P.stats.nlevels += (long)P.glevels[0].size();
+            P.stats.nsteps += (long)P.gsteps[0].size();
         }
         if (!P.graph_nlaunch) P.graph_nlaunch = P.stats.nlaunch;
         HIPCHK(hipGraphLaunch(P.graph_exec, P.stream));
@@ -822,9 +1139,17 @@ int stmmqr_factorize_finish(stmmqr_plan *plan, stmmqr_stats *stats)
     HIPCHK(hipEventElapsedTime(&ms, P.ev[0], P.ev[1])); P.stats.ms_h2d = ms;
     HIPCHK(hipEventElapsedTime(&ms, P.ev[1], P.ev[5])); P.stats.ms_total = ms;
     HIPCHK(hipEventElapsedTime(&ms, P.ev[4], P.ev[5])); P.stats.ms_pack += ms;
+    // STMMQR_DUMPSTEPS=file (detail runs, diagnosis): one line per timeline step with what ran and how long it took
+    FILE *dump = (P.evused && getenv("STMMQR_DUMPSTEPS")) ? fopen(getenv("STMMQR_DUMPSTEPS"), "w") : nullptr;
+    std::vector<float> st_panel, st_upd;
+    if (dump && !P.gsteps.empty()) { st_panel.assign(P.gsteps[0].size(), 0.f); st_upd.assign(P.gsteps[0].size(), 0.f); }
     for (size_t q = 0; q < P.evused; q++) {
         float t = 0;
         HIPCHK(hipEventElapsedTime(&t, P.evpairs[q].a, P.evpairs[q].b));
+        if (dump && (size_t)P.evpairs[q].step < st_panel.size()) {
+            if (P.evpairs[q].cat == 2) st_panel[(size_t)P.evpairs[q].step] += t;
+            if (P.evpairs[q].cat == 3) st_upd[(size_t)P.evpairs[q].step] += t;
+        }
         switch (P.evpairs[q].cat) {
             case 0: P.stats.ms_assemble += t; break;
             case 1: P.stats.ms_front += t; P.stats.ms_small += t; break;
@@ -834,6 +1159,23 @@ int stmmqr_factorize_finish(stmmqr_plan *plan, stmmqr_stats *stats)
         }
     }
     P.evused = 0;
+    if (dump) {
+        for (size_t t = 0; t < st_panel.size(); t++) {
+            const Step &S = P.gsteps[0][t];
+            int maxrows = 0, pwg = 0;
+            long tiles = 0;
+            for (int i = 0; i < S.n_act; i++) {
+                const FrontSym &fsym = P.fs[P.lists[S.act_off + i]];
+                const int p = P.lists[S.plist_off + i];
+                maxrows = std::max(maxrows, stm_panel_rows_est(fsym, p));
+                pwg += stm_use_ca(fsym, p, P.plan_algo, P.ca_min) ? stm_ca_slabs(fsym) : stm_tall_launches(fsym, p, P.tall_min);
+                tiles += (long)stm_upd_ncb(fsym, p) * stm_upd_nsl(fsym);
+            }
+            fprintf(dump, "%zu n_act %d maxrows %d nsub %d pwg %d nca_use %d maxcb %d maxsl %d split %d tiles %ld panel_us %.1f upd_us %.1f\n", t,
+                    S.n_act, maxrows, S.nsub, pwg, S.nca_use, S.maxcb, S.maxsl, S.split, tiles, 1e3 * st_panel[t], 1e3 * st_upd[t]);
+        }
+        fclose(dump);
+    }
 
     // per-front numeric summary (small): flops, ranks
     P.h_fnum.resize((size_t)std::max(1L, P.nf));
@@ -925,6 +1267,7 @@ int stmmqr_plan_set_groups(stmmqr_plan *plan, const int *group)
     LCHK(P.d_Wp2.alloc((size_t)P.wp_doubles));
     LCHK(P.d_tslot.upload(tslot, P.stream));
     LCHK(P.d_lists.upload(P.lists, P.stream));
+    LCHK(P.d_wlists.upload(P.wlists, P.stream));
     HIPCHK(hipStreamSynchronize(P.stream));
     return 0;
 }

@@ -52,12 +52,12 @@ int stm_launch_gather_sx(const double *Ax, const int *smap, double *Sx, int anz,
 int stm_launch_setup(const DevCtx &c, const int *flist, int nfr, hipStream_t st);
 int stm_launch_assemble(const DevCtx &c, const int *flist, const int *nparts, int nfr, int maxparts, hipStream_t st);
 int stm_launch_front_wg(const DevCtx &c, const int *flist, int nfr, int lds_doubles, hipStream_t st);
-int stm_launch_panel(const DevCtx &c, const int *flist, int nfr, int p, int nsub, int defer_ok, int lds_doubles, hipStream_t st);
+int stm_launch_panel(const DevCtx &c, const int *flist, const int *plist, int nfr, int nsub, int defer_ok, int lds_doubles, hipStream_t st);
 int stm_configure_capanel(void);
-int stm_launch_panel_ca(const DevCtx &c, const int *flist, int nfr, int p, int nw, int defer_ok, hipStream_t st);
-int stm_launch_update(const DevCtx &c, const int *flist, int nfr, int p, int cb0, int ncb, hipStream_t st);
-int stm_launch_update_split(const DevCtx &c, const int *flist, int nfr, int p, int cb0, int ncb, int maxsl, double *Wp,
-                            int with_gram, hipStream_t st);
+int stm_launch_panel_ca(const DevCtx &c, const int *flist, const int *plist, int nfr, int nw, int defer_ok, hipStream_t st);
+int stm_launch_update(const DevCtx &c, const int *flist, const int *plist, int nfr, int cb0, int ncb, hipStream_t st);
+int stm_launch_update_split(const DevCtx &c, const int *flist, const int *plist, int nfr, int cb0, int ncb, int maxsl, double *Wp,
+                            const long long *wpoff, int with_gram, hipStream_t st);
 int stm_launch_larft(const DevCtx &c, int f, hipStream_t st);
 int stm_launch_cpack(const DevCtx &c, const int *flist, const int *nparts, int nfr, int maxparts, hipStream_t st);
 int stm_launch_rh_count(const DevCtx &c, const int *flist, int nfr, hipStream_t st);

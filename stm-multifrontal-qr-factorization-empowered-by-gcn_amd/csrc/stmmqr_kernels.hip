@@ -1640,11 +1640,14 @@ __global__ __launch_bounds__(NT) void k_front_wg(DevCtx c, const int *__restrict
 // large fronts: panel and trailing update are separate launches (many workgroups per update)
 // ------------------------------------------------------------------------------------------------
 #define NTP 512               // threads of the large-front panel kernel (8 waves, <= 256 VGPRs each)
-__global__ __launch_bounds__(NTP) void k_panel(DevCtx c, const int *__restrict__ flist, int p, int nsub, int defer_ok, int lds_doubles)
+__global__ __launch_bounds__(NTP) void k_panel(DevCtx c, const int *__restrict__ flist, const int *__restrict__ plist, int nsub,
+                                               int defer_ok, int lds_doubles)
 {
     extern __shared__ double dyn_lds[];
     __shared__ PanelShared ps;
     const int f = flist[blockIdx.x];
+    const int p = plist[blockIdx.x];                           // every front of a step is at its own panel
+    __builtin_amdgcn_s_setprio(3);                             // (critical path: ahead of the side stream's update waves)
     const FrontSym s = c.fs[f];
     if (p >= s.npanels || stm_use_ca(s, p, c.panel_algo, c.ca_min_rows)) return;      // (the Gram-based panel kernel takes those)
     FrontNum *num = &c.fnum[f];
@@ -1674,7 +1677,8 @@ __global__ __launch_bounds__(NTP) void k_panel(DevCtx c, const int *__restrict__
             w = (tmax - g1 > STM_TALL_XWIDE) ? 2 : (tmax - g1 > STM_TALL_WIDE) ? 4 : STM_SW;
             // mode 0: nothing to do or the whole panel is done below by this workgroup (it does not fit the register
             // image, or needs more groups than were launched: more rows than the full-rank estimate)
-            mode = (was_done || tmax - g1 > STM_TALL_MAX || (nbp + w - 1) / w > nsub) ? 0 : 1;
+            // (the groups the PLAN launches for this front -- not the launch's, which other fronts may have raised)
+            mode = (was_done || tmax - g1 > STM_TALL_MAX || (nbp + w - 1) / w > min(nsub, stm_tall_launches(s, p, c.tall_min))) ? 0 : 1;
             __syncthreads();
             if (threadIdx.x == 0) {
                 st_agent(&pd->mode, mode); st_agent(&pd->pg1, g1); st_agent(&pd->pt, g1); st_agent(&pd->tmax, tmax);
@@ -1700,19 +1704,26 @@ __global__ __launch_bounds__(NTP) void k_panel(DevCtx c, const int *__restrict__
             return;
         }
     }
-    if ((c.dbg & 64) || panel_rows(s, num, St, p) > lds_doubles - 65)
+    // One workgroup does the whole panel.  The LDS it stages sub-panels in is a property of the FRONT (stm_front_lds: what
+    // the front would get alone), never of the launch -- the sub-panel width, and with it the rounding, must not depend on
+    // the fronts that share the step.  The host sizes the launch for the fronts PLANNED to come here; a panel that was
+    // planned for the pipeline and fell back (more rows than the full-rank estimate, recovery of a timed-out wait) works
+    // in place when the launch is smaller than that.
+    const int lds_front = stm_front_lds(s);
+    if ((c.dbg & 64) || lds_front > lds_doubles || panel_rows(s, num, St, p) > lds_front - 65)
         dev_panel<NTP, true>(ps, s, num, F, St, c.Tau + s.rp, c.Rdead + s.col1, p, c.tol, c.ntol, T, dyn_lds,
-                             lds_doubles, c.dbg, c.dbgbuf, Tkeep, c.sig);
+                             lds_front, c.dbg, c.dbgbuf, Tkeep, c.sig);
     else
         dev_panel<NTP, false>(ps, s, num, F, St, c.Tau + s.rp, c.Rdead + s.col1, p, c.tol, c.ntol, T, dyn_lds,
-                              lds_doubles, c.dbg, c.dbgbuf, Tkeep, c.sig);
+                              lds_front, c.dbg, c.dbgbuf, Tkeep, c.sig);
     if (threadIdx.x == 0) { pd->mode = 0; pd->t_deferred = 0; }
 }
 
-__global__ __launch_bounds__(NT) void k_update(DevCtx c, const int *__restrict__ flist, int p, int cb0)
+__global__ __launch_bounds__(NT) void k_update(DevCtx c, const int *__restrict__ flist, const int *__restrict__ plist, int cb0)
 {
     extern __shared__ double dyn_lds[];
     const int f = flist[blockIdx.y];
+    const int p = plist[blockIdx.y];
     const FrontSym s = c.fs[f];
     if (p >= s.npanels) return;
     const PanelDesc *pd = &c.fnum[f].pd[p & 1];
@@ -1763,22 +1774,25 @@ __global__ __launch_bounds__(NT) void k_larft(DevCtx c, int f)
 // ------------------------------------------------------------------------------------------------
 #define SLAB STM_UPD_SLAB
 
-__global__ __launch_bounds__(NT) void k_upd_w(DevCtx c, const int *__restrict__ flist, int p, int cb0, double *Wp,
-                                              int maxcb, int maxsl)
+__global__ __launch_bounds__(NT) void k_upd_w(DevCtx c, const int *__restrict__ flist, const int *__restrict__ plist, int cb0,
+                                              int with_gram, double *Wp, const long long *__restrict__ wpoff)
 {
     extern __shared__ double dyn_lds[];
     __shared__ int s_pd[STM_NB];
-    const int fi = blockIdx.z, f = flist[fi];
+    const int fi = blockIdx.z, f = flist[fi], p = plist[fi];
     const FrontSym s = c.fs[f];
     if (p >= s.npanels) return;
     const PanelDesc *pd = &c.fnum[f].pd[p & 1];
     const int g1 = pd->pg1, mp = pd->pt - pd->pg1, nbp = pd->pnb;
     const int cb = blockIdx.x, sl = blockIdx.y;
-    // the column block after the last one (cb == maxcb; launched when T may have been left to this kernel) is the Gram
-    // block: C = V, partial V'V per slab; the last slab workgroup of a front to arrive sums them in slab order and
+    // the front's slice of the workspace: (ncbf + 1) column-block slots of nslf slabs (both symbolic: the host sized it so)
+    const int ncbf = stm_upd_ncb(s, p), nslf = stm_upd_nsl(s);
+    // with_gram: the LAST column block of the launch is the Gram block (T may have been left to this kernel):
+    // C = V, partial V'V per slab; the last slab workgroup of a front to arrive sums them in slab order and
     // builds T (dlarft recurrence) for k_upd_c
-    const bool gram = (cb == maxcb);
+    const bool gram = with_gram && (cb == (int)gridDim.x - 1);
     if (gram && !pd->t_deferred) return;
+    if (!gram && cb0 + cb >= ncbf) return;
     const int c0 = gram ? pd->pk1 : pd->pc0 + (cb0 + cb) * BN;
     if (nbp <= 0 || mp <= 0 || c0 >= s.fn || sl * SLAB >= mp) return;
     const int nc = gram ? nbp : min(BN, s.fn - c0);
@@ -1806,7 +1820,7 @@ __global__ __launch_bounds__(NT) void k_upd_w(DevCtx c, const int *__restrict__ 
         }
         __syncthreads();
     }
-    double *W = Wp + ((long long)(fi * (maxcb + 1) + cb) * maxsl + sl) * (STM_NB * BN);
+    double *W = Wp + wpoff[fi] + ((long long)(gram ? ncbf : cb) * nslf + sl) * (STM_NB * BN);
     if (!gram) {
 #pragma unroll
         for (int r = 0; r < 4; r++) W[(16 * mi + l4 + 4 * r) * BN + 16 * ni + l15] = acc[r];
@@ -1835,11 +1849,10 @@ __global__ __launch_bounds__(NT) void k_upd_w(DevCtx c, const int *__restrict__ 
     if (s_ticket != nsl - 1) return;
     double *s_G = Vs;                                          // [row * WS + col] (the chunk images are free now)
     __shared__ double s_tau[STM_NB];
-    const double *G0 = Wp + ((long long)(fi * (maxcb + 1) + maxcb) * maxsl) * (STM_NB * BN);
+    const double *G0 = Wp + wpoff[fi] + ((long long)ncbf * nslf) * (STM_NB * BN);
     if (tid < STM_NB) s_tau[tid] = (tid < nbp) ? c.Tau[s.rp + pd->pk1 + tid] : 0.0;
     for (int e = tid; e < STM_NB * BN; e += NT) {
-        double gsum = 0;
-        for (int q = 0; q < nsl; q++) gsum += G0[(long long)q * (STM_NB * BN) + e];     // fixed order: deterministic
+        const double gsum = stm_ordered_sum<false>(G0 + e, STM_NB * BN, nsl);      // fixed order: deterministic
         s_G[(e / BN) * WS + (e % BN)] = gsum;                  // G(row, col) = v_row' v_col
     }
     __syncthreads();
@@ -1855,50 +1868,18 @@ __global__ __launch_bounds__(NT) void k_upd_w(DevCtx c, const int *__restrict__ 
     }
 }
 
-__global__ __launch_bounds__(NT) void k_upd_t(DevCtx c, const int *__restrict__ flist, int p, int cb0, double *Wp,
-                                              int maxcb, int maxsl)
-{
-    __shared__ double s_W[STM_NB * WS];
-    const int fi = blockIdx.y, f = flist[fi];
-    const FrontSym s = c.fs[f];
-    if (p >= s.npanels) return;
-    const PanelDesc *pd = &c.fnum[f].pd[p & 1];
-    const int mp = pd->pt - pd->pg1, nbp = pd->pnb;
-    const int cb = blockIdx.x;
-    const int c0 = pd->pc0 + (cb0 + cb) * BN;
-    if (nbp <= 0 || mp <= 0 || c0 >= s.fn) return;
-    const int nsl = (mp + SLAB - 1) / SLAB;
-    const int tid = threadIdx.x;
-    double *W0 = Wp + ((long long)(fi * (maxcb + 1) + cb) * maxsl) * (STM_NB * BN);
-    const double *T = c.Tws + (long long)(2 * c.tslot[f] + (p & 1)) * STM_NB * STM_NB;
-    for (int e = tid; e < STM_NB * BN; e += NT) {
-        double v = 0;
-        for (int sl = 0; sl < nsl; sl++) v += W0[(long long)sl * (STM_NB * BN) + e];
-        s_W[(e / BN) * WS + (e % BN)] = v;
-    }
-    __syncthreads();
-    const int l = tid & 31, cg = tid >> 5;
-    double w2[4] = {0, 0, 0, 0};
-    for (int q = 0; q <= l; q++) {
-        const double tq = T[q + l * STM_NB];
-#pragma unroll
-        for (int x = 0; x < 4; x++) w2[x] += tq * s_W[q * WS + cg * 4 + x];
-    }
-#pragma unroll
-    for (int x = 0; x < 4; x++) W0[l * BN + cg * 4 + x] = w2[x];      // slab 0 slot now holds W2
-}
-
-__global__ __launch_bounds__(NT) void k_upd_c(DevCtx c, const int *__restrict__ flist, int p, int cb0,
-                                              const double *Wp, int maxcb, int maxsl)
+__global__ __launch_bounds__(NT) void k_upd_c(DevCtx c, const int *__restrict__ flist, const int *__restrict__ plist, int cb0,
+                                              const double *Wp, const long long *__restrict__ wpoff)
 {
     extern __shared__ double dyn_lds[];
     __shared__ int s_pd[STM_NB];
-    const int fi = blockIdx.z, f = flist[fi];
+    const int fi = blockIdx.z, f = flist[fi], p = plist[fi];
     const FrontSym s = c.fs[f];
     if (p >= s.npanels) return;
     const PanelDesc *pd = &c.fnum[f].pd[p & 1];
     const int g1 = pd->pg1, mp = pd->pt - pd->pg1, nbp = pd->pnb;
     const int cb = blockIdx.x, sl = blockIdx.y;
+    const int nslf = stm_upd_nsl(s);
     const int c0 = pd->pc0 + (cb0 + cb) * BN;
     if (nbp <= 0 || mp <= 0 || c0 >= s.fn || sl * SLAB >= mp) return;
     // Very tall panels: one workgroup takes 2 or 4 slabs -- every workgroup of a column block sums the same nsl partial
@@ -1925,11 +1906,10 @@ __global__ __launch_bounds__(NT) void k_upd_c(DevCtx c, const int *__restrict__ 
     // launch less per panel); the summation order over the slabs is fixed
     {
         const int nsl = (mp + SLAB - 1) / SLAB;
-        const double *W0 = Wp + ((long long)(fi * (maxcb + 1) + cb) * maxsl) * (STM_NB * BN);
+        const double *W0 = Wp + wpoff[fi] + ((long long)cb * nslf) * (STM_NB * BN);
         const double *T = c.Tws + (long long)(2 * c.tslot[f] + (p & 1)) * STM_NB * STM_NB;
         for (int e = tid; e < STM_NB * BN; e += NT) {
-            double v = 0;
-            for (int q = 0; q < nsl; q++) v += W0[(long long)q * (STM_NB * BN) + e];
+            const double v = stm_ordered_sum<false>(W0 + e, STM_NB * BN, nsl);
             s_W1[(e / BN) * WS + (e % BN)] = v;
             s_T[(e / STM_NB) * WS + (e % STM_NB)] = T[e];          // s_T[col][row] = T(row, col)
         }
@@ -2427,7 +2407,7 @@ __global__ __launch_bounds__(QB_ROWS) void k_qbig_step(DevCtx c, const QbDesc *_
         for (int q = 0; q < STM_NB * STM_NB / QB_ROWS; q++) treg[q] = T[tid + QB_ROWS * q];
         if (tid < STM_NB) {
             const double *wp = Wq + (long long)(pp[0] & 1) * nslab * STM_NB;
-            for (int q = 0; q < nslab; q++) wsum += wp[q * STM_NB + tid];                       // fixed order: deterministic
+            wsum += stm_ordered_sum<false>(wp + tid, STM_NB, nslab);                            // fixed order: deterministic
         }
     }
     if (on[1]) {
@@ -2840,7 +2820,7 @@ int stm_launch_front_wg(const DevCtx &c, const int *flist, int nfr, int lds_doub
     hipLaunchKernelGGL(k_front_wg, dim3(nfr), dim3(NT), bytes, st, c, flist, (int)(bytes / sizeof(double)));
     return (int)hipGetLastError();
 }
-int stm_launch_panel(const DevCtx &c, const int *flist, int nfr, int p, int nsub, int defer_ok, int lds_doubles, hipStream_t st)
+int stm_launch_panel(const DevCtx &c, const int *flist, const int *plist, int nfr, int nsub, int defer_ok, int lds_doubles, hipStream_t st)
 {
     if (nfr <= 0) return 0;
     size_t bytes = (size_t)lds_doubles * sizeof(double);
@@ -2848,33 +2828,33 @@ int stm_launch_panel(const DevCtx &c, const int *flist, int nfr, int p, int nsub
     // One workgroup per column group of the panel pipeline (blockIdx.y); fronts whose panel is not pipelined use group 0.
     // The column groups of a pipelined panel wait for each other, but only ever for groups with a smaller blockIdx.y of the
     // same front, i.e. for workgroups that the in-order dispatch has already started (the assumption of every
-    // decoupled-look-back scan); the waits are bounded and fail the factorization loudly if that ever breaks.
+    // decoupled-look-back scan); the waits are bounded and a wait that runs out is recovered (stmmqr_factorize_device).
     // Oversubscribed launches (more workgroups than the GPU holds: groups start late) are exercised by the tests;
     // STMMQR_DBG bit 9 + STMMQR_CHUNK launch the fronts in chunks instead (tests).
     int K = nfr;
     if (nsub > 1 && (c.dbg & 512)) K = getenv("STMMQR_CHUNK") ? atoi(getenv("STMMQR_CHUNK")) : 1;
     if (K < 1) K = 1;
     for (int i = 0; i < nfr; i += K)
-        hipLaunchKernelGGL(k_panel, dim3(nfr - i < K ? nfr - i : K, nsub), dim3(NTP), bytes, st, c, flist + i, p, nsub, defer_ok,
+        hipLaunchKernelGGL(k_panel, dim3(nfr - i < K ? nfr - i : K, nsub), dim3(NTP), bytes, st, c, flist + i, plist + i, nsub, defer_ok,
                            (int)(bytes / sizeof(double)));
     return (int)hipGetLastError();
 }
-int stm_launch_update(const DevCtx &c, const int *flist, int nfr, int p, int cb0, int ncb, hipStream_t st)
+int stm_launch_update(const DevCtx &c, const int *flist, const int *plist, int nfr, int cb0, int ncb, hipStream_t st)
 {
     if (nfr <= 0 || ncb <= 0) return 0;
-    hipLaunchKernelGGL(k_update, dim3(ncb, nfr), dim3(NT), (size_t)stm_update_lds_bytes(), st, c, flist, p, cb0);
+    hipLaunchKernelGGL(k_update, dim3(ncb, nfr), dim3(NT), (size_t)stm_update_lds_bytes(), st, c, flist, plist, cb0);
     return (int)hipGetLastError();
 }
-int stm_launch_update_split(const DevCtx &c, const int *flist, int nfr, int p, int cb0, int ncb, int maxsl, double *Wp,
-                            int with_gram, hipStream_t st)
+int stm_launch_update_split(const DevCtx &c, const int *flist, const int *plist, int nfr, int cb0, int ncb, int maxsl, double *Wp,
+                            const long long *wpoff, int with_gram, hipStream_t st)
 {
-    if (nfr <= 0 || ncb <= 0 || maxsl <= 0) return 0;
+    if (nfr <= 0 || ncb + (with_gram ? 1 : 0) <= 0 || maxsl <= 0) return 0;
     const size_t lds = (size_t)stm_update_lds_bytes();
     // (with_gram: one more column block, V'V for the fronts whose panel kernel left T to the update)
     // (k_upd_w stages V and C chunks only: 34 KB, four workgroups per CU)
     hipLaunchKernelGGL(k_upd_w, dim3(ncb + (with_gram ? 1 : 0), maxsl, nfr), dim3(NT), (size_t)(2 * BN * VS) * sizeof(double), st, c,
-                       flist, p, cb0, Wp, ncb, maxsl);
-    hipLaunchKernelGGL(k_upd_c, dim3(ncb, maxsl, nfr), dim3(NT), lds, st, c, flist, p, cb0, (const double *)Wp, ncb, maxsl);
+                       flist, plist, cb0, with_gram ? 1 : 0, Wp, wpoff);
+    if (ncb > 0) hipLaunchKernelGGL(k_upd_c, dim3(ncb, maxsl, nfr), dim3(NT), lds, st, c, flist, plist, cb0, (const double *)Wp, wpoff);
     return (int)hipGetLastError();
 }
 int stm_launch_larft(const DevCtx &c, int f, hipStream_t st)

@@ -175,15 +175,22 @@ stm_long stmmqr_front(stm_long m, stm_long n, stm_long npiv, double tol, stm_lon
         const bool split = opt.split_update && msl >= 3;
         Buf<double> d_Wp;
         if (split && !d_Wp.alloc((size_t)((n + 31) / 32 + 1) * (size_t)msl * STM_NB * 32)) return -1;
+        // the launchers take the panel index of every front of a launch from a device list
+        std::vector<int> hp((size_t)std::max(1, X.s.npanels));
+        for (size_t q = 0; q < hp.size(); q++) hp[q] = (int)q;
+        Buf<int> d_pl;
+        Buf<long long> d_wpoff;
+        const std::vector<long long> zoff(1, 0);
+        if (!d_pl.up(hp) || !d_wpoff.up(zoff)) return -1;
         for (int p = 0; p < X.s.npanels && !e; p++) {
             const int k2 = (int)std::min<long>(n, (long)(p + 1) * STM_NB);
             const int ncb = (int)((n - k2 + 31) / 32);
             const int defer_ok = (ncb > 0) ? 1 : 0;
-            if (stm_use_ca(X.s, p, opt.panel_algo)) e = stm_launch_panel_ca(X.c, X.d_flist.p, 1, p, stm_ca_slabs(X.s), defer_ok, nullptr);
-            else e = stm_launch_panel(X.c, X.d_flist.p, 1, p, stm_tall_launches(X.s, p, X.c.tall_min), defer_ok, lds_for(m), nullptr);
+            if (stm_use_ca(X.s, p, opt.panel_algo)) e = stm_launch_panel_ca(X.c, X.d_flist.p, d_pl.p + p, 1, stm_ca_slabs(X.s), defer_ok, nullptr);
+            else e = stm_launch_panel(X.c, X.d_flist.p, d_pl.p + p, 1, stm_tall_launches(X.s, p, X.c.tall_min), defer_ok, lds_for(m), nullptr);
             if (e || ncb <= 0) continue;
-            if (split) e = stm_launch_update_split(X.c, X.d_flist.p, 1, p, 0, ncb, msl, d_Wp.p, 1, nullptr);
-            else e = stm_launch_update(X.c, X.d_flist.p, 1, p, 0, ncb, nullptr);
+            if (split) e = stm_launch_update_split(X.c, X.d_flist.p, d_pl.p + p, 1, 0, ncb, msl, d_Wp.p, d_wpoff.p, 1, nullptr);
+            else e = stm_launch_update(X.c, X.d_flist.p, d_pl.p + p, 1, 0, ncb, nullptr);
         }
         if (hipDeviceSynchronize() != hipSuccess) e = -1;          // (d_Wp is released at the end of this scope)
     }
@@ -264,7 +271,7 @@ int stmmqr_larftb_qtx(stm_long m, stm_long n, stm_long k, stm_long ldc, stm_long
         // a reflector with tau = 0 is the identity; one whose diagonal falls below m does not exist
         if (!X.push_num()) return STMMQR_ERR_DEVICE;
         if (stm_launch_larft(X.c, 0, nullptr)) return STMMQR_ERR_DEVICE;
-        if (stm_launch_update(X.c, X.d_flist.p, 1, 0, 0, (int)((n + 31) / 32), nullptr)) return STMMQR_ERR_DEVICE;
+        if (stm_launch_update(X.c, X.d_flist.p, X.d_flist.p /* panel 0 */, 1, 0, (int)((n + 31) / 32), nullptr)) return STMMQR_ERR_DEVICE;
     }
     if (hipDeviceSynchronize() != hipSuccess) return STMMQR_ERR_DEVICE;
     if (!X.d_F.down(Fd.data(), Fd.size())) return STMMQR_ERR_DEVICE;

@@ -64,7 +64,11 @@ STANDINS = {
     # 13 nnz per row) at 1/6.5 of its size: n = 8000, top front 0.4 n, 4.4e11 flops (the full size, n = 52 022, is
     # ~1.2e14 flops and ~20 GB of factors: 47 minutes for the reference on one core)
     "c5mini_standin": (20, 20, 20, 0x33445F35, False, 2, 1, 6),
-    # ... and at FULL size (gen3d(37, 37, 38), n = 52 022): top fronts above 8192 rows, ~1e14 flops
+    # ... at half the full size: n = 27 000, top fronts far above 8192 rows (the size class the library's 2^31-entries-per-
+    # front limit and Sum(fm_ub * fn) arenas still hold on one GPU)
+    "c5mid_standin": (30, 30, 30, 0x33445F35, False, 2, 1, 6),
+    # ... and at FULL size (gen3d(37, 37, 38), n = 52 022): ~1.2e14 flops; its top fronts exceed 2^31 entries
+    # (R+H block of the root: 2.2e9 doubles), beyond the library's per-front index range -- not a fixture
     "c5_standin": (37, 37, 38, 0x33445F35, False, 2, 1, 6),
 }
 

@@ -83,8 +83,16 @@ def block_sketch(v: np.ndarray) -> np.ndarray:
     """(||v||_2, <v,w1>, <v,w2>) -- order-sensitive fingerprint of one packed block."""
     if v.size == 0:
         return np.zeros(3)
-    w1, w2 = sketch_weights(v.size)
-    return np.array([np.linalg.norm(v), float(v @ w1), float(v @ w2)])
+    if v.size <= (1 << 24):
+        w1, w2 = sketch_weights(v.size)
+        return np.array([np.linalg.norm(v), float(v @ w1), float(v @ w2)])
+    # very large blocks: the same sums in pieces (no index / weight arrays of the block's size)
+    ss = d1 = d2 = 0.0
+    for a in range(0, v.size, 1 << 24):
+        x = v[a:a + (1 << 24)]
+        i = np.arange(a, a + x.size, dtype=np.float64)
+        ss += float(x @ x); d1 += float(x @ np.sin(0.7 * i + 0.3)); d2 += float(x @ np.cos(1.3 * i + 0.1))
+    return np.array([np.sqrt(ss), d1, d2])
 
 
 def determined_mask(Stair, fp: int, fn: int, fm: int) -> np.ndarray:

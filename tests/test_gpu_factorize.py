@@ -86,6 +86,27 @@ def test_gram_panel_everywhere(pkg, oracle, monkeypatch, name, late):
     compare_numeric(oracle, S, G, No, g, ftol=1e-10, name=name)
 
 
+@pytest.mark.parametrize("name", NAMES)
+@pytest.mark.parametrize("bfc,algo", [(64, 0), (16, 0), (16, 2), (8, 1)])
+def test_lookahead_schedule_same_bits(pkg, name, bfc, algo):
+    """options.lookahead (default 1): the update beyond the next panel's columns, the packing of finished fronts and the
+    assembly of the next ones run on a second stream beside the panel chain.  Every kernel does what it does in the serial
+    order: the factors must be the same bits (and the other tests, which run with the default, cover parity)."""
+    g = load_golden(name)
+    out = []
+    try:
+        for la in (0, 1):
+            pkg.set_options(lookahead=la, big_front_cols=bfc, panel_algo=algo)
+            S, G = gpu_run(pkg, g)
+            out.append((G.Stack[:G.rh_total].copy(), G.HTau.copy(), G.HStair.copy(), G.Rdead.copy(), G.rank))
+    finally:
+        pkg.set_options(lookahead=1, big_front_cols=64, panel_algo=0)
+    a, b = out
+    assert a[4] == b[4]
+    for x, y in zip(a[:4], b[:4]):
+        assert np.array_equal(x, y, equal_nan=True)
+
+
 @pytest.mark.parametrize("name,tall_min", [(n, 256) for n in NAMES] +
                          [(n, t) for n in ("syn_grid3d", "syn_rankdef_grid", "bcsstk14", "grid20_standin") for t in (48, 1 << 30)])
 def test_panel_pipeline_threshold(pkg, oracle, name, tall_min):

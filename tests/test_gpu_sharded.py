@@ -36,16 +36,12 @@ def test_sharded_equals_unsharded(name, nranks):
         # the tree of joins: before phase k every contribution block that enters it from another "rank" moves (device
         # to device: export into a device buffer, import from it)
         if k > 0:
-            import ctypes
-            hip = ctypes.CDLL("libamdhip64.so")
             for c, par in sh.cross_edges(sym, owner, phase, k):
                 info = plans[owner[c]].front_info(c)
-                buf = ctypes.c_void_p()
-                assert hip.hipMalloc(ctypes.byref(buf), ctypes.c_size_t(8 * max(info["csize"], 1))) == 0
-                rows = plans[owner[c]].export_front_dev(c, buf.value, info)
-                assert hip.hipDeviceSynchronize() == 0
-                plans[owner[par]].import_front_dev(c, info["fm"], info["rank"], info["cm"], buf.value, rows)
-                assert hip.hipFree(buf) == 0
+                buf = pkg.device_alloc(8 * max(info["csize"], 1))
+                rows = plans[owner[c]].export_front_dev(c, buf, info)
+                plans[owner[par]].import_front_dev(c, info["fm"], info["rank"], info["cm"], buf, rows)
+                pkg.device_free(buf)
                 nmoved += 1
         for r in range(nranks):
             if np.any((owner == r) & (phase == k)):
