@@ -272,6 +272,7 @@ def main():
     ap.add_argument("--panel-algo", type=int, default=None)
     ap.add_argument("--lookahead", type=int, default=None)
     ap.add_argument("--tall-min", type=int, default=None)
+    ap.add_argument("--fused-update", type=int, default=None)
     ap.add_argument("--mode", choices=["replicas", "sharded"], default=None,
                     help="N>1: sharded (default) = ONE matrix, subtrees on the ranks, contribution blocks up a tree of joins "
                          "over RCCL point-to-point (strong scaling); replicas = every rank factorizes its own matrix (weak)")
@@ -302,6 +303,8 @@ def main():
         pkg.set_options(panel_algo=args.panel_algo)
     if args.lookahead is not None:
         pkg.set_options(lookahead=args.lookahead)
+    if args.fused_update is not None:
+        pkg.set_options(fused_update=args.fused_update)
     if args.tall_min is not None:
         pkg.set_options(tall_min_rows=args.tall_min)
     name = args.workload
@@ -423,7 +426,7 @@ def main():
                             "frac": det["bytes_assemble"] / max(det["ms_assemble"], 1e-9) * 1e-6 / PEAK_HBM_GBS}
         roof["ms"] = {k: det[k] for k in ("ms_total", "ms_assemble", "ms_panel", "ms_small", "ms_update", "ms_pack")}
         oname = ORDERING_NAMES.get(int(g["ordering"][0]), str(int(g["ordering"][0]))) if "ordering" in g else "unknown"
-        standin_of = {"xenon1": "xenon1.mtx", "sme3dc": "sme3Dc.mtx", "c5": "3D_51448_3D.mtx (structure only, n = 8000)"}
+        standin_of = {"xenon1": "xenon1.mtx", "sme3dc": "sme3Dc.mtx", "c5mid": "3D_51448_3D.mtx (structure only, n = 27 000)", "c5": "3D_51448_3D.mtx (structure only, n = 8000)"}
         sof = next((v for k, v in standin_of.items() if name.startswith(k)), None)
         wl = (f"{name}: m={S.m} n={S.n} nnz={S.anz} fronts={S.nf} flops/step={flops:.4g}, ordering {oname}" +
               (f" (stand-in for {sof}, absent from the reference checkout)" if "standin" in name and sof else ""))

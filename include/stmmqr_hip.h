@@ -239,7 +239,7 @@ double stmmqr_last_seam_ms(void);
 /* ================================================================================================
  * 3. Configuration / introspection
  * ================================================================================================ */
-/* Defaults: {32, 64, 0, 0, 0, 1, 0, 1}.  Read when a plan is created (or a seam is called); the numerical results do not
+/* Defaults: {32, 64, 0, 0, 0, 1, 0, 1, 0}.  Read when a plan is created (or a seam is called); the numerical results do not
  * depend on them beyond rounding.
  * Environment (diagnosis and tests only): STMMQR_DBG (bit mask, csrc/stmmqr_kernels.h), STMMQR_QBIG_MIN (entries of a
  * front from which Q-apply / back substitution split its rows over workgroups; default 2097152, read at plan time),
@@ -257,6 +257,11 @@ typedef struct stmmqr_options {
     int lookahead;          /* 1 (default): the trailing update beyond the next panel's columns, the packing of finished
                                fronts and the assembly of the next ones run on a second stream beside the panel chain;
                                0: one stream, serial order.  Same bits either way.                                  */
+    int fused_update;       /* 0 (default): the row-parallel trailing update is two launches (k_upd_w, k_upd_c);
+                               1: ONE launch that keeps its tiles of C in registers between V'C and the application
+                               (C read once, written once per panel).  Same bits either way; measured 1.1x - 2.5x slower
+                               on MI355X (the slab workgroups of a column block idle while one of them adds the partial
+                               sums: DESIGN.md 5), kept as an experiment.                                            */
 } stmmqr_options;
 void stmmqr_get_options(stmmqr_options *opt);
 void stmmqr_set_options(const stmmqr_options *opt);

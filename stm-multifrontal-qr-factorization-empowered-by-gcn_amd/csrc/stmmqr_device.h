@@ -146,6 +146,7 @@ struct FrontNum {
     int prog;                // ... STM_PROG*p + 2*(finished groups of panel p) + (1: first half of the next one); monotone
     int perr;                // ... set when a bounded wait ran out (the factorization is reported as failed)
     int gcnt;                // arrival counter of the Gram slabs in k_upd_w (back to 0 after every panel)
+    int tready;              // fused update: step + 1 once T of the panel of that step is in its slot (Gram block's last slab)
     double flops;            // reference flop count of this front  (FLOP_COUNT, :1571)
     double flops_upd;        // the part of `flops` that the trailing update does: sum (t-g) * 4 * (fn - k2), k2 = panel end
     // pending block reflectors, double buffered by panel parity so that the look-ahead schedule can factorize

@@ -71,3 +71,26 @@ __device__ __forceinline__ double stm_ordered_sum(const double *p, long long str
     }
     return v;
 }
+
+// One lane polls *flag (agent scope) until it is >= `target` (the flags of one factorization only grow); bounded, and it
+// gives up at once when *abort is set (some wait of this factorization has already run out: the caller reports that
+// through FrontNum::perr and the factorization is repeated without inter-workgroup waits).  Ends with the workgroup's
+// acquire: plain loads afterwards see what the publisher stored write-through before its flag.
+__device__ __forceinline__ bool stm_wait_ge(const int *flag, int target, int *abort, int *s_ok)
+{
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int ok = 0;
+        for (int it = 0; it < (1 << 22); it++) {
+            if (ld_agent(flag) >= target) { ok = 1; break; }
+            if ((it & 63) == 63 && ld_agent(abort)) break;
+            __builtin_amdgcn_s_sleep(2);
+        }
+        if (!ok) st_agent(abort, 1);
+        *s_ok = ok;
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __syncthreads();
+    return *s_ok != 0;
+}

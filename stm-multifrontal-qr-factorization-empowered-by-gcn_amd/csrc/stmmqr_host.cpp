@@ -30,7 +30,7 @@
 namespace {
 
 thread_local std::string g_err;
-stmmqr_options g_opt = {STM_NB, 64, 0, 0, 0, 1, STM_TALL_MIN, 1};      // (panel_algo 0: by panel height)
+stmmqr_options g_opt = {STM_NB, 64, 0, 0, 0, 1, STM_TALL_MIN, 1, 0};      // (panel_algo 0: by panel height)
 size_t g_chunk[4] = {32, 5000, 4, 4};     // FCHUNK, SMALL, MINCHUNK, MINCHUNK_RATIO (SparseQR.h:16-19)
 
 // offsets inside the reference's sparse_common for the stock LP64 build; verified against the real header
@@ -156,6 +156,10 @@ struct stmmqr_plan {
     DevBuf<int> d_tslot, d_Sp, d_Sjrel, d_Sj0, d_Sleft, d_Child, d_Rjrel, d_Stair, d_Hii, d_Cmap, d_Cursor,
         d_Rhoff, d_lists, d_smap;
     DevBuf<long long> d_wlists;
+    DevBuf<int> d_wcnt, d_wcnt2;         // per column block of the update workspaces: slab tickets (zero between launches)
+    DevBuf<int> d_wflag, d_wflag2;       // ... fused update: step + 1 once W2 of the column block is in its slot
+    DevBuf<int> d_abort;
+    size_t wcnt_n = 1;
     DevBuf<long long> d_Rboff, d_total;
     DevBuf<unsigned long long> d_dbg, d_amax;
     DevBuf<double> d_sig;                           // {sg, 1/sg}: magnitude guard of the panel kernels
@@ -201,6 +205,7 @@ struct stmmqr_plan {
         if (serial_panels) c.dbg = (c.dbg & ~(2048 | 4096)) | 256;   // the one-workgroup LDS / in-place panel for every panel
         c.tall_min = tall_min;
         c.dbgbuf = d_dbg.p;
+        c.abort = d_abort.p;
         return c;
     }
     ~stmmqr_plan()
@@ -686,6 +691,14 @@ int build_plan(stmmqr_plan &P, const stmmqr_symbolic_view &v)
     LCHK(P.d_Tall.alloc((size_t)std::max(1LL, P.tpanels) * STM_NB * STM_NB));
     LCHK(P.d_Wp.alloc((size_t)P.wp_doubles));
     LCHK(P.d_Wp2.alloc((size_t)P.wp_doubles));
+    P.wcnt_n = (size_t)(P.wp_doubles / (STM_NB * 32) + 1);
+    LCHK(P.d_wcnt.alloc(P.wcnt_n));
+    LCHK(P.d_wcnt2.alloc(P.wcnt_n));
+    LCHK(P.d_wflag.alloc(P.wcnt_n));
+    if (!P.d_abort.p) LCHK(P.d_abort.alloc(1));
+    LCHK(P.d_wflag2.alloc(P.wcnt_n));
+    HIPCHK(hipMemset(P.d_wcnt.p, 0, P.wcnt_n * sizeof(int)));
+    HIPCHK(hipMemset(P.d_wcnt2.p, 0, P.wcnt_n * sizeof(int)));
     LCHK(P.d_tslot.upload(tslot, st));
     LCHK(P.d_Sx.alloc((size_t)v.anz));
     LCHK(P.d_Ax.alloc((size_t)v.anz));
@@ -773,6 +786,12 @@ int run_schedule(stmmqr_plan &P, bool detail, int grp, bool first)
         HIPCHK(hipMemsetAsync(P.d_F.p, 0, (size_t)P.farena * sizeof(double), st));
         HIPCHK(hipMemsetAsync(P.d_Rdead.p, 0, (size_t)std::max(1L, P.n), st));
         HIPCHK(hipMemsetAsync(P.d_fnum.p, 0, (size_t)std::max(1L, P.nf) * sizeof(FrontNum), st));
+        // (tickets are back at zero after every launch unless a wait ran out; the flags carry step numbers)
+        HIPCHK(hipMemsetAsync(P.d_wcnt.p, 0, P.wcnt_n * sizeof(int), st));
+        HIPCHK(hipMemsetAsync(P.d_wcnt2.p, 0, P.wcnt_n * sizeof(int), st));
+        HIPCHK(hipMemsetAsync(P.d_wflag.p, 0, P.wcnt_n * sizeof(int), st));
+        HIPCHK(hipMemsetAsync(P.d_wflag2.p, 0, P.wcnt_n * sizeof(int), st));
+        HIPCHK(hipMemsetAsync(P.d_abort.p, 0, sizeof(int), st));
         LCHK(stm_launch_sigma(P.d_Ax.p, (int)P.anz, P.d_amax.p, P.d_sig.p, st));
         LCHK(stm_launch_gather_sx(P.d_Ax.p, P.d_smap.p, P.d_Sx.p, (int)P.anz, st));
         nlaunch += 6;
@@ -823,9 +842,18 @@ int run_schedule(stmmqr_plan &P, bool detail, int grp, bool first)
         const bool split = S.split && g_opt.split_update;
         if (ncb <= 0 && !(gram && split)) return 0;
         const int *act = L0 + S.act_off, *pl = L0 + S.plist_off;
+        const bool main_ws = (Wp == P.d_Wp.p);
         return timed(t_upd, [&]() -> int {
-            if (split) {
-                LCHK(stm_launch_update_split(c, act, pl, S.n_act, cb0, ncb, S.maxsl, Wp, P.d_wlists.p + S.wp_off, gram ? 1 : 0, q));
+            if (split && g_opt.fused_update && S.maxsl <= 256 && !P.serial_panels) {
+                // one launch: C is read and written once (k_upd_f); the epoch of its hand-offs is the step number of the group
+                const int epoch = (int)(&S - SV.data()) + 1 + grp * (1 << 20);
+                LCHK(stm_launch_update_fused(c, act, pl, S.n_act, cb0, ncb, S.maxsl, Wp, P.d_wlists.p + S.wp_off,
+                                             main_ws ? P.d_wcnt.p : P.d_wcnt2.p, main_ws ? P.d_wflag.p : P.d_wflag2.p, epoch,
+                                             gram ? 1 : 0, q));
+                nlaunch++;
+            } else if (split) {
+                LCHK(stm_launch_update_split(c, act, pl, S.n_act, cb0, ncb, S.maxsl, Wp, P.d_wlists.p + S.wp_off,
+                                             main_ws ? P.d_wcnt.p : P.d_wcnt2.p, gram ? 1 : 0, q));
                 nlaunch += 2;
             } else {
                 LCHK(stm_launch_update(c, act, pl, S.n_act, cb0, ncb, q));
@@ -1265,6 +1293,14 @@ int stmmqr_plan_set_groups(stmmqr_plan *plan, const int *group)
     LCHK(P.d_Gp.alloc((size_t)P.tslots * (P.gp_slabs + 1) * STM_NB * STM_NB));
     LCHK(P.d_Wp.alloc((size_t)P.wp_doubles));
     LCHK(P.d_Wp2.alloc((size_t)P.wp_doubles));
+    P.wcnt_n = (size_t)(P.wp_doubles / (STM_NB * 32) + 1);
+    LCHK(P.d_wcnt.alloc(P.wcnt_n));
+    LCHK(P.d_wcnt2.alloc(P.wcnt_n));
+    LCHK(P.d_wflag.alloc(P.wcnt_n));
+    if (!P.d_abort.p) LCHK(P.d_abort.alloc(1));
+    LCHK(P.d_wflag2.alloc(P.wcnt_n));
+    HIPCHK(hipMemset(P.d_wcnt.p, 0, P.wcnt_n * sizeof(int)));
+    HIPCHK(hipMemset(P.d_wcnt2.p, 0, P.wcnt_n * sizeof(int)));
     LCHK(P.d_tslot.upload(tslot, P.stream));
     LCHK(P.d_lists.upload(P.lists, P.stream));
     LCHK(P.d_wlists.upload(P.wlists, P.stream));

@@ -35,6 +35,7 @@ struct DevCtx {
     double tol;
     int ntol;
     unsigned long long *dbgbuf; // [8] phase cycle sums of the panel kernel (STMMQR_DBG bit 4), else unused
+    int *abort;                 // set by the first bounded wait of the fused update that runs out: the others give up at once
     int tall_min;              // stmmqr_options::tall_min_rows at plan time (stm_tall_panel)
     int dbg;                   // env STMMQR_DBG, ablations / cross-checks only: 1 no in-panel apply (LDS panel path),
                                //  2 no T, 4 no dlarf in the LDS sub-panel, 16/32 phase timers (-DSTMMQR_STAMPS builds),
@@ -56,8 +57,10 @@ int stm_launch_panel(const DevCtx &c, const int *flist, const int *plist, int nf
 int stm_configure_capanel(void);
 int stm_launch_panel_ca(const DevCtx &c, const int *flist, const int *plist, int nfr, int nw, int defer_ok, hipStream_t st);
 int stm_launch_update(const DevCtx &c, const int *flist, const int *plist, int nfr, int cb0, int ncb, hipStream_t st);
+int stm_launch_update_fused(const DevCtx &c, const int *flist, const int *plist, int nfr, int cb0, int ncb, int maxsl, double *Wp,
+                            const long long *wpoff, int *wcnt, int *wflag, int epoch, int with_gram, hipStream_t st);
 int stm_launch_update_split(const DevCtx &c, const int *flist, const int *plist, int nfr, int cb0, int ncb, int maxsl, double *Wp,
-                            const long long *wpoff, int with_gram, hipStream_t st);
+                            const long long *wpoff, int *wcnt, int with_gram, hipStream_t st);
 int stm_launch_larft(const DevCtx &c, int f, hipStream_t st);
 int stm_launch_cpack(const DevCtx &c, const int *flist, const int *nparts, int nfr, int maxparts, hipStream_t st);
 int stm_launch_rh_count(const DevCtx &c, const int *flist, int nfr, hipStream_t st);

@@ -1775,7 +1775,7 @@ __global__ __launch_bounds__(NT) void k_larft(DevCtx c, int f)
 #define SLAB STM_UPD_SLAB
 
 __global__ __launch_bounds__(NT) void k_upd_w(DevCtx c, const int *__restrict__ flist, const int *__restrict__ plist, int cb0,
-                                              int with_gram, double *Wp, const long long *__restrict__ wpoff)
+                                              int with_gram, double *Wp, const long long *__restrict__ wpoff, int *wcnt)
 {
     extern __shared__ double dyn_lds[];
     __shared__ int s_pd[STM_NB];
@@ -1821,9 +1821,40 @@ __global__ __launch_bounds__(NT) void k_upd_w(DevCtx c, const int *__restrict__ 
         __syncthreads();
     }
     double *W = Wp + wpoff[fi] + ((long long)(gram ? ncbf : cb) * nslf + sl) * (STM_NB * BN);
+    __shared__ int s_ticket;
+    const int nsl = (mp + SLAB - 1) / SLAB;
     if (!gram) {
+        // The partial W1 of this slab; the LAST slab workgroup of the column block to arrive (ticket) adds the partials in
+        // slab order into slot 0, so that k_upd_c reads 8 KB per workgroup instead of every partial again (at 27 000 rows
+        // 106 partials = 848 KB against 128 KB of V and C per slab: most of that kernel's traffic).  Hand-off as for the
+        // Gram block below: write-through stores, every wave's vmcnt(0), the barrier, one lane's ticket.
+        if (nsl == 1) {
 #pragma unroll
-        for (int r = 0; r < 4; r++) W[(16 * mi + l4 + 4 * r) * BN + 16 * ni + l15] = acc[r];
+            for (int r = 0; r < 4; r++) W[(16 * mi + l4 + 4 * r) * BN + 16 * ni + l15] = acc[r];
+            return;
+        }
+#pragma unroll
+        for (int r = 0; r < 4; r++) st_agent(&W[(16 * mi + l4 + 4 * r) * BN + 16 * ni + l15], acc[r]);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        int *cnt = wcnt + wpoff[fi] / (STM_NB * BN) + cb;          // (one counter per column block: the front's slice has
+                                                                   //  at least ncbf + 1 blocks)
+        if (tid == 0) {
+            s_ticket = __hip_atomic_fetch_add(cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (s_ticket == nsl - 1) {
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __hip_atomic_store(cnt, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+        __syncthreads();
+        if (s_ticket != nsl - 1) return;
+        double *W0 = Wp + wpoff[fi] + ((long long)cb * nslf) * (STM_NB * BN);
+        double v[STM_NB * BN / NT];
+#pragma unroll
+        for (int q = 0; q < STM_NB * BN / NT; q++) v[q] = stm_ordered_sum<true>(W0 + tid + q * NT, STM_NB * BN, nsl);   // fixed order
+#pragma unroll
+        for (int q = 0; q < STM_NB * BN / NT; q++) W0[tid + q * NT] = v[q];
         return;
     }
     // ---- Gram block: the last slab to arrive builds T ----
@@ -1832,11 +1863,9 @@ __global__ __launch_bounds__(NT) void k_upd_w(DevCtx c, const int *__restrict__ 
     // with one lane.
 #pragma unroll
     for (int r = 0; r < 4; r++) st_agent(&W[(16 * mi + l4 + 4 * r) * BN + 16 * ni + l15], acc[r]);
-    __shared__ int s_ticket;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     FrontNum *num = &c.fnum[f];
-    const int nsl = (mp + SLAB - 1) / SLAB;
     if (tid == 0) {
         s_ticket = __hip_atomic_fetch_add(&num->gcnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (s_ticket == nsl - 1) {
@@ -1886,7 +1915,7 @@ __global__ __launch_bounds__(NT) void k_upd_c(DevCtx c, const int *__restrict__ 
     // W (nsl x 8 KB: twice a slab of V and C at 32 slabs), so fewer, longer workgroups read less per updated row.
     // (The rows of C are independent here: the arithmetic does not change.)
     const int nsl_all = (mp + SLAB - 1) / SLAB;
-    const int spw = (nsl_all >= 32) ? 4 : (nsl_all >= 16) ? 2 : 1;
+    const int spw = (nsl_all >= 32) ? 4 : (nsl_all >= 16) ? 2 : 1;      // (1 and 8 measured: 1 is 6% slower at 27 000 rows, 8 the same)
     if (sl % spw) return;
     const int nc = min(BN, s.fn - c0);
     const long long ld = s.ld;
@@ -1909,7 +1938,7 @@ __global__ __launch_bounds__(NT) void k_upd_c(DevCtx c, const int *__restrict__ 
         const double *W0 = Wp + wpoff[fi] + ((long long)cb * nslf) * (STM_NB * BN);
         const double *T = c.Tws + (long long)(2 * c.tslot[f] + (p & 1)) * STM_NB * STM_NB;
         for (int e = tid; e < STM_NB * BN; e += NT) {
-            const double v = stm_ordered_sum<false>(W0 + e, STM_NB * BN, nsl);
+            const double v = W0[e];                                 // (the slabs' partials were added by k_upd_w)
             s_W1[(e / BN) * WS + (e % BN)] = v;
             s_T[(e / STM_NB) * WS + (e % STM_NB)] = T[e];          // s_T[col][row] = T(row, col)
         }
@@ -1955,6 +1984,201 @@ __global__ __launch_bounds__(NT) void k_upd_c(DevCtx c, const int *__restrict__ 
             }
         }
         __syncthreads();
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// The row-parallel update as ONE launch (options.fused_update): a workgroup keeps its 256 x 32 tile of C (and of V) in
+// registers between the two phases, so C is read once and written once per panel (k_upd_w + k_upd_c read it twice: the
+// update of a 27 000-row front is HBM-bound on exactly that) and a launch boundary + a prologue disappear from every
+// step.  Between the phases the slab workgroups of a column block meet through global memory:
+//   every slab   : partial W1 -> its slot (write-through), ticket
+//   last arriver : W1 = sum of the partials in slab order, waits for T (FrontNum::tready, set by the Gram block's last
+//                  slab in this launch or an earlier one), W2 = T' W1 -> slot 0, flag[column block] = epoch
+//   every slab   : waits for the flag, C -= V W2 from its registers, stores C.
+// Grid (slab, column block [0 = Gram block], front): the slab workgroups of a column block are consecutive in dispatch
+// order and a workgroup only waits for workgroups of its own column block and for the Gram block (y = 0) of its front, so
+// the earliest unfinished column block is always completely dispatched as long as the GPU holds gridDim.x workgroups
+// (the host falls back to the two-launch form beyond 256 slabs).  The waits are bounded; one that runs out sets perr.
+// Arithmetic = k_upd_w + k_upd_c exactly (same chunks, same MFMA sequence, same summation order): the same bits.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(NT, 2) void k_upd_f(DevCtx c, const int *__restrict__ flist, const int *__restrict__ plist, int cb0,
+                                              int with_gram, double *Wp, const long long *__restrict__ wpoff, int *wcnt,
+                                              int *wflag, int epoch)
+{
+    extern __shared__ double dyn_lds[];
+    __shared__ int s_pd[STM_NB];
+    __shared__ int s_ticket, s_ok;
+    const int fi = blockIdx.z, f = flist[fi], p = plist[fi];
+    const FrontSym s = c.fs[f];
+    if (p >= s.npanels) return;
+    FrontNum *num = &c.fnum[f];
+    const PanelDesc *pd = &num->pd[p & 1];
+    const int g1 = pd->pg1, mp = pd->pt - pd->pg1, nbp = pd->pnb;
+    const int sl = blockIdx.x;
+    const bool gram = with_gram && blockIdx.y == 0;
+    const int cb = (int)blockIdx.y - (with_gram ? 1 : 0);          // launch-relative column block
+    const int ncbf = stm_upd_ncb(s, p), nslf = stm_upd_nsl(s);
+    if (gram && !pd->t_deferred) return;
+    if (!gram && cb0 + cb >= ncbf) return;
+    const int c0 = gram ? pd->pk1 : pd->pc0 + (cb0 + cb) * BN;
+    if (nbp <= 0 || mp <= 0 || c0 >= s.fn || sl * SLAB >= mp) return;
+    const int nc = gram ? nbp : min(BN, s.fn - c0);
+    const long long ld = s.ld;
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, l15 = lane & 15, l4 = lane >> 4;
+    const int lrow = tid & 63, lcg = tid >> 6;
+    double *Vs = dyn_lds, *Cs = Vs + STM_NB * VS, *Ws = Cs + BN * VS;
+    if (tid < STM_NB) s_pd[tid] = (tid < nbp) ? pd->pdiag[tid] : STM_BIGROW;
+    const double *Vg = c.Farena + s.foff + g1 + (long long)pd->pk1 * ld;
+    double *Cg = c.Farena + s.foff + g1 + (long long)c0 * ld;
+    const int r00 = sl * SLAB, rend = min(mp, (sl + 1) * SLAB);
+    // the whole tile: every load of the workgroup is in flight at once, and the values stay for the second phase
+    UpdChunk ck[SLAB / RB];
+#pragma unroll
+    for (int q = 0; q < SLAB / RB; q++) upd_chunk_load(ck[q], Vg, Cg, ld, r00 + q * RB + lrow, mp, nbp, nc, lcg);
+    __syncthreads();
+    // ---- phase 1: partial W1 = V(slab)' C(slab) (k_upd_w) ----
+    const int mi = wid >> 1, ni = wid & 1;
+    d4 acc = {0, 0, 0, 0};
+#pragma unroll
+    for (int q = 0; q < SLAB / RB; q++) {
+        const int r0 = r00 + q * RB;
+        if (r0 < rend) {
+            upd_chunk_to_lds(ck[q], r0 + lrow, mp, nbp, nc, s_pd, g1, lrow, lcg, Vs, Cs, gram);
+            __syncthreads();
+#pragma unroll
+            for (int kk = 0; kk < RB / 4; kk++) {
+                const double a = Vs[(16 * mi + l15) * VS + 4 * kk + l4];
+                const double b = Cs[(16 * ni + l15) * VS + 4 * kk + l4];
+                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
+            }
+            __syncthreads();
+        }
+    }
+    const int nsl = (mp + SLAB - 1) / SLAB;
+    double *Wslot = Wp + wpoff[fi] + ((long long)(gram ? ncbf : cb) * nslf) * (STM_NB * BN);      // slot 0 of the column block
+    double *W = Wslot + (long long)sl * (STM_NB * BN);
+#pragma unroll
+    for (int r = 0; r < 4; r++) st_agent(&W[(16 * mi + l4 + 4 * r) * BN + 16 * ni + l15], acc[r]);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    double *Tslot = c.Tws + (long long)(2 * c.tslot[f] + (p & 1)) * STM_NB * STM_NB;
+    if (gram) {
+        // ---- Gram block: the last slab to arrive builds T and raises tready (k_upd_w) ----
+        if (tid == 0) {
+            s_ticket = __hip_atomic_fetch_add(&num->gcnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (s_ticket == nsl - 1) {
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __hip_atomic_store(&num->gcnt, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+        __syncthreads();
+        if (s_ticket != nsl - 1) return;
+        double *s_G = Vs;
+        __shared__ double s_tau[STM_NB];
+        if (tid < STM_NB) s_tau[tid] = (tid < nbp) ? c.Tau[s.rp + pd->pk1 + tid] : 0.0;
+        for (int e = tid; e < STM_NB * BN; e += NT) {
+            const double gsum = stm_ordered_sum<true>(Wslot + e, STM_NB * BN, nsl);     // fixed order: deterministic
+            s_G[(e / BN) * WS + (e % BN)] = gsum;
+        }
+        __syncthreads();
+        double *Tkeep = c.Tall ? c.Tall + (long long)(s.tpan + p) * STM_NB * STM_NB : nullptr;
+        double (*s_Tb)[STM_NB + 1] = reinterpret_cast<double (*)[STM_NB + 1]>(Cs);
+        dev_T_from_gram(reinterpret_cast<double (*)[STM_NB + 1]>(s_G), s_Tb, s_tau, nbp);
+        for (int e = tid; e < STM_NB * STM_NB; e += NT) {
+            const int a = e % STM_NB, b = e / STM_NB;
+            const double tv = (a <= b && a < nbp && b < nbp) ? s_Tb[a][b] : 0.0;
+            st_agent(&Tslot[e], tv);
+            if (Tkeep) Tkeep[e] = tv;
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tid == 0) st_agent(&num->tready, epoch);
+        return;
+    }
+    // ---- the column block's meeting point ----
+    int *cnt = wcnt + wpoff[fi] / (STM_NB * BN) + cb;
+    int *flag = wflag + wpoff[fi] / (STM_NB * BN) + cb;
+    bool last = (nsl == 1);
+    if (nsl > 1) {
+        if (tid == 0) {
+            s_ticket = __hip_atomic_fetch_add(cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (s_ticket == nsl - 1) {
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __hip_atomic_store(cnt, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+        __syncthreads();
+        last = (s_ticket == nsl - 1);
+    }
+    double *s_W1 = Vs, *s_T = Cs;                                  // (the chunk images are free between the phases)
+    if (last) {
+        // (>=: with look-ahead the T of the NEXT panel may be announced while the side stream still applies this one)
+        if (pd->t_deferred && !stm_wait_ge(&num->tready, epoch, c.abort, &s_ok)) { if (tid == 0) st_agent(&num->perr, 1); return; }
+        for (int e = tid; e < STM_NB * BN; e += NT) {
+            const double v = stm_ordered_sum<true>(Wslot + e, STM_NB * BN, nsl);        // fixed order: deterministic
+            s_W1[(e / BN) * WS + (e % BN)] = v;
+            s_T[(e / STM_NB) * WS + (e % STM_NB)] = ld_agent(&Tslot[e]);                // s_T[col][row] = T(row, col)
+        }
+        __syncthreads();
+        // W2 = T' W1 (k_upd_c's prologue, done once per column block here)
+        const int l = tid & 31, cg = tid >> 5;
+        double w2[4] = {0, 0, 0, 0};
+        for (int q = 0; q <= l; q++) {
+            const double tq = s_T[l * WS + q];                     // T(q, l)
+#pragma unroll
+            for (int x = 0; x < 4; x++) w2[x] += tq * s_W1[q * WS + cg * 4 + x];
+        }
+#pragma unroll
+        for (int x = 0; x < 4; x++) Ws[l * WS + cg * 4 + x] = w2[x];
+        if (nsl > 1) {
+#pragma unroll
+            for (int x = 0; x < 4; x++) st_agent(&Wslot[l * BN + cg * 4 + x], w2[x]);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (tid == 0) st_agent(flag, epoch);
+        } else
+            __syncthreads();
+    } else {
+        if (!stm_wait_ge(flag, epoch, c.abort, &s_ok)) { if (tid == 0) st_agent(&num->perr, 1); return; }
+        for (int e = tid; e < STM_NB * BN; e += NT) Ws[(e / BN) * WS + (e % BN)] = ld_agent(&Wslot[e]);
+        __syncthreads();
+    }
+    // ---- phase 2: C(slab) -= V(slab) W2 from the registers (k_upd_c) ----
+#pragma unroll
+    for (int q = 0; q < SLAB / RB; q++) {
+        const int r0 = r00 + q * RB;
+        if (r0 < rend) {
+            const int i = r0 + lrow;
+            upd_chunk_to_lds(ck[q], i, mp, nbp, nc, s_pd, g1, lrow, lcg, Vs, Cs);
+            __syncthreads();
+            d4 u0 = {0, 0, 0, 0}, u1 = {0, 0, 0, 0};
+#pragma unroll
+            for (int kk = 0; kk < STM_NB / 4; kk++) {
+                const double a = Vs[(4 * kk + l4) * VS + 16 * wid + l15];
+                const double b0 = Ws[(4 * kk + l4) * WS + l15];
+                const double b1 = Ws[(4 * kk + l4) * WS + 16 + l15];
+                u0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b0, u0, 0, 0, 0);
+                u1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b1, u1, 0, 0, 0);
+            }
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const int row = 16 * wid + l4 + 4 * r;
+                Cs[l15 * VS + row] -= u0[r];
+                Cs[(16 + l15) * VS + row] -= u1[r];
+            }
+            __syncthreads();
+            if (i < mp) {
+#pragma unroll
+                for (int qq = 0; qq < 8; qq++) {
+                    const int col = lcg * 8 + qq;
+                    if (col < nc) Cg[i + col * ld] = Cs[col * VS + lrow];
+                }
+            }
+            __syncthreads();
+        }
     }
 }
 
@@ -2846,15 +3070,24 @@ int stm_launch_update(const DevCtx &c, const int *flist, const int *plist, int n
     return (int)hipGetLastError();
 }
 int stm_launch_update_split(const DevCtx &c, const int *flist, const int *plist, int nfr, int cb0, int ncb, int maxsl, double *Wp,
-                            const long long *wpoff, int with_gram, hipStream_t st)
+                            const long long *wpoff, int *wcnt, int with_gram, hipStream_t st)
 {
     if (nfr <= 0 || ncb + (with_gram ? 1 : 0) <= 0 || maxsl <= 0) return 0;
     const size_t lds = (size_t)stm_update_lds_bytes();
     // (with_gram: one more column block, V'V for the fronts whose panel kernel left T to the update)
     // (k_upd_w stages V and C chunks only: 34 KB, four workgroups per CU)
     hipLaunchKernelGGL(k_upd_w, dim3(ncb + (with_gram ? 1 : 0), maxsl, nfr), dim3(NT), (size_t)(2 * BN * VS) * sizeof(double), st, c,
-                       flist, plist, cb0, with_gram ? 1 : 0, Wp, wpoff);
+                       flist, plist, cb0, with_gram ? 1 : 0, Wp, wpoff, wcnt);
     if (ncb > 0) hipLaunchKernelGGL(k_upd_c, dim3(ncb, maxsl, nfr), dim3(NT), lds, st, c, flist, plist, cb0, (const double *)Wp, wpoff);
+    return (int)hipGetLastError();
+}
+int stm_launch_update_fused(const DevCtx &c, const int *flist, const int *plist, int nfr, int cb0, int ncb, int maxsl, double *Wp,
+                            const long long *wpoff, int *wcnt, int *wflag, int epoch, int with_gram, hipStream_t st)
+{
+    const int ny = ncb + (with_gram ? 1 : 0);
+    if (nfr <= 0 || ny <= 0 || maxsl <= 0) return 0;
+    hipLaunchKernelGGL(k_upd_f, dim3(maxsl, ny, nfr), dim3(NT), (size_t)stm_update_lds_bytes(), st, c, flist, plist, cb0,
+                       with_gram ? 1 : 0, Wp, wpoff, wcnt, wflag, epoch);
     return (int)hipGetLastError();
 }
 int stm_launch_larft(const DevCtx &c, int f, hipStream_t st)

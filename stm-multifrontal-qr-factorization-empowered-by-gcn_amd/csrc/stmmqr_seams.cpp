@@ -180,8 +180,10 @@ stm_long stmmqr_front(stm_long m, stm_long n, stm_long npiv, double tol, stm_lon
         for (size_t q = 0; q < hp.size(); q++) hp[q] = (int)q;
         Buf<int> d_pl;
         Buf<long long> d_wpoff;
+        Buf<int> d_wcnt;
         const std::vector<long long> zoff(1, 0);
-        if (!d_pl.up(hp) || !d_wpoff.up(zoff)) return -1;
+        const std::vector<int> zcnt((size_t)(n + 31) / 32 + 2, 0);
+        if (!d_pl.up(hp) || !d_wpoff.up(zoff) || !d_wcnt.up(zcnt)) return -1;
         for (int p = 0; p < X.s.npanels && !e; p++) {
             const int k2 = (int)std::min<long>(n, (long)(p + 1) * STM_NB);
             const int ncb = (int)((n - k2 + 31) / 32);
@@ -189,7 +191,7 @@ stm_long stmmqr_front(stm_long m, stm_long n, stm_long npiv, double tol, stm_lon
             if (stm_use_ca(X.s, p, opt.panel_algo)) e = stm_launch_panel_ca(X.c, X.d_flist.p, d_pl.p + p, 1, stm_ca_slabs(X.s), defer_ok, nullptr);
             else e = stm_launch_panel(X.c, X.d_flist.p, d_pl.p + p, 1, stm_tall_launches(X.s, p, X.c.tall_min), defer_ok, lds_for(m), nullptr);
             if (e || ncb <= 0) continue;
-            if (split) e = stm_launch_update_split(X.c, X.d_flist.p, d_pl.p + p, 1, 0, ncb, msl, d_Wp.p, d_wpoff.p, 1, nullptr);
+            if (split) e = stm_launch_update_split(X.c, X.d_flist.p, d_pl.p + p, 1, 0, ncb, msl, d_Wp.p, d_wpoff.p, d_wcnt.p, 1, nullptr);
             else e = stm_launch_update(X.c, X.d_flist.p, d_pl.p + p, 1, 0, ncb, nullptr);
         }
         if (hipDeviceSynchronize() != hipSuccess) e = -1;          // (d_Wp is released at the end of this scope)

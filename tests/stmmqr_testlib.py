@@ -43,7 +43,7 @@ SYM_SCALARS = ["m", "n", "anz", "nf", "maxfn", "rjsize", "do_rank_detection", "m
                "ntasks", "ns"]
 
 
-BIG_FIXTURES = ("xenon1_standin", "xenon1_colamd_standin", "sme3dc_standin", "c5mini_standin", "c5_standin")      # full BASELINE size: too slow for the scalar CPU oracle, GPU tests only
+BIG_FIXTURES = ("xenon1_standin", "xenon1_colamd_standin", "sme3dc_standin", "c5mini_standin", "c5mid_standin")      # full BASELINE size: too slow for the scalar CPU oracle, GPU tests only
 
 
 def golden_names(include_big: bool = False):

@@ -90,21 +90,27 @@ def test_gram_panel_everywhere(pkg, oracle, monkeypatch, name, late):
 @pytest.mark.parametrize("bfc,algo", [(64, 0), (16, 0), (16, 2), (8, 1)])
 def test_lookahead_schedule_same_bits(pkg, name, bfc, algo):
     """options.lookahead (default 1): the update beyond the next panel's columns, the packing of finished fronts and the
-    assembly of the next ones run on a second stream beside the panel chain.  Every kernel does what it does in the serial
-    order: the factors must be the same bits (and the other tests, which run with the default, cover parity)."""
+    assembly of the next ones run on a second stream beside the panel chain.  options.fused_update (default 0): the
+    row-parallel update is one launch whose workgroups meet through global memory between V'C and the application.
+    Every kernel does the arithmetic it does in the serial two-launch order: the factors must be the same bits (the other
+    tests, which run with the defaults, cover parity).  STMMQR_LA_MIN=0 sends every eligible step to the side stream."""
+    import os
     g = load_golden(name)
     out = []
+    os.environ["STMMQR_LA_MIN"] = "0"
     try:
-        for la in (0, 1):
-            pkg.set_options(lookahead=la, big_front_cols=bfc, panel_algo=algo)
+        for la, fused in ((0, 0), (1, 0), (0, 1), (1, 1)):
+            pkg.set_options(lookahead=la, fused_update=fused, big_front_cols=bfc, panel_algo=algo)
             S, G = gpu_run(pkg, g)
             out.append((G.Stack[:G.rh_total].copy(), G.HTau.copy(), G.HStair.copy(), G.Rdead.copy(), G.rank))
     finally:
-        pkg.set_options(lookahead=1, big_front_cols=64, panel_algo=0)
-    a, b = out
-    assert a[4] == b[4]
-    for x, y in zip(a[:4], b[:4]):
-        assert np.array_equal(x, y, equal_nan=True)
+        del os.environ["STMMQR_LA_MIN"]
+        pkg.set_options(lookahead=1, fused_update=0, big_front_cols=64, panel_algo=0)
+    a = out[0]
+    for b in out[1:]:
+        assert a[4] == b[4]
+        for x, y in zip(a[:4], b[:4]):
+            assert np.array_equal(x, y, equal_nan=True)
 
 
 @pytest.mark.parametrize("name,tall_min", [(n, 256) for n in NAMES] +
@@ -294,12 +300,13 @@ def test_no_rank_detection_tol_negative(pkg, oracle):
     compare_integers(S, N, numeric_as_ref(S, No))
 
 
-@pytest.mark.parametrize("name", ["xenon1_standin", "xenon1_colamd_standin", "sme3dc_standin", "c5mini_standin", "c5_standin"])
+@pytest.mark.parametrize("name", ["xenon1_standin", "xenon1_colamd_standin", "sme3dc_standin", "c5mini_standin", "c5mid_standin"])
 def test_full_size_standin(pkg, oracle, name):
     """BASELINE configs[2] / [3] sizes (xenon1 stand-in, n = 49 248, 1.5e11 flops; sme3Dc stand-in, n = 43 200, 3 unknowns
     per grid point, 3.4e11 flops) and the structure of configs[4] at n = 8000 (7-point + random long-range couplings: the
-    top front is 0.4 n, 4.4e11 flops): integer outputs and R rows against the reference's golden vectors, backward error
-    through the packed factors, Q orthogonality on probes."""
+    top front is 0.4 n, 4.4e11 flops) and at n = 27 000 (c5mid: the root front is 27 000 x 25 974, 57 slab workgroups per
+    Gram-based panel, 1.6e13 flops, 4.8 GB of packed factors): integer outputs and R rows against the reference's golden
+    vectors, backward error through the packed factors, Q orthogonality on probes."""
     from stmmqr_testlib import GOLDEN
     if not (GOLDEN / f"{name}.npz").exists():
         pytest.skip("fixture not generated (tests/golden/make_golden.py)")
