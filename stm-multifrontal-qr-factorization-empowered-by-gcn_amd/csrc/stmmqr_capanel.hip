@@ -21,7 +21,7 @@
 // REFRESH before it is used: B <- B M, M <- I, G <- B'B from the real rows.  The same rule LAPACK's dgeqp3 applies to
 // its downdated column norms.  So every norm is accurate to CA_K*eps relative, every reflector orthogonal to that
 // accuracy, and the dead-column test |beta| <= tol (:1495) sees an accurate beta.  Validated on the
-// fixtures' real fronts against the unblocked column loop by the numpy model of this algorithm (tests/ca_model.py).
+// fixtures' real fronts against the unblocked column loop by the numpy model of this algorithm (tests/ca_model.py, tests/test_ca_model.py).
 //
 // Several slabs (nB > CA_R): every slab workgroup forms its partial Gram matrix, stores it write-through and takes a
 // ticket; the LAST one to arrive sums the partials in slab order (deterministic), runs the chain alone and publishes M;

@@ -525,7 +525,7 @@ void build_schedule(stmmqr_plan &P, std::vector<int> &tslot)
                 const FrontSym &s = P.fs[f];
                 const long cn = s.fn - s.fp;
                 const long work = cn * std::min((long)s.fm_ub, cn);
-                const int parts = (int)std::min(64L, std::max(1L, (work + 16383) / 16384));
+                const int parts = (int)std::min(512L, std::max(1L, (work + 16383) / 16384));
                 P.lists.push_back(parts);
                 S.cpk_maxparts = std::max(S.cpk_maxparts, parts);
                 freeslots.push_back(tslot[f]);
