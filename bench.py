@@ -284,10 +284,18 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    # STMMQR_BENCH_REHEARSAL=1 (a one-GPU box): every rank on device 0, gloo, contribution blocks through the host -- the
+    # whole multi-process protocol (spawn, rendezvous, partition, phases, exchange, timing) without RCCL / a second GPU
+    rehearsal = world > 1 and os.environ.get("STMMQR_BENCH_REHEARSAL") == "1"
+    if rehearsal:
+        local = 0
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local))
+        if rehearsal:
+            dist.init_process_group(backend="gloo")
+        else:
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local))
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if args.mode is None:
@@ -331,7 +339,7 @@ def main():
     crit = None
     if sharded:
         sh = importlib.import_module(PKG + ".sharded")
-        comm = sh.Comm(dist, dev)
+        comm = sh.Comm(dist, None if rehearsal else dev)
         owner, phase = sh.partition(sym, world)
         crit = sh.critical_path_flops(sym, owner, phase, world)
 
@@ -436,8 +444,10 @@ def main():
             "higher_is_better": True, "scaling": "strong" if sharded else "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": wl,
                        "inputs": "values resident in HBM, factors left in HBM",
-                       "parallelism": (f"subtree-sharded x{world}: tree of joins, contribution blocks device-to-device over RCCL "
-                                       f"point-to-point" if sharded else f"replica x{world}"),
+                       "parallelism": ((f"subtree-sharded x{world}: tree of joins, contribution blocks device-to-device over RCCL "
+                                        f"point-to-point" if sharded else f"replica x{world}") +
+                                       (" -- REHEARSAL: all ranks on ONE GPU, gloo, blocks through the host (not a measurement)"
+                                        if rehearsal else "")),
                        "device_ms_per_step": dev_ms / args.steps, "launches_per_step": st["nlaunch"],
                        "levels": st["nlevels"], "timeline_steps": st["nsteps"]},
             "roofline": roof,
