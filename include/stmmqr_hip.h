@@ -153,6 +153,8 @@ typedef struct stmmqr_stats {
     double ms_small;           /* k_front_wg: whole small fronts                                                    */
     stm_long npanel_launch, nupdate_launch;   /* event pairs behind ms_panel / ms_update (one per timeline step)    */
     stm_long nsteps;           /* steps of the factorization timeline (a big front advances one panel per step)     */
+    double flops_update_pair;  /* the part of flops_update on fronts that take the pair update (two panels per sweep:
+                                  12 instead of 24 algorithmic bytes per updated entry and panel)                     */
 } stmmqr_stats;
 
 typedef struct stmmqr_plan stmmqr_plan;     /* device-resident symbolic plan + arenas; reusable across calls */
@@ -239,7 +241,7 @@ double stmmqr_last_seam_ms(void);
 /* ================================================================================================
  * 3. Configuration / introspection
  * ================================================================================================ */
-/* Defaults: {32, 64, 0, 0, 0, 1, 0, 1, 0}.  Read when a plan is created (or a seam is called); the numerical results do not
+/* Defaults: {32, 64, 0, 0, 0, 1, 0, 1, 0, 1}.  Read when a plan is created (or a seam is called); the numerical results do not
  * depend on them beyond rounding.
  * Environment (diagnosis and tests only): STMMQR_DBG (bit mask, csrc/stmmqr_kernels.h), STMMQR_QBIG_MIN (entries of a
  * front from which Q-apply / back substitution split its rows over workgroups; default 2097152, read at plan time),
@@ -262,6 +264,9 @@ typedef struct stmmqr_options {
                                (C read once, written once per panel).  Same bits either way; measured 1.1x - 2.5x slower
                                on MI355X (the slab workgroups of a column block idle while one of them adds the partial
                                sums: DESIGN.md 5), kept as an experiment.                                            */
+    int pair_update;        /* 1 (default): fronts of >= 16384 rows apply the block reflectors of two consecutive panels in
+                               one sweep over the columns beyond the next two panels (1.5 instead of 3 passes over the
+                               trailing matrix per panel); a property of the front (plan time), it changes rounding only */
 } stmmqr_options;
 void stmmqr_get_options(stmmqr_options *opt);
 void stmmqr_set_options(const stmmqr_options *opt);

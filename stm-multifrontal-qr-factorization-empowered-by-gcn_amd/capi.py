@@ -40,7 +40,8 @@ class Stats(C.Structure):
     _fields_ = [(k, C.c_double) for k in ["flops", "ms_total", "ms_assemble", "ms_front", "ms_pack", "ms_h2d", "ms_d2h",
                                           "ms_host", "bytes_assemble", "bytes_pack", "flops_update", "ms_update"]] + \
                [("nlaunch", C.c_long), ("nlevels", C.c_long), ("ms_panel", C.c_double), ("ms_small", C.c_double),
-                ("npanel_launch", C.c_long), ("nupdate_launch", C.c_long), ("nsteps", C.c_long)]
+                ("npanel_launch", C.c_long), ("nupdate_launch", C.c_long), ("nsteps", C.c_long),
+                ("flops_update_pair", C.c_double)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}
@@ -49,7 +50,7 @@ class Stats(C.Structure):
 class Options(C.Structure):
     _fields_ = [("panel_width", C.c_int), ("big_front_cols", C.c_int), ("verbose", C.c_int), ("use_graph", C.c_int),
                 ("panel_algo", C.c_int), ("split_update", C.c_int), ("tall_min_rows", C.c_int),
-                ("lookahead", C.c_int), ("fused_update", C.c_int)]
+                ("lookahead", C.c_int), ("fused_update", C.c_int), ("pair_update", C.c_int)]
 
 
 def _ip(a):

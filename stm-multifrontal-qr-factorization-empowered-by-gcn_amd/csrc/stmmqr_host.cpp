@@ -30,7 +30,7 @@
 namespace {
 
 thread_local std::string g_err;
-stmmqr_options g_opt = {STM_NB, 64, 0, 0, 0, 1, STM_TALL_MIN, 1, 0};      // (panel_algo 0: by panel height)
+stmmqr_options g_opt = {STM_NB, 64, 0, 0, 0, 1, STM_TALL_MIN, 1, 0, 1};      // (panel_algo 0: by panel height)
 size_t g_chunk[4] = {32, 5000, 4, 4};     // FCHUNK, SMALL, MINCHUNK, MINCHUNK_RATIO (SparseQR.h:16-19)
 
 // offsets inside the reference's sparse_common for the stock LP64 build; verified against the real header
@@ -110,6 +110,11 @@ struct Step {
     int nsub = 1, nca = 1, nca_use = 0, npipe_use = 0, maxcb = 0, maxsl = 0, split = 0;
     int lds_big = 0;       // dynamic LDS of the panel launch when every front may take the one-workgroup panel (recovery, tests)
     int lds_plan = 0;      // ... when only the fronts planned for it do (the pipeline groups need the update's LDS only)
+    // the fronts in flight are listed in three classes: [0, n_norm) every panel's update on all trailing columns;
+    // then the pair-update fronts (is_pair) at an even panel (update of column blocks 0, 1 only) and at an odd panel
+    // (block 0, then the pair update of the two last panels on the columns beyond)
+    int n_norm = 0, n_pe = 0, n_po = 0;
+    int maxsl_pe = 0, maxsl_po = 0, maxcbp_po = 0;
     int cpk_off = 0, cpk_parts_off = 0, n_cpk = 0, cpk_maxparts = 1;   // big fronts whose last panel runs here
 };
 
@@ -138,6 +143,7 @@ struct stmmqr_plan {
     std::vector<std::vector<Level>> glevels;   // [group][level]
     std::vector<std::vector<Step>> gsteps;     // [group][step]
     std::vector<long long> wlists;             // host copy of d_wlists
+    std::vector<char> pair_front;              // per front: takes the pair update (plan time)
     std::vector<int> group;                    // per front: phase on this device, -1 = elsewhere
     int own_off = 0, n_own = 0;
     std::vector<int> lists;              // host copy of d_lists
@@ -312,6 +318,15 @@ void build_schedule(stmmqr_plan &P, std::vector<int> &tslot)
     };
     const int sched_policy = getenv("STMMQR_SCHED") ? atoi(getenv("STMMQR_SCHED")) : 0;
     const bool sched_level = sched_policy == 1;
+    // Pair update (k_upd_w2 / k_upd_c2): a property of the front alone -- it changes the rounding of the front's
+    // trailing updates, and results must not depend on the schedule.  Fronts whose update is bandwidth bound: many rows.
+    const long pair_min = getenv("STMMQR_PAIR_MIN") ? atol(getenv("STMMQR_PAIR_MIN")) : STM_PAIR_MIN_ROWS;
+    auto is_pair = [&](int f) {
+        const FrontSym &s = P.fs[f];
+        return g_opt.pair_update && is_big(f) && s.fm_est >= pair_min && s.npanels >= 4;
+    };
+    P.pair_front.assign(std::max(1L, nf), 0);
+    for (long f = 0; f < nf; f++) P.pair_front[f] = (P.group[f] >= 0 && is_pair((int)f)) ? 1 : 0;
     tslot.assign(std::max(1L, nf), 0);
     P.glevels.assign(ngroups, std::vector<Level>());
     P.gsteps.assign(ngroups, std::vector<Step>());
@@ -482,9 +497,12 @@ void build_schedule(stmmqr_plan &P, std::vector<int> &tslot)
             }
             active.clear();
             for (const auto &fp : panel_at[t]) { active.push_back(fp.first); pan_now[fp.first] = fp.second; }
-            // heaviest update first (the order inside a launch does not change any result)
+            // heaviest update first (the order inside a launch does not change any result); classes: see Step
             auto work_at = [&](int f) { return (long)stm_upd_ncb(P.fs[f], pan_now[f]) * stm_upd_nsl(P.fs[f]); };
-            std::stable_sort(active.begin(), active.end(), [&](int a, int b) { return work_at(a) > work_at(b); });
+            auto cls = [&](int f) { return !is_pair(f) ? 0 : ((pan_now[f] & 1) ? 2 : 1); };
+            std::stable_sort(active.begin(), active.end(), [&](int a, int b) {
+                return cls(a) != cls(b) ? cls(a) < cls(b) : work_at(a) > work_at(b);
+            });
             S.act_off = (int)P.lists.size();
             S.n_act = (int)active.size();
             P.lists.insert(P.lists.end(), active.begin(), active.end());
@@ -498,10 +516,22 @@ void build_schedule(stmmqr_plan &P, std::vector<int> &tslot)
                 const int p = pan_now[f];
                 const int ncb = stm_upd_ncb(s, p), nsl = stm_upd_nsl(s);
                 P.wlists.push_back(wp);
-                wp += (long long)(ncb + 1) * nsl * (STM_NB * 32);                         // (+1: Gram block)
-                ncbsum += ncb;
-                S.maxcb = std::max(S.maxcb, ncb);
-                S.maxsl = std::max(S.maxsl, nsl);
+                // (+1: Gram block; pair-update fronts: two blocks per partial)
+                wp += (long long)(ncb + 1) * nsl * (STM_NB * 32) * (is_pair(f) ? 2 : 1);
+                const int k = cls(f);
+                if (k == 0) {
+                    S.n_norm++;
+                    ncbsum += ncb;
+                    S.maxcb = std::max(S.maxcb, ncb);
+                    S.maxsl = std::max(S.maxsl, nsl);
+                } else if (k == 1) {
+                    S.n_pe++;
+                    S.maxsl_pe = std::max(S.maxsl_pe, nsl);
+                } else {
+                    S.n_po++;
+                    S.maxsl_po = std::max(S.maxsl_po, nsl);
+                    S.maxcbp_po = std::max(S.maxcbp_po, ncb - 1);
+                }
                 S.nsub = std::max(S.nsub, stm_tall_launches(s, p, P.tall_min));
                 S.nca = std::max(S.nca, stm_ca_slabs(s));
                 (stm_use_ca(s, p, g_opt.panel_algo, P.ca_min) ? S.nca_use : S.npipe_use)++;
@@ -840,24 +870,45 @@ int run_schedule(stmmqr_plan &P, bool detail, int grp, bool first)
     // one-workgroup form builds T in every workgroup)
     auto update = [&](const Step &S, int cb0, int ncb, bool gram, double *Wp, hipStream_t q) -> int {
         const bool split = S.split && g_opt.split_update;
-        if (ncb <= 0 && !(gram && split)) return 0;
+        const bool whole = (cb0 == 0 && gram);                 // the step's whole update: the pair-update classes too
+        const bool pairs = whole && (S.n_pe + S.n_po) > 0;
+        if (S.n_norm <= 0 || (ncb <= 0 && !(gram && split))) {
+            if (!pairs) return 0;
+        }
         const int *act = L0 + S.act_off, *pl = L0 + S.plist_off;
         const bool main_ws = (Wp == P.d_Wp.p);
+        int *wcnt = main_ws ? P.d_wcnt.p : P.d_wcnt2.p;
+        const long long *wl = P.d_wlists.p + S.wp_off;
         return timed(t_upd, [&]() -> int {
-            if (split && g_opt.fused_update && S.maxsl <= 256 && !P.serial_panels) {
-                // one launch: C is read and written once (k_upd_f); the epoch of its hand-offs is the step number of the group
-                const int epoch = (int)(&S - SV.data()) + 1 + grp * (1 << 20);
-                LCHK(stm_launch_update_fused(c, act, pl, S.n_act, cb0, ncb, S.maxsl, Wp, P.d_wlists.p + S.wp_off,
-                                             main_ws ? P.d_wcnt.p : P.d_wcnt2.p, main_ws ? P.d_wflag.p : P.d_wflag2.p, epoch,
-                                             gram ? 1 : 0, q));
-                nlaunch++;
-            } else if (split) {
-                LCHK(stm_launch_update_split(c, act, pl, S.n_act, cb0, ncb, S.maxsl, Wp, P.d_wlists.p + S.wp_off,
-                                             main_ws ? P.d_wcnt.p : P.d_wcnt2.p, gram ? 1 : 0, q));
-                nlaunch += 2;
-            } else {
-                LCHK(stm_launch_update(c, act, pl, S.n_act, cb0, ncb, q));
-                nlaunch++;
+            if (S.n_norm > 0 && (ncb > 0 || (gram && split))) {
+                if (split && g_opt.fused_update && S.maxsl <= 256 && !P.serial_panels) {
+                    // one launch: C is read and written once (k_upd_f); the epoch of its hand-offs is the step number of the group
+                    const int epoch = (int)(&S - SV.data()) + 1 + grp * (1 << 20);
+                    LCHK(stm_launch_update_fused(c, act, pl, S.n_norm, cb0, ncb, S.maxsl, Wp, wl, wcnt,
+                                                 main_ws ? P.d_wflag.p : P.d_wflag2.p, epoch, gram ? 1 : 0, q));
+                    nlaunch++;
+                } else if (split) {
+                    LCHK(stm_launch_update_split(c, act, pl, S.n_norm, cb0, ncb, S.maxsl, Wp, wl, wcnt, gram ? 1 : 0, q));
+                    nlaunch += 2;
+                } else {
+                    LCHK(stm_launch_update(c, act, pl, S.n_norm, cb0, ncb, q));
+                    nlaunch++;
+                }
+            }
+            if (pairs) {
+                // even panel: column blocks 0, 1 (the columns of the next two panels), T by the Gram block
+                int o = S.n_norm;
+                if (S.n_pe > 0) {
+                    LCHK(stm_launch_update_split(c, act + o, pl + o, S.n_pe, 0, 2, S.maxsl_pe, Wp, wl + o, wcnt, 1, q));
+                    nlaunch += 2;
+                }
+                // odd panel: block 0, then both panels at once on everything beyond
+                o += S.n_pe;
+                if (S.n_po > 0) {
+                    LCHK(stm_launch_update_split(c, act + o, pl + o, S.n_po, 0, 1, S.maxsl_po, Wp, wl + o, wcnt, 1, q));
+                    LCHK(stm_launch_update_pair(c, act + o, pl + o, S.n_po, S.maxcbp_po, S.maxsl_po, Wp, wl + o, wcnt, q));
+                    nlaunch += 4;
+                }
             }
             return 0;
         });
@@ -878,7 +929,7 @@ int run_schedule(stmmqr_plan &P, bool detail, int grp, bool first)
             cur_step = (int)(&S - SV.data());
             int e = prep(S, st);
             if (!e && S.n_act > 0) e = panels(S);
-            if (!e && S.n_act > 0 && S.maxcb > 0) e = update(S, 0, S.maxcb, true, P.d_Wp.p, st);
+            if (!e && S.n_act > 0) e = update(S, 0, S.maxcb, true, P.d_Wp.p, st);
             if (!e) e = post(S, st);
             if (e) return e;
         }
@@ -914,7 +965,7 @@ int run_schedule(stmmqr_plan &P, bool detail, int grp, bool first)
                 if (ncb > 1) tiles += (long)(ncb - 1) * ((stm_panel_rows_est(fsym, p) + STM_UPD_SLAB - 1) / STM_UPD_SLAB);   // (expected rows, not the bound)
                 pwg += stm_use_ca(fsym, p, P.plan_algo, P.ca_min) ? stm_ca_slabs(fsym) : stm_tall_launches(fsym, p, P.tall_min);
             }
-            return tiles >= la_min && pwg <= la_maxpwg;
+            return tiles >= la_min && pwg <= la_maxpwg && S.n_pe + S.n_po == 0;      // (pair-update steps stay on one stream)
         };
         long side_ev = -1;                                     // last side event the main stream has not waited for
         bool prep_on_side = false;                             // prep(t) was issued on the side stream during step t-1
@@ -931,7 +982,7 @@ int run_schedule(stmmqr_plan &P, bool detail, int grp, bool first)
             if (S.n_act > 0 && (e = panels(S))) return e;
             const bool offload = S.n_act > 0 && S.maxcb > 1 && worth_it(S);
             if (!offload) {
-                if (S.n_act > 0 && S.maxcb > 0) {
+                if (S.n_act > 0) {
                     if (side_ev >= 0) { HIPCHK(hipStreamWaitEvent(st, P.ev_side[side_ev], 0)); side_ev = -1; }
                     if ((e = update(S, 0, S.maxcb, true, P.d_Wp.p, st))) return e;
                 }
@@ -1209,7 +1260,7 @@ int stmmqr_factorize_finish(stmmqr_plan *plan, stmmqr_stats *stats)
     P.h_fnum.resize((size_t)std::max(1L, P.nf));
     if (P.nf > 0)
         HIPCHK(hipMemcpy(P.h_fnum.data(), P.d_fnum.p, (size_t)P.nf * sizeof(FrontNum), hipMemcpyDeviceToHost));
-    double flops = 0, bytes_asm = 0, bytes_pack = 0, fl_upd = 0;
+    double flops = 0, bytes_asm = 0, bytes_pack = 0, fl_upd = 0, fl_upd_pair = 0;
     long rank = 0;
     for (long f = 0; f < P.nf; f++) {
         if (P.group[f] < 0) continue;                  // factorized elsewhere
@@ -1217,6 +1268,7 @@ int stmmqr_factorize_finish(stmmqr_plan *plan, stmmqr_stats *stats)
         const FrontSym &s = P.fs[f];
         flops += nm.flops;
         fl_upd += nm.flops_upd;
+        if ((size_t)f < P.pair_front.size() && P.pair_front[f]) fl_upd_pair += nm.flops_upd;
         rank += nm.rank;
         if (nm.perr) {
             P.panel_wait_failed = true;
@@ -1240,6 +1292,7 @@ int stmmqr_factorize_finish(stmmqr_plan *plan, stmmqr_stats *stats)
     P.rank = rank;
     P.stats.flops = flops;
     P.stats.flops_update = fl_upd;
+    P.stats.flops_update_pair = fl_upd_pair;
     P.stats.bytes_assemble = bytes_asm;
     P.stats.bytes_pack = bytes_pack;
     P.factored = true;

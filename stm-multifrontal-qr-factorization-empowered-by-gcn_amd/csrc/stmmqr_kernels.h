@@ -59,6 +59,8 @@ int stm_launch_panel_ca(const DevCtx &c, const int *flist, const int *plist, int
 int stm_launch_update(const DevCtx &c, const int *flist, const int *plist, int nfr, int cb0, int ncb, hipStream_t st);
 int stm_launch_update_fused(const DevCtx &c, const int *flist, const int *plist, int nfr, int cb0, int ncb, int maxsl, double *Wp,
                             const long long *wpoff, int *wcnt, int *wflag, int epoch, int with_gram, hipStream_t st);
+int stm_launch_update_pair(const DevCtx &c, const int *flist, const int *plist, int nfr, int ncbp, int maxsl, double *Wp,
+                           const long long *wpoff, int *wcnt, hipStream_t st);
 int stm_launch_update_split(const DevCtx &c, const int *flist, const int *plist, int nfr, int cb0, int ncb, int maxsl, double *Wp,
                             const long long *wpoff, int *wcnt, int with_gram, hipStream_t st);
 int stm_launch_larft(const DevCtx &c, int f, hipStream_t st);

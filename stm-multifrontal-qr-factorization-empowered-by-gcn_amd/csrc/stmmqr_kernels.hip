@@ -2182,6 +2182,275 @@ __global__ __launch_bounds__(NT, 2) void k_upd_f(DevCtx c, const int *__restrict
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Pair update (large fronts, stm_use_pair): the block reflectors of TWO consecutive panels a = p-1 (even) and b = p applied
+// in ONE sweep over the columns beyond panel p+1 -- the trailing update of a 27 000-row front is bound by its three
+// passes over C per 32 columns (W = V'C reads it, C -= V W reads and writes it); two panels per sweep make that 1.5.
+//   k_upd_w2 : partial  W1 = V1(slab)' C(slab),  W2 = V2(slab)' C(slab)      (the SAME C: before either application)
+//              last column block: C := V1  ->  G21 = V2'V1
+//              the last slab workgroup of a column block to arrive adds the partials in slab order (as k_upd_w)
+//   k_upd_c2 : Y1 = T1' W1,  Y2 = T2' (W2 - G21 Y1)  -- which is V2'(C - V1 Y1), the second application's own W --,
+//              C(slab) -= V1 Y1 + V2 Y2
+// Exactly H_b' H_a' C in exact arithmetic; the rounding differs from two separate updates, so WHICH fronts take it is a
+// property of the front alone (symbolic), like the choice of the panel kernel.  The columns of the next TWO panels are
+// updated panel by panel (k_upd_w / k_upd_c on column blocks 0, 1 after an even panel, block 0 after an odd one): the
+// panel factorizations need them.  Rows: [g1a, max(pta, ptb)); V1 / V2 are masked by their own diagonals and ends.
+// ------------------------------------------------------------------------------------------------
+struct UpdChunk2 { double v1[8], v2[8], c[8]; };
+__device__ __forceinline__ void upd2_chunk_load(UpdChunk2 &ck, const double *V1g, const double *V2g, const double *Cg, long long ld,
+                                                int i, int mp, int nb1, int nb2, int nc, int lcg)
+{
+    const int ic = min(i, mp - 1);
+#pragma unroll
+    for (int q = 0; q < 8; q++) {
+        const int col = lcg * 8 + q;
+        ck.v1[q] = V1g[ic + (long long)min(col, nb1 - 1) * ld];
+        ck.v2[q] = V2g[ic + (long long)min(col, max(nb2, 1) - 1) * ld];
+        ck.c[q] = Cg[ic + (long long)min(col, nc - 1) * ld];
+    }
+}
+__device__ __forceinline__ void upd2_chunk_to_lds(const UpdChunk2 &ck, int i, int mp, int mp1, int mp2, int nb1, int nb2, int nc,
+                                                  const int *s_pd1, const int *s_pd2, int g1, int lrow, int lcg, double *Vs1,
+                                                  double *Vs2, double *Cs, bool c_is_v1)
+{
+#pragma unroll
+    for (int q = 0; q < 8; q++) {
+        const int col = lcg * 8 + q;
+        const int d1 = s_pd1[col] - g1, d2 = s_pd2[col] - g1;   // (BIGROW beyond nb: everything masked)
+        const double v1 = (i < mp1 && col < nb1 && i >= d1) ? ((i == d1) ? 1.0 : ck.v1[q]) : 0.0;
+        const double v2 = (i < mp2 && col < nb2 && i >= d2) ? ((i == d2) ? 1.0 : ck.v2[q]) : 0.0;
+        Vs1[col * VS + lrow] = v1;
+        Vs2[col * VS + lrow] = v2;
+        Cs[col * VS + lrow] = c_is_v1 ? v1 : ((i < mp && col < nc) ? ck.c[q] : 0.0);
+    }
+}
+
+// the two panel descriptions of a pair and what both kernels derive from them (uniform per workgroup)
+struct PairGeom { int g1, mp, mp1, mp2, nb1, nb2, k1a, k1b, pc0; };
+__device__ __forceinline__ bool pair_geom(const FrontNum *num, int p, PairGeom &G)
+{
+    const PanelDesc *pa = &num->pd[(p - 1) & 1], *pb = &num->pd[p & 1];
+    G.nb1 = pa->pnb;
+    if (G.nb1 <= 0) return false;                               // (panel a did nothing: then b did nothing either)
+    G.nb2 = pb->pnb > 0 ? pb->pnb : 0;
+    G.g1 = pa->pg1;
+    G.mp1 = pa->pt - pa->pg1;
+    G.mp2 = G.nb2 > 0 ? pb->pt - pa->pg1 : 0;
+    G.mp = max(G.mp1, G.mp2);
+    G.k1a = pa->pk1; G.k1b = G.nb2 > 0 ? pb->pk1 : pa->pk1;
+    G.pc0 = pa->pc0 + 2 * STM_NB;                               // first column beyond panel p+1
+    return G.mp > 0;
+}
+
+__global__ __launch_bounds__(NT) void k_upd_w2(DevCtx c, const int *__restrict__ flist, const int *__restrict__ plist, double *Wp,
+                                               const long long *__restrict__ wpoff, int *wcnt)
+{
+    extern __shared__ double dyn_lds[];
+    __shared__ int s_pd1[STM_NB], s_pd2[STM_NB];
+    __shared__ int s_ticket;
+    const int fi = blockIdx.z, f = flist[fi], p = plist[fi];
+    const FrontSym s = c.fs[f];
+    if (p >= s.npanels || !(p & 1)) return;
+    FrontNum *num = &c.fnum[f];
+    PairGeom G;
+    if (!pair_geom(num, p, G)) return;
+    const int ncbp = stm_upd_ncb(s, p) - 1, nslf = stm_upd_nsl(s);   // pair column blocks: beyond block 0 of panel p
+    if (ncbp <= 0) return;
+    const int cb = blockIdx.x, sl = blockIdx.y;
+    const bool gram = (cb == (int)gridDim.x - 1);                    // last block of the launch: G21 = V2'V1
+    if (!gram && cb >= ncbp) return;
+    if (gram && G.nb2 <= 0) return;
+    const int c0 = gram ? G.k1a : G.pc0 + cb * BN;
+    if (c0 >= s.fn || sl * SLAB >= G.mp) return;
+    const int nc = gram ? G.nb1 : min(BN, s.fn - c0);
+    const long long ld = s.ld;
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, l15 = lane & 15, l4 = lane >> 4;
+    double *Vs1 = dyn_lds, *Vs2 = Vs1 + STM_NB * VS, *Cs = Vs2 + STM_NB * VS;
+    const PanelDesc *pa = &num->pd[(p - 1) & 1], *pb = &num->pd[p & 1];
+    if (tid < STM_NB) {
+        s_pd1[tid] = (tid < G.nb1) ? pa->pdiag[tid] : STM_BIGROW;
+        s_pd2[tid] = (tid < G.nb2) ? pb->pdiag[tid] : STM_BIGROW;
+    }
+    __syncthreads();
+    const double *Fb = c.Farena + s.foff + G.g1;
+    const double *V1g = Fb + (long long)G.k1a * ld, *V2g = Fb + (long long)G.k1b * ld, *Cg = Fb + (long long)c0 * ld;
+    const int mi = wid >> 1, ni = wid & 1;
+    d4 acc1 = {0, 0, 0, 0}, acc2 = {0, 0, 0, 0};
+    const int rend = min(G.mp, (sl + 1) * SLAB);
+    UpdChunk2 ck;
+    upd2_chunk_load(ck, V1g, V2g, Cg, ld, sl * SLAB + (tid & 63), G.mp, G.nb1, G.nb2, nc, tid >> 6);
+    for (int r0 = sl * SLAB; r0 < rend; r0 += RB) {
+        upd2_chunk_to_lds(ck, r0 + (tid & 63), G.mp, G.mp1, G.mp2, G.nb1, G.nb2, nc, s_pd1, s_pd2, G.g1, tid & 63, tid >> 6, Vs1, Vs2,
+                          Cs, gram);
+        __syncthreads();
+        if (r0 + RB < rend) upd2_chunk_load(ck, V1g, V2g, Cg, ld, r0 + RB + (tid & 63), G.mp, G.nb1, G.nb2, nc, tid >> 6);
+#pragma unroll
+        for (int kk = 0; kk < RB / 4; kk++) {
+            const double a1 = Vs1[(16 * mi + l15) * VS + 4 * kk + l4];
+            const double a2 = Vs2[(16 * mi + l15) * VS + 4 * kk + l4];
+            const double b = Cs[(16 * ni + l15) * VS + 4 * kk + l4];
+            acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b, acc1, 0, 0, 0);
+            acc2 = __builtin_amdgcn_mfma_f64_16x16x4f64(a2, b, acc2, 0, 0, 0);
+        }
+        __syncthreads();
+    }
+    // slot of (column block, slab): two blocks, W1 then W2; the Gram block is column block ncbp
+    const int nsl = (G.mp + SLAB - 1) / SLAB;
+    double *W0 = Wp + wpoff[fi] + ((long long)(gram ? ncbp : cb) * nslf) * (2 * STM_NB * BN);
+    double *W = W0 + (long long)sl * (2 * STM_NB * BN);
+    if (nsl == 1) {
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            W[(16 * mi + l4 + 4 * r) * BN + 16 * ni + l15] = acc1[r];
+            W[STM_NB * BN + (16 * mi + l4 + 4 * r) * BN + 16 * ni + l15] = acc2[r];
+        }
+        return;
+    }
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+        st_agent(&W[(16 * mi + l4 + 4 * r) * BN + 16 * ni + l15], acc1[r]);
+        st_agent(&W[STM_NB * BN + (16 * mi + l4 + 4 * r) * BN + 16 * ni + l15], acc2[r]);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    int *cnt = wcnt + wpoff[fi] / (STM_NB * BN) + (gram ? ncbp : cb);
+    if (tid == 0) {
+        s_ticket = __hip_atomic_fetch_add(cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (s_ticket == nsl - 1) {
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __hip_atomic_store(cnt, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+    __syncthreads();
+    if (s_ticket != nsl - 1) return;
+    double v[2 * STM_NB * BN / NT];
+#pragma unroll
+    for (int q = 0; q < 2 * STM_NB * BN / NT; q++) v[q] = stm_ordered_sum<true>(W0 + tid + q * NT, 2 * STM_NB * BN, nsl);   // fixed order
+#pragma unroll
+    for (int q = 0; q < 2 * STM_NB * BN / NT; q++) W0[tid + q * NT] = v[q];
+}
+
+__global__ __launch_bounds__(NT) void k_upd_c2(DevCtx c, const int *__restrict__ flist, const int *__restrict__ plist,
+                                               const double *Wp, const long long *__restrict__ wpoff)
+{
+    extern __shared__ double dyn_lds[];
+    __shared__ int s_pd1[STM_NB], s_pd2[STM_NB];
+    const int fi = blockIdx.z, f = flist[fi], p = plist[fi];
+    const FrontSym s = c.fs[f];
+    if (p >= s.npanels || !(p & 1)) return;
+    const FrontNum *num = &c.fnum[f];
+    PairGeom G;
+    if (!pair_geom(num, p, G)) return;
+    const int ncbp = stm_upd_ncb(s, p) - 1, nslf = stm_upd_nsl(s);
+    const int cb = blockIdx.x, sl = blockIdx.y;
+    if (cb >= ncbp) return;
+    const int c0 = G.pc0 + cb * BN;
+    if (c0 >= s.fn || sl * SLAB >= G.mp) return;
+    const int nsl_all = (G.mp + SLAB - 1) / SLAB;
+    const int spw = (nsl_all >= 32) ? 4 : (nsl_all >= 16) ? 2 : 1;
+    if (sl % spw) return;
+    const int nc = min(BN, s.fn - c0);
+    const long long ld = s.ld;
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, l15 = lane & 15, l4 = lane >> 4;
+    double *Vs1 = dyn_lds, *Vs2 = Vs1 + STM_NB * VS, *Cs = Vs2 + STM_NB * VS, *Ws = Cs + BN * VS;     // Ws: [2 * STM_NB][WS]
+    // prologue images in the chunk images (first written after the prologue): 5 x [32][WS] <= 3 x [32][VS]
+    double *s_W1 = dyn_lds, *s_W2 = s_W1 + STM_NB * WS, *s_T1 = s_W2 + STM_NB * WS, *s_T2 = s_T1 + STM_NB * WS,
+           *s_G = s_T2 + STM_NB * WS;
+    const PanelDesc *pa = &num->pd[(p - 1) & 1], *pb = &num->pd[p & 1];
+    if (tid < STM_NB) {
+        s_pd1[tid] = (tid < G.nb1) ? pa->pdiag[tid] : STM_BIGROW;
+        s_pd2[tid] = (tid < G.nb2) ? pb->pdiag[tid] : STM_BIGROW;
+    }
+    const double *Fb = c.Farena + s.foff + G.g1;
+    const double *V1g = Fb + (long long)G.k1a * ld, *V2g = Fb + (long long)G.k1b * ld;
+    double *Cg = c.Farena + s.foff + G.g1 + (long long)c0 * ld;
+    const int lrow = tid & 63, lcg = tid >> 6;
+    UpdChunk2 ck;
+    upd2_chunk_load(ck, V1g, V2g, Cg, ld, sl * SLAB + lrow, G.mp, G.nb1, G.nb2, nc, lcg);
+    {
+        const double *W0 = Wp + wpoff[fi] + ((long long)cb * nslf) * (2 * STM_NB * BN);
+        const double *Gr = Wp + wpoff[fi] + ((long long)ncbp * nslf) * (2 * STM_NB * BN) + STM_NB * BN;     // W2 part of the Gram block
+        const double *T1 = c.Tws + (long long)(2 * c.tslot[f] + ((p - 1) & 1)) * STM_NB * STM_NB;
+        const double *T2 = c.Tws + (long long)(2 * c.tslot[f] + (p & 1)) * STM_NB * STM_NB;
+        const bool has2 = G.nb2 > 0;
+        for (int e = tid; e < STM_NB * BN; e += NT) {
+            s_W1[(e / BN) * WS + (e % BN)] = W0[e];
+            s_W2[(e / BN) * WS + (e % BN)] = has2 ? W0[STM_NB * BN + e] : 0.0;
+            s_G[(e / BN) * WS + (e % BN)] = has2 ? Gr[e] : 0.0;                    // G21(a, b) = v2_a' v1_b
+            s_T1[(e / STM_NB) * WS + (e % STM_NB)] = T1[e];                          // s_T[col][row] = T(row, col)
+            s_T2[(e / STM_NB) * WS + (e % STM_NB)] = has2 ? T2[e] : 0.0;
+        }
+        __syncthreads();
+        const int l = tid & 31, cg = tid >> 5;
+        double y[4] = {0, 0, 0, 0};
+        for (int q = 0; q <= l; q++) {                             // Y1 = T1' W1
+            const double tq = s_T1[l * WS + q];
+#pragma unroll
+            for (int x = 0; x < 4; x++) y[x] += tq * s_W1[q * WS + cg * 4 + x];
+        }
+#pragma unroll
+        for (int x = 0; x < 4; x++) Ws[l * WS + cg * 4 + x] = y[x];
+        __syncthreads();
+        double z[4];                                               // Z = W2 - G21 Y1  ( = V2'(C - V1 Y1) )
+#pragma unroll
+        for (int x = 0; x < 4; x++) z[x] = s_W2[l * WS + cg * 4 + x];
+        for (int b = 0; b < STM_NB; b++) {
+            const double gq = s_G[l * WS + b];
+#pragma unroll
+            for (int x = 0; x < 4; x++) z[x] -= gq * Ws[b * WS + cg * 4 + x];
+        }
+        __syncthreads();                                           // (everyone has read W2 before Z replaces it)
+#pragma unroll
+        for (int x = 0; x < 4; x++) s_W2[l * WS + cg * 4 + x] = z[x];
+        __syncthreads();
+        double y2[4] = {0, 0, 0, 0};
+        for (int q = 0; q <= l; q++) {                             // Y2 = T2' Z
+            const double tq = s_T2[l * WS + q];
+#pragma unroll
+            for (int x = 0; x < 4; x++) y2[x] += tq * s_W2[q * WS + cg * 4 + x];
+        }
+#pragma unroll
+        for (int x = 0; x < 4; x++) Ws[(STM_NB + l) * WS + cg * 4 + x] = y2[x];
+    }
+    __syncthreads();
+    const int rend = min(G.mp, (sl + spw) * SLAB);
+    for (int r0 = sl * SLAB; r0 < rend; r0 += RB) {
+        const int i = r0 + lrow;
+        upd2_chunk_to_lds(ck, i, G.mp, G.mp1, G.mp2, G.nb1, G.nb2, nc, s_pd1, s_pd2, G.g1, lrow, lcg, Vs1, Vs2, Cs, false);
+        __syncthreads();
+        if (r0 + RB < rend) upd2_chunk_load(ck, V1g, V2g, Cg, ld, i + RB, G.mp, G.nb1, G.nb2, nc, lcg);
+        d4 u0 = {0, 0, 0, 0}, u1 = {0, 0, 0, 0};
+#pragma unroll
+        for (int kk = 0; kk < STM_NB / 4; kk++) {
+            const double a = Vs1[(4 * kk + l4) * VS + 16 * wid + l15];
+            u0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, Ws[(4 * kk + l4) * WS + l15], u0, 0, 0, 0);
+            u1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, Ws[(4 * kk + l4) * WS + 16 + l15], u1, 0, 0, 0);
+        }
+#pragma unroll
+        for (int kk = 0; kk < STM_NB / 4; kk++) {
+            const double a = Vs2[(4 * kk + l4) * VS + 16 * wid + l15];
+            u0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, Ws[(STM_NB + 4 * kk + l4) * WS + l15], u0, 0, 0, 0);
+            u1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, Ws[(STM_NB + 4 * kk + l4) * WS + 16 + l15], u1, 0, 0, 0);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const int row = 16 * wid + l4 + 4 * r;
+            Cs[l15 * VS + row] -= u0[r];
+            Cs[(16 + l15) * VS + row] -= u1[r];
+        }
+        __syncthreads();
+        if (i < G.mp) {
+#pragma unroll
+            for (int q = 0; q < 8; q++) {
+                const int col = lcg * 8 + q;
+                if (col < nc) Cg[i + col * ld] = Cs[col * VS + lrow];
+            }
+        }
+        __syncthreads();
+    }
+}
+
 // T of the LAST panel of a front whose panel kernel left it pending (PanelDesc::t_deferred == 2: the Gram-based panel never
 // builds T, and no trailing update follows the last panel).  Only the Q-apply on the resident factors reads it (DevCtx::Tall).
 __device__ void dev_tlast(const DevCtx &c, int f, const FrontSym &s, FrontNum *num, double *scratch)
@@ -3088,6 +3357,16 @@ int stm_launch_update_fused(const DevCtx &c, const int *flist, const int *plist,
     if (nfr <= 0 || ny <= 0 || maxsl <= 0) return 0;
     hipLaunchKernelGGL(k_upd_f, dim3(maxsl, ny, nfr), dim3(NT), (size_t)stm_update_lds_bytes(), st, c, flist, plist, cb0,
                        with_gram ? 1 : 0, Wp, wpoff, wcnt, wflag, epoch);
+    return (int)hipGetLastError();
+}
+int stm_launch_update_pair(const DevCtx &c, const int *flist, const int *plist, int nfr, int ncbp, int maxsl, double *Wp,
+                           const long long *wpoff, int *wcnt, hipStream_t st)
+{
+    if (nfr <= 0 || ncbp <= 0 || maxsl <= 0) return 0;
+    hipLaunchKernelGGL(k_upd_w2, dim3(ncbp + 1, maxsl, nfr), dim3(NT), (size_t)(3 * BN * VS) * sizeof(double), st, c, flist, plist, Wp,
+                       wpoff, wcnt);
+    hipLaunchKernelGGL(k_upd_c2, dim3(ncbp, maxsl, nfr), dim3(NT), (size_t)(3 * BN * VS + 2 * STM_NB * WS) * sizeof(double), st, c, flist,
+                       plist, (const double *)Wp, wpoff);
     return (int)hipGetLastError();
 }
 int stm_launch_larft(const DevCtx &c, int f, hipStream_t st)

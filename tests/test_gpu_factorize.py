@@ -113,6 +113,31 @@ def test_lookahead_schedule_same_bits(pkg, name, bfc, algo):
             assert np.array_equal(x, y, equal_nan=True)
 
 
+@pytest.mark.parametrize("name", NAMES)
+@pytest.mark.parametrize("bfc", [16, 64])
+def test_pair_update_everywhere(pkg, oracle, monkeypatch, name, bfc):
+    """options.pair_update: fronts of >= 16384 rows apply the block reflectors of two consecutive panels in one sweep
+    (k_upd_w2 / k_upd_c2) on the columns beyond the next two panels.  STMMQR_PAIR_MIN=1 gives that path to every large
+    front with at least four panels (here: fn >= 16 / 64): integers, R rows and the factors against the golden vectors and
+    the oracle, exactly as for the one-panel-at-a-time update (different rounding, same tolerances)."""
+    g = load_golden(name)
+    monkeypatch.setenv("STMMQR_PAIR_MIN", "1")
+    pkg.set_options(big_front_cols=bfc)
+    try:
+        S, G = gpu_run(pkg, g)
+    finally:
+        pkg.set_options(big_front_cols=64)
+    N = numeric_from_gpu(S, G)
+    compare_integers(S, N, g)
+    assert G.stats["flops"] == scalar(g, "flopcount")
+    got, ref = rrow_sig_all(S, N), g["num_rrow_sig"]
+    ftol = ILL_CONDITIONED.get(name, 1e-10)
+    scale = np.max(ref[:, 1], initial=1e-300) if name in ILL_CONDITIONED else np.maximum(ref[:, 1:2], 1e-300)
+    assert np.max(np.abs(got - ref) / scale, initial=0.0) <= ftol
+    No = oracle.factorize(S, g["in_Ap"], g["in_Ai"], g["in_Ax"], scalar(g, "in_tol"), int(scalar(g, "in_ntol")))
+    compare_numeric(oracle, S, G, No, g, ftol=1e-10, name=name)
+
+
 @pytest.mark.parametrize("name,tall_min", [(n, 256) for n in NAMES] +
                          [(n, t) for n in ("syn_grid3d", "syn_rankdef_grid", "bcsstk14", "grid20_standin") for t in (48, 1 << 30)])
 def test_panel_pipeline_threshold(pkg, oracle, name, tall_min):
