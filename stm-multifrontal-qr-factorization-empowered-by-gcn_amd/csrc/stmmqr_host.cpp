@@ -316,8 +316,8 @@ void build_schedule(stmmqr_plan &P, std::vector<int> &tslot)
         const FrontSym &s = P.fs[f];
         return s.fn >= g_opt.big_front_cols && s.fm_ub >= 64;
     };
+    // STMMQR_SCHED (experiments): 1 level-synchronous, 2 as soon as possible, 3 envelope rule; unset / 0: chosen per group
     const int sched_policy = getenv("STMMQR_SCHED") ? atoi(getenv("STMMQR_SCHED")) : 0;
-    const bool sched_level = sched_policy == 1;
     // Pair update (k_upd_w2 / k_upd_c2): a property of the front alone -- it changes the rounding of the front's
     // trailing updates, and results must not depend on the schedule.  Fronts whose update is bandwidth bound: many rows.
     const long pair_min = getenv("STMMQR_PAIR_MIN") ? atol(getenv("STMMQR_PAIR_MIN")) : STM_PAIR_MIN_ROWS;
@@ -355,21 +355,31 @@ void build_schedule(stmmqr_plan &P, std::vector<int> &tslot)
             end[f] = t0 + (is_big((int)f) ? P.fs[f].npanels : 1);
             nstep = std::max(nstep, end[f]);
         }
-        if (sched_level) {
-            // the level-synchronous schedule: every front of a tree level starts when the level below has finished
+        // the level-synchronous schedule: every front of a tree level starts when the level below has finished
+        std::vector<int> lstart(nf, 0), lend(nf, 0);
+        int nstep_level = 0;
+        {
             std::vector<int> lvl_end(nlev + 1, 0);
             for (int lv = 0; lv < nlev; lv++) {
                 int e1 = lvl_end[lv];
                 for (long kf = 0; kf < nf; kf++) {
                     const long f = P.Post[kf];
                     if (P.group[f] != grp || level[f] != lv) continue;
-                    start[f] = lvl_end[lv];
-                    end[f] = start[f] + (is_big((int)f) ? P.fs[f].npanels : 1);
-                    e1 = std::max(e1, end[f]);
+                    lstart[f] = lvl_end[lv];
+                    lend[f] = lstart[f] + (is_big((int)f) ? P.fs[f].npanels : 1);
+                    e1 = std::max(e1, lend[f]);
                 }
                 lvl_end[lv + 1] = e1;
             }
-            nstep = lvl_end[nlev];
+            nstep_level = lvl_end[nlev];
+        }
+        // Which order (STMMQR_SCHED unset): the envelope rule reaches the minimum number of steps (nstep here) but its steps
+        // are ~10-15 % longer than those of the level-synchronous order (a launch lasts as long as its slowest front and
+        // rows are only a proxy for that; measured) -- it is taken when it removes more than a fifth of the steps.
+        const bool use_level = sched_policy == 1 || (sched_policy == 0 && 5L * nstep > 4L * nstep_level);
+        if (use_level) {
+            start = lstart; end = lend;
+            nstep = nstep_level;
         }
         std::vector<std::vector<int>> byl(nlev);
         for (long kf = 0; kf < nf; kf++)
@@ -388,14 +398,13 @@ void build_schedule(stmmqr_plan &P, std::vector<int> &tslot)
         }
         // ---- the step timeline ----
         // panel_at[t] = the (big front, panel) pairs of step t; small_at[t] = the small fronts factorized at step t.
-        // Policies (STMMQR_SCHED, experiments): 1 level-synchronous, 2 as soon as possible (above), default the envelope
-        // rule: every step runs the fronts on the longest remaining path (counted in panels up to the root); any other
+        // The envelope rule: every step runs the fronts on the longest remaining path (counted in panels up to the root); any other
         // front that is ready or in flight rides along if its panel is no taller than theirs -- a launch lasts as long
         // as its tallest panel and is configured for it (LDS, column groups), so shorter panels are free while a taller
         // one would make the step of the critical fronts longer.  The minimum number of steps, the cheapest envelope.
         std::vector<std::vector<std::pair<int, int>>> panel_at;
         std::vector<std::vector<int>> small_at;
-        if (sched_policy != 0) {
+        if (use_level || sched_policy == 2) {
             panel_at.assign(nstep, {});
             small_at.assign(nstep, {});
             for (long kf = 0; kf < nf; kf++) {

@@ -1931,10 +1931,9 @@ __global__ __launch_bounds__(NT) void k_upd_c(DevCtx c, const int *__restrict__ 
     const int lrow = tid & 63, lcg = tid >> 6;
     UpdChunk ck;
     upd_chunk_load(ck, Vg, Cg, ld, sl * SLAB + lrow, mp, nbp, nc, lcg);
-    // W2 = T' sum_slabs W1 (every slab workgroup of a column block recomputes it: 32^3 multiply-adds against one
-    // launch less per panel); the summation order over the slabs is fixed
+    // W2 = T' W1 (every slab workgroup of a column block recomputes it: 32^3 multiply-adds against one launch less per
+    // panel); W1 = the slabs' partials added in slab order by k_upd_w
     {
-        const int nsl = (mp + SLAB - 1) / SLAB;
         const double *W0 = Wp + wpoff[fi] + ((long long)cb * nslf) * (STM_NB * BN);
         const double *T = c.Tws + (long long)(2 * c.tslot[f] + (p & 1)) * STM_NB * STM_NB;
         for (int e = tid; e < STM_NB * BN; e += NT) {
