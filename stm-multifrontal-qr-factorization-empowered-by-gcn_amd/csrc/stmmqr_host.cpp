@@ -474,6 +474,19 @@ void build_schedule(stmmqr_plan &P, std::vector<int> &tslot)
                 if (fp.second == P.fs[fp.first].npanels - 1) ending[t].push_back(fp.first);
             }
         }
+        // The packing of finished fronts is batched: k_cpack runs at the last step before some front STARTS (only an
+        // assembly reads a packed block) or at the end of the group -- one launch per tree level in the level-synchronous
+        // order instead of one per step in which a front happens to end.  (T / Gram slots are released at the flush:
+        // k_cpack's extra workgroup may still write the T of the front's last panel.)
+        for (int t = 0, carry_from = -1; t < nstep; t++) {
+            const bool flush = (t + 1 == nstep) || !starting[t + 1].empty();
+            if (carry_from >= 0 && carry_from != t) {
+                ending[t].insert(ending[t].begin(), ending[carry_from].begin(), ending[carry_from].end());
+                ending[carry_from].clear();
+            }
+            carry_from = (flush || ending[t].empty()) ? -1 : t;
+            if (!flush && !ending[t].empty()) carry_from = t;
+        }
         std::vector<Step> &SV = P.gsteps[grp];
         SV.assign(nstep, Step());
         std::vector<int> active, freeslots;                   // big fronts in flight; released T / Gram slots
