@@ -439,7 +439,8 @@ def main():
                             "frac": det["bytes_assemble"] / max(det["ms_assemble"], 1e-9) * 1e-6 / PEAK_HBM_GBS}
         roof["ms"] = {k: det[k] for k in ("ms_total", "ms_assemble", "ms_panel", "ms_small", "ms_update", "ms_pack")}
         oname = ORDERING_NAMES.get(int(g["ordering"][0]), str(int(g["ordering"][0]))) if "ordering" in g else "unknown"
-        standin_of = {"xenon1": "xenon1.mtx", "sme3dc": "sme3Dc.mtx", "c5mid": "3D_51448_3D.mtx (structure only, n = 27 000)", "c5": "3D_51448_3D.mtx (structure only, n = 8000)"}
+        standin_of = {"xenon1": "xenon1.mtx", "sme3dc": "sme3Dc.mtx", "c5mid": "3D_51448_3D.mtx (structure only, n = 27 000)", "c5mini": "3D_51448_3D.mtx (structure only, n = 8000)",
+                      "c5_": "3D_51448_3D.mtx (SURVEY 8d generator at full size, n = 52 022)"}
         sof = next((v for k, v in standin_of.items() if name.startswith(k)), None)
         wl = (f"{name}: m={S.m} n={S.n} nnz={S.anz} fronts={S.nf} flops/step={flops:.4g}, ordering {oname}" +
               (f" (stand-in for {sof}, absent from the reference checkout)" if "standin" in name and sof else ""))

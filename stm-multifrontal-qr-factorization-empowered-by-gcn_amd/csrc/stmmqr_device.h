@@ -144,12 +144,13 @@ struct FrontNum {
     int rank;                // live pivotal columns                (qr_front's return value)
     int done;                // 1 once g reached fm and the tail columns were finalised
     int cm;                  // rows of the contribution block      (qr_cpack's return value)
-    int rsize;               // entries of the packed R+H block     (qr_rhpack's return value)
+    int pad_rs;
     int hdr;                 // tall-panel pipeline: p+1 once the header (mode, pg1, tmax, sw) of panel p is published
     int prog;                // ... STM_PROG*p + 2*(finished groups of panel p) + (1: first half of the next one); monotone
     int perr;                // ... set when a bounded wait ran out (the factorization is reported as failed)
     int gcnt;                // arrival counter of the Gram slabs in k_upd_w (back to 0 after every panel)
     int tready;              // fused update: step + 1 once T of the panel of that step is in its slot (Gram block's last slab)
+    long long rsize;         // entries of the packed R+H block     (qr_rhpack's return value; 2.2e9 at the largest size)
     double flops;            // reference flop count of this front  (FLOP_COUNT, :1571)
     double flops_upd;        // the part of `flops` that the trailing update does: sum (t-g) * 4 * (fn - k2), k2 = panel end
     // pending block reflectors, double buffered by panel parity so that the look-ahead schedule can factorize

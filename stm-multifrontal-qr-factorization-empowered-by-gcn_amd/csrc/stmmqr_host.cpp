@@ -160,7 +160,8 @@ struct stmmqr_plan {
     DevBuf<FrontNum> d_fnum;
     DevBuf<double> d_F, d_C, d_T, d_Gp, d_Tall, d_Sx, d_Ax, d_Tau, d_RH, d_Wp, d_Wp2;
     DevBuf<int> d_tslot, d_Sp, d_Sjrel, d_Sj0, d_Sleft, d_Child, d_Rjrel, d_Stair, d_Hii, d_Cmap, d_Cursor,
-        d_Rhoff, d_lists, d_smap;
+        d_lists, d_smap;
+    DevBuf<long long> d_Rhoff;
     DevBuf<long long> d_wlists;
     DevBuf<int> d_wcnt, d_wcnt2;         // per column block of the update workspaces: slab tickets (zero between launches)
     DevBuf<int> d_wflag, d_wflag2;       // ... fused update: step + 1 once W2 of the column block is in its slot
@@ -668,7 +669,8 @@ int build_plan(stmmqr_plan &P, const stmmqr_symbolic_view &v)
         FrontSym &s = P.fs[f];
         const long fp = P.Super[f + 1] - P.Super[f], fn = P.Rp[f + 1] - P.Rp[f];
         const long fm = P.Fm[f];
-        if (fm * fn >= (1L << 31)) return fail(STMMQR_ERR_TOO_LARGE, "a single front exceeds 2^31 entries");
+        // (front-local offsets are 64-bit on the device: row + column * ld; rows and columns themselves are int32)
+        if (fm * fn >= (1L << 36)) return fail(STMMQR_ERR_TOO_LARGE, "a single front exceeds 2^36 entries");
         s.fn = (int)fn; s.fp = (int)fp; s.col1 = (int)P.Super[f]; s.rp = (int)P.Rp[f]; s.hip = (int)P.Hip[f];
         s.child0 = (int)P.Childp[f]; s.child1 = (int)P.Childp[f + 1];
         s.srow0 = (int)P.Sleft[P.Super[f]]; s.srow1 = (int)P.Sleft[P.Super[f + 1]];

@@ -30,7 +30,7 @@ struct DevCtx {
     char *Rdead;               // [n]
     int *Cmap;                 // [rjsize] for child c, slot Rp[c]+fp+ci: row of the parent
     int *Cursor;               // [rjsize] scratch of k_setup
-    int *Rhoff;                // [rjsize] column offsets inside a packed R+H block
+    long long *Rhoff;          // [rjsize] column offsets inside a packed R+H block
     long long *Rboff;          // [nf] offset of each packed R+H block
     double tol;
     int ntol;

@@ -2507,14 +2507,14 @@ __global__ __launch_bounds__(NT) void k_rh_count(DevCtx c, const int *__restrict
     const int tid = threadIdx.x;
     const int fm = num->fm, n = s.fn, fp = s.fp;
     const int *St = c.Stair + s.rp;
-    int *off = c.Rhoff + s.rp;
+    long long *off = c.Rhoff + s.rp;                   // (64-bit: the block of a 52 000 x 50 000 front has 2.2e9 entries)
     if (fm <= 0 || n <= 0) {
         for (int k = tid; k < n; k += NT) off[k] = 0;
         if (tid == 0) num->rsize = 0;
         return;
     }
     // pass 1: rm(k) = live pivots among columns 0..k (stored temporarily in off[])
-    int carry = 0;
+    long long carry = 0;
     for (int base = 0; base < fp; base += NT) {
         const int k = base + tid;
         const int live = (k < fp && St[k] != 0) ? 1 : 0;
@@ -2524,7 +2524,7 @@ __global__ __launch_bounds__(NT) void k_rh_count(DevCtx c, const int *__restrict
         carry += tot;
     }
     __syncthreads();
-    const int rm = carry;
+    const int rm = (int)carry;
     // pass 2: column lengths -> exclusive offsets
     carry = 0;
     for (int base = 0; base < n; base += NT) {
@@ -2532,7 +2532,7 @@ __global__ __launch_bounds__(NT) void k_rh_count(DevCtx c, const int *__restrict
         int len = 0;
         if (k < fp) {
             const int t = St[k];
-            len = (t == 0) ? off[k] : t;       // dead: rm so far (off[k] excludes k itself since live=0)
+            len = (t == 0) ? (int)off[k] : t;  // dead: rm so far (off[k] excludes k itself since live=0)
         } else if (k < n) {
             const int h = min(rm + (k - fp) + 1, fm);
             len = rm + max(St[k] - h, 0);
@@ -2586,14 +2586,14 @@ __global__ __launch_bounds__(NT) void k_rh_copy(DevCtx c, const int *__restrict_
     const long long ld = s.ld;
     const double *F = c.Farena + s.foff;
     const int *St = c.Stair + s.rp;
-    const int *off = c.Rhoff + s.rp;
+    const long long *off = c.Rhoff + s.rp;
     double *R = RH + c.Rboff[f];
     // one wave per column
     for (int k = blockIdx.x * NW + wid; k < n; k += nparts * NW) {
         const double *Fk = F + k * ld;
         double *Rk = R + off[k];
         if (k < fp) {
-            const int len = ((k + 1 < n) ? off[k + 1] : num->rsize) - off[k];
+            const int len = (int)(((k + 1 < n) ? off[k + 1] : num->rsize) - off[k]);
             for (int i = lane; i < len; i += 64) Rk[i] = Fk[i];
         } else {
             const int h = min(rm + (k - fp) + 1, fm);

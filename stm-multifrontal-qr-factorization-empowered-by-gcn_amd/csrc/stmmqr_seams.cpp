@@ -50,7 +50,8 @@ struct OneFront {
     Buf<FrontSym> d_fs;
     Buf<FrontNum> d_nm;
     Buf<double> d_F, d_C, d_T, d_Gp, d_Tau, d_RH, d_sig;
-    Buf<int> d_St, d_tslot, d_flist, d_Rhoff, d_parts;
+    Buf<int> d_St, d_tslot, d_flist, d_parts;
+    Buf<long long> d_Rhoff;
     Buf<long long> d_Rboff;
     Buf<unsigned long long> d_dbg;
     Buf<char> d_Rdead;
@@ -336,7 +337,7 @@ stm_long qr_rhpack(int keepH, stm_long m, stm_long n, stm_long npiv, stm_long *S
     if (stm_launch_rh_count(X.c, X.d_flist.p, 1, nullptr)) return -1;
     if (stm_launch_rh_copy(X.c, X.d_flist.p, X.d_parts.p, 1, 8, X.d_RH.p, nullptr)) return -1;
     if (hipDeviceSynchronize() != hipSuccess || !X.pull_num()) return -1;
-    std::vector<double> out((size_t)std::max(1, X.nm.rsize));
+    std::vector<double> out((size_t)std::max(1LL, X.nm.rsize));
     if (!X.d_RH.down(out.data(), (size_t)X.nm.rsize)) return -1;
     memmove(R, out.data(), sizeof(double) * (size_t)X.nm.rsize);   // R may alias F (in-place pack)
     if (p_rm) *p_rm = rm;

@@ -23,7 +23,7 @@ import numpy as np
 HERE = Path(__file__).resolve().parent
 ROOT = HERE.parent.parent
 sys.path.insert(0, str(ROOT / "tests"))
-from stmmqr_testlib import block_sketch, determined_part, front_R, rrow_signature  # noqa: E402
+from stmmqr_testlib import determined_sketch, rrow_signature_of_block  # noqa: E402
 
 REFDUMP = ROOT / "oracle" / "_ref" / "refdump"
 REFDATA = Path("/root/reference/Data")
@@ -32,21 +32,19 @@ VALUES_LIMIT = 100000          # nnz; above this the values are regenerated from
 
 
 def parse_dump(path):
+    """records of refdump: name[32], type char, count int64, payload -- read one array at a time (a stack is tens of GB
+    at the largest size: no second copy)"""
     out = {}
     with open(path, "rb") as f:
-        data = f.read()
-    pos = 0
-    while pos < len(data):
-        name = data[pos:pos + 32].split(b"\0")[0].decode(); pos += 32
-        ty = chr(data[pos]); pos += 1
-        (cnt,) = struct.unpack_from("<q", data, pos); pos += 8
-        if ty == "b":
-            a = np.frombuffer(data, np.int8, cnt, pos).copy(); pos += cnt
-        elif ty == "q":
-            a = np.frombuffer(data, np.int64, cnt, pos).copy(); pos += 8 * cnt
-        else:
-            a = np.frombuffer(data, np.float64, cnt, pos).copy(); pos += 8 * cnt
-        out[name] = a
+        while True:
+            head = f.read(41)
+            if len(head) < 41:
+                break
+            name = head[:32].split(b"\0")[0].decode()
+            ty = chr(head[32])
+            (cnt,) = struct.unpack_from("<q", head, 33)
+            dt = {"b": np.int8, "q": np.int64}.get(ty, np.float64)
+            out[name] = np.fromfile(f, dt, cnt)
     return out
 
 
@@ -191,9 +189,9 @@ def compact(name, d):
     Rp, Super, Hm, HStair = d["sym_Rp"], d["sym_Super"], d["num_Hm"], d["num_HStair"]
     for f, a, b in zip(post, order_offs, ends):
         fn, fp = Rp[f + 1] - Rp[f], Super[f + 1] - Super[f]
-        sk[f] = block_sketch(determined_part(stack[a:b], HStair[Rp[f]:Rp[f + 1]], fp, fn, Hm[f]))
+        sk[f] = determined_sketch(stack[a:b], HStair[Rp[f]:Rp[f + 1]], fp, fn, Hm[f])
         rsize[f] = b - a
-        sigs[f] = rrow_signature(front_R(stack[a:b], HStair[Rp[f]:Rp[f + 1]], fp, fn, Hm[f]))
+        sigs[f] = rrow_signature_of_block(stack[a:b], HStair[Rp[f]:Rp[f + 1]], fp, fn, Hm[f])
     out["num_rrow_sig"] = np.concatenate([sigs[f] for f in range(nf)]) if nf else np.zeros((0, 3))
     out["num_rh_sketch"] = sk
     out["num_rh_size"] = rsize

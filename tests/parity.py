@@ -8,7 +8,7 @@ What "identical to the reference" means for this path (see tests/test_oracle_gol
 """
 import numpy as np
 
-from stmmqr_testlib import (aqr_probe_error, front_R, numeric_from_gpu, rrow_signature, scalar)
+from stmmqr_testlib import (aqr_probe_error, front_R, numeric_from_gpu, rrow_signature, rrow_signature_of_block, scalar)
 
 ELEMENTWISE = ("syn_dense6x4", "syn_wide5x8", "syn_dupcol", "syn_emptycol", "syn_chain", "syn_star",
                "syn_rand60x40")
@@ -20,7 +20,7 @@ def rrow_sig_all(S, N):
     out = []
     for f in range(S.nf):
         fn, fp = S.Rp[f + 1] - S.Rp[f], S.Super[f + 1] - S.Super[f]
-        out.append(rrow_signature(front_R(blocks[f], N.HStair[S.Rp[f]:S.Rp[f + 1]], fp, fn, N.Hm[f])))
+        out.append(rrow_signature_of_block(blocks[f], N.HStair[S.Rp[f]:S.Rp[f + 1]], fp, fn, N.Hm[f]))
     return np.concatenate(out) if out else np.zeros((0, 3))
 
 

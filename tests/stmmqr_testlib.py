@@ -43,7 +43,7 @@ SYM_SCALARS = ["m", "n", "anz", "nf", "maxfn", "rjsize", "do_rank_detection", "m
                "ntasks", "ns"]
 
 
-BIG_FIXTURES = ("xenon1_standin", "xenon1_colamd_standin", "sme3dc_standin", "c5mini_standin", "c5mid_standin")      # full BASELINE size: too slow for the scalar CPU oracle, GPU tests only
+BIG_FIXTURES = ("xenon1_standin", "xenon1_colamd_standin", "sme3dc_standin", "c5mini_standin", "c5mid_standin", "c5_standin")      # full BASELINE size: too slow for the scalar CPU oracle, GPU tests only
 
 
 def golden_names(include_big: bool = False):
@@ -157,6 +157,82 @@ def rrow_signature(R: np.ndarray) -> np.ndarray:
     # the diagonal of row i is its first structurally stored entry = largest-|.| leading entry position:
     lead = np.array([np.flatnonzero(R[i])[0] if np.any(R[i]) else 0 for i in range(rm)])
     return np.stack([np.abs(R[np.arange(rm), lead]), np.linalg.norm(R, axis=1), np.abs(R @ w1)], axis=1)
+
+
+HUGE_BLOCK = 1 << 27          # entries of a packed R+H block from which the streaming forms below are used
+
+
+def rrow_signature_of_block(block, Stair, fp: int, fn: int, fm: int) -> np.ndarray:
+    """rrow_signature(front_R(...)) without the dense rm x fn matrix: the columns of the packed block are walked once and
+    per-row accumulators kept (a 50 000 x 50 000 front would need 20 GB dense).  Same definition: |first structurally
+    stored nonzero of the row|, ||row||, |<row, w1>|; the sums run over the columns in order."""
+    if block.size < HUGE_BLOCK:
+        return rrow_signature(front_R(block, Stair, fp, fn, fm))
+    w1, _ = sketch_weights(fn)
+    lead = None
+    rm = 0
+    p = 0
+    cols = []
+    for k in range(fp):
+        t = int(Stair[k])
+        if t == 0:
+            cols.append((p, rm)); p += rm
+        else:
+            if rm < fm:
+                rm += 1
+            cols.append((p, rm)); p += t
+    h = rm
+    for k in range(fp, fn):
+        t = int(Stair[k])
+        h = min(h + 1, fm)
+        cols.append((p, rm)); p += rm + max(t - h, 0)
+    assert p == block.size, (p, block.size)
+    if rm == 0:
+        return np.zeros((0, 3))
+    lead = np.zeros(rm); have = np.zeros(rm, bool); ss = np.zeros(rm); dot = np.zeros(rm)
+    for k, (a, r) in enumerate(cols):
+        if r == 0:
+            continue
+        x = block[a:a + r]
+        ss[:r] += x * x
+        dot[:r] += x * w1[k]
+        new = (~have[:r]) & (x != 0)
+        if new.any():
+            idx = np.flatnonzero(new)
+            lead[idx] = x[idx]; have[idx] = True
+    return np.stack([np.abs(lead), np.sqrt(ss), np.abs(dot)], axis=1)
+
+
+def determined_sketch(block, Stair, fp: int, fn: int, fm: int) -> np.ndarray:
+    """block_sketch(determined_part(...)) without the mask / the copy for very large blocks (same sums, column by column)."""
+    if block.size < HUGE_BLOCK:
+        return block_sketch(determined_part(block, Stair, fp, fn, fm))
+    ss = d1 = d2 = 0.0
+    pos = 0                       # index among the determined entries
+    p = 0
+    rm = 0
+
+    def take(x):
+        nonlocal ss, d1, d2, pos
+        if x.size:
+            i = np.arange(pos, pos + x.size, dtype=np.float64)
+            ss += float(x @ x); d1 += float(x @ np.sin(0.7 * i + 0.3)); d2 += float(x @ np.cos(1.3 * i + 0.1))
+            pos += x.size
+    for k in range(fp):
+        t = int(Stair[k])
+        if t == 0:
+            take(block[p:p + rm]); p += rm
+        else:
+            if rm < fm:
+                rm += 1
+            take(block[p:p + t]); p += t
+    h = rm
+    for k in range(fp, fn):
+        t = int(Stair[k])
+        h = min(h + 1, fm)
+        take(block[p:p + rm]); p += rm + max(t - h, 0)
+    assert p == block.size, (p, block.size)
+    return np.array([np.sqrt(ss), d1, d2])
 
 
 def determined_part(block, Stair, fp, fn, fm):

@@ -325,7 +325,8 @@ def test_no_rank_detection_tol_negative(pkg, oracle):
     compare_integers(S, N, numeric_as_ref(S, No))
 
 
-@pytest.mark.parametrize("name", ["xenon1_standin", "xenon1_colamd_standin", "sme3dc_standin", "c5mini_standin", "c5mid_standin"])
+@pytest.mark.parametrize("name", ["xenon1_standin", "xenon1_colamd_standin", "sme3dc_standin", "c5mini_standin", "c5mid_standin",
+                                  "c5_standin"])
 def test_full_size_standin(pkg, oracle, name):
     """BASELINE configs[2] / [3] sizes (xenon1 stand-in, n = 49 248, 1.5e11 flops; sme3Dc stand-in, n = 43 200, 3 unknowns
     per grid point, 3.4e11 flops) and the structure of configs[4] at n = 8000 (7-point + random long-range couplings: the
