@@ -245,7 +245,7 @@ def run_micro(pkg, args):
     return 0
 
 
-DEFAULT_WORKLOAD = {1: "xenon1_colamd_standin", 2: "xenon1_standin", 4: "sme3dc_standin", 8: "c5mini_standin"}
+DEFAULT_WORKLOAD = {1: "xenon1_colamd_standin", 2: "xenon1_standin", 4: "sme3dc_standin", 8: "c5_standin"}
 
 
 def spawn_ranks(args):
@@ -266,7 +266,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--workload", default=None,
                     help="fixture name or 'micro'; default by --gpus: 1 the xenon1 stand-in in the driver's default (COLAMD) "
-                         "ordering, 2 the METIS-ordered xenon1 stand-in, 4 the sme3Dc stand-in, 8 the configs[4] structure")
+                         "ordering, 2 the METIS-ordered xenon1 stand-in, 4 the sme3Dc stand-in, 8 the configs[4] stand-in at full size "
+                         "(n = 52 022; c5mid_standin / c5mini_standin are the same structure at n = 27 000 / 8000)")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--big-front-cols", type=int, default=None)
     ap.add_argument("--panel-algo", type=int, default=None)

@@ -64,11 +64,11 @@ STANDINS = {
     # 13 nnz per row) at 1/6.5 of its size: n = 8000, top front 0.4 n, 4.4e11 flops (the full size, n = 52 022, is
     # ~1.2e14 flops and ~20 GB of factors: 47 minutes for the reference on one core)
     "c5mini_standin": (20, 20, 20, 0x33445F35, False, 2, 1, 6),
-    # ... at half the full size: n = 27 000, top fronts far above 8192 rows (the size class the library's 2^31-entries-per-
-    # front limit and Sum(fm_ub * fn) arenas still hold on one GPU)
+    # ... at half the full size: n = 27 000, root front 27 000 x 25 974
     "c5mid_standin": (30, 30, 30, 0x33445F35, False, 2, 1, 6),
-    # ... and at FULL size (gen3d(37, 37, 38), n = 52 022): ~1.2e14 flops; its top fronts exceed 2^31 entries
-    # (R+H block of the root: 2.2e9 doubles), beyond the library's per-front index range -- not a fixture
+    # ... and at FULL size (gen3d(37, 37, 38), n = 52 022): 1.156e14 flops, root front 52 022 x 49 959
+    # (2.6e9 entries), 17.6 GB of packed factors; 41 minutes for the reference on one core.  Generated only on request
+    # (make_golden.py c5_standin: ~75 minutes, 21 GB of host memory)
     "c5_standin": (37, 37, 38, 0x33445F35, False, 2, 1, 6),
 }
 

@@ -243,8 +243,7 @@ def main():
     only = set(sys.argv[1:])
     from gen3d import STANDINS
     for name in STANDINS:
-        # (c5_standin: 70 minutes and > 40 GB for the reference, and beyond the library's per-front index range -- only
-        #  when it is asked for by name)
+        # (c5_standin: 75 minutes and 21 GB of host memory -- only when it is asked for by name)
         if name in only or (not only and name != "c5_standin" and not (HERE / f"{name}.npz").exists()):
             run_standin(name)
     if only and only <= set(STANDINS):

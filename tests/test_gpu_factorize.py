@@ -331,8 +331,10 @@ def test_full_size_standin(pkg, oracle, name):
     """BASELINE configs[2] / [3] sizes (xenon1 stand-in, n = 49 248, 1.5e11 flops; sme3Dc stand-in, n = 43 200, 3 unknowns
     per grid point, 3.4e11 flops) and the structure of configs[4] at n = 8000 (7-point + random long-range couplings: the
     top front is 0.4 n, 4.4e11 flops) and at n = 27 000 (c5mid: the root front is 27 000 x 25 974, 57 slab workgroups per
-    Gram-based panel, 1.6e13 flops, 4.8 GB of packed factors): integer outputs and R rows against the reference's golden
-    vectors, backward error through the packed factors, Q orthogonality on probes."""
+    Gram-based panel, 1.6e13 flops, 4.8 GB of packed factors) and at its FULL size n = 52 022 (c5_standin: root front
+    52 022 x 49 959 = 2.6e9 entries -- beyond 32-bit front offsets --, 1.156e14 flops, 17.6 GB of packed factors, 41
+    minutes for the reference): integer outputs and R rows against the reference's golden vectors, backward error through
+    the packed factors, Q orthogonality on probes."""
     from stmmqr_testlib import GOLDEN
     if not (GOLDEN / f"{name}.npz").exists():
         pytest.skip("fixture not generated (tests/golden/make_golden.py)")
