@@ -2413,6 +2413,14 @@ __global__ __launch_bounds__(NT) void k_upd_c2(DevCtx c, const int *__restrict__
         for (int x = 0; x < 4; x++) Ws[(STM_NB + l) * WS + cg * 4 + x] = y2[x];
     }
     __syncthreads();
+    // the B operands of the application (Y = [Y1; Y2], the same for every chunk of the workgroup) stay in registers: the
+    // MFMA loop reads one LDS operand per two MFMAs instead of three
+    double y0[2 * STM_NB / 4], y1[2 * STM_NB / 4];
+#pragma unroll
+    for (int kk = 0; kk < 2 * STM_NB / 4; kk++) {
+        y0[kk] = Ws[(4 * kk + l4) * WS + l15];
+        y1[kk] = Ws[(4 * kk + l4) * WS + 16 + l15];
+    }
     const int rend = min(G.mp, (sl + spw) * SLAB);
     for (int r0 = sl * SLAB; r0 < rend; r0 += RB) {
         const int i = r0 + lrow;
@@ -2423,14 +2431,14 @@ __global__ __launch_bounds__(NT) void k_upd_c2(DevCtx c, const int *__restrict__
 #pragma unroll
         for (int kk = 0; kk < STM_NB / 4; kk++) {
             const double a = Vs1[(4 * kk + l4) * VS + 16 * wid + l15];
-            u0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, Ws[(4 * kk + l4) * WS + l15], u0, 0, 0, 0);
-            u1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, Ws[(4 * kk + l4) * WS + 16 + l15], u1, 0, 0, 0);
+            u0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, y0[kk], u0, 0, 0, 0);
+            u1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, y1[kk], u1, 0, 0, 0);
         }
 #pragma unroll
         for (int kk = 0; kk < STM_NB / 4; kk++) {
             const double a = Vs2[(4 * kk + l4) * VS + 16 * wid + l15];
-            u0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, Ws[(STM_NB + 4 * kk + l4) * WS + l15], u0, 0, 0, 0);
-            u1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, Ws[(STM_NB + 4 * kk + l4) * WS + 16 + l15], u1, 0, 0, 0);
+            u0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, y0[STM_NB / 4 + kk], u0, 0, 0, 0);
+            u1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, y1[STM_NB / 4 + kk], u1, 0, 0, 0);
         }
 #pragma unroll
         for (int r = 0; r < 4; r++) {
