@@ -285,9 +285,13 @@ def test_plan_reuse_across_rank_changes(pkg, oracle, tall_min):
 
 
 @pytest.mark.parametrize("name", ["bcsstk14", "syn_rankdef_grid", "grid20_standin"])
-def test_graph_replay_equals_stream_launches(pkg, name):
-    """options.use_graph: the level schedule captured into a hipGraph (first call) and replayed (later calls, re-captured
-    when tol changes) gives bit-identical factors to the plain stream launches."""
+@pytest.mark.parametrize("two_streams", [False, True])
+def test_graph_replay_equals_stream_launches(pkg, monkeypatch, name, two_streams):
+    """options.use_graph: the schedule captured into a hipGraph (first call) and replayed (later calls, re-captured
+    when tol changes) gives bit-identical factors to the plain stream launches.  two_streams: every eligible step goes to
+    the look-ahead side stream (STMMQR_LA_MIN=0), so the capture contains the fork / join of the two streams."""
+    if two_streams:
+        monkeypatch.setenv("STMMQR_LA_MIN", "0")
     g = load_golden(name)
     S = Symbolic(g)
     tol, ntol = scalar(g, "in_tol"), int(scalar(g, "in_ntol"))
