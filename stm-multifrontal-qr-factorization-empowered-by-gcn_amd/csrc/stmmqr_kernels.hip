@@ -279,6 +279,17 @@ __device__ __forceinline__ void upd_chunk_to_lds(const UpdChunk &ck, int i, int 
     }
 }
 
+__device__ __forceinline__ void upd_chunk_v_to_lds(const UpdChunk &ck, int i, int mp, int nbp, const int *s_pd, int g1, int lrow,
+                                                   int lcg, double *Vs)
+{
+#pragma unroll
+    for (int q = 0; q < 8; q++) {
+        const int col = lcg * 8 + q;
+        const int d = s_pd[col] - g1;
+        Vs[col * VS + lrow] = (i < mp && col < nbp && i >= d) ? ((i == d) ? 1.0 : ck.v[q]) : 0.0;
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // qr_larftb(QR_QTX): C <- (I - V T V')' C for one block of <= BN columns, on fp64 MFMA.
 //   C = F(g1:g1+mp, c0:c0+nc), V = F(g1:g1+mp, k1:k1+nbp) with the unit diagonal of reflector j at absolute row
@@ -1954,9 +1965,16 @@ __global__ __launch_bounds__(NT) void k_upd_c(DevCtx c, const int *__restrict__ 
     }
     __syncthreads();
     const int rend = min(mp, (sl + spw) * SLAB);
+    // C never goes through LDS here: a thread keeps the eight entries of its row that it loaded, V.W2 comes back from the
+    // MFMA layout through the (otherwise unused) C image and the thread subtracts and stores from registers -- two
+    // barriers per chunk instead of three (the next chunk's V image is written after the second one, its product
+    // image after the next first one: every reader of either is past by then)
     for (int r0 = sl * SLAB; r0 < rend; r0 += RB) {
         const int i = r0 + lrow;
-        upd_chunk_to_lds(ck, i, mp, nbp, nc, s_pd, g1, lrow, lcg, Vs, Cs);
+        double cc[8];
+#pragma unroll
+        for (int q = 0; q < 8; q++) cc[q] = ck.c[q];
+        upd_chunk_v_to_lds(ck, i, mp, nbp, s_pd, g1, lrow, lcg, Vs);
         __syncthreads();
         if (r0 + RB < rend) upd_chunk_load(ck, Vg, Cg, ld, i + RB, mp, nbp, nc, lcg);
         d4 u0 = {0, 0, 0, 0}, u1 = {0, 0, 0, 0};
@@ -1971,18 +1989,17 @@ __global__ __launch_bounds__(NT) void k_upd_c(DevCtx c, const int *__restrict__ 
 #pragma unroll
         for (int r = 0; r < 4; r++) {
             const int row = 16 * wid + l4 + 4 * r;
-            Cs[l15 * VS + row] -= u0[r];
-            Cs[(16 + l15) * VS + row] -= u1[r];
+            Cs[l15 * VS + row] = u0[r];
+            Cs[(16 + l15) * VS + row] = u1[r];
         }
         __syncthreads();
         if (i < mp) {
 #pragma unroll
             for (int q = 0; q < 8; q++) {
                 const int col = lcg * 8 + q;
-                if (col < nc) Cg[i + col * ld] = Cs[col * VS + lrow];
+                if (col < nc) Cg[i + col * ld] = cc[q] - Cs[col * VS + lrow];
             }
         }
-        __syncthreads();
     }
 }
 
