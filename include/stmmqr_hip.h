@@ -243,9 +243,15 @@ double stmmqr_last_seam_ms(void);
  * ================================================================================================ */
 /* Defaults: {32, 64, 0, 0, 0, 1, 0, 1, 0, 1}.  Read when a plan is created (or a seam is called); the numerical results do not
  * depend on them beyond rounding.
- * Environment (diagnosis and tests only): STMMQR_DBG (bit mask, csrc/stmmqr_kernels.h), STMMQR_QBIG_MIN (entries of a
- * front from which Q-apply / back substitution split its rows over workgroups; default 2097152, read at plan time),
- * STMMQR_CHUNK (fronts per panel launch with STMMQR_DBG bit 9). */
+ * Environment (diagnosis, tests and experiments only; read at plan time unless noted): STMMQR_DBG (bit mask,
+ * csrc/stmmqr_kernels.h), STMMQR_QBIG_MIN (entries of a front from which Q-apply / back substitution split its rows over
+ * workgroups; default 2097152), STMMQR_CHUNK (fronts per panel launch with STMMQR_DBG bit 9), STMMQR_SCHED (step order:
+ * 1 level-synchronous, 2 as soon as possible, 3 envelope rule; unset: chosen per front group), STMMQR_RIDE (envelope rule:
+ * factor on the height a riding front may have), STMMQR_CA_MIN (rows from which the Gram-based panel is used; 4096),
+ * STMMQR_PAIR_MIN (rows from which a front takes the pair update; 16384), STMMQR_LA_MIN / STMMQR_LA_MAXPWG (look-ahead:
+ * tiles of trailing update from which a step is offloaded, 2500, and the most panel workgroups such a step may have, 48;
+ * read per factorization), STMMQR_SIDE_RESERVE (compute units the side stream leaves alone; 32), STMMQR_DUMPSTEPS=file
+ * (detail runs: one line per step with what ran and how long). */
 typedef struct stmmqr_options {
     int panel_width;        /* Householder panel width on device (<= 32); reference FCHUNK = 32                    */
     int big_front_cols;     /* fronts with fn >= this use the multi-workgroup panel/update path                     */
