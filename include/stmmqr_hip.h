@@ -155,6 +155,9 @@ typedef struct stmmqr_stats {
     stm_long nsteps;           /* steps of the factorization timeline (a big front advances one panel per step)     */
     double flops_update_pair;  /* the part of flops_update on fronts that take the pair update (two panels per sweep:
                                   12 instead of 24 algorithmic bytes per updated entry and panel)                     */
+    stm_long retries;          /* times (part of) the factorization was run again with one-workgroup panels because a bounded
+                                  inter-workgroup wait of a panel kernel ran out (0 in a healthy run: bench.py asserts it)  */
+    double device_bytes;       /* device memory held by the plan when the factorization finished (arenas, factors, workspaces) */
 } stmmqr_stats;
 
 typedef struct stmmqr_plan stmmqr_plan;     /* device-resident symbolic plan + arenas; reusable across calls */
@@ -233,6 +236,11 @@ stm_long stmmqr_front(stm_long m, stm_long n, stm_long npiv, double tol, stm_lon
                       stm_long *Stair, char *Rdead, double *Tau, double *flops);
 int stmmqr_larftb_qtx(stm_long m, stm_long n, stm_long k, stm_long ldc, stm_long ldv, const double *V,
                       const double *Tau, double *C);
+/* qr_larftb with a return code, all four methods (0 QR_QTX, 1 QR_QX: C is m x n and V m x k; 2 QR_XQT, 3 QR_XQ: C is m x n
+ * and V n x k; SparseQR_factorize.c:1851-1904).  The reference-named export qr_larftb calls this and turns a failure into
+ * cc->status < 0 + stmmqr_last_error(), never into a silent return. */
+int stmmqr_larftb(int method, stm_long m, stm_long n, stm_long k, stm_long ldc, stm_long ldv, const double *V,
+                  const double *Tau, double *C);
 /* device time (ms, HIP events) of the kernels of the last qr_front / stmmqr_front / qr_assemble seam call on this
  * thread's device, -1 if none: the seams take host buffers, so their wall time is dominated by the copies; the kernel
  * micro-benchmarks of SURVEY.md 8(d) (bench.py --workload micro) read this instead */

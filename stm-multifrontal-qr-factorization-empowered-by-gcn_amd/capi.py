@@ -41,7 +41,7 @@ class Stats(C.Structure):
                                           "ms_host", "bytes_assemble", "bytes_pack", "flops_update", "ms_update"]] + \
                [("nlaunch", C.c_long), ("nlevels", C.c_long), ("ms_panel", C.c_double), ("ms_small", C.c_double),
                 ("npanel_launch", C.c_long), ("nupdate_launch", C.c_long), ("nsteps", C.c_long),
-                ("flops_update_pair", C.c_double)]
+                ("flops_update_pair", C.c_double), ("retries", C.c_long), ("device_bytes", C.c_double)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}
@@ -79,6 +79,9 @@ lib.stmmqr_front.restype = C.c_long
 lib.stmmqr_front.argtypes = [C.c_long, C.c_long, C.c_long, C.c_double, C.c_long, c_double_p, c_long_p, C.c_char_p,
                              c_double_p, c_double_p]
 lib.stmmqr_larftb_qtx.argtypes = [C.c_long] * 5 + [c_double_p, c_double_p, c_double_p]
+lib.stmmqr_larftb.argtypes = [C.c_int] + [C.c_long] * 5 + [c_double_p, c_double_p, c_double_p]
+lib.qr_larftb.restype = None
+lib.qr_larftb.argtypes = [C.c_int] + [C.c_long] * 5 + [c_double_p, c_double_p, c_double_p, c_double_p, C.c_void_p]
 lib.stmmqr_last_seam_ms.restype = C.c_double
 lib.stmmqr_last_seam_ms.argtypes = []
 lib.qr_cpack.restype = C.c_long
@@ -357,10 +360,9 @@ def last_seam_ms() -> float:
 
 
 def qr_larftb(method, m, n, k, ldc, ldv, V, Tau, Cmat):
-    """qr_larftb, method QR_QTX = 0 (SparseQR.h:255-268): C <- (I - V T V')' C in place."""
-    if method != 0:
-        raise StmmqrError("only QR_QTX is on the factorization path")
-    _check(lib.stmmqr_larftb_qtx(m, n, k, ldc, ldv, _dp(V), _dp(Tau), _dp(Cmat)), "stmmqr_larftb_qtx")
+    """qr_larftb (SparseQR.h:255-268; SparseQR_factorize.c:1851-1904), C in place: method 0 QR_QTX C <- Q'C, 1 QR_QX
+    C <- QC (C m x n, V m x k), 2 QR_XQT C <- CQ', 3 QR_XQ C <- CQ (C m x n, V n x k), Q = I - V T V'."""
+    _check(lib.stmmqr_larftb(method, m, n, k, ldc, ldv, _dp(V), _dp(Tau), _dp(Cmat)), "stmmqr_larftb")
 
 
 def qr_fcsize(m, n, npiv, g):

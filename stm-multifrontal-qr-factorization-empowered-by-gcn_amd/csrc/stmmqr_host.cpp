@@ -26,6 +26,7 @@
 #include "../../include/stmmqr_hip.h"
 #include "stmmqr_device.h"
 #include "stmmqr_kernels.h"
+#include "stmmqr_internal.h"
 
 namespace {
 
@@ -190,7 +191,8 @@ struct stmmqr_plan {
     DevBuf<int> d_Rm;                               // rows of R (live pivots) of the split fronts of a level (k_rbig_*)
     std::vector<QbLevel> level_qbig;               // descriptors (d_qb) of the fronts of each level that take the split Q-apply
     hipGraphExec_t graph_exec = nullptr;           // options.use_graph: the captured schedule of group 0
-    double graph_tol = 0; int graph_ntol = 0, graph_dbg = 0; long graph_nlaunch = 0;
+    double graph_tol = 0; int graph_ntol = 0, graph_dbg = 0, graph_opt = 0; long graph_nlaunch = 0;
+    long sched_gen = 0, graph_gen = -1;            // schedule generation (bumped by every build_schedule) / the captured one
     bool rowmap_ready = false;         // d_Wmap belongs to the factorization currently held
     std::vector<int> level_lds_qa, level_lds_qa_all, level_lds_rs;   // dynamic LDS of k_qapply(_t) / k_rsolve per level of group 0
                                                                      // (_all: the unblocked kernel takes the split fronts too)
@@ -198,6 +200,17 @@ struct stmmqr_plan {
     long last_ntol = 0;
     stmmqr_stats stats = {};
 
+    // device memory held right now (every DevBuf of the plan)
+    double device_bytes() const
+    {
+        double b = 0;
+        auto add = [&](const auto &buf) { b += (double)buf.n * sizeof(*buf.p); };
+        add(d_fs); add(d_fnum); add(d_F); add(d_C); add(d_T); add(d_Gp); add(d_Tall); add(d_Sx); add(d_Ax); add(d_Tau); add(d_RH);
+        add(d_Wp); add(d_Wp2); add(d_tslot); add(d_Sp); add(d_Sjrel); add(d_Sj0); add(d_Sleft); add(d_Child); add(d_Rjrel);
+        add(d_Stair); add(d_Hii); add(d_Cmap); add(d_Cursor); add(d_lists); add(d_smap); add(d_Rhoff); add(d_wlists);
+        add(d_wcnt); add(d_wcnt2); add(d_wflag); add(d_wflag2); add(d_Rboff); add(d_Rdead);
+        return b;
+    }
     DevCtx ctx() const
     {
         DevCtx c;
@@ -307,6 +320,7 @@ int ensure_device(int device)
 // ------------------------------------------------------------------------------------------------
 void build_schedule(stmmqr_plan &P, std::vector<int> &tslot)
 {
+    P.sched_gen++;
     P.tall_min = g_opt.tall_min_rows;
     P.plan_algo = g_opt.panel_algo;
     P.ca_min = getenv("STMMQR_CA_MIN") ? atoi(getenv("STMMQR_CA_MIN")) : STM_CA_MIN_ROWS;
@@ -808,7 +822,49 @@ int set_pattern(stmmqr_plan &P, const stm_long *Ap, const stm_long *Ai)
 // ------------------------------------------------------------------------------------------------
 // the level-batched schedule (device resident inputs -> device resident factors)
 // ------------------------------------------------------------------------------------------------
-int run_schedule(stmmqr_plan &P, bool detail, int grp, bool first)
+// State every factorization starts from (issued by stmmqr_factorize_begin, BEFORE any stmmqr_plan_import_front of the
+// phased interface: an imported front's fm / rank / cm must survive until its parent assembles it).
+int reset_factorization(stmmqr_plan &P)
+{
+    hipStream_t st = P.stream;
+    HIPCHK(hipMemsetAsync(P.d_F.p, 0, (size_t)P.farena * sizeof(double), st));
+    HIPCHK(hipMemsetAsync(P.d_Rdead.p, 0, (size_t)std::max(1L, P.n), st));
+    HIPCHK(hipMemsetAsync(P.d_fnum.p, 0, (size_t)std::max(1L, P.nf) * sizeof(FrontNum), st));
+    // (tickets are back at zero after every launch unless a wait ran out; the flags carry step numbers)
+    HIPCHK(hipMemsetAsync(P.d_wcnt.p, 0, P.wcnt_n * sizeof(int), st));
+    HIPCHK(hipMemsetAsync(P.d_wcnt2.p, 0, P.wcnt_n * sizeof(int), st));
+    HIPCHK(hipMemsetAsync(P.d_wflag.p, 0, P.wcnt_n * sizeof(int), st));
+    HIPCHK(hipMemsetAsync(P.d_wflag2.p, 0, P.wcnt_n * sizeof(int), st));
+    HIPCHK(hipMemsetAsync(P.d_abort.p, 0, sizeof(int), st));
+    LCHK(stm_launch_sigma(P.d_Ax.p, (int)P.anz, P.d_amax.p, P.d_sig.p, st));
+    LCHK(stm_launch_gather_sx(P.d_Ax.p, P.d_smap.p, P.d_Sx.p, (int)P.anz, st));
+    P.stats.nlaunch += 6;
+    return 0;
+}
+
+// Recovery of ONE group of the phased interface after a bounded panel wait ran out in it: everything its fronts wrote is
+// put back to the state reset_factorization left (fronts of other groups and imported fronts are not touched).
+int reset_group(stmmqr_plan &P, int grp)
+{
+    hipStream_t st = P.stream;
+    const FrontNum zero = FrontNum();
+    for (long f = 0; f < P.nf; f++) {
+        if (P.group[f] != grp) continue;
+        const FrontSym &s = P.fs[f];
+        HIPCHK(hipMemsetAsync(P.d_F.p + s.foff, 0, (size_t)s.ld * (size_t)s.fn * sizeof(double), st));
+        HIPCHK(hipMemcpyAsync(P.d_fnum.p + f, &zero, sizeof zero, hipMemcpyHostToDevice, st));
+        if (s.fp > 0) HIPCHK(hipMemsetAsync(P.d_Rdead.p + s.col1, 0, (size_t)s.fp, st));
+    }
+    HIPCHK(hipMemsetAsync(P.d_wcnt.p, 0, P.wcnt_n * sizeof(int), st));
+    HIPCHK(hipMemsetAsync(P.d_wcnt2.p, 0, P.wcnt_n * sizeof(int), st));
+    HIPCHK(hipMemsetAsync(P.d_wflag.p, 0, P.wcnt_n * sizeof(int), st));
+    HIPCHK(hipMemsetAsync(P.d_wflag2.p, 0, P.wcnt_n * sizeof(int), st));
+    HIPCHK(hipMemsetAsync(P.d_abort.p, 0, sizeof(int), st));
+    HIPCHK(hipStreamSynchronize(st));                       // (`zero` lives on this stack frame)
+    return 0;
+}
+
+int run_schedule(stmmqr_plan &P, bool detail, int grp)
 {
     hipStream_t st = P.stream;
     const DevCtx c = P.ctx();
@@ -836,20 +892,6 @@ int run_schedule(stmmqr_plan &P, bool detail, int grp, bool first)
     };
     const int t_asm = CAT_ASM, t_front = CAT_SMALL, t_panel = CAT_PANEL, t_upd = CAT_UPD, t_cpk = CAT_CPK;
 
-    if (first) {
-        HIPCHK(hipMemsetAsync(P.d_F.p, 0, (size_t)P.farena * sizeof(double), st));
-        HIPCHK(hipMemsetAsync(P.d_Rdead.p, 0, (size_t)std::max(1L, P.n), st));
-        HIPCHK(hipMemsetAsync(P.d_fnum.p, 0, (size_t)std::max(1L, P.nf) * sizeof(FrontNum), st));
-        // (tickets are back at zero after every launch unless a wait ran out; the flags carry step numbers)
-        HIPCHK(hipMemsetAsync(P.d_wcnt.p, 0, P.wcnt_n * sizeof(int), st));
-        HIPCHK(hipMemsetAsync(P.d_wcnt2.p, 0, P.wcnt_n * sizeof(int), st));
-        HIPCHK(hipMemsetAsync(P.d_wflag.p, 0, P.wcnt_n * sizeof(int), st));
-        HIPCHK(hipMemsetAsync(P.d_wflag2.p, 0, P.wcnt_n * sizeof(int), st));
-        HIPCHK(hipMemsetAsync(P.d_abort.p, 0, sizeof(int), st));
-        LCHK(stm_launch_sigma(P.d_Ax.p, (int)P.anz, P.d_amax.p, P.d_sig.p, st));
-        LCHK(stm_launch_gather_sx(P.d_Ax.p, P.d_smap.p, P.d_Sx.p, (int)P.anz, st));
-        nlaunch += 6;
-    }
     if (grp < 0 || grp >= (int)P.gsteps.size()) return fail(STMMQR_ERR_INVALID, "no such front group");
     const std::vector<Step> &SV = P.gsteps[grp];
     // prep(t): set up + assemble the fronts that start at step t, factorize the small ones among them (whole, one launch)
@@ -946,7 +988,7 @@ int run_schedule(stmmqr_plan &P, bool detail, int grp, bool first)
         });
     };
     bool la = g_opt.lookahead && !detail && !P.serial_panels && SV.size() > 1;
-    if (la) P.side = side_stream_for(P.device);
+    if (la && !P.side) P.side = side_stream_for(P.device);
     la = la && P.side;
     if (!la) {
         for (const Step &S : SV) {
@@ -1188,7 +1230,7 @@ int stmmqr_factorize_begin(stmmqr_plan *plan, const stm_long *Ap, const stm_long
                               ax_on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, st));
     }
     HIPCHK(hipEventRecord(P.ev[1], st));
-    return 0;
+    return reset_factorization(P);
 }
 
 int stmmqr_factorize_group(stmmqr_plan *plan, int group, int detail)
@@ -1199,30 +1241,68 @@ int stmmqr_factorize_group(stmmqr_plan *plan, int group, int detail)
     int e = 0;
     const bool graph_ok = g_opt.use_graph && !detail && group == 0 && P.first_group && !getenv("STMMQR_DUMPLV");
     if (graph_ok) {
-        // replay the level schedule of group 0 as a hipGraph (captured once per plan and per (tol, ntol, debug mask):
-        // these travel in the kernel arguments)
+        // replay the step schedule of group 0 as a hipGraph, captured once per plan and per everything that travels in the
+        // kernel arguments or decides what is launched: (tol, ntol, debug mask), the schedule generation (set_groups
+        // rebuilds the lists and may move the workspaces) and the run-time options
         const DevCtx c = P.ctx();
-        if (!P.graph_exec || P.graph_tol != c.tol || P.graph_ntol != c.ntol || P.graph_dbg != c.dbg) {
+        const int optkey = (g_opt.lookahead ? 1 : 0) | (g_opt.split_update ? 2 : 0) | (g_opt.fused_update ? 4 : 0) | (P.serial_panels ? 8 : 0);
+        if (!P.graph_exec || P.graph_tol != c.tol || P.graph_ntol != c.ntol || P.graph_dbg != c.dbg || P.graph_gen != P.sched_gen ||
+            P.graph_opt != optkey) {
             if (P.graph_exec) { (void)hipGraphExecDestroy(P.graph_exec); P.graph_exec = nullptr; }
+            P.graph_nlaunch = 0;
+            // everything run_schedule creates lazily is created BEFORE the capture: the device's side stream (device
+            // properties, a CU-masked stream, an atexit handler) and the per-step events of the look-ahead
+            if (g_opt.lookahead && !P.serial_panels && P.gsteps[0].size() > 1) {
+                if (!P.side) P.side = side_stream_for(P.device);
+                for (auto *v : {&P.ev_main, &P.ev_prep, &P.ev_side})
+                    while (v->size() < P.gsteps[0].size() + 1) {
+                        hipEvent_t ev = nullptr;
+                        HIPCHK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+                        v->push_back(ev);
+                    }
+            }
+            const long nl0 = P.stats.nlaunch;
             hipGraph_t gph = nullptr;
+            // the side stream is shared by the plans of a device: captures are serialised against each other (a plan that
+            // factorizes without a graph while another one captures is the caller's to avoid, as for any shared stream)
+            static std::mutex capture_mu;
+            std::lock_guard<std::mutex> lock(capture_mu);
             HIPCHK(hipStreamBeginCapture(P.stream, hipStreamCaptureModeThreadLocal));
-            e = run_schedule(P, false, 0, true);
+            e = run_schedule(P, false, 0);
             const hipError_t ce = hipStreamEndCapture(P.stream, &gph);
             if (e) { if (gph) (void)hipGraphDestroy(gph); return e; }
             HIPCHK(ce);
             HIPCHK(hipGraphInstantiate(&P.graph_exec, gph, nullptr, nullptr, 0));
             (void)hipGraphDestroy(gph);
-            P.graph_tol = c.tol; P.graph_ntol = c.ntol; P.graph_dbg = c.dbg;
+            P.graph_tol = c.tol; P.graph_ntol = c.ntol; P.graph_dbg = c.dbg; P.graph_gen = P.sched_gen; P.graph_opt = optkey;
+            P.graph_nlaunch = P.stats.nlaunch - nl0;
         } else {
             // (the statistics run_schedule accumulates on the host)
             P.stats.nlaunch += P.graph_nlaunch;
             P.stats.nlevels += (long)P.glevels[0].size();
             P.stats.nsteps += (long)P.gsteps[0].size();
         }
-        if (!P.graph_nlaunch) P.graph_nlaunch = P.stats.nlaunch;
         HIPCHK(hipGraphLaunch(P.graph_exec, P.stream));
     } else
-        e = run_schedule(P, detail != 0, group, P.first_group);
+        e = run_schedule(P, detail != 0, group);
+    // Phased use (several groups: the sharded path): a bounded panel wait that ran out is found HERE and the group is run
+    // again with one-workgroup panels (no inter-workgroup waits), exactly as stmmqr_factorize_device does for the whole
+    // factorization -- the other groups and the imported fronts are not touched.  One group: the check is finish's.
+    if (!e && P.glevels.size() > 1 && !P.serial_panels) {
+        HIPCHK(hipStreamSynchronize(P.stream));
+        P.h_fnum.resize((size_t)std::max(1L, P.nf));
+        if (P.nf > 0) HIPCHK(hipMemcpy(P.h_fnum.data(), P.d_fnum.p, (size_t)P.nf * sizeof(FrontNum), hipMemcpyDeviceToHost));
+        bool failed = false;
+        for (long f = 0; f < P.nf && !failed; f++) failed = (P.group[f] == group && P.h_fnum[f].perr != 0);
+        if (failed) {
+            if (g_opt.verbose) fprintf(stderr, "[stmmqr_hip] a panel wait ran out in group %d: running it again with one-workgroup panels\n", group);
+            P.stats.retries++;
+            e = reset_group(P, group);
+            P.serial_panels = true;
+            if (!e) e = run_schedule(P, detail != 0, group);
+            P.serial_panels = false;
+        }
+    }
     P.first_group = false;
     return e;
 }
@@ -1319,6 +1399,7 @@ int stmmqr_factorize_finish(stmmqr_plan *plan, stmmqr_stats *stats)
     P.stats.flops_update_pair = fl_upd_pair;
     P.stats.bytes_assemble = bytes_asm;
     P.stats.bytes_pack = bytes_pack;
+    P.stats.device_bytes = P.device_bytes();
     P.factored = true;
     P.begun = false;
     if (stats) *stats = P.stats;
@@ -1338,6 +1419,7 @@ int stmmqr_factorize_device(stmmqr_plan *plan, const stm_long *Ap, const stm_lon
         plan->serial_panels = (attempt == 1);
         plan->panel_wait_failed = false;
         int e = stmmqr_factorize_begin(plan, Ap, Ai, Ax, ax_on_device, tol, ntol);
+        if (!e && attempt == 1) plan->stats.retries = 1;            // (visible in stmmqr_stats: bench.py asserts 0)
         for (int g = 0; g < (int)plan->glevels.size() && !e; g++) e = stmmqr_factorize_group(plan, g, detail);
         if (!e) e = stmmqr_factorize_finish(plan, stats);
         const bool retry = e && plan->panel_wait_failed && attempt == 0;
@@ -1345,8 +1427,7 @@ int stmmqr_factorize_device(stmmqr_plan *plan, const stm_long *Ap, const stm_lon
         if (!retry) return e;
         if (g_opt.verbose) fprintf(stderr, "[stmmqr_hip] a panel wait ran out: factorizing again with one-workgroup panels\n");
         if (stats && detail) stats->nlaunch = -1;
-        Ap = nullptr; Ai = nullptr;                  // (the pattern is set)
-        if (!ax_on_device) continue;                 // host values are uploaded again by begin
+        Ap = nullptr; Ai = nullptr;                  // (the pattern is set; begin uploads / copies the values again)
     }
     return fail(STMMQR_ERR_DEVICE, "panel kernels failed twice");
 }
@@ -1357,25 +1438,31 @@ int stmmqr_plan_set_groups(stmmqr_plan *plan, const int *group)
     if (!plan || !group) return fail(STMMQR_ERR_INVALID, "null plan / groups");
     stmmqr_plan &P = *plan;
     HIPCHK(hipSetDevice(P.device));
-    for (long f = 0; f < P.nf; f++) {
-        P.group[f] = group[f];
-        // a front and the children it assembles must not be split inside one phase in the wrong order
+    // validate BEFORE anything of the plan changes: a refused call leaves groups and schedule as they were
+    for (long f = 0; f < P.nf; f++)
         for (long q = P.Childp[f]; q < P.Childp[f + 1]; q++)
             if (group[f] >= 0 && group[P.Child[q]] > group[f])
                 return fail(STMMQR_ERR_INVALID, "a child is scheduled in a later phase than its parent");
-    }
+    if (P.begun) return fail(STMMQR_ERR_INVALID, "stmmqr_plan_set_groups between factorize_begin and factorize_finish");
+    HIPCHK(hipStreamSynchronize(P.stream));
+    for (long f = 0; f < P.nf; f++) P.group[f] = group[f];
+    // a captured schedule describes the old step lists and workspaces
+    if (P.graph_exec) { (void)hipGraphExecDestroy(P.graph_exec); P.graph_exec = nullptr; }
+    P.graph_nlaunch = 0;
     std::vector<int> tslot;
     build_schedule(P, tslot);
-    LCHK(P.d_T.alloc((size_t)2 * P.tslots * STM_NB * STM_NB));
-    LCHK(P.d_Gp.alloc((size_t)P.tslots * (P.gp_slabs + 1) * STM_NB * STM_NB));
-    LCHK(P.d_Wp.alloc((size_t)P.wp_doubles));
-    LCHK(P.d_Wp2.alloc((size_t)P.wp_doubles));
-    P.wcnt_n = (size_t)(P.wp_doubles / (STM_NB * 32) + 1);
-    LCHK(P.d_wcnt.alloc(P.wcnt_n));
-    LCHK(P.d_wcnt2.alloc(P.wcnt_n));
-    LCHK(P.d_wflag.alloc(P.wcnt_n));
+    // workspaces only grow (a regrouping of the same tree usually needs what it needed before)
+    auto grow = [](auto &buf, size_t n) -> int { return buf.n >= n && buf.p ? 0 : buf.alloc(n); };
+    LCHK(grow(P.d_T, (size_t)2 * P.tslots * STM_NB * STM_NB));
+    LCHK(grow(P.d_Gp, (size_t)P.tslots * (P.gp_slabs + 1) * STM_NB * STM_NB));
+    LCHK(grow(P.d_Wp, (size_t)P.wp_doubles));
+    LCHK(grow(P.d_Wp2, (size_t)P.wp_doubles));
+    P.wcnt_n = std::max(P.wcnt_n, (size_t)(P.wp_doubles / (STM_NB * 32) + 1));
+    LCHK(grow(P.d_wcnt, P.wcnt_n));
+    LCHK(grow(P.d_wcnt2, P.wcnt_n));
+    LCHK(grow(P.d_wflag, P.wcnt_n));
     if (!P.d_abort.p) LCHK(P.d_abort.alloc(1));
-    LCHK(P.d_wflag2.alloc(P.wcnt_n));
+    LCHK(grow(P.d_wflag2, P.wcnt_n));
     HIPCHK(hipMemset(P.d_wcnt.p, 0, P.wcnt_n * sizeof(int)));
     HIPCHK(hipMemset(P.d_wcnt2.p, 0, P.wcnt_n * sizeof(int)));
     LCHK(P.d_tslot.upload(tslot, P.stream));
@@ -1873,6 +1960,10 @@ int stmmqr_factorize_arrays(const stmmqr_symbolic_view *sym, const stm_long *Ap,
 static inline int &cc_int(stm_sparse_common *cc, size_t off) { return *(int *)((char *)cc + off); }
 static inline size_t &cc_size(stm_sparse_common *cc, size_t off) { return *(size_t *)((char *)cc + off); }
 static inline double &cc_dbl(stm_sparse_common *cc, size_t off) { return *(double *)((char *)cc + off); }
+
+// (stmmqr_internal.h: shared with stmmqr_seams.cpp / stmmqr_symbolic.cpp; local to the library)
+int stm_fail(int code, const char *msg) { return fail(code, msg ? msg : ""); }
+void stm_cc_set_status(stm_sparse_common *cc, int code) { if (cc) cc_int(cc, g_layout.status) = code; }
 
 // SparseCore_malloc semantics (src/core/SparseCore_common.c:603-655): malloc(max(1,n)*size) + counters
 static void *cc_malloc(size_t n, size_t size, stm_sparse_common *cc, bool zero = false)

@@ -64,6 +64,7 @@ int stm_launch_update_pair(const DevCtx &c, const int *flist, const int *plist, 
 int stm_launch_update_split(const DevCtx &c, const int *flist, const int *plist, int nfr, int cb0, int ncb, int maxsl, double *Wp,
                             const long long *wpoff, int *wcnt, int with_gram, hipStream_t st);
 int stm_launch_larft(const DevCtx &c, int f, hipStream_t st);
+int stm_launch_update_notrans(const DevCtx &c, int f, int ncb, hipStream_t st);   // qr_larftb seam, QR_QX
 int stm_launch_cpack(const DevCtx &c, const int *flist, const int *nparts, int nfr, int maxparts, hipStream_t st);
 int stm_launch_rh_count(const DevCtx &c, const int *flist, int nfr, hipStream_t st);
 int stm_launch_rh_scan(const DevCtx &c, const int *post, int nf, long long *rh_total, hipStream_t st);

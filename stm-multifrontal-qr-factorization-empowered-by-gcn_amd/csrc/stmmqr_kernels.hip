@@ -303,6 +303,8 @@ __device__ __forceinline__ void dev_T_from_gram(double (*G)[STM_NB + 1], double 
 // tau != nullptr: T was left to the update by the panel kernel (PanelDesc::t_deferred) -- G = V'V is accumulated beside
 // W1 (per 256-row slab, slabs added in order: bit-identical to the Gram block of k_upd_w) and T is built here by every
 // workgroup for itself (dev_T_from_gram); Tout / Tkeep (may be null) receive it from the caller's first column block.
+// TN = true (qr_larftb seam, method QR_QX only): C <- (I - V T V') C, i.e. W2 = T W1 instead of T' W1.
+template <bool TN = false>
 __device__ void dev_update_block(double *F, long long ld, int g1, int mp, int k1, int nbp, const int *diag,
                                  const double *T, int c0, int nc, double *lds, const double *tau = nullptr,
                                  double *Tout = nullptr, double *Tkeep = nullptr)
@@ -379,6 +381,13 @@ __device__ void dev_update_block(double *F, long long ld, int g1, int mp, int k1
     {
         const int l = tid & 31, cg = tid >> 5;          // 8 groups x 4 columns
         double w2[4] = {0, 0, 0, 0};
+        if (TN) {
+            for (int q = l; q < nbp; q++) {                // row l of the upper triangular T
+                const double tq = build_t ? s_Tm[l * WS + q] : T[l + q * STM_NB];
+#pragma unroll
+                for (int x = 0; x < 4; x++) w2[x] += tq * Ws[q * WS + cg * 4 + x];
+            }
+        } else
         for (int q = 0; q <= l; q++) {
             const double tq = build_t ? s_Tm[q * WS + l] : T[q + l * STM_NB];
 #pragma unroll
@@ -1752,6 +1761,19 @@ __global__ __launch_bounds__(NT) void k_update(DevCtx c, const int *__restrict__
     }
     dev_update_block(c.Farena + s.foff, s.ld, pd->pg1, pd->pt - pd->pg1, pd->pk1, pd->pnb, pd->pdiag, Tw, c0,
                      min(BN, s.fn - c0), dyn_lds);
+}
+
+// qr_larftb seam, method QR_QX: the pending block reflector of FrontNum::pd[0] applied WITHOUT the transpose,
+// C <- (I - V T V') C (dlarfb 'L','N','F','C', SparseQR_factorize.c:1880-1886); T from k_larft
+__global__ __launch_bounds__(NT) void k_update_n(DevCtx c, int f)
+{
+    extern __shared__ double dyn_lds[];
+    const FrontSym s = c.fs[f];
+    const PanelDesc *pd = &c.fnum[f].pd[0];
+    const int c0 = pd->pc0 + (int)blockIdx.x * BN;
+    if (c0 >= s.fn) return;
+    dev_update_block<true>(c.Farena + s.foff, s.ld, pd->pg1, pd->pt - pd->pg1, pd->pk1, pd->pnb, pd->pdiag,
+                           c.Tws + (long long)(2 * c.tslot[f]) * STM_NB * STM_NB, c0, min(BN, s.fn - c0), dyn_lds);
 }
 
 // standalone T factor of the pending block reflector described by FrontNum (qr_larftb seam)
@@ -3393,6 +3415,12 @@ int stm_launch_update_pair(const DevCtx &c, const int *flist, const int *plist, 
                        plist, (const double *)Wp, wpoff);
     return (int)hipGetLastError();
 }
+int stm_launch_update_notrans(const DevCtx &c, int f, int ncb, hipStream_t st)
+{
+    if (ncb <= 0) return 0;
+    hipLaunchKernelGGL(k_update_n, dim3(ncb), dim3(NT), (size_t)stm_update_lds_bytes(), st, c, f);
+    return (int)hipGetLastError();
+}
 int stm_launch_larft(const DevCtx &c, int f, hipStream_t st)
 {
     hipLaunchKernelGGL(k_larft, dim3(1), dim3(NT), (size_t)stm_update_lds_bytes(), st, c, f);
@@ -3484,6 +3512,7 @@ int stm_configure_kernels(void)
     CK(hipFuncSetAttribute((const void *)k_front_wg, hipFuncAttributeMaxDynamicSharedMemorySize, 122880));
     CK(hipFuncSetAttribute((const void *)k_panel, hipFuncAttributeMaxDynamicSharedMemorySize, 131072));
     CK(hipFuncSetAttribute((const void *)k_update, hipFuncAttributeMaxDynamicSharedMemorySize, 65536));
+    CK(hipFuncSetAttribute((const void *)k_update_n, hipFuncAttributeMaxDynamicSharedMemorySize, 65536));
     CK(hipFuncSetAttribute((const void *)k_qapply, hipFuncAttributeMaxDynamicSharedMemorySize, 131072));
     CK(hipFuncSetAttribute((const void *)k_qapply_t, hipFuncAttributeMaxDynamicSharedMemorySize, 131072));
     CK(hipFuncSetAttribute((const void *)k_rsolve, hipFuncAttributeMaxDynamicSharedMemorySize, 131072));

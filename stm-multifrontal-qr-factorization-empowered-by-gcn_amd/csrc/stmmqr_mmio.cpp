@@ -21,6 +21,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <new>
 #include <string>
 #include <vector>
 
@@ -53,8 +54,8 @@ const char *stmmqr_mm_last_error(void) { return g_mm_err.c_str(); }
 
 void stmmqr_free(void *p) { free(p); }
 
-int stmmqr_read_matrix_market(const char *path, stm_long *m_out, stm_long *n_out, stm_long *nnz_out, stm_long **Ap_out,
-                              stm_long **Ai_out, double **Ax_out)
+static int read_mm(const char *path, stm_long *m_out, stm_long *n_out, stm_long *nnz_out, stm_long **Ap_out,
+                   stm_long **Ai_out, double **Ax_out)
 {
     auto bad = [&](const char *msg) { g_mm_err = msg; return STMMQR_ERR_INVALID; };
     if (!path || !m_out || !n_out || !nnz_out || !Ap_out || !Ai_out || !Ax_out) return bad("null argument");
@@ -101,13 +102,26 @@ int stmmqr_read_matrix_market(const char *path, stm_long *m_out, stm_long *n_out
     if (nitems < 2 || nitems > 4 || l1 < 0 || l2 < 0) { fclose(f); return bad("bad size line"); }
     if (dense || (nitems == 2 && !got_banner) || nitems == 2) { fclose(f); return bad("input matrix must be sparse"); }
     if (nitems == 4) stype = (l4 < 0) ? LOWER : (l4 > 0) ? UPPER : UNSYM;
+    // (:268, :361-366) sizes beyond Int_max are refused; a negative entry count is one after the conversion to size_t
+    const double int_max = 9223372036854775807.0;
+    if (!(l1 <= int_max) || !(l2 <= int_max)) { fclose(f); return bad("bad size line"); }
+    if (!(l3 >= 0) || !(l3 <= int_max) || l3 > 4.0e12) { fclose(f); g_mm_err = "problem too large"; return STMMQR_ERR_TOO_LARGE; }
     const long nrow = (long)l1, ncol = (long)l2, nnz = (long)l3;
+    // (:311-315) a rectangular matrix is unsymmetric whatever the banner or the size line says: no other triangle
+    if (nrow != ncol) stype = UNSYM;
     const bool unknown = (stype == UNKNOWN), skew = (stype == SKEW);
     // prefer = 1: everything that is not plainly unsymmetric gets the other triangle
     bool expand = (stype != UNSYM);
     std::vector<long> Ti, Tj;
     std::vector<double> Tx;
-    Ti.reserve((size_t)nnz * 2); Tj.reserve((size_t)nnz * 2); Tx.reserve((size_t)nnz * 2);
+    {
+        // (the file cannot hold more entries than it has bytes / 4: a wrong count must not drive the reservation)
+        const long pos0 = ftell(f);
+        long fsz = -1;
+        if (pos0 >= 0 && fseek(f, 0, SEEK_END) == 0) { fsz = ftell(f); (void)fseek(f, pos0, SEEK_SET); }
+        const size_t cap = (fsz >= 0) ? std::min<size_t>((size_t)nnz, (size_t)fsz / 4 + 1) : (size_t)std::min<long>(nnz, 1L << 20);
+        Ti.reserve(cap * 2); Tj.reserve(cap * 2); Tx.reserve(cap * 2);
+    }
     bool is_lower = true, is_upper = true, one_based = true, pattern = false;
     long imax = 0, jmax = 0;
     int nshould = 0;
@@ -159,6 +173,8 @@ int stmmqr_read_matrix_market(const char *path, stm_long *m_out, stm_long *n_out
     //  skew-symmetric pattern keeps +1 on both sides, as the reference's Tx[p] = -Tx[k] runs before the values exist --
     //  its Tx is uninitialised there; pattern + skew is not a case the driver's test set contains)
     if (pattern) std::fill(Tx.begin(), Tx.end(), 1.0);
+    for (size_t k = 0; k < Ti.size(); k++)
+        if (Ti[k] < 0 || Ti[k] >= nrow || Tj[k] < 0 || Tj[k] >= ncol) return bad("indices out of range");
     // ---- triplet -> CSC: columns sorted by row, duplicates summed ----
     const size_t nt = Ti.size();
     std::vector<long> cnt((size_t)ncol + 1, 0);
@@ -186,6 +202,21 @@ int stmmqr_read_matrix_market(const char *path, stm_long *m_out, stm_long *n_out
     Ap[ncol] = out;
     *m_out = nrow; *n_out = ncol; *nnz_out = out; *Ap_out = Ap; *Ai_out = Ai; *Ax_out = Ax;
     return 0;
+}
+
+int stmmqr_read_matrix_market(const char *path, stm_long *m_out, stm_long *n_out, stm_long *nnz_out, stm_long **Ap_out,
+                              stm_long **Ai_out, double **Ax_out)
+{
+    // nothing may be thrown across the C ABI
+    try {
+        return read_mm(path, m_out, n_out, nnz_out, Ap_out, Ai_out, Ax_out);
+    } catch (const std::bad_alloc &) {
+        g_mm_err = "out of memory";
+        return STMMQR_ERR_OUT_OF_MEMORY;
+    } catch (...) {
+        g_mm_err = "invalid matrix file";
+        return STMMQR_ERR_INVALID;
+    }
 }
 
 }  // extern "C"

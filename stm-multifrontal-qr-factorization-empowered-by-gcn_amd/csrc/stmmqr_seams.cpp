@@ -17,6 +17,7 @@
 #include "../../include/stmmqr_hip.h"
 #include "stmmqr_device.h"
 #include "stmmqr_kernels.h"
+#include "stmmqr_internal.h"
 
 extern "C" int stmmqr_device_count(void);
 
@@ -246,48 +247,87 @@ stm_long qr_front(stm_long m, stm_long n, stm_long npiv, double tol, stm_long nt
 }
 
 // ---------------------------------------------------------------------------------------------
-// qr_larftb, method QR_QTX (SparseQR.h:255-268 / SparseQR_factorize.c:1851-1904)
-// C (m x n, ldc) <- (I - V T V')' C with V m x k unit lower trapezoidal (ldv)
+// qr_larftb, all four methods (SparseQR.h:255-268 / SparseQR_factorize.c:1851-1904; callers: qr_front :1473-1594 with
+// QR_QTX, qr_panel SparseQR.c:1659,1663 with any of the four).
+//   left side  (QR_QTX 0 / QR_QX 1):  C (m x n, ldc) <- (I - V T V')' C  /  (I - V T V') C,  V m x k unit lower trapezoidal
+//   right side (QR_XQT 2 / QR_XQ 3):  C (m x n, ldc) <- C (I - V T V')'  /  C (I - V T V'),  V n x k
+// The right-side forms are the left-side ones on C' (C Q' = (Q C')', C Q = (Q' C')'): the transposition happens on the
+// host copy, the reflectors run through the same MFMA update kernel as the factorization (k_update; its no-transpose
+// twin k_update_n for Q).  More than 32 reflectors are applied 32 at a time: first block first for Q', last first for Q.
 // ---------------------------------------------------------------------------------------------
-int stmmqr_larftb_qtx(stm_long m, stm_long n, stm_long k, stm_long ldc, stm_long ldv, const double *V,
-                      const double *Tau, double *C)
+static int larftb_left(bool notrans, stm_long m, stm_long n, stm_long k, stm_long ldc, stm_long ldv, const double *V,
+                       const double *Tau, double *C)
 {
     if (m <= 0 || n <= 0 || k <= 0) return 0;
-    if (!device_ready()) return STMMQR_ERR_DEVICE;
+    if (!device_ready()) return stm_fail(STMMQR_ERR_DEVICE, "qr_larftb: no usable gfx950 device (there is no CPU fallback)");
+    if (ldc < m || ldv < m) return stm_fail(STMMQR_ERR_INVALID, "qr_larftb: leading dimension smaller than the row count");
     // device image [V | C] in one column-major array
     OneFront X;
-    if (!X.init(m, k + n, 0, nullptr, m, nullptr)) return STMMQR_ERR_OUT_OF_MEMORY;
+    if (!X.init(m, k + n, 0, nullptr, m, nullptr)) return stm_fail(STMMQR_ERR_OUT_OF_MEMORY, "qr_larftb: device allocation failed");
     std::vector<double> Fd((size_t)X.s.ld * (size_t)(k + n), 0.0);
     for (stm_long j = 0; j < k; j++) memcpy(&Fd[(size_t)j * X.s.ld], V + j * ldv, sizeof(double) * (size_t)m);
     for (stm_long j = 0; j < n; j++) memcpy(&Fd[(size_t)(k + j) * X.s.ld], C + j * ldc, sizeof(double) * (size_t)m);
-    if (hipMemcpy(X.d_F.p, Fd.data(), Fd.size() * sizeof(double), hipMemcpyHostToDevice) != hipSuccess) return STMMQR_ERR_DEVICE;
+    if (hipMemcpy(X.d_F.p, Fd.data(), Fd.size() * sizeof(double), hipMemcpyHostToDevice) != hipSuccess)
+        return stm_fail(STMMQR_ERR_DEVICE, "qr_larftb: upload failed");
     std::vector<double> tau((size_t)(k + n), 0.0);
     for (stm_long j = 0; j < k; j++) tau[j] = Tau[j];
-    if (hipMemcpy(X.d_Tau.p, tau.data(), tau.size() * sizeof(double), hipMemcpyHostToDevice) != hipSuccess) return STMMQR_ERR_DEVICE;
-    // H_1..H_k applied block by block, first block first (Q' C = H_k ... H_1 C)
-    for (stm_long k1 = 0; k1 < k; k1 += STM_NB) {
+    if (hipMemcpy(X.d_Tau.p, tau.data(), tau.size() * sizeof(double), hipMemcpyHostToDevice) != hipSuccess)
+        return stm_fail(STMMQR_ERR_DEVICE, "qr_larftb: upload failed");
+    const stm_long nblk = (k + STM_NB - 1) / STM_NB;
+    for (stm_long b = 0; b < nblk; b++) {
+        // Q' C = H_k ... H_1 C: first block first;  Q C = H_1 ... H_k C: last block first
+        const stm_long k1 = (notrans ? nblk - 1 - b : b) * STM_NB;
         const int nb = (int)std::min<stm_long>(STM_NB, k - k1);
         PanelDesc &pd = X.nm.pd[0];
         pd.pg1 = (int)std::min(k1, m); pd.pt = (int)m; pd.pk1 = (int)k1; pd.pnb = nb; pd.pc0 = (int)k;
         for (int j = 0; j < STM_NB; j++)
             pd.pdiag[j] = (j < nb && k1 + j < m && tau[k1 + j] != 0.0) ? (int)(k1 + j) : STM_BIGROW;
         // a reflector with tau = 0 is the identity; one whose diagonal falls below m does not exist
-        if (!X.push_num()) return STMMQR_ERR_DEVICE;
-        if (stm_launch_larft(X.c, 0, nullptr)) return STMMQR_ERR_DEVICE;
-        if (stm_launch_update(X.c, X.d_flist.p, X.d_flist.p /* panel 0 */, 1, 0, (int)((n + 31) / 32), nullptr)) return STMMQR_ERR_DEVICE;
+        if (!X.push_num()) return stm_fail(STMMQR_ERR_DEVICE, "qr_larftb: upload failed");
+        if (stm_launch_larft(X.c, 0, nullptr)) return stm_fail(STMMQR_ERR_DEVICE, "qr_larftb: T kernel launch failed");
+        const int ncb = (int)((n + 31) / 32);
+        const int e = notrans ? stm_launch_update_notrans(X.c, 0, ncb, nullptr)
+                              : stm_launch_update(X.c, X.d_flist.p, X.d_flist.p /* panel 0 */, 1, 0, ncb, nullptr);
+        if (e) return stm_fail(STMMQR_ERR_DEVICE, "qr_larftb: update kernel launch failed");
     }
-    if (hipDeviceSynchronize() != hipSuccess) return STMMQR_ERR_DEVICE;
-    if (!X.d_F.down(Fd.data(), Fd.size())) return STMMQR_ERR_DEVICE;
+    if (hipDeviceSynchronize() != hipSuccess) return stm_fail(STMMQR_ERR_DEVICE, "qr_larftb: kernel failed");
+    if (!X.d_F.down(Fd.data(), Fd.size())) return stm_fail(STMMQR_ERR_DEVICE, "qr_larftb: download failed");
     for (stm_long j = 0; j < n; j++) memcpy(C + j * ldc, &Fd[(size_t)(k + j) * X.s.ld], sizeof(double) * (size_t)m);
     return 0;
+}
+
+int stmmqr_larftb(int method, stm_long m, stm_long n, stm_long k, stm_long ldc, stm_long ldv, const double *V,
+                  const double *Tau, double *C)
+{
+    if (m <= 0 || n <= 0 || k <= 0) return 0;                              // (SparseQR_factorize.c:1864-1867)
+    if (method < 0 || method > 3) return stm_fail(STMMQR_ERR_INVALID, "qr_larftb: unknown method");
+    if (!V || !Tau || !C) return stm_fail(STMMQR_ERR_INVALID, "qr_larftb: null operand");
+    if (method == 0 || method == 1) return larftb_left(method == 1, m, n, k, ldc, ldv, V, Tau, C);
+    // right side: work on Ct = C' (n x m)
+    if (ldc < m) return stm_fail(STMMQR_ERR_INVALID, "qr_larftb: leading dimension smaller than the row count");
+    std::vector<double> Ct((size_t)n * (size_t)m);
+    for (stm_long j = 0; j < n; j++)
+        for (stm_long i = 0; i < m; i++) Ct[(size_t)j + (size_t)i * (size_t)n] = C[i + j * ldc];
+    // C Q' = (Q C')' (method 2 -> no transpose), C Q = (Q' C')' (method 3 -> transpose)
+    const int e = larftb_left(method == 2, n, m, k, n, ldv, V, Tau, Ct.data());
+    if (e) return e;
+    for (stm_long j = 0; j < n; j++)
+        for (stm_long i = 0; i < m; i++) C[i + j * ldc] = Ct[(size_t)j + (size_t)i * (size_t)n];
+    return 0;
+}
+
+int stmmqr_larftb_qtx(stm_long m, stm_long n, stm_long k, stm_long ldc, stm_long ldv, const double *V,
+                      const double *Tau, double *C)
+{
+    return stmmqr_larftb(0, m, n, k, ldc, ldv, V, Tau, C);
 }
 
 void qr_larftb(int method, stm_long m, stm_long n, stm_long k, stm_long ldc, stm_long ldv, double *V, double *Tau,
                double *C, double *W, stm_sparse_common *cc)
 {
-    (void)W; (void)cc;
-    if (method != 0) return;          // only QR_QTX is on the factorization path
-    (void)stmmqr_larftb_qtx(m, n, k, ldc, ldv, V, Tau, C);
+    (void)W;                                    // (T and the dlarfb workspace live on the device)
+    const int e = stmmqr_larftb(method, m, n, k, ldc, ldv, V, Tau, C);
+    if (e) stm_cc_set_status(cc, e);            // never silent: cc->status < SPARSE_OK + stmmqr_last_error()
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -199,8 +199,11 @@ def test_panel_wait_timeout_is_recovered(pkg, oracle, monkeypatch, name):
     N = numeric_from_gpu(S, G)
     compare_integers(S, N, g)
     assert G.stats["flops"] == scalar(g, "flopcount")
+    assert G.stats["retries"] == 1                      # the recovery is visible in the statistics, never silent
     No = oracle.factorize(S, g["in_Ap"], g["in_Ai"], g["in_Ax"], scalar(g, "in_tol"), int(scalar(g, "in_ntol")))
     compare_numeric(oracle, S, G, No, g, ftol=1e-10, name=name)
+    S2, G2 = gpu_run(pkg, g)
+    assert G2.stats["retries"] == 0                     # ... and a healthy run reports none
 
 
 @pytest.mark.parametrize("chunk", [None, 3, 40])

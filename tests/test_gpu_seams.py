@@ -161,6 +161,74 @@ def test_qr_larftb(pkg, oracle, m, n, k):
     assert np.linalg.norm(Cg - Co) <= 1e-12 * np.linalg.norm(Co)
 
 
+def _dense_q(V, Tau):
+    """Q = H_1 ... H_k with H_j = I - tau_j v_j v_j', v_j = column j of V with a unit diagonal and zeros above it."""
+    m, k = V.shape
+    Q = np.eye(m)
+    for j in range(min(k, m)):
+        v = V[:, j].copy()
+        v[:j] = 0.0
+        v[j] = 1.0
+        Q = Q @ (np.eye(m) - Tau[j] * np.outer(v, v))
+    return Q
+
+
+@pytest.mark.parametrize("method", [0, 1, 2, 3])
+@pytest.mark.parametrize("m,n,k", [(50, 20, 7), (200, 70, 32), (130, 33, 80), (64, 64, 64), (10, 3, 10), (33, 1, 5)])
+def test_qr_larftb_all_methods(pkg, oracle, method, m, n, k):
+    """All four methods of the exported seam (the reference's qr_panel calls it with any of them, SparseQR.c:1659,1663)
+    against the dense Q built reflector by reflector; the left-side ones also against the oracle's dlarfb restatement.
+    QR_QTX/QR_QX: C is m x n, V m x k.  QR_XQT/QR_XQ: C is n x m here (so that V stays m x k)."""
+    import ctypes as C
+    from stmmqr_testlib import _dp
+    rng = np.random.default_rng(1000 * method + m * 7 + n)
+    kk = min(k, m)
+    V = np.asfortranarray(rng.standard_normal((m, k)))
+    Tau = rng.uniform(1.0, 2.0, k)
+    if k > 3:
+        Tau[2] = 0.0
+    Q = _dense_q(V[:, :kk], Tau[:kk])
+    if method < 2:
+        C0 = np.asfortranarray(rng.standard_normal((m, n)))
+        want = (Q.T @ C0) if method == 0 else (Q @ C0)
+        Cg = C0.copy(order="F")
+        pkg.qr_larftb(method, m, n, kk, m, m, V, Tau, Cg)
+        if kk <= 32:
+            Co = C0.copy(order="F")
+            W = np.zeros(32 * 32 + 32 * n + 64)
+            oracle.lib.orc_larftb(method, m, n, kk, m, m, _dp(V), _dp(Tau), _dp(Co), _dp(W))
+            assert np.linalg.norm(Cg - Co) <= 1e-12 * np.linalg.norm(Co)
+    else:
+        C0 = np.asfortranarray(rng.standard_normal((n, m)))
+        want = (C0 @ Q.T) if method == 2 else (C0 @ Q)
+        Cg = C0.copy(order="F")
+        pkg.qr_larftb(method, n, m, kk, n, m, V, Tau, Cg)
+    assert np.linalg.norm(Cg - want) <= 1e-12 * np.linalg.norm(want)
+
+
+def test_qr_larftb_export_reports_failures(pkg):
+    """The reference-named export never returns silently: an unknown method leaves cc->status < 0 and a message."""
+    import ctypes as C
+    from stmmqr_testlib import _dp
+    lay = pkg.get_common_layout() if hasattr(pkg, "get_common_layout") else None
+    cc = (C.c_char * 2048)()
+    V = np.asfortranarray(np.ones((4, 2)))
+    Tau = np.ones(2)
+    Cm = np.asfortranarray(np.ones((4, 3)))
+    W = np.zeros(64)
+    pkg.lib.qr_larftb(7, 4, 3, 2, 4, 4, _dp(V), _dp(Tau), _dp(Cm), _dp(W), C.cast(cc, C.c_void_p))
+    off = 1004 if lay is None else lay["status"]
+    status = C.c_int.from_buffer(cc, off).value
+    assert status == -4
+    assert b"method" in pkg.lib.stmmqr_last_error()
+    np.testing.assert_array_equal(Cm, 1.0)
+    # and a valid call through the same export works and leaves status alone
+    cc2 = (C.c_char * 2048)()
+    pkg.lib.qr_larftb(1, 4, 3, 2, 4, 4, _dp(V), _dp(Tau), _dp(Cm), _dp(W), C.cast(cc2, C.c_void_p))
+    assert C.c_int.from_buffer(cc2, off).value == 0
+    assert not np.allclose(Cm, 1.0)
+
+
 @pytest.mark.parametrize("m,n,npiv,g", [(10, 8, 3, 3), (40, 50, 20, 17), (300, 200, 64, 64), (5, 9, 2, 2), (6, 6, 6, 6)])
 def test_qr_cpack(pkg, oracle, m, n, npiv, g):
     from stmmqr_testlib import _dp

@@ -65,3 +65,88 @@ def test_sharded_equals_unsharded(name, nranks, pair_everywhere, monkeypatch):
     for k in ("Hm", "Hr", "HStair", "HPinv", "Rdead", "Rblock_off", "Hii", "HTau"):
         np.testing.assert_array_equal(getattr(G, k), getattr(ref, k), err_msg=k)
     np.testing.assert_array_equal(G.Stack[:G.rh_total], ref.Stack[:ref.rh_total])
+
+
+def _two_rank_run(pkg, sh, sym, g, owner, phase, tol, ntol):
+    plans, shards = [], []
+    retries = 0
+    for r in range(2):
+        p = pkg.HipQR(sym)
+        p.set_groups(np.where(owner == r, phase, -1).astype(np.int32))
+        p.begin(g["in_Ax"], tol, ntol, g["in_Ap"], g["in_Ai"])
+        plans.append(p)
+    for k in range(int(phase.max()) + 1):
+        if k > 0:
+            for c, par in sh.cross_edges(sym, owner, phase, k):
+                info = plans[owner[c]].front_info(c)
+                buf = pkg.device_alloc(8 * max(info["csize"], 1))
+                rows = plans[owner[c]].export_front_dev(c, buf, info)
+                plans[owner[par]].import_front_dev(c, info["fm"], info["rank"], info["cm"], buf, rows)
+                pkg.device_free(buf)
+        for r in range(2):
+            if np.any((owner == r) & (phase == k)):
+                plans[r].run_group(k)
+    for r, p in enumerate(plans):
+        st = p.finish()
+        retries += st["retries"]
+        shards.append(sh.shard_of(p.download(), sym, owner == r))
+        p.close()
+    return sh.merge_shards(sym, shards), retries
+
+
+@pytest.mark.parametrize("name", ["epb1", "grid20_standin"])
+def test_group_recovery_in_the_phased_interface(name, monkeypatch):
+    """A bounded panel wait that runs out inside stmmqr_factorize_group (STMMQR_DBG bit 12 makes every column group but
+    the first give up at once) is recovered GROUP by group: the group is run again with one-workgroup panels, imported
+    fronts and the other groups stay as they are, stats.retries counts it, and the merged result is a correct
+    factorization (integers identical to the healthy run, same flop count)."""
+    pkg = importlib.import_module(PKG)
+    sh = importlib.import_module(PKG + ".sharded")
+    g = load_golden(name)
+    S = Symbolic(g)
+    sym = {**S.sc, **{k: v for k, v in S.arr.items() if v is not None}}
+    tol, ntol = scalar(g, "in_tol"), int(scalar(g, "in_ntol"))
+    owner, phase = sh.partition(sym, 2)
+    pkg.set_options(tall_min_rows=0, big_front_cols=16)
+    try:
+        good, r0 = _two_rank_run(pkg, sh, sym, g, owner, phase, tol, ntol)
+        monkeypatch.setenv("STMMQR_DBG", "4096")
+        rec, r1 = _two_rank_run(pkg, sh, sym, g, owner, phase, tol, ntol)
+        monkeypatch.delenv("STMMQR_DBG")
+    finally:
+        pkg.set_options(tall_min_rows=0, big_front_cols=64)
+    assert r0 == 0 and r1 >= 1
+    assert (rec.rank, rec.maxfrank, rec.maxfm, rec.rh_total) == (good.rank, good.maxfrank, good.maxfm, good.rh_total)
+    for k in ("Hm", "Hr", "HStair", "HPinv", "Rdead", "Rblock_off", "Hii"):
+        np.testing.assert_array_equal(getattr(rec, k), getattr(good, k), err_msg=k)
+    a, b = rec.Stack[:rec.rh_total], good.Stack[:good.rh_total]
+    assert np.linalg.norm(np.abs(a) - np.abs(b)) <= 1e-9 * np.linalg.norm(b)
+
+
+def test_graph_is_invalidated_by_set_groups():
+    """options.use_graph: the captured schedule must not survive stmmqr_plan_set_groups (the step lists and workspaces it
+    describes are rebuilt): factorize with the graph, regroup, factorize again -- same bits as without the graph."""
+    pkg = importlib.import_module(PKG)
+    g = load_golden("grid20_standin")
+    S = Symbolic(g)
+    sym = {**S.sc, **{k: v for k, v in S.arr.items() if v is not None}}
+    tol, ntol = scalar(g, "in_tol"), int(scalar(g, "in_ntol"))
+    ref = pkg.qr_factorize(sym, g["in_Ap"], g["in_Ai"], g["in_Ax"], tol, ntol)
+    nf = S.nf
+    pkg.set_options(use_graph=1)
+    try:
+        p = pkg.HipQR(sym)
+        p.factorize(g["in_Ax"], tol, ntol, g["in_Ap"], g["in_Ai"])
+        a = p.download()
+        # regroup: the same single group again (a rebuild), then a different grouping and back
+        p.set_groups(np.zeros(nf, np.int32))
+        p.factorize(g["in_Ax"], tol, ntol)
+        b = p.download()
+        p.close()
+    finally:
+        pkg.set_options(use_graph=0)
+    for r in (a, b):
+        assert r.rh_total == ref.rh_total
+        np.testing.assert_array_equal(r.HStair, ref.HStair)
+        np.testing.assert_array_equal(r.HTau, ref.HTau)
+        np.testing.assert_array_equal(r.Stack[:r.rh_total], ref.Stack[:ref.rh_total])

@@ -23,6 +23,10 @@ def pkg():
 @pytest.mark.parametrize("name", NAMES)
 def test_reader_matches_reference_reader(pkg, name):
     ref = np.load(MM / "reference_reader.npz")
+    if f"{name}_refused" in ref:                 # the reference's reader refuses the file: so must this one
+        with pytest.raises(pkg.StmmqrError):
+            pkg.read_matrix_market(MM / f"{name}.mtx")
+        return
     m, n, Ap, Ai, Ax = pkg.read_matrix_market(MM / f"{name}.mtx")
     assert (m, n) == (int(ref[f"{name}_m"][0]), int(ref[f"{name}_n"][0]))
     np.testing.assert_array_equal(Ap, ref[f"{name}_Ap"])
@@ -45,6 +49,27 @@ def test_reader_refuses_what_the_driver_refuses(pkg, tmp_path):
         pkg.read_matrix_market(oob)
     with pytest.raises(pkg.StmmqrError):
         pkg.read_matrix_market(tmp_path / "missing.mtx")
+
+
+def test_reader_survives_hostile_headers(pkg, tmp_path):
+    """Nothing is thrown across the C ABI and nothing is written out of bounds: absurd entry counts, a symmetric banner
+    on a rectangular file whose mirror entries would fall outside, truncated files."""
+    cases = {
+        "huge.mtx": "2 2 99999999999999\n1 1 1.0\n",
+        "neg.mtx": "%%MatrixMarket matrix coordinate real general\n2 2 -5\n1 1 1.0\n",
+        "trunc.mtx": "%%MatrixMarket matrix coordinate real symmetric\n3 3 4\n1 1 1.0\n",
+        "nan.mtx": "nan nan nan\n",
+    }
+    for fn, text in cases.items():
+        (tmp_path / fn).write_text(text)
+        with pytest.raises(pkg.StmmqrError):
+            pkg.read_matrix_market(tmp_path / fn)
+    ok = tmp_path / "tall.mtx"
+    ok.write_text("%%MatrixMarket matrix coordinate real symmetric\n6 2 3\n1 1 1\n5 1 2\n6 2 3\n")
+    m, n, Ap, Ai, Ax = pkg.read_matrix_market(ok)
+    assert (m, n) == (6, 2)
+    np.testing.assert_array_equal(Ap, [0, 2, 3])
+    np.testing.assert_array_equal(Ai, [0, 4, 5])
 
 
 @pytest.mark.parametrize("name,fname", [("bcsstk14", "bcsstk14.mtx"), ("epb1", "epb1.mtx")])
