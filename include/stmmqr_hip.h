@@ -296,6 +296,28 @@ int stmmqr_read_matrix_market(const char *path, stm_long *nrow, stm_long *ncol, 
 const char *stmmqr_mm_last_error(void);
 void stmmqr_free(void *p);
 
+/* ---- own symbolic phase ---------------------------------------------------------------------------
+ * stmmqr_analyze replaces qr_analyze (STMMQR/include/SparseQR.h; src/qr/SparseQR_analyze.c:20-700) as SparseQR() calls it
+ * (SparseQR.c:338 ordering GIVEN with Q1fill, :360 FIXED on Y): the supernodal analysis of A(:,Q)'A(:,Q) (elimination
+ * tree, column counts, relaxed supernodes: SparseChol_analyze_p2 / SparseChol_super_symbolic2), the frontal tree and its
+ * weighted post-order, S = A(P,Q) in row form, front sizes, staircases, flop and stack bounds.  A: CSC pattern (m x n,
+ * Long indices; values are not needed).  Quser: the fill-reducing column permutation (NULL = natural order).
+ * relax: supernode amalgamation knobs (NULL = the library defaults 4/16/48, 0.8/0.1/0.05; stmmqr_relax_for_qr gives what
+ * the driver's Relaxfactor_setting(n, nnz, RELAX_FOR_QR) sets, SparseCore_common.c:1172-1203, qrtest.c:153).
+ * The result is bit-identical to the reference's qr_symbolic for the same inputs (tests/test_symbolic.py); it says
+ * ntasks = ns = 1 (the reference's serial analysis): tree parallelism is this library's scheduler.
+ * Host-only: no device is touched. */
+typedef struct stmmqr_relax { stm_long nrelax[3]; double zrelax[3]; } stmmqr_relax;
+typedef struct stmmqr_analysis stmmqr_analysis;       /* owns every array the qr_symbolic view points to */
+void stmmqr_relax_for_qr(stm_long n, stm_long nnz, stmmqr_relax *relax);
+int stmmqr_analyze(stm_long m, stm_long n, const stm_long *Ap, const stm_long *Ai, const stm_long *Quser,
+                   int do_rank_detection, const stmmqr_relax *relax, stmmqr_analysis **out);
+const stm_qr_symbolic *stmmqr_analysis_symbolic(const stmmqr_analysis *a);   /* borrowed, valid until stmmqr_analysis_free */
+/* info[0..7] = flop bound (cc->SPQR_flopcount_bound), fl and lnz of the Cholesky analysis, QR_CHUNK_FLAG (fl/lnz >= 1000,
+ * SparseChol_analyze.c:727-730), bound on nnz(R), bound on nnz(H) (SPQR_istat[0..1]), maxstack, nf */
+int stmmqr_analysis_info(const stmmqr_analysis *a, double *info);
+void stmmqr_analysis_free(stmmqr_analysis *a);
+
 void stmmqr_shutdown(void);                           /* optional end-of-use call for dlopen()ing hosts: device sync  */
 /* Device buffers for hosts without HIP bindings of their own (FFI callers of stmmqr_export_front_dev /
  * stmmqr_import_front_dev, device-resident A values): allocated by the HIP runtime THIS library is bound to, on the

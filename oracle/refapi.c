@@ -137,9 +137,12 @@ int main(int argc, char **argv)
         SparseCore_free_dense(&X0, cc); SparseCore_free_dense(&B, cc);
     }
     put_l("status_end", cc->status);
-    fclose(g_out);
     SparseQR_free(&QR, cc);                       /* (qr_freenum releases what this repository's qr_factorize allocated) */
     SparseCore_free_sparse(&A, cc);
+    /* what is still allocated now is the common workspace only: the same count and bytes in both links */
+    put_l("malloc_count_exit", (long)cc->malloc_count);
+    put_l("memory_inuse_exit", (long)cc->memory_inuse);
+    fclose(g_out);
     printf("malloc_count at exit = %ld\n", (long)cc->malloc_count);
     SparseCore_finish(cc);
     return 0;

@@ -414,6 +414,55 @@ class QrNumericC(C.Structure):
                [(k, c_long_p) for k in ("Hii", "HPinv", "Hm", "Hr")] + [("maxfm", C.c_long)]
 
 
+class Relax(C.Structure):
+    _fields_ = [("nrelax", C.c_long * 3), ("zrelax", C.c_double * 3)]
+
+
+lib.stmmqr_relax_for_qr.restype = None
+lib.stmmqr_relax_for_qr.argtypes = [C.c_long, C.c_long, C.POINTER(Relax)]
+lib.stmmqr_analyze.argtypes = [C.c_long, C.c_long, c_long_p, c_long_p, c_long_p, C.c_int, C.POINTER(Relax), C.POINTER(C.c_void_p)]
+lib.stmmqr_analysis_symbolic.restype = C.POINTER(QrSymbolicC)
+lib.stmmqr_analysis_symbolic.argtypes = [C.c_void_p]
+lib.stmmqr_analysis_info.argtypes = [C.c_void_p, c_double_p]
+lib.stmmqr_analysis_free.restype = None
+lib.stmmqr_analysis_free.argtypes = [C.c_void_p]
+
+
+def relax_for_qr(n: int, nnz: int) -> Relax:
+    """Relaxfactor_setting(n, nnz, RELAX_FOR_QR) (SparseCore_common.c:1172-1203, called by the driver at qrtest.c:153)."""
+    r = Relax()
+    lib.stmmqr_relax_for_qr(n, nnz, C.byref(r))
+    return r
+
+
+def analyze(m: int, n: int, Ap, Ai, Qfill=None, do_rank_detection: bool = True, relax: Relax | None = None) -> dict:
+    """qr_analyze (SparseQR_analyze.c:20-700) on plain arrays: the whole qr_symbolic as a dict of numpy arrays / ints,
+    plus 'info' = [flop bound, fl, lnz, QR_CHUNK_FLAG, nnz(R) bound, nnz(H) bound, maxstack, nf].  Host-only."""
+    Ap = np.ascontiguousarray(Ap, I64)
+    Ai = np.ascontiguousarray(Ai, I64)
+    Q = None if Qfill is None else np.ascontiguousarray(Qfill, I64)
+    h = C.c_void_p()
+    _check(lib.stmmqr_analyze(m, n, _ip(Ap), _ip(Ai), _ip(Q), 1 if do_rank_detection else 0,
+                              None if relax is None else C.byref(relax), C.byref(h)), "stmmqr_analyze")
+    try:
+        S = lib.stmmqr_analysis_symbolic(h).contents
+        nf, anz = S.nf, S.anz
+        out = {k: int(getattr(S, k)) for k in ("m", "n", "anz", "nf", "maxfn", "rjsize", "do_rank_detection", "maxstack", "hisize",
+                                               "keepH", "ntasks", "ns")}
+        sizes = {"Sp": m + 1, "Sj": anz, "Qfill": n, "PLinv": m, "Sleft": n + 2, "Parent": nf + 1, "Child": nf + 1,
+                 "Childp": nf + 2, "Super": nf + 1, "Rp": nf + 1, "Rj": S.Rp[nf] if nf > 0 else 0, "Post": nf + 1, "Hip": nf + 1,
+                 "Fm": nf + 1, "Cm": nf + 1}
+        for k, cnt in sizes.items():
+            ptr = getattr(S, k)
+            out[k] = np.ctypeslib.as_array(ptr, shape=(cnt,)).copy() if cnt > 0 else np.zeros(0, I64)
+        info = np.zeros(8)
+        _check(lib.stmmqr_analysis_info(h, _dp(info)), "stmmqr_analysis_info")
+        out["info"] = info
+        return out
+    finally:
+        lib.stmmqr_analysis_free(h)
+
+
 def read_matrix_market(path):
     """The driver's Matrix Market reader (SparseCore_read_matrix with prefer = 1, qrtest.c:112): (m, n, Ap, Ai, Ax) of the
     unsymmetric CSC with both triangles."""

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Generate tests/golden/api_reference.npz: the outputs of the REFERENCE's public API (SparseQR -> QR_qmult x 4 methods ->
+"""Generate tests/golden/api/api_reference.npz: the outputs of the REFERENCE's public API (SparseQR -> QR_qmult x 4 methods ->
 QR_solve x 4 systems, oracle/refapi.c) on the small fixtures, from the compiled reference with nothing interposed.
 Build container only:   make -C oracle ref && python tests/golden/make_api_golden.py
 tests/test_relinked_reference.py runs the same program linked as INTEGRATION.md 1 prescribes (reference minus
@@ -58,8 +58,8 @@ def main():
             for k, v in d.items():
                 out[f"{key}:{k}"] = v
             print(f"{key:24s} m={d['m'][0]} n={d['n'][0]} rank={d['rank'][0]} {text.strip().splitlines()[0]}")
-    np.savez_compressed(HERE / "api_reference.npz", **out)
-    print("wrote", HERE / "api_reference.npz", (HERE / "api_reference.npz").stat().st_size // 1024, "KiB")
+    np.savez_compressed(HERE / "api" / "api_reference.npz", **out)
+    print("wrote", HERE / "api" / "api_reference.npz", (HERE / "api" / "api_reference.npz").stat().st_size // 1024, "KiB")
 
 
 if __name__ == "__main__":

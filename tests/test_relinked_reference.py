@@ -3,7 +3,7 @@ SparseQR_factorize.o and SparseQR_multithreads.o and linked against libstmmqr_hi
 INTEGRATION.md 2).  In it the reference's SparseQR() calls this repository's qr_factorize (SparseQR.c:349,371), its
 qr_panel calls this repository's qr_larftb with ALL FOUR methods (SparseQR.c:1659,1663) and its qr_freenum releases what
 the library allocated.  The program (oracle/refapi.c) runs QR_qmult x {QTX, QX, XQT, XQ} and QR_solve x 4 systems; its
-outputs are compared with those of the same program linked against the pure reference (tests/golden/api_reference.npz,
+outputs are compared with those of the same program linked against the pure reference (tests/golden/api/api_reference.npz,
 generator tests/golden/make_api_golden.py).  Needs a GPU and the prebuilt oracle/_ref (travels with the snapshot)."""
 import os
 import sys
@@ -15,11 +15,13 @@ import pytest
 ROOT = Path(__file__).resolve().parent.parent
 sys.path.insert(0, str(ROOT / "tests" / "golden"))
 RELINKED = ROOT / "oracle" / "_ref" / "refapi_relinked"
-GOLD = ROOT / "tests" / "golden" / "api_reference.npz"
+GOLD = ROOT / "tests" / "golden" / "api" / "api_reference.npz"
 pytestmark = [pytest.mark.gpu, pytest.mark.skipif(not RELINKED.exists(), reason="oracle/_ref/refapi_relinked not built")]
 
-# fixtures whose factorization has no noise pivots: every output is determined, compared entry by entry
-EXACT = {"syn_grid3d", "syn_star", "syn_chain", "syn_rand60x40", "syn_wide5x8", "bcsstk14", "epb1"}
+# fixtures whose factorization has no rounding-noise pivots (tests/parity.py ELEMENTWISE): every output is
+# determined and compared entry by entry; elsewhere Householder vectors of noise rows are arbitrary rotations (MKL and a
+# restated LAPACK already differ there), so only what IS determined is compared
+EXACT = {"syn_star", "syn_chain", "syn_rand60x40", "syn_wide5x8", "syn_dupcol"}
 CASES = [("bcsstk14", -1), ("epb1", -1), ("epb1", 0), ("syn_grid3d", -1), ("syn_dupcol", -1), ("syn_rankdef_grid", -1),
          ("syn_wide5x8", -1), ("syn_star", -1), ("syn_chain", -1), ("syn_rand60x40", -1), ("lns_3937", -1)]
 
@@ -42,8 +44,9 @@ def test_relinked_reference_api(tmp_path, name, ordering):
     env = dict(os.environ, MKL_THREADING_LAYER="SEQUENTIAL")
     got, text = run_refapi(RELINKED, mtx, ordering, env, timeout=300)
     m, n, nr = int(ref["m"][0]), int(ref["n"][0]), 3
-    assert "malloc_count at exit = 0" in text                       # qr_freenum released everything the library allocated
-    for k in ("m", "n", "rank", "n1rows", "n1cols", "status_after_factorize", "status_end"):
+    # (malloc_count / memory_inuse at exit: qr_freenum released everything the library allocated -- what is left is the
+    #  common workspace, the same count and the same bytes as in the pure reference's run)
+    for k in ("m", "n", "rank", "n1rows", "n1cols", "status_after_factorize", "status_end", "malloc_count_exit", "memory_inuse_exit"):
         assert int(got[k][0]) == int(ref[k][0]), k
     for meth in range(4):
         assert int(got[f"qmult_{meth}_status"][0]) == 0             # (a failing qr_larftb seam leaves cc->status < 0)
