@@ -119,8 +119,13 @@ def test_group_recovery_in_the_phased_interface(name, monkeypatch):
     assert (rec.rank, rec.maxfrank, rec.maxfm, rec.rh_total) == (good.rank, good.maxfrank, good.maxfm, good.rh_total)
     for k in ("Hm", "Hr", "HStair", "HPinv", "Rdead", "Rblock_off", "Hii"):
         np.testing.assert_array_equal(getattr(rec, k), getattr(good, k), err_msg=k)
-    a, b = rec.Stack[:rec.rh_total], good.Stack[:good.rh_total]
-    assert np.linalg.norm(np.abs(a) - np.abs(b)) <= 1e-9 * np.linalg.norm(b)
+    # floating point: the one-workgroup panels round differently (and rotate rounding-noise rows differently), so the
+    # recovered factors are checked as a factorization -- against the oracle through the sign-invariant comparisons
+    from parity import compare_numeric
+    from stmmqr_testlib import Oracle
+    orc = Oracle()
+    No = orc.factorize(S, g["in_Ap"], g["in_Ai"], g["in_Ax"], tol, ntol)
+    compare_numeric(orc, S, rec, No, g, ftol=1e-10, name=name)
 
 
 def test_graph_is_invalidated_by_set_groups():
