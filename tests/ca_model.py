@@ -10,6 +10,7 @@ from stmmqr_testlib import Oracle, Symbolic, load_golden, scalar, _ip, _dp, I64,
 from oracle_plan import OraclePlan
 
 NB = 32
+MODE = "ca"          # "cab": the blocked form (ca_panel_blocked)
 STATS = {"panels": 0, "refresh": 0, "cols": 0, "maxerr": 0.0}
 BUCK = {}
 
@@ -107,6 +108,161 @@ def ca_panel(F, Stair, Tau, Rdead, k1, nb, g, rank, npiv, ntol, tol, K):
     return g, rank, done, diag, tlast
 
 
+def ca_panel_blocked(F, Stair, Tau, Rdead, k1, nb, g, rank, npiv, ntol, tol, K, SB=8):
+    """Blocked form of ca_panel (csrc/stmmqr_capanel.hip, round 3): the panel is factorized in sub-blocks of SB columns.
+    Inside a sub-block only its SB candidate pivot rows P are explicit; every other row -- the rest of the top block (Lt)
+    and the bottom rows B -- enters through one SB x (remaining columns) Gram block GL, so the column chain works on
+    SB x SB matrices (T1 = At[P, sub-block], GL11, M11: one entry per lane of ONE wave, no workgroup barrier per column);
+    the sub-block's reflectors are then applied to the columns behind it as ONE block reflector on the small matrices
+    (At, M, G).  Refresh rule as in ca_panel, checked inside the chain (the chain stops, what it finished is applied, the
+    Gram matrix is formed again from the real rows)."""
+    m, n = F.shape
+    g1 = g
+    k2 = k1 + nb
+    tmax = min(m, max(int(Stair[k2 - 1]), g1 + nb))
+    r_top1 = min(tmax, g1 + nb)
+    At = F[g1:r_top1, k1:k2].copy()
+    nt = At.shape[0]
+    B = F[r_top1:tmax, k1:k2]
+    nB = B.shape[0]
+    M = np.eye(nb)
+    G = B.T @ B
+    Gref = np.diag(G).copy() + (At * At).sum(axis=0)
+    jref = -1
+    diag = [None] * nb
+    done = False
+    tlast = g1
+    STATS["panels"] += 1
+    c0 = 0
+    while c0 < nb and not done:
+        if g >= m:
+            for kk in range(k1 + c0, n):
+                if kk < npiv:
+                    Rdead[kk] = 1; Stair[kk] = 0
+                else:
+                    Stair[kk] = m
+                Tau[kk] = 0
+            done = True
+            break
+        c1 = min(c0 + SB, nb); w = c1 - c0
+        gi0 = g - g1
+        npr = min(SB, nt - gi0)
+        P = slice(gi0, gi0 + npr); Lt = slice(gi0 + npr, nt)
+        GB11 = G[c0:c1, c0:c1].copy(); GB12 = G[c0:c1, c1:nb].copy()
+        AL = At[Lt, :]
+        GL = G[c0:c1, c0:nb] + AL[:, c0:c1].T @ AL[:, c0:nb]
+        GL11o = GL[:, :w].copy(); GL12 = GL[:, w:].copy()
+        GL11 = GL11o.copy()
+        T1 = At[P, c0:c1].copy()
+        M11 = np.eye(w)
+        tau_l = np.zeros(w); dl = [None] * w
+        nd = 0; flag = False
+        for jj in range(w):
+            j = c0 + jj; k = k1 + j
+            if g >= m:
+                break
+            gi = g - g1; pl = gi - gi0
+            t = max(g + 1, int(Stair[k]))
+            alpha = T1[pl, jj]
+            stop = float(T1[pl + 1:, jj] @ T1[pl + 1:, jj])
+            gjj = float(GL11[jj, jj])
+            ss = stop + gjj
+            tot = alpha * alpha + max(ss, 0.0)
+            below = (nt - (gi0 + npr)) + nB
+            if j != jref and below > 0 and (Gref[j] > K * tot or (ss <= 0 and not (stop == 0 and gjj == 0))):
+                flag = True
+                break
+            ss = max(ss, 0.0)
+            STATS["cols"] += 1
+            if ss == 0.0:
+                beta, tau, scal = alpha, 0.0, 0.0
+            else:
+                beta = -np.copysign(np.sqrt(alpha * alpha + ss), alpha)
+                tau = (beta - alpha) / beta
+                scal = 1.0 / (alpha - beta)
+            dead = (k < ntol) and (abs(beta) <= tol)
+            nd += 1
+            if dead:
+                T1[pl:, jj] = 0.0
+                M11[:, jj] = 0.0
+                Stair[k] = 0; Tau[k] = 0; Rdead[k] = 1
+                if k == npiv - 1:
+                    rank = g
+                continue
+            Stair[k] = t; Tau[k] = tau; diag[j] = g; dl[jj] = pl; tau_l[jj] = tau
+            if tau != 0.0:
+                vtop = T1[pl + 1:, jj] * scal
+                gjx = GL11[jj, jj + 1:].copy()
+                wv = T1[pl, jj + 1:] + vtop @ T1[pl + 1:, jj + 1:] + scal * gjx
+                cw = tau * wv
+                T1[pl, jj + 1:] -= cw
+                T1[pl + 1:, jj + 1:] -= np.outer(vtop, cw)
+                T1[pl + 1:, jj] = vtop
+                c = cw * scal
+                M11[:, jj + 1:] -= np.outer(M11[:, jj], c)
+                M11[:, jj] *= scal
+                GL11[jj + 1:, jj + 1:] -= np.outer(c, gjx) + np.outer(gjx, c) - gjj * np.outer(c, c)
+            else:
+                M11[:, jj] = 0.0
+            T1[pl, jj] = beta
+            tlast = t
+            g += 1
+            if k == npiv - 1:
+                rank = g
+        # ---- apply the nd reflectors of the sub-block to everything behind them ----
+        At[P, c0:c1] = T1
+        if nd > 0:
+            Mn = M11[:, :nd]
+            VP = np.zeros((npr, nd))
+            for q in range(nd):
+                if dl[q] is None or tau_l[q] == 0.0:
+                    continue
+                VP[dl[q], q] = 1.0
+                VP[dl[q] + 1:, q] = T1[dl[q] + 1:, q]
+            Kf = VP.T @ VP + Mn.T @ GL11o @ Mn
+            Tf = np.zeros((nd, nd))
+            for b_ in range(nd):
+                Tf[b_, b_] = tau_l[b_]
+                if b_ > 0 and tau_l[b_] != 0:
+                    Tf[:b_, b_] = -tau_l[b_] * (Tf[:b_, :b_] @ Kf[:b_, b_])
+            W2 = VP.T @ At[P, c1:nb] + Mn.T @ GL12
+            Y2 = Tf.T @ W2
+            At[P, c1:nb] -= VP @ Y2
+            At[Lt, c0:c1] = At[Lt, c0:c1] @ M11
+            At[Lt, c1:nb] -= At[Lt, c0:c0 + nd] @ Y2
+            M[:, c0:c1] = M[:, c0:c1] @ M11
+            M[:, c1:nb] -= M[:, c0:c0 + nd] @ Y2
+            if not flag:
+                ZB = Mn.T @ GB12
+                KB = Mn.T @ GB11 @ Mn
+                G[c1:nb, c1:nb] -= Y2.T @ ZB + ZB.T @ Y2 - Y2.T @ KB @ Y2
+        if flag:
+            if nB > 0:
+                B[:, :] = B @ M
+                M = np.eye(nb)
+                G = B.T @ B
+            gi = g - g1
+            Gref = np.diag(G).copy() + (At[gi:, :] * At[gi:, :]).sum(axis=0)
+            jref = c0 + nd
+            STATS["refresh"] += 1
+        c0 += nd
+        if nd == 0 and not flag:
+            break                                   # (g >= m at the first column of the sub-block: handled at the loop head)
+    if g >= m and not done and c0 < nb:
+        pass
+    B[:, :] = B @ M
+    F[g1:r_top1, k1:k2] = At
+    if not done and g >= m and c0 < nb:
+        for kk in range(k1 + c0, n):
+            if kk < npiv:
+                Rdead[kk] = 1; Stair[kk] = 0
+            else:
+                Stair[kk] = m
+            Tau[kk] = 0
+        done = True
+    return g, rank, done, diag, tlast
+
+
 def classic_panel(F, Stair, Tau, Rdead, k1, nb, g, rank, npiv, ntol, tol):
     m, n = F.shape
     g1 = g; k2 = k1 + nb
@@ -167,6 +323,8 @@ def front_qr(F, Stair, npiv, tol, ntol, mode, K=100.0):
             break
         if mode == "ca":
             g, rank, done, diag, tlast = ca_panel(F, Stair, Tau, Rdead, k1, nb, g, rank, npiv, ntol, tol, K)
+        elif mode == "cab":
+            g, rank, done, diag, tlast = ca_panel_blocked(F, Stair, Tau, Rdead, k1, nb, g, rank, npiv, ntol, tol, K)
         else:
             g, rank, done, diag, tlast = classic_panel(F, Stair, Tau, Rdead, k1, nb, g, rank, npiv, ntol, tol)
         # trailing update with the explicit V
@@ -240,7 +398,7 @@ def main(name=None, K=None, minfn=None):
                 Sto = np.ctypeslib.as_array(Stp, shape=(fn,))
                 Fc = F0.copy(order="F"); Stc = St0.copy()
                 before = dict(STATS)
-                rk, Tauc, Rdc = front_qr(Fc, Stc, fp, tolv, ntolf, "ca", K)
+                rk, Tauc, Rdc = front_qr(Fc, Stc, fp, tolv, ntolf, MODE, K)
                 # compare: integer outputs, R up to sign, backward error
                 same_int = (rk == r) and np.array_equal(Stc, Sto)
                 # R part: rows < g ... compare |R| upper part rows up to live count
