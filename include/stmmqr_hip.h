@@ -318,6 +318,37 @@ const stm_qr_symbolic *stmmqr_analysis_symbolic(const stmmqr_analysis *a);   /* 
 int stmmqr_analysis_info(const stmmqr_analysis *a, double *info);
 void stmmqr_analysis_free(stmmqr_analysis *a);
 
+/* ---- SURVEY.md 8 (f2 stage 2, f4): SparseQR() without the reference ---------------------------------------------------
+ * stmmqr_sparseqr replaces SparseQR (STMMQR/include/SparseQR.h:25-31; src/qr/SparseQR.c:66-450): column singletons
+ * (qr_1colamd :515-1128), the fill-reducing ordering (COLAMD: src/base/colamd.c + the column elimination tree's post-order,
+ * SparseChol_colamd), R1 / Y (:216-329), the symbolic analysis (stmmqr_analyze) and the numeric factorization on the device.
+ * ordering: the reference's QR_ORDERING_* values (SparseQR_definitions.h:6-21): 0 FIXED, 1 NATURAL, 2 COLAMD, 3 GIVEN (Quser,
+ * an extension: the reference's SparseQR has no such argument), 7 DEFAULT (= COLAMD as in the stock build); AMD (5), NESDIS (6),
+ * METIS (10, 11) and the best-of strategies (4, 8, 9) are third-party packages in the reference and are refused here.
+ * tol < 0: no rank detection.  relax: see stmmqr_analyze.  Bit-identical to the reference's Q1fill / P1inv / R1 / Y / qr_symbolic
+ * on the committed fixtures (tests/test_sparseqr_symbolic.py).
+ * stmmqr_sparseqr_symbolic is the host half alone (no device), stmmqr_sparseqr_numeric the device half. */
+typedef struct stmmqr_qr stmmqr_qr;
+int stmmqr_sparseqr(int ordering, double tol, stm_long m, stm_long n, const stm_long *Ap, const stm_long *Ai, const double *Ax,
+                    const stm_long *Quser, const stmmqr_relax *relax, int device, stmmqr_qr **out);
+int stmmqr_sparseqr_symbolic(int ordering, double tol, stm_long m, stm_long n, const stm_long *Ap, const stm_long *Ai,
+                             const double *Ax, const stm_long *Quser, const stmmqr_relax *relax, stmmqr_qr **out);
+int stmmqr_sparseqr_numeric(stmmqr_qr *qr, int device);
+void stmmqr_sparseqr_free(stmmqr_qr *qr);
+/* info[0..11] = rank, n1rows, n1cols, nf, analyze seconds (ordering + analysis: Ana_time), factorize seconds (the qr_factorize
+ * interval: Fac_time), flops (the reference's count), flop bound, device ms of the factorization, ordering used,
+ * QR_CHUNK_FLAG, retries */
+int stmmqr_sparseqr_info(const stmmqr_qr *qr, double *info);
+const stm_long *stmmqr_sparseqr_q1fill(const stmmqr_qr *qr);                      /* [n] column permutation (singletons first) */
+const stm_qr_symbolic *stmmqr_sparseqr_symbolic_view(const stmmqr_qr *qr);       /* qr_symbolic of A or Y */
+stmmqr_plan *stmmqr_sparseqr_plan(stmmqr_qr *qr);                                 /* the device plan holding the factors */
+int stmmqr_sparseqr_y(const stmmqr_qr *qr, const stm_long **Yp, const stm_long **Yi, const double **Yx);
+/* QR_qmult (SparseQR.h:403-409): X nrow x ncol (m x k for methods 0 QR_QTX / 1 QR_QX, k x m for 2 QR_XQT / 3 QR_XQ), result
+ * in Y (same shape).  QR_solve (SparseQR.h:411-417): systems 0..3 as in stmmqr_plan_rsolve, singleton rows included. */
+int stmmqr_sparseqr_qmult(stmmqr_qr *qr, int method, const double *X, stm_long ldx, stm_long nrow, stm_long ncol, double *Y,
+                          stm_long ldy);
+int stmmqr_sparseqr_solve(stmmqr_qr *qr, int system, const double *B, stm_long ldb, stm_long nrhs, double *X, stm_long ldx);
+
 void stmmqr_shutdown(void);                           /* optional end-of-use call for dlopen()ing hosts: device sync  */
 /* Device buffers for hosts without HIP bindings of their own (FFI callers of stmmqr_export_front_dev /
  * stmmqr_import_front_dev, device-resident A values): allocated by the HIP runtime THIS library is bound to, on the

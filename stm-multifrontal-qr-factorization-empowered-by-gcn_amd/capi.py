@@ -463,6 +463,107 @@ def analyze(m: int, n: int, Ap, Ai, Qfill=None, do_rank_detection: bool = True, 
         lib.stmmqr_analysis_free(h)
 
 
+lib.stmmqr_sparseqr.argtypes = [C.c_int, C.c_double, C.c_long, C.c_long, c_long_p, c_long_p, c_double_p, c_long_p, C.POINTER(Relax), C.c_int,
+                                C.POINTER(C.c_void_p)]
+lib.stmmqr_sparseqr_symbolic.argtypes = [C.c_int, C.c_double, C.c_long, C.c_long, c_long_p, c_long_p, c_double_p, c_long_p, C.POINTER(Relax),
+                                         C.POINTER(C.c_void_p)]
+lib.stmmqr_sparseqr_numeric.argtypes = [C.c_void_p, C.c_int]
+lib.stmmqr_sparseqr_free.restype = None
+lib.stmmqr_sparseqr_free.argtypes = [C.c_void_p]
+lib.stmmqr_sparseqr_info.argtypes = [C.c_void_p, c_double_p]
+lib.stmmqr_sparseqr_q1fill.restype = c_long_p
+lib.stmmqr_sparseqr_q1fill.argtypes = [C.c_void_p]
+lib.stmmqr_sparseqr_symbolic_view.restype = C.POINTER(QrSymbolicC)
+lib.stmmqr_sparseqr_symbolic_view.argtypes = [C.c_void_p]
+lib.stmmqr_sparseqr_y.argtypes = [C.c_void_p, C.POINTER(c_long_p), C.POINTER(c_long_p), C.POINTER(c_double_p)]
+lib.stmmqr_sparseqr_qmult.argtypes = [C.c_void_p, C.c_int, c_double_p, C.c_long, C.c_long, C.c_long, c_double_p, C.c_long]
+lib.stmmqr_sparseqr_solve.argtypes = [C.c_void_p, C.c_int, c_double_p, C.c_long, C.c_long, c_double_p, C.c_long]
+
+
+def _symbolic_dict(S, m, n) -> dict:
+    nf, anz = S.nf, S.anz
+    out = {k: int(getattr(S, k)) for k in ("m", "n", "anz", "nf", "maxfn", "rjsize", "do_rank_detection", "maxstack", "hisize", "keepH",
+                                           "ntasks", "ns")}
+    sizes = {"Sp": m + 1, "Sj": anz, "Qfill": n, "PLinv": m, "Sleft": n + 2, "Parent": nf + 1, "Child": nf + 1, "Childp": nf + 2,
+             "Super": nf + 1, "Rp": nf + 1, "Rj": S.Rp[nf] if nf > 0 else 0, "Post": nf + 1, "Hip": nf + 1, "Fm": nf + 1, "Cm": nf + 1}
+    for k, cnt in sizes.items():
+        out[k] = np.ctypeslib.as_array(getattr(S, k), shape=(cnt,)).copy() if cnt > 0 else np.zeros(0, I64)
+    return out
+
+
+class SparseQR:
+    """SparseQR() / QR_qmult / QR_solve / SparseQR_free of the reference (STMMQR/include/SparseQR.h:25-36,403-417) on this library
+    alone: singletons + COLAMD + symbolic analysis on the host, numeric factorization and the Q / R operations on the device.
+    symbolic_only=True stops after the host half (no GPU needed)."""
+
+    def __init__(self, m, n, Ap, Ai, Ax, ordering=7, tol=-2.0, relax: Relax | None = None, Quser=None, device=-1, symbolic_only=False):
+        self.m, self.n = int(m), int(n)
+        self._A = (np.ascontiguousarray(Ap, I64), np.ascontiguousarray(Ai, I64), np.ascontiguousarray(Ax, np.float64))
+        Q = None if Quser is None else np.ascontiguousarray(Quser, I64)
+        self._h = C.c_void_p()
+        rp = None if relax is None else C.byref(relax)
+        if symbolic_only:
+            _check(lib.stmmqr_sparseqr_symbolic(ordering, tol, m, n, _ip(self._A[0]), _ip(self._A[1]), _dp(self._A[2]), _ip(Q), rp,
+                                                C.byref(self._h)), "stmmqr_sparseqr_symbolic")
+        else:
+            _check(lib.stmmqr_sparseqr(ordering, tol, m, n, _ip(self._A[0]), _ip(self._A[1]), _dp(self._A[2]), _ip(Q), rp, device,
+                                       C.byref(self._h)), "stmmqr_sparseqr")
+
+    def numeric(self, device=-1):
+        _check(lib.stmmqr_sparseqr_numeric(self._h, device), "stmmqr_sparseqr_numeric")
+
+    def close(self):
+        if self._h:
+            lib.stmmqr_sparseqr_free(self._h)
+            self._h = None
+
+    __del__ = close
+
+    @property
+    def info(self) -> dict:
+        v = np.zeros(12)
+        _check(lib.stmmqr_sparseqr_info(self._h, _dp(v)), "stmmqr_sparseqr_info")
+        keys = ["rank", "n1rows", "n1cols", "nf", "ana_seconds", "fac_seconds", "flops", "flop_bound", "ms_device", "ordering", "chunk_flag",
+                "retries"]
+        return dict(zip(keys, v.tolist()))
+
+    @property
+    def Q1fill(self):
+        return np.ctypeslib.as_array(lib.stmmqr_sparseqr_q1fill(self._h), shape=(max(self.n, 1),))[:self.n].copy()
+
+    def symbolic(self) -> dict:
+        S = lib.stmmqr_sparseqr_symbolic_view(self._h).contents
+        return _symbolic_dict(S, S.m, S.n)
+
+    def Y(self):
+        """(Yp, Yi, Yx) of the matrix handed to the numeric phase when singletons were removed, else None"""
+        p, i, x = c_long_p(), c_long_p(), c_double_p()
+        _check(lib.stmmqr_sparseqr_y(self._h, C.byref(p), C.byref(i), C.byref(x)), "stmmqr_sparseqr_y")
+        if not p:
+            return None
+        n2 = self.n - int(self.info["n1cols"])
+        Yp = np.ctypeslib.as_array(p, shape=(n2 + 1,)).copy()
+        nz = int(Yp[-1])
+        return Yp, np.ctypeslib.as_array(i, shape=(max(nz, 1),))[:nz].copy(), np.ctypeslib.as_array(x, shape=(max(nz, 1),))[:nz].copy()
+
+    def qmult(self, method, X):
+        X = np.asfortranarray(X, dtype=np.float64)
+        if X.ndim == 1:
+            X = X.reshape(-1, 1, order="F")
+        Y = np.zeros_like(X, order="F")
+        _check(lib.stmmqr_sparseqr_qmult(self._h, method, _dp(X), X.shape[0], X.shape[0], X.shape[1], _dp(Y), Y.shape[0]), "stmmqr_sparseqr_qmult")
+        return Y
+
+    def solve(self, system, B):
+        B = np.asfortranarray(B, dtype=np.float64)
+        if B.ndim == 1:
+            B = B.reshape(-1, 1, order="F")
+        rows = self.n if system <= 1 else self.m
+        X = np.zeros((rows, B.shape[1]), order="F")
+        _check(lib.stmmqr_sparseqr_solve(self._h, system, _dp(B), B.shape[0], B.shape[1], _dp(X), rows), "stmmqr_sparseqr_solve")
+        return X
+
+
 def read_matrix_market(path):
     """The driver's Matrix Market reader (SparseCore_read_matrix with prefer = 1, qrtest.c:112): (m, n, Ap, Ai, Ax) of the
     unsymmetric CSC with both triangles."""

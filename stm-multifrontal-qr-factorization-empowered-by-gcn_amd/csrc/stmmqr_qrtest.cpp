@@ -1,19 +1,23 @@
-// stmmqr_qrtest.cpp -- the reference's Matrix Market test driver on the MI355X numeric path.
+// stmmqr_qrtest.cpp -- the reference's Matrix Market test driver on this library alone.
 //
 //     stmmqr_qrtest <matrix.mtx> <graph_id> [ordering]        (argument-compatible with STMMQR/test/qrtest.c:65-217)
-//       ordering: 0 AMD, 1 COLAMD, 2 METIS, 3 NESDIS, absent = default (qrtest.c:155-169)
+//       ordering: 0 AMD, 1 COLAMD, 2 METIS, 3 NESDIS, absent = default = COLAMD (qrtest.c:155-169)
 //
-// Prints the reference driver's lines ("Matrix %6ld-by-%-6ld nnz: %6ld", "SparseQR TOTAL time:", "res = %8.1e") and
-// appends "graph_id  Ana_time  Fac_time  total  res" to ./Results/QR_Time.txt exactly as qrtest.c:125-128,189-201 does.
+// Prints the reference driver's lines ("Matrix %6ld-by-%-6ld nnz: %6ld", "QR use COLAMD", "Analyze time:", "Factorize time:",
+// "SparseQR TOTAL time:", "res = %8.1e") and appends "graph_id  Ana_time  Fac_time  total  res" to ./Results/QR_Time.txt exactly
+// as qrtest.c:125-128,189-201 does.
 //
-// What runs where.  The matrix is read by THIS library's reader (stmmqr_read_matrix_market); the numeric factorization
-// is THIS library's qr_factorize (gfx950).  The symbolic analysis and the SparseQR() / QR_qmult / QR_solve orchestration
-// around the seam are the reference's own, consumed unchanged (BASELINE north_star): they come from a shared library
-// built from the reference, named by --reflib=<path> or the environment variable STMMQR_REFERENCE_LIB (a maintainer's
-// libsparseqr build).  The reference library is loaded AFTER this library with RTLD_GLOBAL, so its internal call of
-// qr_factorize (SparseQR.c:349,371) binds to the symbol exported here -- the drop-in seam of INTEGRATION.md, without
-// relinking anything.  Without a reference library the driver stops with exit code 2: there is no symbolic phase in this
-// repository yet.
+// What runs where.  Everything is this library: the reader (stmmqr_read_matrix_market), singletons + COLAMD + symbolic
+// analysis on the host and the numeric factorization on the device (stmmqr_sparseqr), and the residual check of
+// qrtest.c:11-53 -- b = A [0..n-1], y = Q'b, x = E (R \ y) -- on the factors that stay resident in HBM
+// (stmmqr_sparseqr_qmult / stmmqr_sparseqr_solve).  No reference code is needed or loaded.
+//
+// AMD, METIS and NESDIS are third-party ordering packages in the reference (component #8) and are not rebuilt
+// here: for `ordering` 0, 2, 3 the driver needs a library built from the reference, named by --reflib=<path> or the
+// environment variable STMMQR_REFERENCE_LIB; then the reference's SparseQR() runs around this library's qr_factorize
+// (the drop-in seam of INTEGRATION.md: this library is loaded first with RTLD_GLOBAL, so the reference's internal call of
+// qr_factorize, SparseQR.c:349,371, and qr_panel's calls of qr_larftb bind to the symbols exported here).  Without one the
+// driver says so and stops with exit code 2.
 //
 // The graph-feature side files of the reference driver (Results/QR_Node.txt, QR_Edge.txt: input of the GCN ordering
 // classifier, qrtest.c:105-109) are opened for append like the reference does and left untouched: out of scope.
@@ -24,6 +28,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
+#include <algorithm>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -110,12 +115,57 @@ int main(int argc, char **argv)
     if (maxnorm == 0) maxnorm = 1;
     const double tol = 20 * ((double)m + (double)n) * DBL_EPSILON * maxnorm;
 
-    // ---- the reference around the seam ----
+    long ordarg = -1;
+    if (pos.size() >= 3) ordarg = atoi(pos[2]);
+    const bool need_reference = (ordarg == 0 || ordarg == 2 || ordarg == 3);        // AMD / METIS / NESDIS
+    if (!need_reference) {
+        // ---- everything on this library (qrtest.c:144-204) ----
+        stmmqr_relax relax;
+        stmmqr_relax_for_qr(n, nnz, &relax);                                        // Relaxfactor_setting (qrtest.c:153)
+        chunk_getSettings(32, 5000, 4, 4);                                          // (qrtest.c:152)
+        stmmqr_qr *QR = nullptr;
+        const double t0 = now();
+        printf("QR use COLAMD \n");                                                 // (SparseQR.c:935)
+        const int e = stmmqr_sparseqr(7 /* QR_ORDERING_DEFAULT */, tol, m, n, Ap, Ai, Ax, nullptr, &relax, -1, &QR);
+        const double t1 = now();
+        if (e) { fprintf(stderr, "stmmqr_qrtest: SparseQR failed (%d): %s\n", e, stmmqr_last_error()); return 3; }
+        double info[12];
+        (void)stmmqr_sparseqr_info(QR, info);
+        printf("\nAnalyze time: %lf\n", info[4]);                                   // (SparseQR.c:342, -DPRINT_TIME)
+        printf("Factorize time: %lf\n", info[5]);                                   // (:354)
+        printf("SparseQR TOTAL time: %f\n\n", t1 - t0);
+        if (fresult) fprintf(fresult, "%lf\t%lf\t%lf\t", info[4], info[5], t1 - t0);
+        // check_error (qrtest.c:11-53)
+        std::vector<double> x0((size_t)std::max<stm_long>(n, 1)), b((size_t)std::max<stm_long>(m, 1), 0.0), y((size_t)std::max<stm_long>(m, 1)),
+            xs((size_t)std::max<stm_long>(n, 1));
+        for (stm_long j = 0; j < n; j++) {
+            x0[(size_t)j] = (double)j;
+            for (stm_long p = Ap[j]; p < Ap[j + 1]; p++) b[(size_t)Ai[p]] += Ax[p] * (double)j;
+        }
+        double res = NAN;
+        int e2 = stmmqr_sparseqr_qmult(QR, 0 /* QR_QTX */, b.data(), std::max<stm_long>(m, 1), m, 1, y.data(), std::max<stm_long>(m, 1));
+        if (!e2) e2 = stmmqr_sparseqr_solve(QR, 1 /* QR_RETX_EQUALS_B */, y.data(), std::max<stm_long>(m, 1), 1, xs.data(), std::max<stm_long>(n, 1));
+        if (e2) fprintf(stderr, "stmmqr_qrtest: solve failed (%d): %s\n", e2, stmmqr_last_error());
+        else {
+            double d = 0;
+            for (stm_long j = 0; j < n; j++) { const double q = xs[(size_t)j] - (double)j; d += q * q; }
+            res = std::sqrt(d) / (double)n;
+        }
+        printf("res = %8.1e\n", res);
+        if (fresult) { fprintf(fresult, "%8.1e\n", res); fclose(fresult); }
+        if (getenv("STMMQR_QRTEST_VERBOSE"))
+            printf("rank = %ld  n1rows = %ld  n1cols = %ld  nf = %ld  flops = %.6g  device ms = %.3f  GFLOP/s = %.1f\n", (long)info[0], (long)info[1],
+                   (long)info[2], (long)info[3], info[6], info[8], info[8] > 0 ? info[6] / info[8] * 1e-6 : 0.0);
+        stmmqr_sparseqr_free(QR);
+        stmmqr_free(Ap); stmmqr_free(Ai); stmmqr_free(Ax);
+        stmmqr_shutdown();
+        return e2 ? 3 : 0;
+    }
+    // ---- AMD / METIS / NESDIS: the reference's SparseQR() around this library's seam ----
     if (!reflib) {
-        fprintf(stderr, "stmmqr_qrtest: no reference library given (--reflib=<path> or STMMQR_REFERENCE_LIB).\n"
-                        "  The symbolic analysis is the reference's own (consumed unchanged); this repository provides the\n"
-                        "  Matrix Market reader and the numeric factorization.  Matrix read: %ld x %ld, %ld entries, tol %.3e\n",
-                (long)m, (long)n, (long)nnz, tol);
+        fprintf(stderr, "stmmqr_qrtest: ordering %ld (0 AMD, 2 METIS, 3 NESDIS) is a third-party package of the reference and not built here;\n"
+                        "  name a library built from the reference (--reflib=<path> or STMMQR_REFERENCE_LIB), or use COLAMD (1 / default).\n"
+                        "  Matrix read: %ld x %ld, %ld entries, tol %.3e\n", ordarg, (long)m, (long)n, (long)nnz, tol);
         return 2;
     }
     // this library first and global, so that the reference's call of qr_factorize binds here
@@ -180,7 +230,7 @@ int main(int argc, char **argv)
 
     // ---- check_error (qrtest.c:11-53): x = 0..n-1, b = A x, y = Q'b, x_sol = E (R \\ y) ----
     double one[2] = {1, 0}, zero[2] = {0, 0};
-    ref_dense *X = r_zeros((size_t)n, 1, 1, cc), *B = r_zeros((size_t)n, 1, 1, cc);
+    ref_dense *X = r_zeros((size_t)n, 1, 1, cc), *B = r_zeros((size_t)m, 1, 1, cc);
     for (stm_long i = 0; i < n; i++) ((double *)X->x)[i] = (double)i;
     r_sdmult(A, 0, one, zero, X, B, cc);
     ref_dense *Y = r_qmult(0 /* QR_QTX */, QR, B, cc);

@@ -50,11 +50,11 @@ DRIVER = ROOT / "stm-multifrontal-qr-factorization-empowered-by-gcn_amd" / "stmm
 REFLIB = ROOT / "oracle" / "_ref" / "libstmmqr_ref.so"
 
 
-@pytest.mark.parametrize("name,ordering", [("bcsstk14", None), ("epb1", None), ("epb1", "1"), ("syn_grid3d", "0")])
-def test_qrtest_compatible_driver(tmp_path, name, ordering):
-    """stmmqr_qrtest <matrix.mtx> <graph_id> [ordering] (csrc/stmmqr_qrtest.cpp): the reference driver's arguments, printed
-    lines and Results/QR_Time.txt record (STMMQR/test/qrtest.c:65-217), with this repository's Matrix Market reader and
-    numeric factorization; the reference library named with --reflib provides the symbolic analysis around the seam."""
+@pytest.mark.parametrize("name,ordering", [("epb1", "0"), ("syn_grid3d", "0"), ("syn_grid3d", "2")])
+def test_qrtest_driver_with_reference_orderings(tmp_path, name, ordering):
+    """stmmqr_qrtest with an ordering that is a third-party package of the reference (0 AMD, 2 METIS): the reference library
+    named with --reflib provides SparseQR() (ordering + analysis) around this library's qr_factorize / qr_larftb, loaded as
+    INTEGRATION.md describes.  (Default / COLAMD runs need no reference at all: tests/test_gpu_sparseqr.py.)"""
     if not DRIVER.exists() or not REFLIB.exists():
         pytest.skip("driver or reference library not built")
     from stmmqr_testlib import load_golden, scalar
@@ -62,7 +62,7 @@ def test_qrtest_compatible_driver(tmp_path, name, ordering):
     mtx = tmp_path / "a.mtx"
     write_mtx(mtx, g)
     (tmp_path / "Results").mkdir()
-    args = [str(DRIVER), str(mtx), "42"] + ([ordering] if ordering is not None else []) + [f"--reflib={REFLIB}"]
+    args = [str(DRIVER), str(mtx), "42", ordering, f"--reflib={REFLIB}"]
     env = dict(os.environ, MKL_THREADING_LAYER="SEQUENTIAL")
     out = subprocess.run(args, capture_output=True, text=True, env=env, timeout=180, cwd=tmp_path)
     assert out.returncode == 0, out.stdout + out.stderr
@@ -73,8 +73,4 @@ def test_qrtest_compatible_driver(tmp_path, name, ordering):
     rec = (tmp_path / "Results" / "QR_Time.txt").read_text().split()
     assert rec[0] == "42" and len(rec) == 5 and float(rec[4]) == res
     assert float(rec[2]) > 0                                        # Fac_time of the interposed factorization
-    if ordering is None and scalar(g, "QR_rank") == scalar(g, "A_n"):
-        assert res <= max(10 * scalar(g, "res"), 1e-9)               # the reference's own run of the same driver flow
-    # without a reference library the driver says what is missing and stops
-    out2 = subprocess.run([str(DRIVER), str(mtx), "1"], capture_output=True, text=True, env=env, timeout=60, cwd=tmp_path)
-    assert out2.returncode == 2 and "no reference library" in out2.stderr
+    assert res <= 1e-9
