@@ -349,6 +349,25 @@ int stmmqr_sparseqr_qmult(stmmqr_qr *qr, int method, const double *X, stm_long l
                           stm_long ldy);
 int stmmqr_sparseqr_solve(stmmqr_qr *qr, int system, const double *B, stm_long ldb, stm_long nrhs, double *X, stm_long ldx);
 
+/* ---- R / H out in sparse form, LQ (STMMQR/src/qr/SparseLQ.c; prototypes SparseQR.h:282-340) ---------
+ * qr_rcount / qr_rconvert / qr_trapezoidal keep the reference's names, argument lists and results (bit for bit: they move
+ * data).  They read a qr_numeric on the host -- the one qr_factorize returned.  stmmqr_plan_export_r does the same for the
+ * factorization a plan holds in HBM (one download): R as compressed sparse columns over the columns of the factorized matrix,
+ * optionally H (one column per live reflector, unit diagonal stored, rows = the permuted row ids) and its Tau; every output
+ * array is malloc'ed (stmmqr_free).  stmmqr_sparselq = SparseLQ: the QR object of A' (L = R'). */
+void qr_rcount(stm_qr_symbolic *QRsym, stm_qr_numeric *QRnum, stm_long n1rows, stm_long econ, stm_long n2, int getT, stm_long *Ra,
+               stm_long *Rb, stm_long *H2p, stm_long *p_nh);
+void qr_rconvert(stm_qr_symbolic *QRsym, stm_qr_numeric *QRnum, stm_long n1rows, stm_long econ, stm_long n2, int getT,
+                 stm_long *Rap, stm_long *Rai, double *Rax, stm_long *Rbp, stm_long *Rbi, double *Rbx, stm_long *H2p, stm_long *H2i,
+                 double *H2x, double *H2Tau);
+stm_long qr_trapezoidal(stm_long n, stm_long *Rp, stm_long *Ri, double *Rx, stm_long bncols, stm_long *Qfill,
+                        int skip_if_trapezoidal, stm_long **p_Tp, stm_long **p_Ti, double **p_Tx, stm_long **p_Qtrap,
+                        stm_sparse_common *cc);
+int stmmqr_plan_export_r(stmmqr_plan *plan, const stm_qr_symbolic *sym, stm_long econ, stm_long **Rp, stm_long **Ri, double **Rx,
+                         stm_long *nh, stm_long **Hp, stm_long **Hi, double **Hx, double **HTau);
+int stmmqr_sparselq(int ordering, double tol, stm_long m, stm_long n, const stm_long *Ap, const stm_long *Ai, const double *Ax,
+                    const stmmqr_relax *relax, int device, stmmqr_qr **out);
+
 void stmmqr_shutdown(void);                           /* optional end-of-use call for dlopen()ing hosts: device sync  */
 /* Device buffers for hosts without HIP bindings of their own (FFI callers of stmmqr_export_front_dev /
  * stmmqr_import_front_dev, device-resident A values): allocated by the HIP runtime THIS library is bound to, on the

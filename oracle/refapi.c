@@ -120,6 +120,36 @@ int main(int argc, char **argv)
         SparseCore_free_dense(&X, cc);
         SparseCore_free_dense(&B, cc);
     }
+    /* ---- R and H in sparse form (SparseLQ.c: qr_rcount :102, qr_rconvert :299, qr_trapezoidal :519) on the multifrontal
+     *      part; small inputs only (the arrays go into a committed fixture) ---- */
+    if (m <= 500) {
+        qr_symbolic *S = QR->QRsym; qr_numeric *N = QR->QRnum;
+        const Long n2s = S->n, econ = S->m;
+        Long *Ra = calloc((size_t)n2s + 1, sizeof(Long)), *H2p = calloc((size_t)S->rjsize + 2, sizeof(Long)), nh = 0;
+        qr_rcount(S, N, 0, econ, n2s, 0, Ra, NULL, H2p, &nh);
+        Long *Rpp = malloc(((size_t)n2s + 1) * sizeof(Long)), tot = 0;
+        for (Long j = 0; j < n2s; j++) { Rpp[j] = tot; tot += Ra[j]; }
+        Rpp[n2s] = tot;
+        Long *fill = malloc(((size_t)n2s + 1) * sizeof(Long));
+        memcpy(fill, Rpp, ((size_t)n2s + 1) * sizeof(Long));
+        Long *Rai = malloc((size_t)(tot > 0 ? tot : 1) * sizeof(Long)); double *Rax = malloc((size_t)(tot > 0 ? tot : 1) * sizeof(double));
+        const Long hnz = H2p[nh];
+        Long *H2i = malloc((size_t)(hnz > 0 ? hnz : 1) * sizeof(Long)); double *H2x = malloc((size_t)(hnz > 0 ? hnz : 1) * sizeof(double));
+        double *H2Tau = malloc((size_t)(nh > 0 ? nh : 1) * sizeof(double));
+        qr_rconvert(S, N, 0, econ, n2s, 0, fill, Rai, Rax, NULL, NULL, NULL, H2p, H2i, H2x, H2Tau);
+        put("rc_Rp", 'q', (long)n2s + 1, Rpp); put("rc_Ri", 'q', (long)tot, Rai); put("rc_Rx", 'd', (long)tot, Rax);
+        put_l("rc_nh", nh); put("rc_Hp", 'q', (long)nh + 1, H2p); put("rc_Hi", 'q', (long)hnz, H2i); put("rc_Hx", 'd', (long)hnz, H2x);
+        put("rc_HTau", 'd', (long)nh, H2Tau);
+        Long *Tp, *Ti, *Qtrap; double *Tx;
+        Long trank = qr_trapezoidal(n2s, Rpp, Rai, Rax, 0, S->Qfill, 0, &Tp, &Ti, &Tx, &Qtrap, cc);
+        put_l("rc_trap_rank", trank);
+        if (Tp) {
+            put("rc_Tp", 'q', (long)n2s + 1, Tp); put("rc_Ti", 'q', (long)tot, Ti); put("rc_Tx", 'd', (long)tot, Tx); put("rc_Qtrap", 'q', (long)n2s, Qtrap);
+            SparseCore_free(n2s + 1, sizeof(Long), Tp, cc); SparseCore_free(tot, sizeof(Long), Ti, cc);
+            SparseCore_free(tot, sizeof(double), Tx, cc); SparseCore_free(n2s, sizeof(Long), Qtrap, cc);
+        }
+        free(Ra); free(H2p); free(Rpp); free(fill); free(Rai); free(Rax); free(H2i); free(H2x); free(H2Tau);
+    }
     /* ---- the driver's own acceptance flow (qrtest.c:11-53): b = A [0..n-1], x = E R \ (Q'b) ---- */
     {
         double one[2] = {1, 0}, zero[2] = {0, 0};

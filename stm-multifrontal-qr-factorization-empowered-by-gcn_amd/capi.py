@@ -480,6 +480,23 @@ lib.stmmqr_sparseqr_qmult.argtypes = [C.c_void_p, C.c_int, c_double_p, C.c_long,
 lib.stmmqr_sparseqr_solve.argtypes = [C.c_void_p, C.c_int, c_double_p, C.c_long, C.c_long, c_double_p, C.c_long]
 
 
+lib.stmmqr_sparseqr_plan.restype = C.c_void_p
+lib.stmmqr_sparseqr_plan.argtypes = [C.c_void_p]
+lib.stmmqr_plan_export_r.argtypes = [C.c_void_p, C.POINTER(QrSymbolicC), C.c_long, C.POINTER(c_long_p), C.POINTER(c_long_p),
+                                     C.POINTER(c_double_p), c_long_p, C.POINTER(c_long_p), C.POINTER(c_long_p), C.POINTER(c_double_p),
+                                     C.POINTER(c_double_p)]
+lib.stmmqr_sparselq.argtypes = [C.c_int, C.c_double, C.c_long, C.c_long, c_long_p, c_long_p, c_double_p, C.POINTER(Relax), C.c_int,
+                                C.POINTER(C.c_void_p)]
+lib.stmmqr_free.restype = None
+lib.stmmqr_free.argtypes = [C.c_void_p]
+
+
+def _take(ptr, count, dtype):
+    out = np.ctypeslib.as_array(ptr, shape=(max(count, 1),))[:count].astype(dtype, copy=True)
+    lib.stmmqr_free(C.cast(ptr, C.c_void_p))
+    return out
+
+
 def _symbolic_dict(S, m, n) -> dict:
     nf, anz = S.nf, S.anz
     out = {k: int(getattr(S, k)) for k in ("m", "n", "anz", "nf", "maxfn", "rjsize", "do_rank_detection", "maxstack", "hisize", "keepH",
@@ -545,6 +562,38 @@ class SparseQR:
         Yp = np.ctypeslib.as_array(p, shape=(n2 + 1,)).copy()
         nz = int(Yp[-1])
         return Yp, np.ctypeslib.as_array(i, shape=(max(nz, 1),))[:nz].copy(), np.ctypeslib.as_array(x, shape=(max(nz, 1),))[:nz].copy()
+
+    def export_r(self, econ=None, with_h=True) -> dict:
+        """qr_rcount + qr_rconvert (SparseLQ.c:102-517) on the factors resident in HBM: R of the multifrontal part as CSC over
+        the columns of the factorized matrix (Rp, Ri, Rx) and, with_h, H as CSC (Hp, Hi, Hx) + HTau."""
+        Sptr = lib.stmmqr_sparseqr_symbolic_view(self._h)
+        S = Sptr.contents
+        econ = S.m if econ is None else econ
+        Rp, Ri, Hp, Hi = c_long_p(), c_long_p(), c_long_p(), c_long_p()
+        Rx, Hx, Ht = c_double_p(), c_double_p(), c_double_p()
+        nh = C.c_long(0)
+        _check(lib.stmmqr_plan_export_r(lib.stmmqr_sparseqr_plan(self._h), Sptr, econ, C.byref(Rp), C.byref(Ri), C.byref(Rx),
+                                        C.byref(nh) if with_h else None, C.byref(Hp) if with_h else None, C.byref(Hi) if with_h else None,
+                                        C.byref(Hx) if with_h else None, C.byref(Ht) if with_h else None), "stmmqr_plan_export_r")
+        n = S.n
+        out = {"Rp": _take(Rp, n + 1, I64)}
+        out["Ri"], out["Rx"] = _take(Ri, int(out["Rp"][-1]), I64), _take(Rx, int(out["Rp"][-1]), np.float64)
+        if with_h:
+            out["Hp"] = _take(Hp, nh.value + 1, I64)
+            hnz = int(out["Hp"][-1])
+            out["Hi"], out["Hx"], out["HTau"] = _take(Hi, hnz, I64), _take(Hx, hnz, np.float64), _take(Ht, nh.value, np.float64)
+        return out
+
+    @classmethod
+    def lq(cls, m, n, Ap, Ai, Ax, tol=-2.0, relax: Relax | None = None, device=-1):
+        """SparseLQ (SparseLQ.c:691-734): the QR object of A' (L = R')."""
+        self = cls.__new__(cls)
+        self.m, self.n = int(n), int(m)
+        self._A = (np.ascontiguousarray(Ap, I64), np.ascontiguousarray(Ai, I64), np.ascontiguousarray(Ax, np.float64))
+        self._h = C.c_void_p()
+        _check(lib.stmmqr_sparselq(7, tol, m, n, _ip(self._A[0]), _ip(self._A[1]), _dp(self._A[2]), None if relax is None else C.byref(relax),
+                                   device, C.byref(self._h)), "stmmqr_sparselq")
+        return self
 
     def qmult(self, method, X):
         X = np.asfortranarray(X, dtype=np.float64)

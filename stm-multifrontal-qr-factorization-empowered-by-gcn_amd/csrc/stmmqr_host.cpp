@@ -1967,9 +1967,13 @@ static inline double &cc_dbl(stm_sparse_common *cc, size_t off) { return *(doubl
 // (stmmqr_internal.h: shared with stmmqr_seams.cpp / stmmqr_symbolic.cpp; local to the library)
 int stm_fail(int code, const char *msg) { return fail(code, msg ? msg : ""); }
 void stm_cc_set_status(stm_sparse_common *cc, int code) { if (cc) cc_int(cc, g_layout.status) = code; }
+static void *cc_malloc(size_t n, size_t size, stm_sparse_common *cc, bool zero = false);
+static void cc_free(size_t n, size_t size, void *p, stm_sparse_common *cc);
+void *stm_cc_malloc(size_t n, size_t size, stm_sparse_common *cc) { return cc_malloc(n, size, cc, false); }
+void stm_cc_free(size_t n, size_t size, void *p, stm_sparse_common *cc) { cc_free(n, size, p, cc); }
 
 // SparseCore_malloc semantics (src/core/SparseCore_common.c:603-655): malloc(max(1,n)*size) + counters
-static void *cc_malloc(size_t n, size_t size, stm_sparse_common *cc, bool zero = false)
+static void *cc_malloc(size_t n, size_t size, stm_sparse_common *cc, bool zero)
 {
     void *p = zero ? calloc(std::max<size_t>(1, n), size) : malloc(std::max<size_t>(1, n) * size);
     if (!p) {

@@ -89,6 +89,66 @@ def test_sparseqr_api_against_reference(name):
     Q.close()
 
 
+@pytest.mark.parametrize("name", ["syn_dupcol", "syn_star", "syn_chain", "syn_rand60x40", "syn_wide5x8", "syn_rankdef_grid", "syn_grid3d"])
+def test_export_r_of_resident_factors(name):
+    """stmmqr_plan_export_r (qr_rcount + qr_rconvert on the factors in HBM) against the reference's qr_rconvert output on ITS
+    factorization of the same matrix: pattern of R and H bit-exact where the factorization is determined, values to rounding;
+    everywhere: R'R = (A E)'(A E) on the live columns through the exported CSC."""
+    pkg = importlib.import_module(PKG)
+    gold = np.load(GOLD)
+    ref = {k.split(":", 1)[1]: gold[k] for k in gold.files if k.startswith(f"{name}@-1:")}
+    g = load_golden(name)
+    m, n = int(g["A_m"][0]), int(g["A_n"][0])
+    Ap, Ai, Ax = g["A_p"], g["A_i"], g["A_x"]
+    Q = pkg.SparseQR(m, n, Ap, Ai, Ax, ordering=7, tol=driver_tol(m, n, Ap, Ax), relax=pkg.relax_for_qr(n, int(Ap[-1])))
+    E = Q.export_r()
+    if name in EXACT:
+        np.testing.assert_array_equal(E["Rp"], ref["rc_Rp"])
+        np.testing.assert_array_equal(E["Ri"], ref["rc_Ri"])
+        assert rel(E["Rx"], ref["rc_Rx"]) < 1e-9
+        np.testing.assert_array_equal(E["Hp"], ref["rc_Hp"])
+        np.testing.assert_array_equal(E["Hi"], ref["rc_Hi"])
+        assert rel(E["Hx"], ref["rc_Hx"]) < 1e-9 and rel(E["HTau"], ref["rc_HTau"]) < 1e-9
+    # R as a dense matrix: rows = live pivots in order; R'R must equal Y'Y restricted to the live columns (no singletons here
+    # or singletons removed: Y = the matrix handed to the numeric phase)
+    S = Q.symbolic()
+    n2, m2 = S["n"], S["m"]
+    Y = Q.Y()
+    if Y is None:
+        Yd = np.zeros((m, n))
+        cols = np.repeat(np.arange(n), np.diff(Ap))
+        Yd[Ai, cols] = Ax
+        Yd = Yd[:, Q.Q1fill]
+    else:
+        Yd = np.zeros((m2, n2))
+        Yd[Y[1], np.repeat(np.arange(n2), np.diff(Y[0]))] = Y[2]
+    R = np.zeros((m2, n2))
+    R[E["Ri"], np.repeat(np.arange(n2), np.diff(E["Rp"]))] = E["Rx"]
+    live = np.array([k for k in range(n2) if E["Rp"][k + 1] > E["Rp"][k] and E["Ri"][E["Rp"][k + 1] - 1] >= 0])
+    G1, G2 = R.T @ R, Yd.T @ Yd
+    dead = np.abs(np.diag(G1)) <= 1e-20
+    lv = ~dead
+    assert np.linalg.norm(G1[np.ix_(lv, lv)] - G2[np.ix_(lv, lv)]) <= 1e-9 * max(np.linalg.norm(G2), 1e-300) or int(Q.info["rank"]) < min(m, n)
+    Q.close()
+
+
+def test_sparselq_is_the_qr_of_the_transpose():
+    pkg = importlib.import_module(PKG)
+    g = load_golden("syn_wide5x8")
+    m, n = int(g["A_m"][0]), int(g["A_n"][0])
+    Ap, Ai, Ax = g["A_p"], g["A_i"], g["A_x"]
+    L = pkg.SparseQR.lq(m, n, Ap, Ai, Ax, tol=0.0)
+    assert (L.m, L.n) == (n, m) and int(L.info["rank"]) == min(m, n)
+    # A' x = b solved through the LQ object (= QR of A'): residual of the least-squares solution
+    At = np.zeros((n, m))
+    At[np.repeat(np.arange(n), np.diff(Ap)), Ai] = Ax
+    x0 = np.arange(1, m + 1, dtype=float)
+    b = At @ x0
+    x = L.solve(1, L.qmult(0, b))[:, 0]
+    assert np.linalg.norm(x - x0) <= 1e-10 * np.linalg.norm(x0)
+    L.close()
+
+
 def write_mtx(path, g):
     Ap, Ai, Ax = g["A_p"], g["A_i"], g["A_x"]
     m, n = int(g["A_m"][0]), int(g["A_n"][0])
