@@ -201,23 +201,40 @@ def _import(plan, f, fm, rank, cm, tC, trows, comm):
         plan.import_front(f, fm, rank, cm, tC.cpu().numpy(), trows.cpu().numpy())
 
 
+class ShardPlan:
+    """What one rank needs to know about a partition, computed ONCE per (plan, partition) -- not per factorization: this
+    rank's groups (installed in the plan: a schedule rebuild and a few device allocations) and, per phase, the cross-rank
+    edges it sends or receives."""
+
+    def __init__(self, plan, sym: dict, owner, phase, comm):
+        self.owner, self.phase = np.asarray(owner), np.asarray(phase)
+        r = comm.rank
+        self.group = np.where(self.owner == r, self.phase, -1).astype(np.int32)
+        plan.set_groups(self.group)
+        self.nphase = int(self.phase.max(initial=0)) + 1
+        parent, _, _ = tree_arrays(sym)
+        cross = [(int(c), int(parent[c])) for c in range(int(sym["nf"])) if parent[c] >= 0 and self.owner[c] != self.owner[parent[c]]]
+        self.out = [[(c, p) for c, p in cross if self.phase[p] == k and self.owner[c] == r] for k in range(self.nphase)]
+        self.inn = [[(c, p) for c, p in cross if self.phase[p] == k and self.owner[p] == r] for k in range(self.nphase)]
+        self.has = [bool(np.any(self.group == k)) for k in range(self.nphase)]
+
+
 def factorize_sharded(plan, sym: dict, Ax, tol, ntol, comm: Comm, Ap=None, Ai=None, owner=None, phase=None,
-                      device_ptr=None):
-    """Run one sharded factorization.  `plan` is this rank's compute object.  Returns (stats, owner, phase)."""
-    nf = int(sym["nf"])
-    if owner is None:
-        owner, phase = partition(sym, comm.size)
-    r = comm.rank
-    group = np.where(owner == r, phase, -1).astype(np.int32)
-    plan.set_groups(group)
+                      device_ptr=None, shard_plan: ShardPlan | None = None):
+    """Run one sharded factorization.  `plan` is this rank's compute object.  Returns (stats, owner, phase).
+    shard_plan: the ShardPlan of (plan, owner, phase) when the caller factorizes repeatedly (bench.py): the groups are then
+    installed once, outside any timed region."""
+    if shard_plan is None:
+        if owner is None:
+            owner, phase = partition(sym, comm.size)
+        shard_plan = ShardPlan(plan, sym, owner, phase, comm)
+    owner, phase, group = shard_plan.owner, shard_plan.phase, shard_plan.group
     plan.begin(Ax, tol, ntol, Ap, Ai, device_ptr=device_ptr)
-    nphase = int(phase.max(initial=0)) + 1
+    nphase = shard_plan.nphase
     for k in range(nphase):
         if k > 0 and comm.size > 1:
             # contribution blocks move up the tree only where subtrees join: every edge entering phase k from another rank
-            edges = cross_edges(sym, owner, phase, k)
-            mine_out = [(c, p) for c, p in edges if owner[c] == r]
-            mine_in = [(c, p) for c, p in edges if owner[p] == r]
+            mine_out, mine_in = shard_plan.out[k], shard_plan.inn[k]
             out = [(c, p) + _export(plan, c, comm) for c, p in mine_out]
             metas_in = [comm.empty(4, np.int64) for _ in mine_in]
             comm.exchange([(comm.tensor(np.array([i["fm"], i["rank"], i["cm"], i["csize"]], I64)), int(owner[p]))
@@ -235,7 +252,7 @@ def factorize_sharded(plan, sym: dict, Ax, tol, ntol, comm: Comm, Ap=None, Ai=No
             comm.exchange(sends, recvs)
             for (c, p), m, (bC, bR) in zip(mine_in, metas, bufs):
                 _import(plan, c, m[0], m[1], m[2], bC[:m[3]], bR[:m[2]], comm)
-        if np.any(group == k):
+        if shard_plan.has[k]:
             plan.run_group(k)
     stats = plan.finish()
     return stats, owner, phase
@@ -256,7 +273,7 @@ def shard_of(N, sym: dict, owned):
             "maxfrank": int(N.maxfrank)}
 
 
-def merge_shards(sym: dict, shards):
+def merge_shards(sym: dict, shards, ntol=None):
     """Reference-format result from per-rank shards: packed R+H blocks in Post order (the single shrunk stack of
     the reference's serial run), H arrays merged, HPinv / Hii by qr_hpinv."""
     from .capi import QRNumeric
@@ -286,20 +303,21 @@ def merge_shards(sym: dict, shards):
             G.Hm[f], G.Hr[f] = hm, sh["Hr"][f]
             G.Rdead[Super[f]:Super[f + 1]] = sh["Rdead"][Super[f]:Super[f + 1]]
     G.rank = int(G.Hr[:nf].sum())
-    G.rank1 = G.rank
+    # rank1 = live pivots among the first ntol columns (SparseQR_factorize.c:726-740)
+    G.rank1 = G.rank if ntol is None or ntol >= n else int(np.count_nonzero(G.Rdead[:max(int(ntol), 0)] == 0))
     G.maxfrank = mf
     hpinv(sym, G)
     return G
 
 
-def gather_numeric(plan, sym: dict, comm: Comm, owner):
+def gather_numeric(plan, sym: dict, comm: Comm, owner, ntol=None):
     """Assemble the reference-format result on rank 0 (other ranks return None): every rank downloads the fronts it
     factorized and ships the arrays of its shard to rank 0 (point-to-point, one batched group; this is the API consumer's
     "give me the factors on the host" -- it is not part of a factorization step)."""
     N = plan.download()
     shard = shard_of(N, sym, owner == comm.rank)
     if comm.size == 1:
-        return merge_shards(sym, [shard])
+        return merge_shards(sym, [shard], ntol)
     keys_f = ["Stack", "HTau"]
     keys_i = ["Rblock_off", "HStair", "Hii", "Hm", "Hr"]
     host = Comm(comm.dist, None) if comm.dist.get_backend() != "nccl" else comm
@@ -334,7 +352,7 @@ def gather_numeric(plan, sym: dict, comm: Comm, owner):
         for k, a in zip(keys_f, af):
             sh[k] = a
         shards.append(sh)
-    return merge_shards(sym, shards)
+    return merge_shards(sym, shards, ntol)
 
 
 def hpinv(sym: dict, G):
