@@ -102,16 +102,25 @@ def test_export_r_of_resident_factors(name):
     Ap, Ai, Ax = g["A_p"], g["A_i"], g["A_x"]
     Q = pkg.SparseQR(m, n, Ap, Ai, Ax, ordering=7, tol=driver_tol(m, n, Ap, Ax), relax=pkg.relax_for_qr(n, int(Ap[-1])))
     E = Q.export_r()
+    S = Q.symbolic()
     if name in EXACT:
-        np.testing.assert_array_equal(E["Rp"], ref["rc_Rp"])
-        np.testing.assert_array_equal(E["Ri"], ref["rc_Ri"])
-        assert rel(E["Rx"], ref["rc_Rx"]) < 1e-9
-        np.testing.assert_array_equal(E["Hp"], ref["rc_Hp"])
-        np.testing.assert_array_equal(E["Hi"], ref["rc_Hi"])
-        assert rel(E["Hx"], ref["rc_Hx"]) < 1e-9 and rel(E["HTau"], ref["rc_HTau"]) < 1e-9
+        # Which stored entries are EXACTLY zero is not an invariant of the algorithm (a fill position the reference's
+        # column-by-column dlarf leaves at 0.0 can carry 1e-17 after a blocked update, and the other way round): the exported
+        # matrices are compared entry by entry as matrices, the patterns through their significant entries
+        def dense(p, i, x, nrow, ncol):
+            D = np.zeros((nrow, ncol))
+            D[i, np.repeat(np.arange(ncol), np.diff(p))] = x
+            return D
+        Rg, Rr = dense(E["Rp"], E["Ri"], E["Rx"], S["m"], S["n"]), dense(ref["rc_Rp"], ref["rc_Ri"], ref["rc_Rx"], S["m"], S["n"])
+        scale = np.abs(Rr).max()
+        assert np.abs(Rg - Rr).max() <= 1e-11 * scale
+        np.testing.assert_array_equal(np.abs(Rg) > 1e-9 * scale, np.abs(Rr) > 1e-9 * scale)
+        assert len(E["Hp"]) == len(ref["rc_Hp"])                      # the same live reflectors
+        nh = len(E["HTau"])
+        Hg, Hr_ = dense(E["Hp"], E["Hi"], E["Hx"], S["m"], nh), dense(ref["rc_Hp"], ref["rc_Hi"], ref["rc_Hx"], S["m"], nh)
+        assert np.abs(Hg - Hr_).max() <= 1e-10 and rel(E["HTau"], ref["rc_HTau"]) < 1e-10
     # R as a dense matrix: rows = live pivots in order; R'R must equal Y'Y restricted to the live columns (no singletons here
     # or singletons removed: Y = the matrix handed to the numeric phase)
-    S = Q.symbolic()
     n2, m2 = S["n"], S["m"]
     Y = Q.Y()
     if Y is None:
