@@ -116,7 +116,7 @@ def cpu_baseline(name, g, budget_s=30.0):
                     f.write("%%MatrixMarket matrix coordinate real general\n%d %d %d\n" % (m, n, len(Ax)))
                     np.savetxt(f, np.c_[Ai + 1, cols + 1, Ax], fmt="%d %d %.17g")
                 # best of 3 for legs under ~15 s (box-to-box spread of one run: 11.6-15.8 s on the default workload), one run above
-                reps = 3 if ref_s * 1.3 < 15.0 else int(max(1, min(3, budget_s / 2 / max(ref_s * 1.3, 1e-3))))
+                reps = 3 if ref_s < 15.0 else int(max(1, min(3, budget_s / 2 / max(ref_s * 1.3, 1e-3))))
                 ordering = str(int(g["ordering"][0])) if "ordering" in g else "-1"
                 omap = {"5": "0", "2": "1", "11": "2", "6": "3"}      # QR_ORDERING_* -> refdump selector
                 legs = []

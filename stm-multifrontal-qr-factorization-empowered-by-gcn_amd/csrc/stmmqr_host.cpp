@@ -1392,6 +1392,7 @@ int stmmqr_factorize_finish(stmmqr_plan *plan, stmmqr_stats *stats)
                 hb[0], hb[1], hb[2], hb[3], hb[4]);
         fprintf(stderr, "[last group of the panel pipeline, cycles] load %llu  waits %llu  apply-loads %llu  applies %llu  factor %llu  gram %llu\n", hb[6],
                 hb[7], hb[12], hb[8] + hb[11], hb[9], hb[10]);
+        fprintf(stderr, "[Gram-based panels] panels %llu  refresh rounds %llu  slab workgroups %llu\n", hb[13], hb[14], hb[15]);
         HIPCHK(hipMemset(P.d_dbg.p, 0, sizeof hb));
     }
     P.rank = rank;
