@@ -45,13 +45,12 @@ struct CaShared {
     double At[STM_NB][STM_NB + 1];      // top block, At[i][x] = F(g1 + i, k1 + x)  (during the chain: in the owner's registers)
     double G[STM_NB][STM_NB + 1];       // Gram matrix of the bottom rows (upper triangle + diagonal are maintained)
     double M[STM_NB][STM_NB + 1];       // pending column operations: current B = stored B * M
-    // blocked chain (round 3): the strips of one sub-block of <= 8 columns, handed between the workgroup and the chain wave
-    double Ts[8][STM_NB + 1];           // candidate pivot rows of the sub-block x panel columns
-    double GLs[8][STM_NB + 1];          // Gram rows of the block's columns over EVERY row below the candidates (rest of At + B)
-    double Ms[8][STM_NB + 1];           // column operations of the sub-block: rows = the block's columns
-    double ZB[8][STM_NB + 1];           // G(block, block) Ms(:, behind the block)
-    int io[8];                          // in: g, rank, tlast;  out: [3] columns done, [4] flag, [5] g, [6] rank, [7] tlast
-    long long fl[2];                    // flop count / reflector lengths of the sub-block (FLOP_COUNT :1571)
+    // vectors handed from one column step to the next, double buffered by step parity (a step reads one set and writes
+    // the other; ONE barrier per step):
+    double part[2][16][STM_NB];         // partial sums (16 row groups) of  sum_{i > pivot row} At(i, j) At(i, x)
+    double colA[2][STM_NB], rowA[2][STM_NB];   // column j / pivot row of the top block, current values
+    double colN[2][STM_NB];             // column j + 1 before step j's update
+    double gj[2][STM_NB], mjv[2][STM_NB];      // row j of G (x >= j), column j of M
     double gref[STM_NB];                // norm^2 of each column (rows >= pivot row) when G was last formed
     double tau[STM_NB];
     int stair[STM_NB], st_out[STM_NB], diag[STM_NB], dead[STM_NB];
@@ -140,98 +139,6 @@ __device__ __forceinline__ void ca_publish_block(const double (*src)[STM_NB + 1]
     for (int e = threadIdx.x; e < STM_NB * STM_NB; e += CA_NT) st_agent(&dst[e], src[e >> 5][e & 31]);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-}
-
-// value of lane `src` (any lane, run time) -- ds_bpermute
-__device__ __forceinline__ double ca_shfl(double v, int src) { return __shfl(v, src, 64); }
-__device__ __forceinline__ double ca_pick4(const double (&a)[4], int b) { return b == 0 ? a[0] : (b == 1 ? a[1] : (b == 2 ? a[2] : a[3])); }
-
-// The column recurrence of one sub-block (columns [c0, c1) of the aligned block of 8), run by ONE wave.
-// Lane (i, xs) = (lane >> 3, lane & 7) holds, for the four panel columns x = xs + 8 b, entry (i, x) of the three strips:
-//   Ts  row i = candidate pivot row gi0 + i of the top block (rows >= npr: zero),
-//   GLs row i = Gram products of block column 8 bb + i with column x over all rows below the candidates,
-//   Ms  row i = coefficient of block column 8 bb + i in the current column x (B and the rest of the top block: cur = orig Ms).
-// Per column j (pivot row pl inside the candidates): |x|^2 and v'a_x from the explicit rows (stride-8 sum over the lanes of a
-// column) + the Gram strip; dlarfg; the rank-1 update of Ts, the column operation on Ms, the congruence on GLs.  Everything a
-// step needs from another lane travels by ds_bpermute / DPP: no barrier, no LDS array.  Results: strips back in LDS, per
-// column HStair / HTau / diagonal row / dead flag, and cs.io / cs.fl.
-__device__ __noinline__ void ca_chain(CaShared &cs, int c0, int c1, int gi0, int npr, int nbp, int g1, int m, int n, int k1, int npiv,
-                                      int ntol, double tol, double sg, double isg, int jref, bool has_below)
-{
-    const int lane = threadIdx.x & 63, i = lane >> 3, xs = lane & 7, bb = c0 >> 3;
-    double tq[4], gq[4], mq[4];
-#pragma unroll
-    for (int b = 0; b < 4; b++) { tq[b] = cs.Ts[i][xs + 8 * b]; gq[b] = cs.GLs[i][xs + 8 * b]; mq[b] = cs.Ms[i][xs + 8 * b]; }
-    int g = cs.io[0], rank = cs.io[1], tlast = cs.io[2];
-    long long iflops = 0, ilen = 0;
-    int nd = 0, flag = 0;
-    for (int j = c0; j < c1; j++) {
-        if (g >= m) { flag = 2; break; }
-        const int jx = j & 7, pl = g - g1 - gi0, k = k1 + j;
-        const int t = max(g + 1, cs.stair[j]);
-        const double tb = ca_pick4(tq, bb), gb = ca_pick4(gq, bb), mb = ca_pick4(mq, bb);
-        const double colT = ca_shfl(tb, (lane & 56) | jx);              // Ts(i, j)
-        const double alpha = ca_shfl(colT, pl << 3);                     // Ts(pl, j)
-        const double pm = (i > pl && i < npr) ? colT * sg : 0.0;         // (one operand carries the magnitude guard)
-        double rowT[4], gjx[4], d[4];
-#pragma unroll
-        for (int b = 0; b < 4; b++) {
-            rowT[b] = ca_shfl(tq[b], (pl << 3) | xs);                    // Ts(pl, x)
-            gjx[b] = ca_shfl(gq[b], (jx << 3) | xs);                     // GL(j, x)
-            d[b] = wave_sum_stride8(pm * tq[b]);                         // sum_{i > pl} Ts(i, j) Ts(i, x)
-        }
-        const double dj = ca_shfl(ca_pick4(d, bb), jx);
-        const double gjj = ca_shfl(ca_pick4(gjx, bb), jx);
-        const double ssr = dj + gjj;
-        const bool unresolved = (ssr <= 0.0) && !(dj == 0.0 && gjj == 0.0);
-        const double ss = fmax(ssr, 0.0);
-        const double total = alpha * (alpha * sg) + ss;                  // (one factor sg, as ss and gref)
-        if (j != jref && has_below && (unresolved || cs.gref[j] > CA_K * total)) { flag = 1; break; }
-        // ---- dlarfg; ss == 0 (no row below the diagonal, or all of them zero) gives H = I ----
-        const bool ident = (ss == 0.0);
-        double bbeta, tau0, scal0, scals0;
-        stm_larfg_guarded(alpha, ss, sg, isg, bbeta, tau0, scal0, scals0);
-        const double beta = ident ? alpha : bbeta;
-        const bool dead = (k < ntol) && (fabs(beta) <= tol);             // (:1495-1544) column zeroed, g does not advance
-        const bool upd = !ident && !dead;
-        const double scal = upd ? scal0 : 0.0, scals = upd ? scals0 : 0.0;
-        const double tau = upd ? tau0 : 0.0;
-        double cc[4];
-        const double vi = (i == pl) ? 1.0 : ((i > pl && i < npr) ? colT * scal : 0.0);
-#pragma unroll
-        for (int b = 0; b < 4; b++) {
-            const int x = xs + 8 * b;
-            const bool on = upd && x > j && x < nbp;
-            const double cw = on ? tau * (rowT[b] + scals * (d[b] + gjx[b])) : 0.0;     // tau v'a_x
-            cc[b] = cw * scal;
-            tq[b] -= vi * cw;
-        }
-        const double mcol = ca_shfl(mb, (lane & 56) | jx);               // Ms(i, j)
-        const double ccq = ca_shfl(ca_pick4(cc, bb), i);                 // c of block column 8 bb + i (lane i = row 0, xs = i)
-        const double gqj = ca_shfl(gb, (lane & 56) | jx);                // GL(block column i, j)
-        // the finished column: beta (0 if dead) on the diagonal, v below it (zeros if dead / H = I); b_j <- b_j scal
-        const double fin = (i < pl) ? tb : ((i == pl) ? (dead ? 0.0 : beta) : (upd ? vi : 0.0));
-#pragma unroll
-        for (int b = 0; b < 4; b++) {
-            const bool isj = (xs == jx) && (b == bb);
-            mq[b] -= mcol * cc[b];
-            if (i > jx) gq[b] -= ccq * gjx[b] + cc[b] * gqj - ccq * cc[b] * gjj;
-            tq[b] = isj ? fin : tq[b];
-            mq[b] = isj ? (upd ? mcol * scal : 0.0) : mq[b];
-        }
-        if (lane == 0) { cs.st_out[j] = dead ? 0 : t; cs.tau[j] = tau; cs.diag[j] = dead ? STM_BIGROW : g; cs.dead[j] = dead ? 1 : 0; }
-        if (!dead) {
-            iflops += (long long)(t - g) * (3 + 4 * (long long)(n - k - 1));
-            ilen += (t - g);
-            tlast = t;
-            g++;
-        }
-        if (k == npiv - 1) rank = g;                      // (:1604-1608) also taken on a dead last pivot
-        nd++;
-    }
-#pragma unroll
-    for (int b = 0; b < 4; b++) { cs.Ts[i][xs + 8 * b] = tq[b]; cs.Ms[i][xs + 8 * b] = mq[b]; }
-    if (lane == 0) { cs.io[3] = nd; cs.io[4] = flag; cs.io[5] = g; cs.io[6] = rank; cs.io[7] = tlast; cs.fl[0] = iflops; cs.fl[1] = ilen; }
 }
 
 __global__ __launch_bounds__(CA_NT) void k_panel_ca(DevCtx c, const int *__restrict__ flist, const int *__restrict__ plist, int defer_ok)
@@ -387,104 +294,65 @@ __global__ __launch_bounds__(CA_NT) void k_panel_ca(DevCtx c, const int *__restr
         cs.gref[tid] = cs.G[tid][tid] + a2;
         cs.tau[tid] = 0; cs.diag[tid] = STM_BIGROW; cs.st_out[tid] = 0; cs.dead[tid] = 0;
     }
-    ca_set_identity(cs);
+    // The chain keeps At, G and M distributed over the registers of the 512 threads -- thread (tx, ig) owns rows ig and
+    // ig + 16 of column tx of each -- and only the vectors a column step needs travel through LDS.  EVERY wave computes the
+    // scalars of a step for itself (same inputs, same instructions: same bits), so a step is: loads, dlarfg scalars,
+    // the updates of the thread's six entries, the partial dots of the next column, stores, ONE barrier.
+    const int tx = tid & 31, ig = tid >> 5, i0 = ig, i1 = ig + 16, half = lane >> 5;
+    double at0 = cs.At[i0][tx], at1 = cs.At[i1][tx];
+    double gq0 = cs.G[i0][tx], gq1 = cs.G[i1][tx];
+    double m0 = (i0 == tx) ? 1.0 : 0.0, m1 = (i1 == tx) ? 1.0 : 0.0;
+    {
+        // what the first column step reads: column 0 / row 0 of the top block, row 0 of G, column 0 of M, the partial dots
+        // of column 0 below row 0, column 1
+        if (tx == 0) { cs.colA[0][i0] = at0; cs.colA[0][i1] = at1; cs.mjv[0][i0] = m0; cs.mjv[0][i1] = m1; }
+        if (tx == 1) { cs.colN[0][i0] = at0; cs.colN[0][i1] = at1; }
+        if (i0 == 0) { cs.rowA[0][tx] = at0; cs.gj[0][tx] = gq0; }
+        const double c0 = cs.At[i0][0], c1 = cs.At[i1][0];
+        cs.part[0][ig][tx] = ((i0 > 0) ? (at0 * sg) * c0 : 0.0) + (at1 * sg) * c1;
+    }
+    const int stairx = cs.stair[tx];
     __syncthreads();
+
     TL(4);
-    // The chain is BLOCKED (round 3): the panel is factorized in sub-blocks of at most 8 columns (aligned to 8).  Inside a
-    // sub-block only its (at most) 8 candidate pivot rows are explicit; every other row -- the rest of the top block and the
-    // bottom rows -- enters through one 8 x 32 strip of Gram products, so the column recurrence works on three 8 x 32 strips
-    // (pivot rows Ts, Gram rows GLs, column operations Ms: four entries per lane each) inside ONE wave, without a workgroup
-    // barrier or an LDS round trip per column (ca_chain); what the sub-block did is then applied to the rest of the top block,
-    // to M and to G by all threads as small dense products (a handful of barriers per 8 columns instead of one per column).
     const int ntol = min(c.ntol - s.col1, npiv);
     const double tol = c.tol;
-    int c0 = 0, jref = -1, ncols_done = nbp;
-    int g = g1, rank = rank0, done = 0, tlast = g1;
+    int j = 0, jref = 0, ncols_done = nbp;
+    int g = g1, rank = rank0, done = 0, tlast = g1;        // (every thread advances them identically)
     long long iflops = 0, ilen = 0;                        // the reference's flop count: integers, exact in fp64 (FLOP_COUNT :1571)
-    while (c0 < nbp) {
-        if (g >= m) { ncols_done = c0; break; }
-        const int bb = c0 >> 3, c1 = min(bb * 8 + 8, nbp), gi0 = g - g1, npr = min(8, nt - gi0), lt0 = gi0 + npr;
-        // ---- A: the three strips of this sub-block ----
-        if (tid < 8 * STM_NB) {
-            const int q = tid >> 5, x = tid & 31, colq = bb * 8 + q;
-            const bool vq = colq >= c0 && colq < c1, vx = x >= c0 && x < nbp;
-            double gl = 0.0;
-            if (vq && vx) {
-                gl = cs.G[colq][x];
-                for (int i = lt0; i < nt; i++) gl += (cs.At[i][colq] * sg) * cs.At[i][x];
-            }
-            cs.GLs[q][x] = gl;
-            cs.Ts[q][x] = (q < npr && vx) ? cs.At[gi0 + q][x] : 0.0;
-            cs.Ms[q][x] = (vq && colq == x) ? 1.0 : 0.0;
-        }
-        if (tid == 0) { cs.io[0] = g; cs.io[1] = rank; cs.io[2] = tlast; cs.fl[0] = 0; cs.fl[1] = 0; }
-        __syncthreads();
-        // ---- B: the column recurrence of the sub-block, one wave ----
-        if (wid == 0)
-            ca_chain(cs, c0, c1, gi0, npr, nbp, g1, m, n, k1, npiv, ntol, tol, sg, isg, jref, (nt - lt0) + nB > 0);
-        __syncthreads();
-        const int nd = cs.io[3], flag = cs.io[4];          // columns done; 0 / 1 refresh wanted at column c0 + nd / 2 rows ran out
-        g = cs.io[5]; rank = cs.io[6]; tlast = cs.io[7];
-        iflops += cs.fl[0]; ilen += cs.fl[1];
-        // ---- C: what the sub-block did, applied to everything behind it ----
-        if (nd > 0) {
-            const int b8 = bb * 8;
-            for (int e = tid; e < 8 * STM_NB; e += CA_NT) {
-                const int r = e >> 5, x = e & 31;
-                if (r < npr && x >= c0 && x < nbp) cs.At[gi0 + r][x] = cs.Ts[r][x];
-                double z = 0.0;
-                if (!flag && x >= c1 && x < nbp) {
+    int my_st = 0, my_dead = 0, my_diag = STM_BIGROW;      // lane x keeps the results of panel column x
+    double my_tau = 0.0;
+    while (j < nbp) {
+        if (g >= m) { ncols_done = j; break; }
+        const int par = j & 1, np = par ^ 1, jn = j + 1;
+        const int gi = g - g1, k = k1 + j;
+        TC(40);
+        // ---- loads, all unconditional ----
+        double pq[8];
 #pragma unroll
-                    for (int q = 0; q < 8; q++) z += cs.G[b8 + r][b8 + q] * cs.Ms[q][x];
-                }
-                cs.ZB[r][x] = z;
-            }
+        for (int q = 0; q < 8; q++) pq[q] = cs.part[par][2 * q + half][tx];
+        const double gjx = cs.gj[par][tx], rowx = cs.rowA[par][tx];
+        const double cA0 = cs.colA[par][i0], cA1 = cs.colA[par][i1], alpha = cs.colA[par][gi];
+        const double mj0 = cs.mjv[par][i0], mj1 = cs.mjv[par][i1];
+        double bn0 = cs.colN[par][i0], bn1 = cs.colN[par][i1];
+        const double gji0 = cs.gj[par][i0], gji1 = cs.gj[par][i1], gjj = cs.gj[par][j];
+        const double grefj = cs.gref[j];
+        const int t = max(g + 1, __builtin_amdgcn_readlane(stairx, j));
+        double d = ((pq[0] + pq[1]) + (pq[2] + pq[3])) + ((pq[4] + pq[5]) + (pq[6] + pq[7]));
+        d = xor32_add(d);
+        TC(41);
+        const double dj = rdlane(d, j);
+        const double ssr = dj + gjj;
+        const bool unresolved = (ssr <= 0.0) && !(dj == 0.0 && gjj == 0.0);
+        const double ss = fmax(ssr, 0.0);
+        const double total = alpha * (alpha * sg) + ss;                      // (one factor sg, as ss and gref)
+        TC(42);
+        if (j != jref && nB > 0 && (unresolved || grefj > CA_K * total)) {
+            // ---- REFRESH: G has lost too much of column j: B <- B M, M <- I, G <- B'B from the real rows ----
+            cs.M[i0][tx] = m0; cs.M[i1][tx] = m1;
+            cs.At[i0][tx] = at0; cs.At[i1][tx] = at1;
             __syncthreads();
-            // new values first (into registers), then the stores: rows are updated in place from their own old entries
-            double nat[2], nmm[2], ngg[2];
-            const int nlt = nt - lt0;
-#pragma unroll
-            for (int u = 0; u < 2; u++) {
-                const int e = tid + CA_NT * u, li = e >> 5, x = e & 31;
-                const bool vx = x >= c0 && x < nbp;
-                double va = 0.0, vm = 0.0, vg = 0.0;
-                if (vx) {
-                    const int ia = min(lt0 + li, STM_NB - 1);
-                    va = (x < c1) ? 0.0 : cs.At[ia][x];
-                    vm = (x < c1) ? 0.0 : cs.M[li][x];
-#pragma unroll
-                    for (int q = 0; q < 8; q++) {
-                        const double mqx = cs.Ms[q][x];
-                        va += cs.At[ia][b8 + q] * mqx;
-                        vm += cs.M[li][b8 + q] * mqx;
-                    }
-                    if (!flag && x >= c1 && li >= c1 && li < nbp) {
-                        vg = cs.G[li][x];
-#pragma unroll
-                        for (int l = 0; l < 8; l++) vg += cs.Ms[l][li] * (cs.G[b8 + l][x] + cs.ZB[l][x]) + cs.G[li][b8 + l] * cs.Ms[l][x];
-                    }
-                }
-                nat[u] = va; nmm[u] = vm; ngg[u] = vg;
-            }
-            __syncthreads();
-#pragma unroll
-            for (int u = 0; u < 2; u++) {
-                const int e = tid + CA_NT * u, li = e >> 5, x = e & 31;
-                if (x >= c0 && x < nbp) {
-                    if (li < nlt) cs.At[lt0 + li][x] = nat[u];
-                    cs.M[li][x] = nmm[u];
-                    if (!flag && x >= c1 && li >= c1 && li < nbp) cs.G[li][x] = ngg[u];
-                }
-            }
-            __syncthreads();
-        }
-        c0 += nd;
-        if (flag == 2) { ncols_done = c0; break; }
-        if (flag == 1) {
-            // ---- REFRESH: G has lost too much of column c0: B <- B M, M <- I, G <- B'B from the real rows ----
-            // (no bottom rows: only the top block can have lost accuracy, and it is explicit -- the strips of the next
-            //  sub-block are formed from it afresh; nobody else holds rows, nothing to exchange)
-            if (nwf > 1 && nB > 0) {
+            if (nwf > 1) {
                 // one more exchange round: publish M, every slab workgroup applies it, forms its Gram matrix, arrives
                 ca_publish_block(cs.M, Gp + (long long)c.gp_slabs * (STM_NB * STM_NB));
                 if (tid == 0) { st_agent(&pd->sw, 0); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); st_agent(&num->prog, STM_PROG * p + 1 + round); }
@@ -501,23 +369,90 @@ __global__ __launch_bounds__(CA_NT) void k_panel_ca(DevCtx c, const int *__restr
                     cs.G[e >> 5][e & 31] = stm_ordered_sum<true>(Gp + e, STM_NB * STM_NB, nwact);
                 }
                 __syncthreads();
-            } else if (nr > 0) {
+            } else {
                 ca_apply(cs, S, nr);
                 ca_gram(cs, S, nr, sg);
             }
-            ca_set_identity(cs);
+            // back to registers: the fresh G, M = I; republish what the retried step reads (row j of G, column j of M)
+            gq0 = cs.G[i0][tx]; gq1 = cs.G[i1][tx];
+            m0 = (i0 == tx) ? 1.0 : 0.0; m1 = (i1 == tx) ? 1.0 : 0.0;
+            if (i0 == j) cs.gj[par][tx] = gq0;
+            if (i1 == j) cs.gj[par][tx] = gq1;
+            if (tx == j) { cs.mjv[par][i0] = m0; cs.mjv[par][i1] = m1; }
             if (tid < STM_NB) {
-                const int gi = g - g1;
                 double a2 = 0;
                 for (int i = gi; i < nt; i++) a2 += (cs.At[i][tid] * sg) * cs.At[i][tid];
                 cs.gref[tid] = cs.G[tid][tid] + a2;
             }
             __syncthreads();
-            jref = c0;
+            jref = j;
             if (tid == 0 && c.dbgbuf && (c.dbg & 16)) atomicAdd(&c.dbgbuf[14], 1ull);        // (diagnosis: refresh rounds)
-            TL(30 + (c0 & 15));
+            TL(30 + (j & 15));
+            continue;                                   // (the top block did not change: the partial dots of column j stand)
         }
+        // ---- dlarfg; ss == 0 (no row below the diagonal, or all of them zero) gives H = I.
+        //      sqrt / reciprocals by v_rsq_f64 / v_rcp_f64 + Newton steps (the library forms cost 700 cycles per column)
+        const bool ident = (ss == 0.0);
+        double bb, tau0, scal0, scals0;
+        stm_larfg_guarded(alpha, ss, sg, isg, bb, tau0, scal0, scals0);
+        const double beta = ident ? alpha : bb;
+        const bool dead = (k < ntol) && (fabs(beta) <= tol);                 // (:1495-1544) column zeroed, g does not advance
+        const bool upd = !ident && !dead;
+        const double scal = upd ? scal0 : 0.0, scals = upd ? scals0 : 0.0;   // 1 / (alpha - beta), and the same over sg
+        const double tau = upd ? tau0 : 0.0;
+        TC(43);
+        const bool on = upd && tx > j && tx < nbp;
+        const double cwx = on ? tau * (rowx + scals * (d + gjx)) : 0.0;       // tau v'a_x
+        const double ccx = cwx * scal;
+        const double cwn = rdlane(cwx, jn & 31);                             // (lane jn; 0 when jn == nbp: `on` is false there)
+        const double ccA = rdlane(ccx, 2 * wid), ccB = rdlane(ccx, 2 * wid + 1);          // cc[i0]: my row group is 2 wid + half
+        const double ccC = rdlane(ccx, (2 * wid + 16) & 31), ccD = rdlane(ccx, (2 * wid + 17) & 31);
+        const double ci0 = half ? ccB : ccA, ci1 = half ? ccD : ccC;
+        const double v0 = (i0 == gi) ? 1.0 : ((i0 > gi && i0 < nt) ? cA0 * scal : 0.0);
+        const double v1 = (i1 == gi) ? 1.0 : ((i1 > gi && i1 < nt) ? cA1 * scal : 0.0);
+        // ---- the updates of my entries (cwx = ccx = 0 unless this is a live reflector and my column is behind it) ----
+        at0 -= v0 * cwx; at1 -= v1 * cwx;
+        bn0 -= v0 * cwn; bn1 -= v1 * cwn;
+        m0 -= mj0 * ccx; m1 -= mj1 * ccx;
+        gq0 -= (i0 > j && tx >= i0) ? (ci0 * gjx + ccx * gji0 - ci0 * ccx * gjj) : 0.0;
+        gq1 -= (i1 > j && tx >= i1) ? (ci1 * gjx + ccx * gji1 - ci1 * ccx * gjj) : 0.0;
+        const bool isj = (tx == j);
+        // my column is the finished one: beta (0 if dead) on the diagonal, v below it (zeros if dead / H = I)
+        const double nd = dead ? 0.0 : beta;
+        at0 = isj ? ((i0 < gi) ? at0 : ((i0 == gi) ? nd : (upd ? v0 : 0.0))) : at0;
+        at1 = isj ? ((i1 < gi) ? at1 : ((i1 == gi) ? nd : (upd ? v1 : 0.0))) : at1;
+        m0 = isj ? (upd ? m0 * scal : 0.0) : m0;                              // b_j <- b_j scal; dead / identity: zero column
+        m1 = isj ? (upd ? m1 * scal : 0.0) : m1;
+        const int gin = dead ? gi : gi + 1;
+        cs.part[np][ig][tx] = ((i0 > gin) ? (at0 * sg) * bn0 : 0.0) + ((i1 > gin) ? (at1 * sg) * bn1 : 0.0);
+        if (tx == jn) { cs.colA[np][i0] = at0; cs.colA[np][i1] = at1; cs.mjv[np][i0] = m0; cs.mjv[np][i1] = m1; }
+        if (tx == jn + 1) { cs.colN[np][i0] = at0; cs.colN[np][i1] = at1; }
+        if (i0 == gin) cs.rowA[np][tx] = at0;
+        if (i1 == gin) cs.rowA[np][tx] = at1;
+        if (i0 == jn) cs.gj[np][tx] = gq0;
+        if (i1 == jn) cs.gj[np][tx] = gq1;
+        // ---- bookkeeping (registers) ----
+        my_st = isj ? (dead ? 0 : t) : my_st;
+        my_dead = isj ? (dead ? 1 : 0) : my_dead;
+        my_diag = isj ? (dead ? STM_BIGROW : g) : my_diag;
+        my_tau = isj ? tau : my_tau;
+        if (!dead) {
+            iflops += (long long)(t - g) * (3 + 4 * (long long)(n - k - 1));
+            ilen += (t - g);
+            tlast = t;
+            g++;
+        }
+        if (k == npiv - 1) rank = g;                      // (:1604-1608) also taken on a dead last pivot
+        TC(46);
+        __syncthreads();
+        TC(47);
+        j++;
+        if ((j & 7) == 0) TL(8 + (j >> 3));
     }
+    // the distributed images and the per-column results go back to LDS for the final application / stores
+    cs.M[i0][tx] = m0; cs.M[i1][tx] = m1;
+    cs.At[i0][tx] = at0; cs.At[i1][tx] = at1;
+    if (tid < STM_NB) { cs.st_out[tid] = my_st; cs.dead[tid] = my_dead; cs.diag[tid] = my_diag; cs.tau[tid] = my_tau; }
     const double flops = (double)iflops, lensum = (double)ilen;
     if (tid == 0 && c.dbgbuf && (c.dbg & 16)) { atomicAdd(&c.dbgbuf[13], 1ull); atomicAdd(&c.dbgbuf[15], (unsigned long long)nwact); }   // (panels, slabs)
     __syncthreads();

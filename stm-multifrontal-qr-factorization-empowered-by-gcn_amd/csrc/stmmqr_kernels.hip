@@ -2415,11 +2415,8 @@ __global__ __launch_bounds__(NT) void k_upd_c2(DevCtx c, const int *__restrict__
         s_pd2[tid] = (tid < G.nb2) ? pb->pdiag[tid] : STM_BIGROW;
     }
     const double *Fb = c.Farena + s.foff + G.g1;
-    const double *V1g = Fb + (long long)G.k1a * ld, *V2g = Fb + (long long)G.k1b * ld;
-    double *Cg = c.Farena + s.foff + G.g1 + (long long)c0 * ld;
-    const int lrow = tid & 63, lcg = tid >> 6;
-    UpdChunk2 ck;
-    upd2_chunk_load(ck, V1g, V2g, Cg, ld, sl * SLAB + lrow, G.mp, G.nb1, G.nb2, nc, lcg);
+    const double *__restrict__ V1g = Fb + (long long)G.k1a * ld, *__restrict__ V2g = Fb + (long long)G.k1b * ld;
+    double *__restrict__ Cg = c.Farena + s.foff + G.g1 + (long long)c0 * ld;
     {
         const double *W0 = Wp + wpoff[fi] + ((long long)cb * nslf) * (2 * STM_NB * BN);
         const double *Gr = Wp + wpoff[fi] + ((long long)ncbp * nslf) * (2 * STM_NB * BN) + STM_NB * BN;     // W2 part of the Gram block
@@ -2466,48 +2463,71 @@ __global__ __launch_bounds__(NT) void k_upd_c2(DevCtx c, const int *__restrict__
         for (int x = 0; x < 4; x++) Ws[(STM_NB + l) * WS + cg * 4 + x] = y2[x];
     }
     __syncthreads();
-    // the B operands of the application (Y = [Y1; Y2], the same for every chunk of the workgroup) stay in registers: the
-    // MFMA loop reads one LDS operand per two MFMAs instead of three
-    double y0[2 * STM_NB / 4], y1[2 * STM_NB / 4];
+    // Round 3: the application runs WITHOUT LDS and without barriers.  The product is formed transposed,
+    //     D(col, row) = C(row, col) - sum_k Y(k, col) V(row, k),
+    // so that (i) C is the accumulator operand the MFMA starts from -- lane (l15, l4) holds D(col l4 + 4 r, row l15): for a
+    // fixed r the 64 lanes touch 4 columns x 16 consecutive rows, i.e. four full 128-byte segments of the column-major front,
+    // loaded from and stored to global memory directly in that layout -- and (ii) V is the B operand B(k, row): 16 consecutive
+    // rows of 4 reflector columns per load, again whole segments, with the unit-diagonal / zero mask applied in registers.
+    // Y (negated) is the A operand and stays in registers for the whole workgroup.  A wave takes every fourth 16-row tile of
+    // the workgroup's rows; the loads of its next tile are in flight during the 32 MFMAs of the current one.
+    double yn0[2 * STM_NB / 4], yn1[2 * STM_NB / 4];
 #pragma unroll
     for (int kk = 0; kk < 2 * STM_NB / 4; kk++) {
-        y0[kk] = Ws[(4 * kk + l4) * WS + l15];
-        y1[kk] = Ws[(4 * kk + l4) * WS + 16 + l15];
+        yn0[kk] = -Ws[(4 * kk + l4) * WS + l15];
+        yn1[kk] = -Ws[(4 * kk + l4) * WS + 16 + l15];
     }
-    const int rend = min(G.mp, (sl + spw) * SLAB);
-    for (int r0 = sl * SLAB; r0 < rend; r0 += RB) {
-        const int i = r0 + lrow;
-        upd2_chunk_to_lds(ck, i, G.mp, G.mp1, G.mp2, G.nb1, G.nb2, nc, s_pd1, s_pd2, G.g1, lrow, lcg, Vs1, Vs2, Cs, false);
-        __syncthreads();
-        if (r0 + RB < rend) upd2_chunk_load(ck, V1g, V2g, Cg, ld, i + RB, G.mp, G.nb1, G.nb2, nc, lcg);
-        d4 u0 = {0, 0, 0, 0}, u1 = {0, 0, 0, 0};
+    int dv1[STM_NB / 4], dv2[STM_NB / 4];               // row (relative to g1) of the unit diagonal of reflector 4 kk + l4
 #pragma unroll
-        for (int kk = 0; kk < STM_NB / 4; kk++) {
-            const double a = Vs1[(4 * kk + l4) * VS + 16 * wid + l15];
-            u0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, y0[kk], u0, 0, 0, 0);
-            u1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, y1[kk], u1, 0, 0, 0);
-        }
-#pragma unroll
-        for (int kk = 0; kk < STM_NB / 4; kk++) {
-            const double a = Vs2[(4 * kk + l4) * VS + 16 * wid + l15];
-            u0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, y0[STM_NB / 4 + kk], u0, 0, 0, 0);
-            u1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, y1[STM_NB / 4 + kk], u1, 0, 0, 0);
-        }
+    for (int kk = 0; kk < STM_NB / 4; kk++) {
+        const int col = 4 * kk + l4;
+        dv1[kk] = (col < G.nb1) ? s_pd1[col] - G.g1 : STM_BIGROW;
+        dv2[kk] = (col < G.nb2) ? s_pd2[col] - G.g1 : STM_BIGROW;
+    }
+    const int rbeg = sl * SLAB, rend = min(G.mp, (sl + spw) * SLAB);
+    const int ntile = (rend - rbeg + 15) >> 4;
+    struct Tile { double c0[4], c1[4], v1[STM_NB / 4], v2[STM_NB / 4]; };
+    auto load_tile = [&](Tile &t, int tix) {
+        const int row = min(rbeg + 16 * tix + l15, G.mp - 1);                          // (clamped: masked afterwards)
 #pragma unroll
         for (int r = 0; r < 4; r++) {
-            const int row = 16 * wid + l4 + 4 * r;
-            Cs[l15 * VS + row] -= u0[r];
-            Cs[(16 + l15) * VS + row] -= u1[r];
+            t.c0[r] = Cg[row + (long long)min(l4 + 4 * r, nc - 1) * ld];
+            t.c1[r] = Cg[row + (long long)min(16 + l4 + 4 * r, nc - 1) * ld];
         }
-        __syncthreads();
+#pragma unroll
+        for (int kk = 0; kk < STM_NB / 4; kk++) {
+            t.v1[kk] = V1g[row + (long long)min(4 * kk + l4, G.nb1 - 1) * ld];
+            t.v2[kk] = V2g[row + (long long)min(4 * kk + l4, max(G.nb2, 1) - 1) * ld];
+        }
+    };
+    Tile cur, nxt;
+    if (wid < ntile) load_tile(cur, wid);
+    for (int tix = wid; tix < ntile; tix += NW) {
+        if (tix + NW < ntile) load_tile(nxt, tix + NW);
+        const int i = rbeg + 16 * tix + l15;                                           // my row (relative to g1)
+        d4 a0 = {cur.c0[0], cur.c0[1], cur.c0[2], cur.c0[3]}, a1 = {cur.c1[0], cur.c1[1], cur.c1[2], cur.c1[3]};
+#pragma unroll
+        for (int kk = 0; kk < STM_NB / 4; kk++) {
+            const int d = dv1[kk];
+            const double b = (i < G.mp1 && i >= d) ? ((i == d) ? 1.0 : cur.v1[kk]) : 0.0;
+            a0 = __builtin_amdgcn_mfma_f64_16x16x4f64(yn0[kk], b, a0, 0, 0, 0);
+            a1 = __builtin_amdgcn_mfma_f64_16x16x4f64(yn1[kk], b, a1, 0, 0, 0);
+        }
+#pragma unroll
+        for (int kk = 0; kk < STM_NB / 4; kk++) {
+            const int d = dv2[kk];
+            const double b = (i < G.mp2 && i >= d) ? ((i == d) ? 1.0 : cur.v2[kk]) : 0.0;
+            a0 = __builtin_amdgcn_mfma_f64_16x16x4f64(yn0[STM_NB / 4 + kk], b, a0, 0, 0, 0);
+            a1 = __builtin_amdgcn_mfma_f64_16x16x4f64(yn1[STM_NB / 4 + kk], b, a1, 0, 0, 0);
+        }
         if (i < G.mp) {
 #pragma unroll
-            for (int q = 0; q < 8; q++) {
-                const int col = lcg * 8 + q;
-                if (col < nc) Cg[i + col * ld] = Cs[col * VS + lrow];
+            for (int r = 0; r < 4; r++) {
+                if (l4 + 4 * r < nc) Cg[i + (long long)(l4 + 4 * r) * ld] = a0[r];
+                if (16 + l4 + 4 * r < nc) Cg[i + (long long)(16 + l4 + 4 * r) * ld] = a1[r];
             }
         }
-        __syncthreads();
+        cur = nxt;
     }
 }
 
