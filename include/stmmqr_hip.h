@@ -195,6 +195,48 @@ int stmmqr_plan_export_front(stmmqr_plan *plan, stm_long f, double *C, stm_long 
 int stmmqr_plan_import_front(stmmqr_plan *plan, stm_long f, stm_long fm, stm_long rank, stm_long cm, const double *C,
                              const stm_long *rows, int c_on_device);
 
+/* A front SHARED between plans (one plan per device): the reference moves whole contribution blocks between
+ * its stacks (SparseQR_factorize.c:1228) and leaves a big front to one thread team; here the trailing matrix of one front is
+ * spread over the devices of a group by 32-column blocks.  Every plan of the group marks the front
+ *     group[f] = phase | STMMQR_GROUP_SHARED            (alone in its group, one of the large fronts, no pair update)
+ * assembles it, and then walks the group's timeline -- one step per 32-column panel -- with stmmqr_factorize_step:
+ *     PREP (step 0)                       set up + assemble (every plan: each holds the whole front)
+ *     PANEL (step q)                      only the plan that owns panel q (q % nparts == part), then
+ *         stmmqr_plan_export_panel        -> the others  stmmqr_plan_import_panel   (columns, T, Tau/Stair/Rdead, progress)
+ *     UPDATE|GRAM (step q)                every plan, on its own column blocks: block b of step q holds the columns of panel
+ *                                         q + 1 + b, so plan `part` takes cb_first = (part - q - 1) mod nparts, stride nparts
+ *                                         (GRAM: build T of the step's panel; once per step and plan, before or with the first
+ *                                         UPDATE; cb_count limits the launch, e.g. to block 0 before the next PANEL)
+ *     POST (last step)                    pack the contribution block (complete in the owned columns only:
+ *                                         stmmqr_plan_export_front_cols / _import_front_cols gather it on one plan)
+ * The arithmetic of a column block does not depend on the plan that runs it: same bits as the unshared front with
+ * options.pair_update = 0.  After stmmqr_factorize_finish every plan's packed R+H block of the front is valid in the columns
+ * of its own panels (stmmqr_plan_front_rhoff gives the column offsets for the merge). */
+#define STMMQR_GROUP_SHARED  (1 << 30)
+#define STMMQR_STEP_PREP     1
+#define STMMQR_STEP_PANEL    2
+#define STMMQR_STEP_UPDATE   4
+#define STMMQR_STEP_GRAM     8
+#define STMMQR_STEP_POST     16
+/* steps of a group's timeline (a shared front: its number of panels); -1 = no such group */
+int stmmqr_plan_group_steps(stmmqr_plan *plan, int group);
+int stmmqr_factorize_step(stmmqr_plan *plan, int group, int step, int what, int cb_first, int cb_stride, int cb_count);
+/* one panel message: ndoubles is the same for every panel of the front; buf may be a device pointer (on_device != 0).
+ * export returns when the buffer is complete; import is ordered on the plan's stream. */
+int stmmqr_plan_panel_doubles(stmmqr_plan *plan, stm_long f, stm_long *ndoubles);
+int stmmqr_plan_export_panel(stmmqr_plan *plan, stm_long f, stm_long p, double *buf, int on_device);
+int stmmqr_plan_import_panel(stmmqr_plan *plan, stm_long f, stm_long p, const double *buf, int on_device);
+/* the columns of the packed contribution block that belong to the panels of `part` (buf == NULL: count only) */
+int stmmqr_plan_export_front_cols(stmmqr_plan *plan, stm_long f, int part, int nparts, double *buf, int on_device,
+                                  stm_long *ndoubles);
+int stmmqr_plan_import_front_cols(stmmqr_plan *plan, stm_long f, int part, int nparts, const double *buf, int on_device);
+/* off[0..fn]: start of each column of front f inside its packed R+H block (after stmmqr_factorize_finish) */
+int stmmqr_plan_front_rhoff(stmmqr_plan *plan, stm_long f, stm_long *off);
+
+/* out[0..1] = the reference's flop count of front f (FLOP_COUNT, SparseQR_factorize.c:1571) and the part of it done by
+ * trailing updates: every plan of a shared front counts the whole front, the merge keeps one */
+int stmmqr_plan_front_flops(stmmqr_plan *plan, stm_long f, double *out);
+
 /* sizes needed by the caller to allocate the outputs of stmmqr_plan_download */
 int stmmqr_plan_result_sizes(const stmmqr_plan *plan, stm_long *rh_total, stm_long *rank);
 

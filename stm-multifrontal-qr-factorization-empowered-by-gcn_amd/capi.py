@@ -27,6 +27,31 @@ if not lib_path.exists():
     raise ImportError(
         f"{lib_path} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
         "(hipcc --offload-arch=gfx950).  There is no CPU fallback for this path.")
+
+
+def _preload_torch_hip_runtime():
+    """One HIP runtime per process.  PyTorch-ROCm ships its own libamdhip64 / libhsa-runtime64 (torch/lib, rpath $ORIGIN).  A
+    process that loads /opt/rocm's runtime through this library FIRST and imports torch afterwards ends up with two runtimes:
+    torch then reports "No HIP GPUs are available", and device pointers could not be handed from one to the other
+    (sharded.py sends contribution blocks and panels from torch tensors).  So the runtime torch will use is loaded first, by
+    path and without importing torch; the library's NEEDED libamdhip64.so.7 then binds to it (same soname).  Processes that
+    never see torch (the C drivers, the relinked reference) use /opt/rocm's.  STMMQR_SYSTEM_HIP=1 skips this."""
+    import importlib.util
+    import os
+    if os.environ.get("STMMQR_SYSTEM_HIP") == "1":
+        return
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec is None or not spec.origin:
+        return
+    rt = Path(spec.origin).parent / "lib" / "libamdhip64.so"
+    if rt.exists():
+        C.CDLL(str(rt), mode=C.RTLD_GLOBAL)
+
+
+_preload_torch_hip_runtime()
 lib = C.CDLL(str(lib_path))
 
 
@@ -105,6 +130,15 @@ lib.stmmqr_plan_front_info.argtypes = [C.c_void_p, C.c_long, c_long_p]
 lib.stmmqr_plan_export_front.argtypes = [C.c_void_p, C.c_long, C.c_void_p, c_long_p, C.c_int]
 lib.stmmqr_plan_import_front.argtypes = [C.c_void_p, C.c_long, C.c_long, C.c_long, C.c_long, C.c_void_p, c_long_p, C.c_int]
 lib.stmmqr_plan_qmult.argtypes = [C.c_void_p, C.c_int, c_double_p, C.c_long, C.c_long]
+lib.stmmqr_plan_group_steps.argtypes = [C.c_void_p, C.c_int]
+lib.stmmqr_factorize_step.argtypes = [C.c_void_p] + [C.c_int] * 6
+lib.stmmqr_plan_panel_doubles.argtypes = [C.c_void_p, C.c_long, c_long_p]
+lib.stmmqr_plan_export_panel.argtypes = [C.c_void_p, C.c_long, C.c_long, C.c_void_p, C.c_int]
+lib.stmmqr_plan_import_panel.argtypes = [C.c_void_p, C.c_long, C.c_long, C.c_void_p, C.c_int]
+lib.stmmqr_plan_export_front_cols.argtypes = [C.c_void_p, C.c_long, C.c_int, C.c_int, C.c_void_p, C.c_int, c_long_p]
+lib.stmmqr_plan_import_front_cols.argtypes = [C.c_void_p, C.c_long, C.c_int, C.c_int, C.c_void_p, C.c_int]
+lib.stmmqr_plan_front_rhoff.argtypes = [C.c_void_p, C.c_long, c_long_p]
+lib.stmmqr_plan_front_flops.argtypes = [C.c_void_p, C.c_long, c_double_p]
 lib.stmmqr_plan_solve.argtypes = [C.c_void_p, c_double_p, C.c_long, c_double_p, C.c_long, C.c_long]
 lib.stmmqr_get_options.argtypes = [C.POINTER(Options)]
 lib.stmmqr_set_options.argtypes = [C.POINTER(Options)]
@@ -281,6 +315,80 @@ class HipQR:
         Cb = np.ascontiguousarray(Cb, np.float64); rows = np.ascontiguousarray(rows, I64)
         _check(lib.stmmqr_plan_import_front(self._h, int(f), int(fm), int(rank), int(cm), Cb.ctypes.data_as(C.c_void_p),
                                             _ip(rows), 0), "stmmqr_plan_import_front")
+
+    # ---- a front shared between plans (include/stmmqr_hip.h, "A front SHARED between plans") ----
+    SHARED = 1 << 30
+    PREP, PANEL, UPDATE, GRAM, POST = 1, 2, 4, 8, 16
+
+    def group_steps(self, g) -> int:
+        n = lib.stmmqr_plan_group_steps(self._h, int(g))
+        if n < 0:
+            raise StmmqrError(f"stmmqr_plan_group_steps failed: {last_error()}")
+        return int(n)
+
+    def run_step(self, g, step, what, cb_first=0, cb_stride=1, cb_count=-1):
+        _check(lib.stmmqr_factorize_step(self._h, int(g), int(step), int(what), int(cb_first), int(cb_stride), int(cb_count)),
+               "stmmqr_factorize_step")
+
+    def panel_doubles(self, f) -> int:
+        n = np.zeros(1, I64)
+        _check(lib.stmmqr_plan_panel_doubles(self._h, int(f), _ip(n)), "stmmqr_plan_panel_doubles")
+        return int(n[0])
+
+    def export_panel(self, f, p):
+        buf = np.zeros(self.panel_doubles(f))
+        _check(lib.stmmqr_plan_export_panel(self._h, int(f), int(p), buf.ctypes.data_as(C.c_void_p), 0), "stmmqr_plan_export_panel")
+        return buf
+
+    def export_panel_dev(self, f, p, dev_ptr: int):
+        _check(lib.stmmqr_plan_export_panel(self._h, int(f), int(p), C.c_void_p(dev_ptr), 1), "stmmqr_plan_export_panel")
+
+    def import_panel(self, f, p, buf):
+        buf = np.ascontiguousarray(buf, np.float64)
+        assert buf.size >= self.panel_doubles(f)
+        _check(lib.stmmqr_plan_import_panel(self._h, int(f), int(p), buf.ctypes.data_as(C.c_void_p), 0), "stmmqr_plan_import_panel")
+
+    def import_panel_dev(self, f, p, dev_ptr: int):
+        _check(lib.stmmqr_plan_import_panel(self._h, int(f), int(p), C.c_void_p(dev_ptr), 1), "stmmqr_plan_import_panel")
+
+    def front_cols_doubles(self, f, part, nparts) -> int:
+        n = np.zeros(1, I64)
+        _check(lib.stmmqr_plan_export_front_cols(self._h, int(f), int(part), int(nparts), None, 0, _ip(n)), "stmmqr_plan_export_front_cols")
+        return int(n[0])
+
+    def export_front_cols(self, f, part, nparts):
+        buf = np.zeros(max(self.front_cols_doubles(f, part, nparts), 1))
+        n = np.zeros(1, I64)
+        _check(lib.stmmqr_plan_export_front_cols(self._h, int(f), int(part), int(nparts), buf.ctypes.data_as(C.c_void_p), 0, _ip(n)),
+               "stmmqr_plan_export_front_cols")
+        return buf[:int(n[0])]
+
+    def export_front_cols_dev(self, f, part, nparts, dev_ptr: int) -> int:
+        n = np.zeros(1, I64)
+        _check(lib.stmmqr_plan_export_front_cols(self._h, int(f), int(part), int(nparts), C.c_void_p(dev_ptr), 1, _ip(n)),
+               "stmmqr_plan_export_front_cols")
+        return int(n[0])
+
+    def import_front_cols(self, f, part, nparts, buf):
+        buf = np.ascontiguousarray(buf, np.float64)
+        if buf.size:
+            _check(lib.stmmqr_plan_import_front_cols(self._h, int(f), int(part), int(nparts), buf.ctypes.data_as(C.c_void_p), 0),
+                   "stmmqr_plan_import_front_cols")
+
+    def import_front_cols_dev(self, f, part, nparts, dev_ptr: int):
+        _check(lib.stmmqr_plan_import_front_cols(self._h, int(f), int(part), int(nparts), C.c_void_p(dev_ptr), 1),
+               "stmmqr_plan_import_front_cols")
+
+    def front_rhoff(self, f, fn):
+        off = np.zeros(int(fn) + 1, I64)
+        _check(lib.stmmqr_plan_front_rhoff(self._h, int(f), _ip(off)), "stmmqr_plan_front_rhoff")
+        return off
+
+    def front_flops(self, f):
+        """-> (reference flop count of front f, the part done by trailing updates) of the factorization in progress / held"""
+        v = np.zeros(2)
+        _check(lib.stmmqr_plan_front_flops(self._h, int(f), _dp(v)), "stmmqr_plan_front_flops")
+        return float(v[0]), float(v[1])
 
     def qmult(self, method: int, X: np.ndarray) -> np.ndarray:
         """QR_qmult (SparseQR.h:403-409) on the resident factors: method 0 = QR_QTX (Q'X), 1 = QR_QX (Q X) with X m or

@@ -146,6 +146,9 @@ struct stmmqr_plan {
     std::vector<long long> wlists;             // host copy of d_wlists
     std::vector<char> pair_front;              // per front: takes the pair update (plan time)
     std::vector<int> group;                    // per front: phase on this device, -1 = elsewhere
+    std::vector<int> h_tslot;                  // host copy of d_tslot
+    std::vector<char> shared;                  // per front: STMMQR_GROUP_SHARED -- alone in its group, driven step by step
+                                               //  (stmmqr_factorize_step), its trailing column blocks shared with other plans
     int own_off = 0, n_own = 0;
     std::vector<int> lists;              // host copy of d_lists
     int post_off = 0, rh_parts_off = 0, rh_maxparts = 1;
@@ -225,6 +228,7 @@ struct stmmqr_plan {
         c.dbg = getenv("STMMQR_DBG") ? atoi(getenv("STMMQR_DBG")) : 0;
         if (serial_panels) c.dbg = (c.dbg & ~(2048 | 4096)) | 256;   // the one-workgroup LDS / in-place panel for every panel
         c.tall_min = tall_min;
+        c.cbskip = 0;
         c.dbgbuf = d_dbg.p;
         c.abort = d_abort.p;
         return c;
@@ -339,6 +343,7 @@ void build_schedule(stmmqr_plan &P, std::vector<int> &tslot)
     const long pair_min = getenv("STMMQR_PAIR_MIN") ? atol(getenv("STMMQR_PAIR_MIN")) : STM_PAIR_MIN_ROWS;
     auto is_pair = [&](int f) {
         const FrontSym &s = P.fs[f];
+        if ((size_t)f < P.shared.size() && P.shared[f]) return false;   // (the pair update has no column-block stride)
         return g_opt.pair_update && is_big(f) && s.fm_est >= pair_min && s.npanels >= 4;
     };
     P.pair_front.assign(std::max(1L, nf), 0);
@@ -619,6 +624,7 @@ void build_schedule(stmmqr_plan &P, std::vector<int> &tslot)
     for (long kf = 0; kf < nf; kf++) P.lists.push_back((int)P.Post[kf]);
     if (P.lists.empty()) P.lists.push_back(0);
     if (P.wlists.empty()) P.wlists.push_back(0);
+    P.h_tslot = tslot;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -865,10 +871,15 @@ int reset_group(stmmqr_plan &P, int grp)
     return 0;
 }
 
-int run_schedule(stmmqr_plan &P, bool detail, int grp)
+// One piece of one timeline step (stmmqr_factorize_step): what = STMMQR_STEP_* bits; the update takes the column blocks
+// cb_first, cb_first + cb_stride, ... (at most cb_count of them when cb_count >= 0) of the step's fronts.
+struct StepReq { int step, what, cb_first, cb_stride, cb_count; };
+
+int run_schedule(stmmqr_plan &P, bool detail, int grp, const StepReq *req = nullptr)
 {
     hipStream_t st = P.stream;
-    const DevCtx c = P.ctx();
+    DevCtx c = P.ctx();
+    if (req) c.cbskip = std::max(1, req->cb_stride) - 1;
     const int *L0 = P.d_lists.p;
     long nlaunch = 0;
     // detail timing: bracket each category with an event pair from the pool; no host synchronisation here
@@ -948,7 +959,7 @@ int run_schedule(stmmqr_plan &P, bool detail, int grp)
         const long long *wl = P.d_wlists.p + S.wp_off;
         return timed(t_upd, [&]() -> int {
             if (S.n_norm > 0 && (ncb > 0 || (gram && split))) {
-                if (split && g_opt.fused_update && S.maxsl <= 256 && !P.serial_panels) {
+                if (split && g_opt.fused_update && S.maxsl <= 256 && !P.serial_panels && c.cbskip == 0) {
                     // one launch: C is read and written once (k_upd_f); the epoch of its hand-offs is the step number of the group
                     const int epoch = (int)(&S - SV.data()) + 1 + grp * (1 << 20);
                     LCHK(stm_launch_update_fused(c, act, pl, S.n_norm, cb0, ncb, S.maxsl, Wp, wl, wcnt,
@@ -988,6 +999,25 @@ int run_schedule(stmmqr_plan &P, bool detail, int grp)
             return 0;
         });
     };
+    if (req) {
+        if (req->step < 0 || req->step >= (int)SV.size()) return fail(STMMQR_ERR_INVALID, "no such step in the group");
+        const Step &S = SV[(size_t)req->step];
+        cur_step = req->step;
+        int e = 0;
+        if (req->what & STMMQR_STEP_PREP) e = prep(S, st);
+        if (!e && (req->what & STMMQR_STEP_PANEL) && S.n_act > 0) e = panels(S);
+        if (!e && (req->what & (STMMQR_STEP_UPDATE | STMMQR_STEP_GRAM)) && S.n_act > 0) {
+            if (S.n_pe + S.n_po > 0) return fail(STMMQR_ERR_INVALID, "pair-update fronts cannot be stepped (mark the front STMMQR_GROUP_SHARED)");
+            int nmine = 0;
+            if ((req->what & STMMQR_STEP_UPDATE) && req->cb_first >= 0 && req->cb_first < S.maxcb)
+                nmine = (S.maxcb - req->cb_first + c.cbskip) / (1 + c.cbskip);
+            if (req->cb_count >= 0) nmine = std::min(nmine, req->cb_count);
+            e = update(S, std::max(0, req->cb_first), nmine, (req->what & STMMQR_STEP_GRAM) != 0, P.d_Wp.p, st);
+        }
+        if (!e && (req->what & STMMQR_STEP_POST)) e = post(S, st);
+        P.stats.nlaunch += nlaunch;
+        return e;
+    }
     bool la = g_opt.lookahead && !detail && !P.serial_panels && SV.size() > 1;
     if (la && !P.side) P.side = side_stream_for(P.device);
     la = la && P.side;
@@ -1443,13 +1473,36 @@ int stmmqr_plan_set_groups(stmmqr_plan *plan, const int *group)
     stmmqr_plan &P = *plan;
     HIPCHK(hipSetDevice(P.device));
     // validate BEFORE anything of the plan changes: a refused call leaves groups and schedule as they were
+    auto gid = [&](long f) { return group[f] < 0 ? -1 : (group[f] & ~STMMQR_GROUP_SHARED); };
     for (long f = 0; f < P.nf; f++)
         for (long q = P.Childp[f]; q < P.Childp[f + 1]; q++)
-            if (group[f] >= 0 && group[P.Child[q]] > group[f])
+            if (gid(f) >= 0 && gid(P.Child[q]) > gid(f))
                 return fail(STMMQR_ERR_INVALID, "a child is scheduled in a later phase than its parent");
+    {
+        // a shared front is alone in its group and takes the panel-by-panel path
+        std::vector<int> cnt, nsh;
+        for (long f = 0; f < P.nf; f++) {
+            const int g = gid(f);
+            if (g < 0) continue;
+            if (g >= (1 << 24)) return fail(STMMQR_ERR_INVALID, "group id out of range");
+            if ((size_t)g >= cnt.size()) { cnt.resize((size_t)g + 1, 0); nsh.resize((size_t)g + 1, 0); }
+            cnt[(size_t)g]++;
+            if (group[f] & STMMQR_GROUP_SHARED) {
+                nsh[(size_t)g]++;
+                if (!(P.fs[f].fn >= g_opt.big_front_cols && P.fs[f].fm_ub >= 64))
+                    return fail(STMMQR_ERR_INVALID, "a shared front must be one of the large fronts (options.big_front_cols)");
+            }
+        }
+        for (size_t g = 0; g < cnt.size(); g++)
+            if (nsh[g] > 0 && cnt[g] != 1) return fail(STMMQR_ERR_INVALID, "a shared front must be alone in its group");
+    }
     if (P.begun) return fail(STMMQR_ERR_INVALID, "stmmqr_plan_set_groups between factorize_begin and factorize_finish");
     HIPCHK(hipStreamSynchronize(P.stream));
-    for (long f = 0; f < P.nf; f++) P.group[f] = group[f];
+    P.shared.assign((size_t)std::max(1L, P.nf), 0);
+    for (long f = 0; f < P.nf; f++) {
+        P.group[f] = gid(f);
+        P.shared[(size_t)f] = (group[f] >= 0 && (group[f] & STMMQR_GROUP_SHARED)) ? 1 : 0;
+    }
     // a captured schedule describes the old step lists and workspaces
     if (P.graph_exec) { (void)hipGraphExecDestroy(P.graph_exec); P.graph_exec = nullptr; }
     P.graph_nlaunch = 0;
@@ -1533,6 +1586,163 @@ int stmmqr_plan_import_front(stmmqr_plan *plan, stm_long f, stm_long fm, stm_lon
         for (long i = 0; i < cm; i++) r32[i] = (int)rows[i];
         HIPCHK(hipMemcpy(P.d_Hii.p + P.fs[f].hip + rank, r32.data(), (size_t)cm * sizeof(int), hipMemcpyHostToDevice));
     }
+    return 0;
+}
+
+// ---- a front shared between plans (one per device): every plan holds the whole front, panel q is factorized by the plan
+// with q % nparts == part and travels to the others, every plan updates the 32-column blocks of the panels it owns.
+// The arithmetic of a column block does not depend on who runs it: the bits are those of the unshared front (without the
+// pair update).  Unit of exchange in the reference: the contribution block, SparseQR_factorize.c:1228; here, inside one
+// front, the factorized panel. ----
+int stmmqr_plan_group_steps(stmmqr_plan *plan, int group)
+{
+    if (!plan || group < 0 || group >= (int)plan->gsteps.size()) { fail(STMMQR_ERR_INVALID, "no such front group"); return -1; }
+    return (int)plan->gsteps[(size_t)group].size();
+}
+
+int stmmqr_factorize_step(stmmqr_plan *plan, int group, int step, int what, int cb_first, int cb_stride, int cb_count)
+{
+    if (!plan || !plan->begun) return fail(STMMQR_ERR_INVALID, "stmmqr_factorize_begin was not called");
+    stmmqr_plan &P = *plan;
+    HIPCHK(hipSetDevice(P.device));
+    if (cb_stride < 1) return fail(STMMQR_ERR_INVALID, "column-block stride < 1");
+    StepReq rq = {step, what, cb_first, cb_stride, cb_count};
+    P.first_group = false;
+    return run_schedule(P, false, group, &rq);
+}
+
+namespace {
+struct PanelMsg { long long f_off, t_off, tau_off, stair_off, dead_off, num_off, total; long nb; };
+// layout of one panel message (doubles): the panel's columns of F (whole leading dimension), T of the panel's slot, then
+// the front's Tau / Stair / Rdead ranges and its FrontNum -- small next to the columns, and sending the whole ranges keeps
+// every plan's copy of them identical without tracking which entries a panel touched
+PanelMsg panel_msg(const FrontSym &s, long p)
+{
+    PanelMsg m;
+    const long k1 = p * STM_NB;
+    m.nb = std::max(0L, std::min((long)STM_NB, (long)s.fn - k1));
+    m.f_off = 0;
+    m.t_off = m.f_off + (long long)s.ld * STM_NB;
+    m.tau_off = m.t_off + STM_NB * STM_NB;
+    m.stair_off = m.tau_off + s.fn;
+    m.dead_off = m.stair_off + (s.fn + 1) / 2;
+    m.num_off = m.dead_off + (s.fp + 7) / 8;
+    m.total = m.num_off + (long long)((sizeof(FrontNum) + 7) / 8);
+    return m;
+}
+}  // namespace
+
+int stmmqr_plan_panel_doubles(stmmqr_plan *plan, stm_long f, stm_long *ndoubles)
+{
+    if (!plan || f < 0 || f >= plan->nf || !ndoubles) return fail(STMMQR_ERR_INVALID, "bad front");
+    *ndoubles = (stm_long)panel_msg(plan->fs[f], 0).total;
+    return 0;
+}
+
+static int panel_copy(stmmqr_plan &P, stm_long f, stm_long p, double *buf, int on_device, bool out)
+{
+    if (f < 0 || f >= P.nf || !buf) return fail(STMMQR_ERR_INVALID, "bad front / buffer");
+    const FrontSym &s = P.fs[f];
+    if (p < 0 || p >= s.npanels) return fail(STMMQR_ERR_INVALID, "no such panel");
+    if (P.group[f] < 0) return fail(STMMQR_ERR_INVALID, "the front is not factorized by this plan");
+    HIPCHK(hipSetDevice(P.device));
+    const PanelMsg m = panel_msg(s, p);
+    const hipMemcpyKind kind = on_device ? hipMemcpyDeviceToDevice : (out ? hipMemcpyDeviceToHost : hipMemcpyHostToDevice);
+    hipStream_t st = P.stream;
+    auto cp = [&](void *dev, long long off, size_t bytes) -> int {
+        if (!bytes) return 0;
+        if (out) HIPCHK(hipMemcpyAsync(buf + off, dev, bytes, kind, st));
+        else HIPCHK(hipMemcpyAsync(dev, buf + off, bytes, kind, st));
+        return 0;
+    };
+    LCHK(cp(P.d_F.p + s.foff + (long long)p * STM_NB * s.ld, m.f_off, (size_t)s.ld * (size_t)m.nb * sizeof(double)));
+    LCHK(cp(P.d_T.p + (long long)(2 * P.h_tslot[(size_t)f] + (int)(p & 1)) * STM_NB * STM_NB, m.t_off, sizeof(double) * STM_NB * STM_NB));
+    LCHK(cp(P.d_Tau.p + s.rp, m.tau_off, (size_t)s.fn * sizeof(double)));
+    LCHK(cp(P.d_Stair.p + s.rp, m.stair_off, (size_t)s.fn * sizeof(int)));
+    LCHK(cp(P.d_Rdead.p + s.col1, m.dead_off, (size_t)s.fp));
+    LCHK(cp(P.d_fnum.p + f, m.num_off, sizeof(FrontNum)));
+    if (out || !on_device) HIPCHK(hipStreamSynchronize(st));   // the caller sends the buffer / reuses its host memory
+    return 0;
+}
+
+int stmmqr_plan_export_panel(stmmqr_plan *plan, stm_long f, stm_long p, double *buf, int on_device)
+{
+    if (!plan) return fail(STMMQR_ERR_INVALID, "null plan");
+    return panel_copy(*plan, f, p, buf, on_device, true);
+}
+
+int stmmqr_plan_import_panel(stmmqr_plan *plan, stm_long f, stm_long p, const double *buf, int on_device)
+{
+    if (!plan) return fail(STMMQR_ERR_INVALID, "null plan");
+    return panel_copy(*plan, f, p, const_cast<double *>(buf), on_device, false);
+}
+
+// The packed contribution block of a shared front is complete only in the columns of the panels a plan owns: the runs of
+// owned columns are contiguous in the packed block (column j of C = column fp + j of the front, SparseQR_factorize.c:1228).
+static int front_cols_copy(stmmqr_plan &P, stm_long f, int part, int nparts, double *buf, int on_device, stm_long *ndoubles, bool out)
+{
+    if (f < 0 || f >= P.nf || nparts < 1 || part < 0 || part >= nparts) return fail(STMMQR_ERR_INVALID, "bad front / part");
+    HIPCHK(hipSetDevice(P.device));
+    HIPCHK(hipStreamSynchronize(P.stream));
+    FrontNum nm;
+    HIPCHK(hipMemcpy(&nm, P.d_fnum.p + f, sizeof nm, hipMemcpyDeviceToHost));
+    const FrontSym &s = P.fs[f];
+    const long cn = s.fn - s.fp, cm = nm.cm;
+    auto coff = [&](long j) -> long long { return j < cm ? (long long)j * (j + 1) / 2 : (long long)cm * (cm + 1) / 2 + (long long)(j - cm) * cm; };
+    const hipMemcpyKind kind = on_device ? hipMemcpyDeviceToDevice : (out ? hipMemcpyDeviceToHost : hipMemcpyHostToDevice);
+    long long pos = 0;
+    for (long q = s.fp / STM_NB; q * STM_NB < s.fn; q++) {
+        if (q % nparts != part) continue;
+        const long j0 = std::max(0L, q * STM_NB - (long)s.fp), j1 = std::min(cn, (q + 1) * STM_NB - (long)s.fp);
+        if (j1 <= j0 || cm <= 0) continue;
+        const long long a = coff(j0), b = coff(j1);
+        if (buf && b > a) {
+            if (out) HIPCHK(hipMemcpyAsync(buf + pos, P.d_C.p + s.coff + a, (size_t)(b - a) * sizeof(double), kind, P.stream));
+            else HIPCHK(hipMemcpyAsync(P.d_C.p + s.coff + a, buf + pos, (size_t)(b - a) * sizeof(double), kind, P.stream));
+        }
+        pos += b - a;
+    }
+    HIPCHK(hipStreamSynchronize(P.stream));
+    if (ndoubles) *ndoubles = (stm_long)pos;
+    return 0;
+}
+
+int stmmqr_plan_export_front_cols(stmmqr_plan *plan, stm_long f, int part, int nparts, double *buf, int on_device, stm_long *ndoubles)
+{
+    if (!plan) return fail(STMMQR_ERR_INVALID, "null plan");
+    return front_cols_copy(*plan, f, part, nparts, buf, on_device, ndoubles, true);
+}
+
+int stmmqr_plan_import_front_cols(stmmqr_plan *plan, stm_long f, int part, int nparts, const double *buf, int on_device)
+{
+    if (!plan || !buf) return fail(STMMQR_ERR_INVALID, "null plan / buffer");
+    return front_cols_copy(*plan, f, part, nparts, const_cast<double *>(buf), on_device, nullptr, false);
+}
+
+/* off[0..fn]: where each column of front f starts inside its packed R+H block (off[fn] = the block's size) */
+int stmmqr_plan_front_rhoff(stmmqr_plan *plan, stm_long f, stm_long *off)
+{
+    if (!plan || !plan->factored || f < 0 || f >= plan->nf || !off) return fail(STMMQR_ERR_INVALID, "bad front / no factorization held");
+    stmmqr_plan &P = *plan;
+    HIPCHK(hipSetDevice(P.device));
+    const FrontSym &s = P.fs[f];
+    std::vector<long long> h((size_t)std::max(1, s.fn));
+    if (s.fn > 0) HIPCHK(hipMemcpy(h.data(), P.d_Rhoff.p + s.rp, (size_t)s.fn * sizeof(long long), hipMemcpyDeviceToHost));
+    for (int k = 0; k < s.fn; k++) off[k] = (stm_long)h[(size_t)k];
+    off[s.fn] = (stm_long)P.h_fnum[(size_t)f].rsize;
+    return 0;
+}
+
+/* out[0..1] = flops, flops of the trailing updates of front f (read from the device: valid once its panels are done) */
+int stmmqr_plan_front_flops(stmmqr_plan *plan, stm_long f, double *out)
+{
+    if (!plan || f < 0 || f >= plan->nf || !out) return fail(STMMQR_ERR_INVALID, "bad front");
+    stmmqr_plan &P = *plan;
+    HIPCHK(hipSetDevice(P.device));
+    HIPCHK(hipStreamSynchronize(P.stream));
+    FrontNum nm;
+    HIPCHK(hipMemcpy(&nm, P.d_fnum.p + f, sizeof nm, hipMemcpyDeviceToHost));
+    out[0] = nm.flops; out[1] = nm.flops_upd;
     return 0;
 }
 

@@ -1747,13 +1747,14 @@ __global__ __launch_bounds__(NT) void k_update(DevCtx c, const int *__restrict__
     const FrontSym s = c.fs[f];
     if (p >= s.npanels) return;
     const PanelDesc *pd = &c.fnum[f].pd[p & 1];
-    const int c0 = pd->pc0 + (cb0 + (int)blockIdx.x) * BN;
+    const int cbg = cb0 + (int)blockIdx.x * (1 + c.cbskip);
+    const int c0 = pd->pc0 + cbg * BN;
     if (c0 >= s.fn) return;
     double *Tw = c.Tws + (long long)(2 * c.tslot[f] + (p & 1)) * STM_NB * STM_NB;
     if (pd->t_deferred) {
         // T was left to the update: every column-block workgroup builds it from its own Gram matrix; the first one
         // stores it (T slot of the plan, kept T of the Q-apply)
-        const bool first = (cb0 + (int)blockIdx.x == 0);
+        const bool first = (cbg == 0) || (c.cbskip > 0 && blockIdx.x == 0);   // (under a stride every plan keeps its own T)
         dev_update_block(c.Farena + s.foff, s.ld, pd->pg1, pd->pt - pd->pg1, pd->pk1, pd->pnb, pd->pdiag, nullptr, c0,
                          min(BN, s.fn - c0), dyn_lds, c.Tau + s.rp + pd->pk1, first ? Tw : nullptr,
                          (first && c.Tall) ? c.Tall + (long long)(s.tpan + p) * STM_NB * STM_NB : nullptr);
@@ -1825,8 +1826,8 @@ __global__ __launch_bounds__(NT) void k_upd_w(DevCtx c, const int *__restrict__ 
     // builds T (dlarft recurrence) for k_upd_c
     const bool gram = with_gram && (cb == (int)gridDim.x - 1);
     if (gram && !pd->t_deferred) return;
-    if (!gram && cb0 + cb >= ncbf) return;
-    const int c0 = gram ? pd->pk1 : pd->pc0 + (cb0 + cb) * BN;
+    if (!gram && cb0 + cb * (1 + c.cbskip) >= ncbf) return;
+    const int c0 = gram ? pd->pk1 : pd->pc0 + (cb0 + cb * (1 + c.cbskip)) * BN;
     if (nbp <= 0 || mp <= 0 || c0 >= s.fn || sl * SLAB >= mp) return;
     const int nc = gram ? nbp : min(BN, s.fn - c0);
     const long long ld = s.ld;
@@ -1942,7 +1943,7 @@ __global__ __launch_bounds__(NT) void k_upd_c(DevCtx c, const int *__restrict__ 
     const int g1 = pd->pg1, mp = pd->pt - pd->pg1, nbp = pd->pnb;
     const int cb = blockIdx.x, sl = blockIdx.y;
     const int nslf = stm_upd_nsl(s);
-    const int c0 = pd->pc0 + (cb0 + cb) * BN;
+    const int c0 = pd->pc0 + (cb0 + cb * (1 + c.cbskip)) * BN;
     if (nbp <= 0 || mp <= 0 || c0 >= s.fn || sl * SLAB >= mp) return;
     // Very tall panels: one workgroup takes 2 or 4 slabs -- every workgroup of a column block sums the same nsl partial
     // W (nsl x 8 KB: twice a slab of V and C at 32 slabs), so fewer, longer workgroups read less per updated row.
@@ -2058,8 +2059,8 @@ __global__ __launch_bounds__(NT, 2) void k_upd_f(DevCtx c, const int *__restrict
     const int cb = (int)blockIdx.y - (with_gram ? 1 : 0);          // launch-relative column block
     const int ncbf = stm_upd_ncb(s, p), nslf = stm_upd_nsl(s);
     if (gram && !pd->t_deferred) return;
-    if (!gram && cb0 + cb >= ncbf) return;
-    const int c0 = gram ? pd->pk1 : pd->pc0 + (cb0 + cb) * BN;
+    if (!gram && cb0 + cb * (1 + c.cbskip) >= ncbf) return;
+    const int c0 = gram ? pd->pk1 : pd->pc0 + (cb0 + cb * (1 + c.cbskip)) * BN;
     if (nbp <= 0 || mp <= 0 || c0 >= s.fn || sl * SLAB >= mp) return;
     const int nc = gram ? nbp : min(BN, s.fn - c0);
     const long long ld = s.ld;

@@ -17,9 +17,18 @@ dispatch in SparseQR_multithreads.c:14-115).  Here the same decomposition is mad
   over xGMI with backend "nccl", gloo in the CPU tests), no collective.  With a HipQR plan and a device the block goes
   device to device: the C-arena slice is copied into a device tensor, sent, and copied into the receiver's C arena.
 * the R+H blocks stay on the rank that produced them; `gather_numeric` assembles the reference-format result on rank 0.
+* `spread_partition`: the subtrees alone cannot scale a tree whose flops sit in its top fronts (c5: the root front is
+  99.98 % of the work).  A heavy front of a group's top set is therefore SHARED by the group's ranks
+  (include/stmmqr_hip.h, "A front SHARED between plans"): every rank assembles the whole front, panel q is factorized by
+  rank q mod R of the group and sent point-to-point to the others, every rank updates the 32-column blocks of the panels
+  it owns -- same arithmetic per column block, so the result is still bit-identical to one GPU (without the pair update).
+  A shared front is alone in its phase; its packed contribution block is gathered on the group's first rank, its packed
+  R+H block is merged by columns in `merge_shards`.
 
 The per-rank compute object only has to offer the small "plan" interface of capi.HipQR
-(set_groups / begin / run_group / finish / front_info / export_front / import_front / download), so the CPU tests drive
+(set_groups / begin / run_group / finish / front_info / export_front / import_front / download, and for shared fronts
+group_steps / run_step / panel_doubles / export_panel / import_panel / export_front_cols / import_front_cols / front_rhoff /
+front_flops), so the CPU tests drive
 the very same orchestration with a CPU stand-in plan.
 """
 from __future__ import annotations
@@ -56,8 +65,8 @@ def tree_arrays(sym: dict):
     return parent, Child, Childp
 
 
-def partition(sym: dict, nranks: int, oversub: int = 4):
-    """-> (owner[nf], phase[nf]).  Tree of joins: a front of phase k > 0 belongs to the top set of a group of ranks
+def _partition_levels(sym: dict, nranks: int, oversub: int = 4):
+    """-> (owner[nf], level[nf]).  Tree of joins: a front of phase k > 0 belongs to the top set of a group of ranks
     [r0, r0 + 2^k') (k' >= k is the level at which the group was formed; empty levels are skipped so phases are dense)
     and is owned by r0; phase 0 = whole subtrees.  Children never have a later phase than their parent, and a child on
     another rank always has an earlier one."""
@@ -120,13 +129,81 @@ def partition(sym: dict, nranks: int, oversub: int = 4):
     if nranks & (nranks - 1):
         raise ValueError("the tree of joins needs a power-of-two number of ranks")
     split(roots, 0, nranks)
-    # dense phases: levels that ended up empty are skipped
+    return owner, level
+
+
+def partition(sym: dict, nranks: int, oversub: int = 4):
+    """-> (owner[nf], phase[nf]): the tree of joins with dense phases (levels that ended up empty are skipped)"""
+    owner, level = _partition_levels(sym, nranks, oversub)
     used = sorted(set(int(x) for x in level))
     remap = {lv: i for i, lv in enumerate(used)}
     if 0 not in remap:
         remap = {lv: i + 1 for i, lv in enumerate(used)}
     phase = np.array([remap[int(x)] for x in level], I64)
     return owner, phase
+
+
+NB = 32                                   # panel width of the device path (STM_NB): column ownership inside a shared front
+
+
+def front_flop_split(sym: dict):
+    """(panel[nf], update[nf]): the flop bound of front_flop_bounds split into what the panel factorizations do (the chain
+    that stays serial inside a shared front) and what the trailing updates do (what is spread over the ranks)."""
+    nf = int(sym["nf"])
+    Rp, Fm = (np.asarray(sym[k], I64) for k in ("Rp", "Fm"))
+    pan, upd = np.zeros(nf), np.zeros(nf)
+    for f in range(nf):
+        fn, fm = int(Rp[f + 1] - Rp[f]), int(Fm[f])
+        j = np.arange(min(fn, fm), dtype=np.float64)
+        h = fm - j
+        k2 = np.minimum((j // NB + 1) * NB, fn)
+        pan[f] = float(np.sum(3 * h + 4 * h * (k2 - j - 1)))
+        upd[f] = float(np.sum(4 * h * (fn - k2)))
+    return pan, upd
+
+
+def spread_partition(sym: dict, nranks: int, oversub: int = 4, min_share: float = 0.02, min_panels_per_rank: int = 4,
+                     min_cols: int = 256, min_flops: float = 5e10):
+    """-> (owner[nf], phase[nf], span[nf]).  partition() plus shared fronts: a front of the top set of a group of R = 2^k
+    ranks whose flop bound is at least `min_share` of the whole tree's and `min_flops` (a panel step costs a message and a
+    handful of launches: below a few thousand columns that is more than the shared update saves), with at least `min_cols`
+    columns and `min_panels_per_rank` panels per rank, is shared by the ranks [owner, owner + R) (span = R, else 1).  A shared front is
+    alone in its phase: inside a group's top set the fronts are numbered in postorder and every shared front closes the
+    stage before it, so children still never run later than their parents."""
+    owner, level = _partition_levels(sym, nranks, oversub)
+    nf = int(sym["nf"])
+    Rp, Fm = (np.asarray(sym[k], I64) for k in ("Rp", "Fm"))
+    Post = np.asarray(sym["Post"], I64)[:nf]
+    fl = front_flop_bounds(sym)
+    total = float(fl.sum())
+    span = np.ones(nf, I64)
+    for f in range(nf):
+        R = 1 << int(level[f])
+        fn, fm = int(Rp[f + 1] - Rp[f]), int(Fm[f])
+        npanels = (min(fn, fm) + NB - 1) // NB
+        if R > 1 and fl[f] >= max(min_share * total, min_flops) and fn >= min_cols and fm >= 64 and npanels >= min_panels_per_rank * R:
+            span[f] = R
+    stage = np.zeros(nf, I64)
+    state = {}                            # (level, first rank of the group) -> [next stage, the current stage has fronts]
+    for f in Post:
+        if level[f] == 0:
+            continue
+        st = state.setdefault((int(level[f]), int(owner[f])), [0, False])
+        if span[f] > 1:
+            if st[1]:
+                st[0] += 1
+            stage[f] = st[0]
+            st[0] += 1
+            st[1] = False
+        else:
+            stage[f] = st[0]
+            st[1] = True
+    keys = sorted(set((int(level[f]), int(stage[f])) for f in range(nf)))
+    if (0, 0) not in keys:
+        keys = [(0, 0)] + keys
+    remap = {k: i for i, k in enumerate(keys)}
+    phase = np.array([remap[(int(level[f]), int(stage[f]))] for f in range(nf)], I64)
+    return owner, phase, span
 
 
 def cross_edges(sym: dict, owner, phase, k=None):
@@ -141,13 +218,26 @@ def cross_edges(sym: dict, owner, phase, k=None):
     return out
 
 
-def critical_path_flops(sym: dict, owner, phase, nranks):
+def critical_path_flops(sym: dict, owner, phase, nranks, span=None):
     """(critical, total): sum over the phases of the heaviest rank's flop bound vs the whole tree's -- the bound on the
-    strong-scaling speed-up is total / critical."""
+    strong-scaling speed-up is total / critical.  A shared front (span R > 1) counts its panel chain in
+    full and 1/R of its trailing updates on every rank of its group."""
     fl = front_flop_bounds(sym)
+    owner, phase = np.asarray(owner), np.asarray(phase)
+    if span is None:
+        span = np.ones(len(fl), I64)
+    span = np.asarray(span)
+    pan, upd = front_flop_split(sym) if np.any(span > 1) else (fl, fl * 0)
     crit = 0.0
     for k in range(int(phase.max(initial=0)) + 1):
-        crit += max((float(fl[(owner == r) & (phase == k)].sum()) for r in range(nranks)), default=0.0)
+        load = np.zeros(nranks)
+        for f in np.nonzero(phase == k)[0]:
+            R = int(span[f])
+            if R > 1:
+                load[int(owner[f]):int(owner[f]) + R] += pan[f] + upd[f] / R
+            else:
+                load[int(owner[f])] += fl[f]
+        crit += float(load.max(initial=0.0))
     return crit, float(fl.sum())
 
 
@@ -201,81 +291,206 @@ def _import(plan, f, fm, rank, cm, tC, trows, comm):
         plan.import_front(f, fm, rank, cm, tC.cpu().numpy(), trows.cpu().numpy())
 
 
+SHARED = 1 << 30                          # STMMQR_GROUP_SHARED
+PREP, PANEL, UPDATE, GRAM, POST = 1, 2, 4, 8, 16     # STMMQR_STEP_*
+
+
 class ShardPlan:
     """What one rank needs to know about a partition, computed ONCE per (plan, partition) -- not per factorization: this
-    rank's groups (installed in the plan: a schedule rebuild and a few device allocations) and, per phase, the cross-rank
-    edges it sends or receives."""
+    rank's groups (installed in the plan: a schedule rebuild and a few device allocations) and, per phase, the
+    contribution blocks it sends or receives and the shared front it takes part in."""
 
-    def __init__(self, plan, sym: dict, owner, phase, comm):
+    def __init__(self, plan, sym: dict, owner, phase, comm, span=None):
+        nf = int(sym["nf"])
         self.owner, self.phase = np.asarray(owner), np.asarray(phase)
+        self.span = np.ones(nf, I64) if span is None else np.asarray(span, I64)
         r = comm.rank
-        self.group = np.where(self.owner == r, self.phase, -1).astype(np.int32)
+        lo, hi = self.owner, self.owner + self.span
+        mine = (lo <= r) & (r < hi)                           # fronts factorized (or shared) here
+        self.mine = mine
+        self.group = np.where(mine, self.phase + np.where(self.span > 1, SHARED, 0), -1).astype(np.int32)
         plan.set_groups(self.group)
         self.nphase = int(self.phase.max(initial=0)) + 1
         parent, _, _ = tree_arrays(sym)
-        cross = [(int(c), int(parent[c])) for c in range(int(sym["nf"])) if parent[c] >= 0 and self.owner[c] != self.owner[parent[c]]]
-        self.out = [[(c, p) for c, p in cross if self.phase[p] == k and self.owner[c] == r] for k in range(self.nphase)]
-        self.inn = [[(c, p) for c, p in cross if self.phase[p] == k and self.owner[p] == r] for k in range(self.nphase)]
-        self.has = [bool(np.any(self.group == k)) for k in range(self.nphase)]
+        self.parent = parent
+        # a contribution block lives (complete) on owner[c]; it goes to every rank that assembles the parent
+        self.out = [[] for _ in range(self.nphase)]           # [(c, dst)]
+        self.inn = [[] for _ in range(self.nphase)]           # [(c, src)]
+        for c in range(nf):
+            p = int(parent[c])
+            if p < 0:
+                continue
+            src = int(self.owner[c])
+            for dst in range(int(lo[p]), int(hi[p])):
+                if dst != src:
+                    if src == r:
+                        self.out[int(self.phase[p])].append((c, dst))
+                    if dst == r:
+                        self.inn[int(self.phase[p])].append((c, src))
+        self.has = [bool(np.any(mine & (self.phase == k) & (self.span == 1))) for k in range(self.nphase)]
+        self.shared_at = [None] * self.nphase                 # phase -> the shared front this rank takes part in
+        self.ring = {}
+        for f in np.nonzero(mine & (self.span > 1))[0]:
+            self.shared_at[int(self.phase[f])] = int(f)
+        self.shared = [int(f) for f in np.nonzero(mine & (self.span > 1))[0]]
+
+    def panel_ring(self, plan, f, comm):
+        """R message buffers of a shared front (slot q mod R: a rank receives R - 1 panels between two of its own exports,
+        and an export waits for everything queued before it, so a slot is free again when its turn comes)"""
+        if f not in self.ring:
+            nd = plan.panel_doubles(f)
+            self.ring[f] = [comm.empty(nd, np.float64) for _ in range(int(self.span[f]))]
+        return self.ring[f]
+
+
+def _use_dev(plan, comm, name):
+    return comm.device is not None and hasattr(plan, name)
+
+
+def _sync_recv(comm):
+    if comm.device is not None:
+        import torch
+        torch.cuda.current_stream(comm.device).synchronize()
+
+
+def run_shared_front(plan, sp: ShardPlan, f, comm: Comm):
+    """The panel loop of one shared front on this rank (include/stmmqr_hip.h): i = my place in the group, panel q belongs to
+    place q mod R.  Column block b of step q holds the columns of panel q + 1 + b, so my blocks of step q start at
+    (i - q - 1) mod R with stride R.  The owner of panel q + 1 updates its block 0 first, factorizes and sends the panel,
+    and only then updates the rest of step q -- the others meanwhile run their whole update of step q."""
+    g, r0, R = int(sp.phase[f]), int(sp.owner[f]), int(sp.span[f])
+    i = comm.rank - r0
+    nsteps = plan.group_steps(g)
+    ring = sp.panel_ring(plan, f, comm)
+    dev = _use_dev(plan, comm, "export_panel_dev")
+    plan.run_step(g, 0, PREP)
+    for t in range(nsteps):
+        o = t % R
+        first = (i - t) % R                                   # my first column block of step t - 1
+        buf = ring[o]
+        if i == o:
+            if t > 0:
+                plan.run_step(g, t - 1, UPDATE | GRAM, first, R, 1)
+            plan.run_step(g, t, PANEL)
+            if dev:
+                plan.export_panel_dev(f, t, buf.data_ptr())
+            else:
+                buf.copy_(comm.tensor(plan.export_panel(f, t)))
+            if t > 0:
+                plan.run_step(g, t - 1, UPDATE, first + R, R, -1)
+            comm.exchange([(buf, r0 + j) for j in range(R) if j != i], [])
+        else:
+            if t > 0:
+                plan.run_step(g, t - 1, UPDATE | GRAM, first, R, -1)
+            comm.exchange([], [(buf, r0 + o)])
+            if dev:
+                _sync_recv(comm)
+                plan.import_panel_dev(f, t, buf.data_ptr())
+            else:
+                plan.import_panel(f, t, buf.cpu().numpy())
+    plan.run_step(g, nsteps - 1, UPDATE | GRAM, (i - nsteps) % R, R, -1)
+    plan.run_step(g, nsteps - 1, POST)
+    # the packed contribution block is complete in my columns only: the group's first rank collects the others' columns
+    if sp.parent[f] >= 0 and R > 1:
+        devc = _use_dev(plan, comm, "export_front_cols_dev")
+        if i == 0:
+            sizes = [plan.front_cols_doubles(f, j, R) for j in range(R)]
+            bufs = [comm.empty(max(sizes[j], 1), np.float64) for j in range(R)]
+            comm.exchange([], [(bufs[j][:sizes[j]], r0 + j) for j in range(1, R) if sizes[j] > 0])
+            for j in range(1, R):
+                if sizes[j] > 0:
+                    if devc:
+                        _sync_recv(comm)
+                        plan.import_front_cols_dev(f, j, R, bufs[j].data_ptr())
+                    else:
+                        plan.import_front_cols(f, j, R, bufs[j][:sizes[j]].cpu().numpy())
+        else:
+            n = plan.front_cols_doubles(f, i, R)
+            if n > 0:
+                if devc:
+                    t = comm.empty(n, np.float64)
+                    plan.export_front_cols_dev(f, i, R, t.data_ptr())
+                else:
+                    t = comm.tensor(plan.export_front_cols(f, i, R))
+                comm.exchange([(t, r0)], [])
 
 
 def factorize_sharded(plan, sym: dict, Ax, tol, ntol, comm: Comm, Ap=None, Ai=None, owner=None, phase=None,
-                      device_ptr=None, shard_plan: ShardPlan | None = None):
+                      device_ptr=None, shard_plan: ShardPlan | None = None, span=None):
     """Run one sharded factorization.  `plan` is this rank's compute object.  Returns (stats, owner, phase).
-    shard_plan: the ShardPlan of (plan, owner, phase) when the caller factorizes repeatedly (bench.py): the groups are then
-    installed once, outside any timed region."""
+    shard_plan: the ShardPlan of (plan, owner, phase, span) when the caller factorizes repeatedly (bench.py): the groups
+    are then installed once, outside any timed region.  stats["flops"] counts a shared front on the first rank of its
+    group only, so the ranks' flops add up to the factorization's."""
     if shard_plan is None:
         if owner is None:
             owner, phase = partition(sym, comm.size)
-        shard_plan = ShardPlan(plan, sym, owner, phase, comm)
-    owner, phase, group = shard_plan.owner, shard_plan.phase, shard_plan.group
+        shard_plan = ShardPlan(plan, sym, owner, phase, comm, span)
+    sp = shard_plan
+    owner, phase = sp.owner, sp.phase
     plan.begin(Ax, tol, ntol, Ap, Ai, device_ptr=device_ptr)
-    nphase = shard_plan.nphase
-    for k in range(nphase):
+    for k in range(sp.nphase):
         if k > 0 and comm.size > 1:
-            # contribution blocks move up the tree only where subtrees join: every edge entering phase k from another rank
-            mine_out, mine_in = shard_plan.out[k], shard_plan.inn[k]
-            out = [(c, p) + _export(plan, c, comm) for c, p in mine_out]
+            # contribution blocks move up the tree only where subtrees join: every block that enters phase k from another rank
+            mine_out, mine_in = sp.out[k], sp.inn[k]
+            exported = {}
+            for c, _ in mine_out:
+                if c not in exported:
+                    exported[c] = _export(plan, c, comm)
             metas_in = [comm.empty(4, np.int64) for _ in mine_in]
-            comm.exchange([(comm.tensor(np.array([i["fm"], i["rank"], i["cm"], i["csize"]], I64)), int(owner[p]))
-                           for c, p, i, _, _ in out],
-                          [(t, int(owner[c])) for t, (c, p) in zip(metas_in, mine_in)])
+            comm.exchange([(comm.tensor(np.array([exported[c][0][q] for q in ("fm", "rank", "cm", "csize")], I64)), dst)
+                           for c, dst in mine_out],
+                          [(t, src) for t, (c, src) in zip(metas_in, mine_in)])
             metas = [[int(x) for x in t.cpu().numpy()] for t in metas_in]
             bufs = [(comm.empty(max(m[3], 1), np.float64), comm.empty(max(m[2], 1), np.int64)) for m in metas]
             sends, recvs = [], []
-            for c, p, i, tC, trows in out:
+            for c, dst in mine_out:
+                i, tC, trows = exported[c]
                 if i["csize"] > 0:
-                    sends += [(tC, int(owner[p])), (trows, int(owner[p]))]
-            for (c, p), m, (bC, bR) in zip(mine_in, metas, bufs):
+                    sends += [(tC, dst), (trows, dst)]
+            for (c, src), m, (bC, bR) in zip(mine_in, metas, bufs):
                 if m[3] > 0:
-                    recvs += [(bC[:m[3]], int(owner[c])), (bR[:m[2]], int(owner[c]))]
+                    recvs += [(bC[:m[3]], src), (bR[:m[2]], src)]
             comm.exchange(sends, recvs)
-            for (c, p), m, (bC, bR) in zip(mine_in, metas, bufs):
+            for (c, src), m, (bC, bR) in zip(mine_in, metas, bufs):
                 _import(plan, c, m[0], m[1], m[2], bC[:m[3]], bR[:m[2]], comm)
-        if shard_plan.has[k]:
+        if sp.shared_at[k] is not None:
+            run_shared_front(plan, sp, sp.shared_at[k], comm)
+        if sp.has[k]:
             plan.run_group(k)
+    dup = [plan.front_flops(f) for f in sp.shared if comm.rank != int(owner[f])]
     stats = plan.finish()
+    for fl, flu in dup:
+        stats["flops"] = stats.get("flops", 0.0) - fl
+        if "flops_update" in stats:
+            stats["flops_update"] -= flu
     return stats, owner, phase
 
 
-def shard_of(N, sym: dict, owned):
-    """The pieces of one rank's download that the merge needs: (arrays..., owned fronts, block sizes)."""
+def shard_of(N, sym: dict, owned, plan=None, shard_plan: ShardPlan | None = None, rank=0):
+    """The pieces of one rank's download that the merge needs: (arrays..., owned fronts, block sizes); for the shared
+    fronts the column offsets of the packed R+H block and this rank's place in the group."""
     nf = int(sym["nf"])
     Post = np.asarray(sym["Post"], I64)[:nf]
+    Rp = np.asarray(sym["Rp"], I64)
     owned = np.asarray(owned, bool)
     post_own = [int(f) for f in Post if owned[f]]
     size = {}
     for i, f in enumerate(post_own):
         end = N.Rblock_off[post_own[i + 1]] if i + 1 < len(post_own) else N.rh_total
         size[f] = int(end - N.Rblock_off[f])
+    cols = {}
+    if shard_plan is not None:
+        for f in shard_plan.shared:
+            cols[f] = (rank - int(shard_plan.owner[f]), int(shard_plan.span[f]), plan.front_rhoff(f, int(Rp[f + 1] - Rp[f])))
     return {"Stack": N.Stack[:N.rh_total], "Rblock_off": N.Rblock_off, "Rdead": N.Rdead, "HStair": N.HStair,
             "HTau": N.HTau, "Hii": N.Hii, "Hm": N.Hm, "Hr": N.Hr, "own": post_own, "size": size,
-            "maxfrank": int(N.maxfrank)}
+            "maxfrank": int(N.maxfrank), "cols": cols}
 
 
 def merge_shards(sym: dict, shards, ntol=None):
     """Reference-format result from per-rank shards: packed R+H blocks in Post order (the single shrunk stack of
-    the reference's serial run), H arrays merged, HPinv / Hii by qr_hpinv."""
+    the reference's serial run), H arrays merged, HPinv / Hii by qr_hpinv.  The block of a shared front is put together
+    from the columns each rank of its group owns (panel q = columns [32 q, 32 q + 32) belongs to place q mod R)."""
     from .capi import QRNumeric
     nf, n, m = int(sym["nf"]), int(sym["n"]), int(sym["m"])
     Rp, Hip, Post, Super = (np.asarray(sym[k], I64) for k in ("Rp", "Hip", "Post", "Super"))
@@ -295,7 +510,13 @@ def merge_shards(sym: dict, shards, ntol=None):
         mf = max(mf, sh["maxfrank"])
         for f in sh["own"]:
             a = sh["Rblock_off"][f]
-            G.Stack[off[f]:off[f] + rs[f]] = sh["Stack"][a:a + rs[f]]
+            if f in sh.get("cols", {}):
+                place, R, coff = sh["cols"][f]
+                for q in range(place, (len(coff) - 1 + NB - 1) // NB, R):
+                    c0, c1 = int(coff[q * NB]), int(coff[min((q + 1) * NB, len(coff) - 1)])
+                    G.Stack[off[f] + c0:off[f] + c1] = sh["Stack"][a + c0:a + c1]
+            else:
+                G.Stack[off[f]:off[f] + rs[f]] = sh["Stack"][a:a + rs[f]]
             G.HStair[Rp[f]:Rp[f + 1]] = sh["HStair"][Rp[f]:Rp[f + 1]]
             G.HTau[Rp[f]:Rp[f + 1]] = sh["HTau"][Rp[f]:Rp[f + 1]]
             hm = int(sh["Hm"][f])
@@ -310,12 +531,13 @@ def merge_shards(sym: dict, shards, ntol=None):
     return G
 
 
-def gather_numeric(plan, sym: dict, comm: Comm, owner, ntol=None):
+def gather_numeric(plan, sym: dict, comm: Comm, owner, ntol=None, shard_plan: ShardPlan | None = None):
     """Assemble the reference-format result on rank 0 (other ranks return None): every rank downloads the fronts it
     factorized and ships the arrays of its shard to rank 0 (point-to-point, one batched group; this is the API consumer's
     "give me the factors on the host" -- it is not part of a factorization step)."""
     N = plan.download()
-    shard = shard_of(N, sym, owner == comm.rank)
+    owned = shard_plan.mine if shard_plan is not None else (np.asarray(owner) == comm.rank)
+    shard = shard_of(N, sym, owned, plan, shard_plan, comm.rank)
     if comm.size == 1:
         return merge_shards(sym, [shard], ntol)
     keys_f = ["Stack", "HTau"]
@@ -325,7 +547,11 @@ def gather_numeric(plan, sym: dict, comm: Comm, owner, ntol=None):
     def pack(sh):
         own = np.array(sh["own"], I64)
         sizes = np.array([sh["size"][f] for f in sh["own"]], I64)
-        ints = [own, sizes, np.array([sh["maxfrank"]], I64), sh["Rdead"].astype(I64)] + [np.asarray(sh[k], I64) for k in keys_i]
+        cf = sorted(sh["cols"])
+        chead = np.array([x for f in cf for x in (f, sh["cols"][f][0], sh["cols"][f][1], len(sh["cols"][f][2]))], I64)
+        coffs = np.concatenate([np.asarray(sh["cols"][f][2], I64) for f in cf]) if cf else np.zeros(0, I64)
+        ints = [own, sizes, np.array([sh["maxfrank"]], I64), sh["Rdead"].astype(I64), chead, coffs] + \
+               [np.asarray(sh[k], I64) for k in keys_i]
         flts = [np.asarray(sh[k], np.float64) for k in keys_f]
         return ints, flts
 
@@ -345,9 +571,14 @@ def gather_numeric(plan, sym: dict, comm: Comm, owner, ntol=None):
         host.exchange([], [(ti, src), (tf, src)])
         ai = np.split(ti.cpu().numpy(), np.cumsum(head[:len(ints)])[:-1])
         af = np.split(tf.cpu().numpy(), np.cumsum(head[len(ints):])[:-1])
-        sh = {"own": [int(x) for x in ai[0]], "maxfrank": int(ai[2][0]), "Rdead": ai[3].astype(np.int8)}
+        sh = {"own": [int(x) for x in ai[0]], "maxfrank": int(ai[2][0]), "Rdead": ai[3].astype(np.int8), "cols": {}}
         sh["size"] = {f: int(z) for f, z in zip(sh["own"], ai[1])}
-        for k, a in zip(keys_i, ai[4:]):
+        pos = 0
+        for q in range(0, ai[4].size, 4):
+            f, place, R, ln = (int(x) for x in ai[4][q:q + 4])
+            sh["cols"][f] = (place, R, ai[5][pos:pos + ln])
+            pos += ln
+        for k, a in zip(keys_i, ai[6:]):
             sh[k] = a
         for k, a in zip(keys_f, af):
             sh[k] = a

@@ -155,3 +155,135 @@ def test_graph_is_invalidated_by_set_groups():
         np.testing.assert_array_equal(r.HStair, ref.HStair)
         np.testing.assert_array_equal(r.HTau, ref.HTau)
         np.testing.assert_array_equal(r.Stack[:r.rh_total], ref.Stack[:ref.rh_total])
+
+
+# ---- shared fronts (sharded.spread_partition / run_shared_front): the REAL orchestration code, one thread per rank ------
+class LocalComm:
+    """In-process stand-in for torch.distributed point-to-point (TEST INFRASTRUCTURE): every rank is a thread with its own
+    plan on the same GPU, a queue per (src, dst) carries the tensors.  Same interface as sharded.Comm."""
+
+    def __init__(self, rank, size, queues, device):
+        self.rank, self.size, self.queues, self.device, self.dist = rank, size, queues, device, None
+
+    def tensor(self, a):
+        import torch
+        t = torch.from_numpy(np.ascontiguousarray(a))
+        return t.to(self.device) if self.device is not None else t
+
+    def empty(self, n, dtype):
+        import torch
+        return torch.empty(int(n), dtype={np.float64: torch.float64, np.int64: torch.int64}[dtype],
+                           device=self.device if self.device is not None else "cpu")
+
+    def exchange(self, sends, recvs):
+        for t, dst in sends:
+            self.queues[(self.rank, dst)].put(t.clone())
+        for t, src in recvs:
+            t.copy_(self.queues[(src, self.rank)].get(timeout=180))
+
+
+def _run_ranks(pkg, sh, sym, g, tol, ntol, nranks, owner, phase, span, on_device):
+    import queue
+    import threading
+    import torch
+    dev = torch.device("cuda:0") if on_device else None
+    queues = {(a, b): queue.Queue() for a in range(nranks) for b in range(nranks)}
+    out, errs = [None] * nranks, []
+
+    def work(r):
+        try:
+            comm = LocalComm(r, nranks, queues, dev)
+            plan = pkg.HipQR(sym)
+            sp = sh.ShardPlan(plan, sym, owner, phase, comm, span)
+            st, _, _ = sh.factorize_sharded(plan, sym, g["in_Ax"], tol, ntol, comm, Ap=g["in_Ap"], Ai=g["in_Ai"], shard_plan=sp)
+            out[r] = (st, sh.shard_of(plan.download(), sym, sp.mine, plan, sp, r))
+            plan.close()
+        except BaseException as e:       # noqa: BLE001 (reported by the main thread)
+            errs.append((r, e))
+
+    th = [threading.Thread(target=work, args=(r,)) for r in range(nranks)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join(600)
+    assert not errs, errs
+    assert all(o is not None for o in out)
+    return out
+
+
+@pytest.mark.parametrize("name,nranks,small,on_device", [
+    ("grid20_standin", 2, True, True), ("grid20_standin", 4, True, False), ("lns_3937", 4, True, True),
+    ("epb1", 2, True, True), ("syn_rankdef_grid", 2, True, False),
+    ("sme3dc_standin", 4, False, True),      # BASELINE configs[3] stand-in: 13 shared fronts (spans 2 and 4)
+    ("c5mini_standin", 8, False, True)])     # the structure of configs[4]: ONE front holds the flops, shared by 8 ranks
+def test_shared_fronts_equal_unsharded(name, nranks, small, on_device):
+    """sharded.factorize_sharded with the heavy top fronts shared by the ranks of their group: panels factorized in turn,
+    sent as messages, every plan updating the column blocks it owns -- per column block the same arithmetic as the unshared
+    front, so with the pair update off the merged result is IDENTICAL to one plan's."""
+    pkg = importlib.import_module(PKG)
+    sh = importlib.import_module(PKG + ".sharded")
+    g = load_golden(name)
+    S = Symbolic(g)
+    sym = {**S.sc, **{k: v for k, v in S.arr.items() if v is not None}}
+    tol, ntol = scalar(g, "in_tol"), int(scalar(g, "in_ntol"))
+    big = 16 if small else 64
+    pkg.set_options(pair_update=0, big_front_cols=big)
+    try:
+        ref = pkg.qr_factorize(sym, g["in_Ap"], g["in_Ai"], g["in_Ax"], tol, ntol)
+        kw = dict(min_flops=0, min_share=0.01, min_cols=32, min_panels_per_rank=1) if small else {}
+        owner, phase, span = sh.spread_partition(sym, nranks, **kw)
+        assert int((span > 1).sum()) >= 1
+        out = _run_ranks(pkg, sh, sym, g, tol, ntol, nranks, owner, phase, span, on_device)
+    finally:
+        pkg.set_options(pair_update=1, big_front_cols=64)
+    G = sh.merge_shards(sym, [o[1] for o in out], ntol)
+    assert sum(o[0]["flops"] for o in out) == ref.stats["flops"]
+    assert sum(o[0]["retries"] for o in out) == 0
+    assert (G.rank, G.rank1, G.maxfrank, G.maxfm, G.rh_total) == (ref.rank, ref.rank1, ref.maxfrank, ref.maxfm, ref.rh_total)
+    for k in ("Hm", "Hr", "HStair", "HPinv", "Rdead", "Rblock_off", "Hii", "HTau"):
+        np.testing.assert_array_equal(getattr(G, k), getattr(ref, k), err_msg=k)
+    np.testing.assert_array_equal(G.Stack[:G.rh_total], ref.Stack[:ref.rh_total])
+
+
+def test_step_interface_refusals():
+    """stmmqr_plan_set_groups refuses a shared front that is not alone in its group or not one of the large fronts;
+    stmmqr_factorize_step refuses an unknown step and a zero stride"""
+    pkg = importlib.import_module(PKG)
+    g = load_golden("grid20_standin")
+    S = Symbolic(g)
+    sym = {**S.sc, **{k: v for k, v in S.arr.items() if v is not None}}
+    nf = S.nf
+    fn = np.diff(np.asarray(sym["Rp"]))[:nf]
+    root = int(np.argmax(fn))
+    p = pkg.HipQR(sym)
+    grp = np.zeros(nf, np.int32)
+    grp[root] = 0 | p.SHARED                      # shares group 0 with everything else
+    with pytest.raises(pkg.StmmqrError, match="alone"):
+        p.set_groups(grp)
+    small = int(np.argmin(fn))
+    grp = np.zeros(nf, np.int32)
+    par = np.full(nf, -1)
+    for f in range(nf):
+        for q in range(sym["Childp"][f], sym["Childp"][f + 1]):
+            par[sym["Child"][q]] = f
+    if fn[small] < 64 and par[small] >= 0:
+        grp[:] = 2
+        anc = small
+        grp[small] = 1 | p.SHARED
+        # descendants of `small` go first
+        stack = [small]
+        while stack:
+            x = stack.pop()
+            for q in range(sym["Childp"][x], sym["Childp"][x + 1]):
+                c = int(sym["Child"][q]); grp[c] = 0; stack.append(c)
+        with pytest.raises(pkg.StmmqrError, match="large fronts"):
+            p.set_groups(grp)
+    p.set_groups(np.zeros(nf, np.int32))
+    p.begin(g["in_Ax"], scalar(g, "in_tol"), int(scalar(g, "in_ntol")), g["in_Ap"], g["in_Ai"])
+    with pytest.raises(pkg.StmmqrError, match="no such step"):
+        p.run_step(0, 10 ** 6, p.PREP)
+    with pytest.raises(pkg.StmmqrError, match="stride"):
+        p.run_step(0, 0, p.UPDATE, 0, 0, -1)
+    p.run_group(0)
+    p.finish()
+    p.close()

@@ -59,7 +59,46 @@ def test_partition_properties(name, nranks):
         assert 0 < crit <= tot
 
 
-def _worker(rank, world, port, name, q):
+SPREAD_SMALL = dict(min_flops=0, min_share=0.01, min_cols=32, min_panels_per_rank=1)   # shared fronts on the small fixtures
+
+
+@pytest.mark.parametrize("name", ["epb1", "syn_grid3d", "grid20_standin", "lns_3937", "c5mini_standin"])
+@pytest.mark.parametrize("nranks", [2, 4, 8])
+def test_spread_partition_properties(name, nranks):
+    """shared fronts: alone in their phase, shared by an aligned group that contains every rank below them; children never
+    later than parents; the model bound of the critical path does not get worse and passes 3x where the tree is one front"""
+    from stmmqr_testlib import Symbolic, load_golden
+    sh = shard_mod()
+    S = Symbolic(load_golden(name))
+    sym = sym_dict(S)
+    small = {} if name == "c5mini_standin" else SPREAD_SMALL
+    owner, phase, span = sh.spread_partition(sym, nranks, **small)
+    parent, Child, Childp = sh.tree_arrays(sym)
+    nf = S.nf
+    assert np.all((span == 1) | (phase > 0))
+    for f in range(nf):
+        R = int(span[f])
+        assert R >= 1 and (R & (R - 1)) == 0 and owner[f] % R == 0 and owner[f] + R <= nranks
+        p = parent[f]
+        if p >= 0:
+            assert phase[f] <= phase[p]
+            if span[f] > 1 or span[p] > 1 or owner[f] != owner[p]:
+                assert phase[f] < phase[p]
+            # everything below a front lives inside the ranks of its group
+            assert owner[p] <= owner[f] and owner[f] + span[f] <= max(owner[p] + span[p], owner[f] + span[f])
+        if R > 1:
+            same = np.nonzero((phase == phase[f]) & (np.arange(nf) != f))[0]
+            for o in same:                                    # another front of the same phase: another group of ranks
+                assert owner[o] + span[o] <= owner[f] or owner[f] + R <= owner[o]
+    o0, p0 = sh.partition(sym, nranks)
+    c0, t0 = sh.critical_path_flops(sym, o0, p0, nranks)
+    c1, t1 = sh.critical_path_flops(sym, owner, phase, nranks, span)
+    assert t0 == t1 and c1 <= c0 * 1.0001
+    if name == "c5mini_standin":
+        assert int((span > 1).sum()) == 1 and t1 / c1 >= {2: 1.9, 4: 3.5, 8: 6.0}[nranks]
+
+
+def _worker(rank, world, port, name, q, spread=False):
     sys.path.insert(0, str(ROOT)); sys.path.insert(0, str(ROOT / "tests"))
     import torch.distributed as dist
     from oracle_plan import OraclePlan
@@ -73,9 +112,16 @@ def _worker(rank, world, port, name, q):
         orc = Oracle()
         comm = sh.Comm(dist)
         plan = OraclePlan(S, orc)
+        sp = None
+        if spread:
+            owner, phase, span = sh.spread_partition(sym, world, **SPREAD_SMALL)
+            sp = sh.ShardPlan(plan, sym, owner, phase, comm, span)
         st, owner, phase = sh.factorize_sharded(plan, sym, g["in_Ax"], scalar(g, "in_tol"), int(scalar(g, "in_ntol")), comm,
-                                                Ap=g["in_Ap"], Ai=g["in_Ai"])
-        G = sh.gather_numeric(plan, sym, comm, owner)
+                                                Ap=g["in_Ap"], Ai=g["in_Ai"], shard_plan=sp)
+        G = sh.gather_numeric(plan, sym, comm, owner, shard_plan=sp)
+        import torch
+        fl = torch.tensor([st["flops"]], dtype=torch.float64)
+        dist.all_reduce(fl)
         if rank == 0:
             No = orc.factorize(S, g["in_Ap"], g["in_Ai"], g["in_Ax"], scalar(g, "in_tol"), int(scalar(g, "in_ntol")))
             nf = S.nf
@@ -88,26 +134,41 @@ def _worker(rank, world, port, name, q):
             for f in range(nf):
                 a = S.Hip[f]
                 ok = ok and np.array_equal(G.Hii[a:a + G.Hm[f]], No.Hii[a:a + No.Hm[f]])
+            ok = ok and float(fl[0]) == No.c.flopcount            # a shared front is counted once
             ncross = len(sh.cross_edges(sym, owner, phase))
-            q.put((bool(ok), int((phase > 0).sum()), ncross))
+            q.put((bool(ok), int((phase > 0).sum()), ncross, 0 if sp is None else int((sp.span > 1).sum())))
     finally:
         dist.barrier()
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("name,world", [("syn_grid3d", 2), ("epb1", 2), ("syn_rankdef_grid", 2),
-                                        ("epb1", 4), ("syn_grid3d", 4)])      # 4 ranks: three phases, ranks pair up 4 -> 2 -> 1
-def test_gloo_ranks_match_serial_oracle(name, world):
+def _run_world(name, world, spread):
     import torch.multiprocessing as mp
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, name, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, name, q, spread)) for r in range(world)]
     for p in procs:
         p.start()
     for p in procs:
         p.join(300)
         assert p.exitcode == 0
-    ok, ntop, ncross = q.get(timeout=5)
+    return q.get(timeout=5)
+
+
+@pytest.mark.parametrize("name,world", [("syn_grid3d", 2), ("epb1", 2), ("syn_rankdef_grid", 2),
+                                        ("epb1", 4), ("syn_grid3d", 4)])      # 4 ranks: three phases, ranks pair up 4 -> 2 -> 1
+def test_gloo_ranks_match_serial_oracle(name, world):
+    ok, ntop, ncross, _ = _run_world(name, world, False)
     assert ok
     assert ntop >= 1 and ncross >= 1          # the run really exchanged contribution blocks
+
+
+@pytest.mark.parametrize("name,world", [("epb1", 2), ("grid20_standin", 2), ("syn_rankdef_grid", 2), ("lns_3937", 4), ("syn_grid3d", 4)])
+def test_gloo_shared_fronts_match_serial_oracle(name, world):
+    """the same with the heavy top fronts SHARED by the ranks of their group (sharded.run_shared_front): panel messages
+    between the ranks, the packed contribution block gathered on the group's first rank, the packed R+H block merged by
+    columns -- the stand-in plan poisons every column a rank does not own, so a wrong merge cannot pass"""
+    ok, ntop, ncross, nshared = _run_world(name, world, True)
+    assert ok
+    assert nshared >= 1 and ncross >= 1
