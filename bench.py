@@ -286,6 +286,9 @@ def main():
     ap.add_argument("--mode", choices=["replicas", "sharded"], default=None,
                     help="N>1: sharded (default) = ONE matrix, subtrees on the ranks, contribution blocks up a tree of joins "
                          "over RCCL point-to-point (strong scaling); replicas = every rank factorizes its own matrix (weak)")
+    ap.add_argument("--spread", type=int, default=1,
+                    help="sharded mode: 1 (default) = the heavy top fronts are SHARED by the ranks of their group (panels in turn, "
+                         "every rank updates its own 32-column blocks: sharded.spread_partition); 0 = subtrees only")
     args = ap.parse_args()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(spawn_ranks(args))
@@ -352,9 +355,17 @@ def main():
     if sharded:
         sh = importlib.import_module(PKG + ".sharded")
         comm = sh.Comm(dist, None if rehearsal else dev)
-        owner, phase = sh.partition(sym, world)
-        crit = sh.critical_path_flops(sym, owner, phase, world)
-        shard_plan = sh.ShardPlan(plan, sym, owner, phase, comm)     # groups + edge lists once, outside the timed region
+        owner0, phase0 = sh.partition(sym, world)
+        crit_sub = sh.critical_path_flops(sym, owner0, phase0, world)
+        if args.spread:
+            # (a shared front never takes the pair update, so its bits are those of ONE device with --pair-update 0)
+            owner, phase, span = sh.spread_partition(sym, world)
+        else:
+            owner, phase, span = owner0, phase0, None
+        crit = sh.critical_path_flops(sym, owner, phase, world, span)
+        o_all, p_all, s_all = sh.spread_partition(sym, world, min_step_flops=0)   # (the flop model without the latency threshold)
+        crit_all = sh.critical_path_flops(sym, o_all, p_all, world, s_all)
+        shard_plan = sh.ShardPlan(plan, sym, owner, phase, comm, span)   # groups + edge lists once, outside the timed region
 
         def step():
             return sh.factorize_sharded(plan, sym, None, tol, ntol, comm, device_ptr=Ax.data_ptr(), shard_plan=shard_plan)[0]
@@ -466,7 +477,9 @@ def main():
             "config": {"workload": wl,
                        "inputs": "values resident in HBM, factors left in HBM",
                        "parallelism": ((f"subtree-sharded x{world}: tree of joins, contribution blocks device-to-device over RCCL "
-                                        f"point-to-point" if sharded else f"replica x{world}") +
+                                        f"point-to-point" + ("; heavy top fronts shared by their rank group (panels in turn, 32-column "
+                                                             "blocks of the trailing matrix per rank)" if args.spread else "")
+                                        if sharded else f"replica x{world}") +
                                        (" -- REHEARSAL: all ranks on ONE GPU, gloo, blocks through the host (not a measurement)"
                                         if rehearsal else "")),
                        "device_ms_per_step": dev_ms / args.steps, "launches_per_step": st["nlaunch"],
@@ -475,8 +488,15 @@ def main():
             "roofline": roof,
         }
         if crit is not None:
+            # model bound of the strong-scaling speed-up: whole tree's flop bound / flop bound on the critical path (per phase
+            # the heaviest rank; a shared front = its panel chain + 1/R of its updates).  A MODEL: no multi-GPU hardware run of
+            # this path was possible on the one-GPU build box; message and launch latency per panel step are not in it.
             out["config"]["critical_path_flop_share"] = crit[0] / max(crit[1], 1.0)
             out["config"]["strong_scaling_bound"] = crit[1] / max(crit[0], 1.0)
+            out["config"]["strong_scaling_bound_subtrees_only"] = crit_sub[1] / max(crit_sub[0], 1.0)
+            out["config"]["shared_fronts"] = 0 if span is None else int((np.asarray(span) > 1).sum())
+            # ... and if every heavy top front were shared regardless of the per-step latency threshold of spread_partition
+            out["config"]["strong_scaling_bound_all_heavy_fronts_shared"] = crit_all[1] / max(crit_all[0], 1.0)
         # SURVEY 8 (f1), outside the timed region: Q'b and the least-squares solve on the factors still resident in HBM
         # (wall time including the copies of the vectors), with the residual the reference's driver prints
         try:

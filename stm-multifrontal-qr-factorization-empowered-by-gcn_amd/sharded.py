@@ -163,11 +163,13 @@ def front_flop_split(sym: dict):
 
 
 def spread_partition(sym: dict, nranks: int, oversub: int = 4, min_share: float = 0.02, min_panels_per_rank: int = 4,
-                     min_cols: int = 256, min_flops: float = 5e10):
+                     min_cols: int = 256, min_flops: float = 0.0, min_step_flops: float = 2e10):
     """-> (owner[nf], phase[nf], span[nf]).  partition() plus shared fronts: a front of the top set of a group of R = 2^k
-    ranks whose flop bound is at least `min_share` of the whole tree's and `min_flops` (a panel step costs a message and a
-    handful of launches: below a few thousand columns that is more than the shared update saves), with at least `min_cols`
-    columns and `min_panels_per_rank` panels per rank, is shared by the ranks [owner, owner + R) (span = R, else 1).  A shared front is
+    ranks whose flop bound is at least `min_share` of the whole tree's and `min_flops`, and at least `min_step_flops` per
+    panel step (every step costs a message, a stream synchronisation and a handful of launches -- a few hundred
+    microseconds through torch.distributed -- while a 5000-column front updates in ~150 us per step on one GPU: sharing pays
+    from roughly 25 000 columns upwards, i.e. for configs[4]'s root front, not for the xenon1 / sme3Dc stand-ins), with at
+    least `min_cols` columns and `min_panels_per_rank` panels per rank, is shared by the ranks [owner, owner + R) (span = R, else 1).  A shared front is
     alone in its phase: inside a group's top set the fronts are numbered in postorder and every shared front closes the
     stage before it, so children still never run later than their parents."""
     owner, level = _partition_levels(sym, nranks, oversub)
@@ -181,7 +183,7 @@ def spread_partition(sym: dict, nranks: int, oversub: int = 4, min_share: float 
         R = 1 << int(level[f])
         fn, fm = int(Rp[f + 1] - Rp[f]), int(Fm[f])
         npanels = (min(fn, fm) + NB - 1) // NB
-        if R > 1 and fl[f] >= max(min_share * total, min_flops) and fn >= min_cols and fm >= 64 and npanels >= min_panels_per_rank * R:
+        if R > 1 and fl[f] >= max(min_share * total, min_flops, min_step_flops * npanels) and fn >= min_cols and fm >= 64 and npanels >= min_panels_per_rank * R:
             span[f] = R
     stage = np.zeros(nf, I64)
     state = {}                            # (level, first rank of the group) -> [next stage, the current stage has fronts]

@@ -230,7 +230,7 @@ def test_shared_fronts_equal_unsharded(name, nranks, small, on_device):
     pkg.set_options(pair_update=0, big_front_cols=big)
     try:
         ref = pkg.qr_factorize(sym, g["in_Ap"], g["in_Ai"], g["in_Ax"], tol, ntol)
-        kw = dict(min_flops=0, min_share=0.01, min_cols=32, min_panels_per_rank=1) if small else {}
+        kw = dict(min_step_flops=0, min_share=0.01, min_cols=32, min_panels_per_rank=1) if small else dict(min_step_flops=0)
         owner, phase, span = sh.spread_partition(sym, nranks, **kw)
         assert int((span > 1).sum()) >= 1
         out = _run_ranks(pkg, sh, sym, g, tol, ntol, nranks, owner, phase, span, on_device)

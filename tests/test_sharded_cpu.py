@@ -59,7 +59,7 @@ def test_partition_properties(name, nranks):
         assert 0 < crit <= tot
 
 
-SPREAD_SMALL = dict(min_flops=0, min_share=0.01, min_cols=32, min_panels_per_rank=1)   # shared fronts on the small fixtures
+SPREAD_SMALL = dict(min_flops=0, min_step_flops=0, min_share=0.01, min_cols=32, min_panels_per_rank=1)   # shared fronts on the small fixtures
 
 
 @pytest.mark.parametrize("name", ["epb1", "syn_grid3d", "grid20_standin", "lns_3937", "c5mini_standin"])
@@ -71,7 +71,7 @@ def test_spread_partition_properties(name, nranks):
     sh = shard_mod()
     S = Symbolic(load_golden(name))
     sym = sym_dict(S)
-    small = {} if name == "c5mini_standin" else SPREAD_SMALL
+    small = dict(min_step_flops=0) if name == "c5mini_standin" else SPREAD_SMALL
     owner, phase, span = sh.spread_partition(sym, nranks, **small)
     parent, Child, Childp = sh.tree_arrays(sym)
     nf = S.nf
