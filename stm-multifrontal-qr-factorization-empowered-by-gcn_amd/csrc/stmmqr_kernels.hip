@@ -1429,7 +1429,12 @@ __device__ __forceinline__ void dev_tall_group(PanelShared &ps, const FrontSym &
     };
     int flushed = 0, jdone = SWT;
     lds_barrier();                                             // ps.stair
-    for (int j = 0; j < sw && !prev_done; j++) {
+    // (fully unrolled over the group's columns: column j works on the register columns j .. SWT-1 only -- no dot products or
+    //  updates of columns that have already been retired, no rotation of the register image; same operations on the live
+    //  columns in the same order, so the same bits as the rotating loop)
+#pragma unroll
+    for (int j = 0; j < SWT; j++) {
+        if (j >= sw || prev_done) continue;
         const int jp = c0 + j, k = k1 + jp;
         if (j == SWT / 2 && b + 1 < ns) {
             flush_cols(0, min(j, jdone)); flushed = j;
@@ -1457,15 +1462,15 @@ __device__ __forceinline__ void dev_tall_group(PanelShared &ps, const FrontSym &
 #pragma unroll
             for (int r = 0; r < RPT; r++) {
                 const int i = rb + tid + NTH * r;
-                const double xv = (i > g && i < t) ? a[r][0] * sg : 0.0;   // (one operand carries the magnitude guard)
+                const double xv = (i > g && i < t) ? a[r][j] * sg : 0.0;   // (one operand carries the magnitude guard)
 #pragma unroll
-                for (int x = 0; x < SWT; x++) part[x] += xv * a[r][x];
+                for (int x = j; x < SWT; x++) part[x - j] += xv * a[r][x];
             }
             const bool owner = (tid == g - rb);                // holds row g in a[0][.]  (g - rb < STM_NB <= NTH)
             const int tpar = par;
             if (owner) {
 #pragma unroll
-                for (int x = 0; x < SWT; x++) ps.top[tpar][x] = a[0][x];
+                for (int x = j; x < SWT; x++) ps.top[tpar][x - j] = a[0][x];
             }
             TCY(1);
             block_reduce8<NTH>(ps, par, part, sum);
@@ -1484,20 +1489,20 @@ __device__ __forceinline__ void dev_tall_group(PanelShared &ps, const FrontSym &
             TCY(3);
             double w[8];
 #pragma unroll
-            for (int x = 1; x < SWT; x++) w[x] = tau * (ps.top[tpar][x] + scals * sum[x]);    // 0 unless upd
+            for (int x = 1; x < SWT - j; x++) w[x] = tau * (ps.top[tpar][x] + scals * sum[x]);    // 0 unless upd
 #pragma unroll
             for (int r = 0; r < RPT; r++) {
                 const int i = rb + tid + NTH * r;
                 const bool act = (i > g && i < t);
-                const double v = act ? a[r][0] * scal : 0.0;    // (upd false: the entries are zero already, or dead)
-                a[r][0] = act ? v : ((dead && i >= g) ? 0.0 : a[r][0]);
+                const double v = act ? a[r][j] * scal : 0.0;    // (upd false: the entries are zero already, or dead)
+                a[r][j] = act ? v : ((dead && i >= g) ? 0.0 : a[r][j]);
 #pragma unroll
-                for (int x = 1; x < SWT; x++) a[r][x] -= w[x] * v;
+                for (int x = j + 1; x < SWT; x++) a[r][x] -= w[x - j] * v;
             }
             if (owner) {
 #pragma unroll
-                for (int x = 1; x < SWT; x++) a[0][x] -= w[x];
-                a[0][0] = dead ? 0.0 : beta;
+                for (int x = j + 1; x < SWT; x++) a[0][x] -= w[x - j];
+                a[0][j] = dead ? 0.0 : beta;
             }
             if (tid == 0) {          // (flushed to global memory before each publish: flush_cols below)
                 ps.st_out[j] = dead ? 0 : t; ps.tau[j] = tau; ps.diag[j] = dead ? STM_BIGROW : g; ps.dead[j] = dead ? 1 : 0;
@@ -1512,16 +1517,13 @@ __device__ __forceinline__ void dev_tall_group(PanelShared &ps, const FrontSym &
             if (k == npiv - 1) rank = g;                       // (:1604-1608) also taken on a dead last pivot
             TCY(4);
         }
-        // ---- retire register column 0 to F and rotate ----
+        // ---- retire register column j to F ----
         {
             double *dst = F + (long long)k * ld;
 #pragma unroll
             for (int r = 0; r < RPT; r++) {
                 const int i = rb + tid + NTH * r;
-                if (i < tmax) st_agent(&dst[i], a[r][0]);       // write-through: read by the other groups of this launch
-#pragma unroll
-                for (int x = 0; x + 1 < SWT; x++) a[r][x] = a[r][x + 1];
-                a[r][SWT - 1] = 0.0;
+                if (i < tmax) st_agent(&dst[i], a[r][j]);       // write-through: read by the other groups of this launch
             }
         }
         TCY(5);
@@ -1657,6 +1659,235 @@ __global__ __launch_bounds__(NT) void k_front_wg(DevCtx c, const int *__restrict
 }
 
 // ------------------------------------------------------------------------------------------------
+// Wave-pipelined panel (short panels: at most STM_WP_ROWS rows).  ONE workgroup, one WAVE per group of WP_SW columns,
+// every wave holds all the rows of its columns in registers (lane l: rows rb + l + 64 r).  The column step of qr_front
+// (SparseQR_factorize.c:1434-1609: dlarfg, dlarf on the rest of the group) then needs no workgroup barrier and no LDS
+// round trip: the 8 sums of a step are one DPP reduction inside the wave.  Finished columns go to an image of the panel
+// in LDS; the waves after the owner apply them (dlarf, one wave reduction each) as they appear -- the hand-off is an LDS
+// flag per column (release / acquire at workgroup scope), polled by the consumer.  A wave only ever waits for waves
+// before it, all of them resident in the same workgroup: no bounded waits, no global-memory flags.
+// Which panels come here is decided from the front's own rows when the panel starts (k_panel, mode 2), so the results
+// do not depend on the fronts that share the step or the device.
+// ------------------------------------------------------------------------------------------------
+#define WP_SW 4                          // columns per wave: 8 waves = the 512 threads of k_panel
+struct WaveShared {
+    int ready[STM_NB];                   // column j of the panel is in the LDS image, its scalars below are valid
+    int d[STM_NB], t[STM_NB];            // unit-diagonal row of reflector j (STM_BIGROW: none) / one past its last row
+    double tau[STM_NB];
+    // the scalars that travel along the chain of columns: state AFTER the last finished column
+    int g, rank, done, tlast, nlive, jdone;
+    long long iflops, ilen;
+};
+
+template <int RPT>
+__device__ __forceinline__ void dev_wave_panel(PanelShared &ps, WaveShared &wsh, const FrontSym &s, FrontNum *num, PanelDesc *pd,
+                                               double *F, int *St, double *Tau, char *Rdead, int p, int g1, int tmax, double tol,
+                                               int ntol_global, double *Tout, double *lds, double *Tkeep, int defer_ok,
+                                               const double *sigp)
+{
+    constexpr int SW = WP_SW, NTH = 64 * (STM_NB / WP_SW), RS = 64 * RPT;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int m = num->fm, n = s.fn, npiv = s.fp;
+    const long long ld = s.ld;
+    const int k1 = p * STM_NB, k2 = min(n, k1 + STM_NB), nbp = k2 - k1;
+    const int c0 = SW * w, sw = max(0, min(SW, nbp - c0));
+    const int rb = g1;
+    const double flops_before = num->flops;
+    if (tid < STM_NB) {
+        wsh.ready[tid] = 0; wsh.d[tid] = STM_BIGROW; wsh.t[tid] = 0; wsh.tau[tid] = 0.0;
+        ps.stair[tid] = (tid < nbp) ? St[k1 + tid] : 0;
+        ps.st_out[tid] = 0; ps.dead[tid] = 0;
+    }
+    if (tid == 0) {
+        wsh.g = g1; wsh.rank = num->rank; wsh.done = 0; wsh.tlast = g1; wsh.nlive = 0; wsh.jdone = STM_NB;
+        wsh.iflops = 0; wsh.ilen = 0;
+    }
+    double a[RPT][SW];
+#pragma unroll
+    for (int x = 0; x < SW; x++) {
+        const double *src = F + (long long)(k1 + c0 + min(x, max(sw, 1) - 1)) * ld;
+#pragma unroll
+        for (int r = 0; r < RPT; r++) {
+            const int i = rb + lane + 64 * r;
+            const double val = src[min(i, tmax - 1)];
+            a[r][x] = (x < sw && i < tmax) ? val : 0.0;
+        }
+    }
+    __syncthreads();
+    auto wait_col = [&](int j) {
+        while (__hip_atomic_load(&wsh.ready[j], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) == 0) __builtin_amdgcn_s_sleep(1);
+    };
+    const int ntol = min(ntol_global - s.col1, npiv);
+    const double sg = sigp ? sigp[0] : 1.0, isg = sigp ? sigp[1] : 1.0;
+    if (sw > 0) {
+        // ---- the reflectors of the waves before mine, one dlarf each, as they appear ----
+        for (int j = 0; j < c0; j++) {
+            wait_col(j);
+            const double tau = wsh.tau[j];
+            const int d = wsh.d[j];
+            if (tau == 0.0 || d >= STM_BIGROW) continue;
+            const double *vs = lds + j * RS;
+            double v[RPT], pv[8];
+#pragma unroll
+            for (int x = 0; x < 8; x++) pv[x] = 0.0;
+#pragma unroll
+            for (int r = 0; r < RPT; r++) {
+                const int i = rb + lane + 64 * r;
+                const double val = vs[lane + 64 * r];           // (rows beyond a column's staircase are zero)
+                v[r] = (i < d) ? 0.0 : ((i == d) ? 1.0 : val);
+#pragma unroll
+                for (int x = 0; x < SW; x++) pv[x] += v[r] * a[r][x];
+            }
+            const double rw = wave_reduce8(pv);
+            double wv[SW];
+            wv[0] = tau * lane_bcast<red8_lane(0)>(rw); wv[1] = tau * lane_bcast<red8_lane(1)>(rw);
+            wv[2] = tau * lane_bcast<red8_lane(2)>(rw); wv[3] = tau * lane_bcast<red8_lane(3)>(rw);
+#pragma unroll
+            for (int r = 0; r < RPT; r++) {
+#pragma unroll
+                for (int x = 0; x < SW; x++) a[r][x] -= wv[x] * v[r];
+            }
+        }
+        if (c0 > 0) wait_col(c0 - 1);                            // (a skipped reflector above was still waited for)
+        int g = wsh.g, rank = wsh.rank, done = wsh.done, tlast = wsh.tlast, nlive = wsh.nlive, jdone = wsh.jdone;
+        long long iflops = wsh.iflops, ilen = wsh.ilen;
+        // ---- my columns ----
+#pragma unroll
+        for (int x = 0; x < SW; x++) {
+            if (x >= sw) continue;
+            const int jp = c0 + x, k = k1 + jp;
+            if (!done && g >= m) {
+                // no rows left: remaining pivotal columns are dead, remaining columns are empty (:1444-1458)
+                for (int kk = k + lane; kk < n; kk += 64) {
+                    if (kk < npiv) { Rdead[kk] = (char)1; St[kk] = 0; }
+                    else St[kk] = m;
+                    Tau[kk] = 0.0;
+                }
+                for (int jj = jp + lane; jj < STM_NB; jj += 64) pd->pdiag[jj] = STM_BIGROW;
+                done = 1;
+                jdone = jp;
+            }
+            if (!done) {
+                const int t = max(g + 1, ps.stair[jp]);
+                double part[8];
+#pragma unroll
+                for (int e = 0; e < 8; e++) part[e] = 0.0;
+#pragma unroll
+                for (int r = 0; r < RPT; r++) {
+                    const int i = rb + lane + 64 * r;
+                    const double xv = (i > g && i < t) ? a[r][x] * sg : 0.0;   // (one operand carries the magnitude guard)
+#pragma unroll
+                    for (int y = x; y < SW; y++) part[y - x] += xv * a[r][y];
+                }
+                const double rw = wave_reduce8(part);
+                const double sum0 = lane_bcast<red8_lane(0)>(rw), sum1 = lane_bcast<red8_lane(1)>(rw);
+                const double sum2 = lane_bcast<red8_lane(2)>(rw), sum3 = lane_bcast<red8_lane(3)>(rw);
+                const double sum[4] = {sum0, sum1, sum2, sum3};
+                const int ol = g - rb;                            // lane that holds row g in a[0][.]  (g - rb < STM_NB)
+                double top[SW];
+#pragma unroll
+                for (int y = x; y < SW; y++)
+                    top[y - x] = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(a[0][y]), ol),
+                                                  __builtin_amdgcn_readlane(__double2loint(a[0][y]), ol));
+                const double alpha = top[0], ss = sum[0];
+                double bb, tau0, scal0, scals0;
+                stm_larfg_guarded(alpha, ss, sg, isg, bb, tau0, scal0, scals0);
+                const bool ident = (ss == 0.0);
+                const double beta = ident ? alpha : bb;
+                const bool dead = (k < ntol) && (fabs(beta) <= tol);    // (:1495-1544) column zeroed, g does not advance
+                const bool upd = !ident && !dead;
+                const double tau = upd ? tau0 : 0.0;
+                const double scal = upd ? scal0 : 0.0, scals = upd ? scals0 : 0.0;
+                double wv[SW];
+#pragma unroll
+                for (int y = 1; y < SW - x; y++) wv[y] = tau * (top[y] + scals * sum[y]);     // 0 unless upd
+#pragma unroll
+                for (int r = 0; r < RPT; r++) {
+                    const int i = rb + lane + 64 * r;
+                    const bool act = (i > g && i < t);
+                    const double v = act ? a[r][x] * scal : 0.0;
+                    a[r][x] = act ? v : ((dead && i >= g) ? 0.0 : a[r][x]);
+#pragma unroll
+                    for (int y = x + 1; y < SW; y++) a[r][y] -= wv[y - x] * v;
+                }
+                if (lane == ol) {
+#pragma unroll
+                    for (int y = x + 1; y < SW; y++) a[0][y] -= wv[y - x];
+                    a[0][x] = dead ? 0.0 : beta;
+                }
+                if (lane == 0) {
+                    ps.st_out[jp] = dead ? 0 : t; ps.tau[jp] = tau; ps.diag[jp] = dead ? STM_BIGROW : g; ps.dead[jp] = dead ? 1 : 0;
+                    wsh.tau[jp] = tau; wsh.d[jp] = dead ? STM_BIGROW : g; wsh.t[jp] = t;
+                }
+                if (!dead) {
+                    iflops += (long long)(t - g) * (3 + 4 * (long long)(n - k - 1));
+                    ilen += (t - g);
+                    nlive += (tau != 0.0);
+                    tlast = t;
+                    g++;
+                }
+                if (k == npiv - 1) rank = g;                       // (:1604-1608) also taken on a dead last pivot
+            }
+            // ---- the column goes to F and, for the waves after mine, to the LDS image ----
+            {
+                double *dst = F + (long long)k * ld;
+                double *vs = lds + jp * RS;
+#pragma unroll
+                for (int r = 0; r < RPT; r++) {
+                    const int i = rb + lane + 64 * r;
+                    if (i < tmax) dst[i] = a[r][x];
+                    vs[lane + 64 * r] = a[r][x];
+                }
+            }
+            if (x == sw - 1 || done) {
+                // hand the chain to the next wave (after my last column; at once when the rows ran out: the columns after this
+                // one carry no reflector, their owners only store)
+                if (lane == 0) {
+                    wsh.g = g; wsh.rank = rank; wsh.done = done; wsh.tlast = tlast; wsh.nlive = nlive; wsh.jdone = jdone;
+                    wsh.iflops = iflops; wsh.ilen = ilen;
+                }
+            }
+            if (lane == 0) {
+                __hip_atomic_store(&wsh.ready[jp], 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
+        }
+    }
+    __syncthreads();
+    // ---- bookkeeping of the panel (what the last column group of the pipeline does) ----
+    const int g = wsh.g, tlast = wsh.tlast, jdone = wsh.jdone, done = wsh.done;
+    const double lensum = (double)wsh.ilen;
+    if (tid < min(nbp, jdone)) {
+        const int kk = k1 + tid;
+        St[kk] = ps.st_out[tid]; Tau[kk] = ps.tau[tid]; pd->pdiag[tid] = ps.diag[tid];
+        if (ps.dead[tid]) Rdead[kk] = (char)1;
+    }
+    const int defer_t = (defer_ok && k2 < n && tlast > g1) ? 1 : 0;   // (as dev_tall_group: T of a panel with trailing columns
+                                                                      //  is built by the update that follows)
+    if (tid == 0) {
+        num->g = g; num->rank = wsh.rank; num->done = done;
+        num->flops = flops_before + (double)wsh.iflops;
+        pd->sg[0] = g1; pd->st[0] = tlast; pd->pt = tlast; pd->nlive = wsh.nlive; pd->lensum = lensum;
+        pd->done_group = done ? 0 : -1;
+        pd->t_deferred = defer_t;
+        pd->pk1 = k1; pd->pnb = nbp; pd->pc0 = k2;
+        num->flops_upd += 4.0 * (double)(n - k2) * lensum;
+    }
+    if (defer_t) return;
+    __syncthreads();                                               // pdiag / Tau / F of this workgroup: visible to all its threads
+    if (tid < STM_NB) {
+        ps.diag[tid] = (tid < nbp) ? pd->pdiag[tid] : STM_BIGROW;  // (columns past a `done` point were reset there)
+        ps.tau[tid] = (tid < nbp) ? Tau[k1 + tid] : 0.0;
+    }
+    __syncthreads();
+    dev_gram_T<NTH>(F + (long long)k1 * ld, ld, g1, tlast, nbp, ps.diag, ps.tau, ps.G, ps.T, Tout, lds);
+    if (Tkeep)
+        for (int e = tid; e < STM_NB * STM_NB; e += NTH) {
+            const int ai = e % STM_NB, bi = e / STM_NB;
+            Tkeep[e] = (ai < nbp && bi < nbp && ai <= bi) ? ps.T[ai][bi] : 0.0;
+        }
+}
+
+// ------------------------------------------------------------------------------------------------
 // large fronts: panel and trailing update are separate launches (many workgroups per update)
 // ------------------------------------------------------------------------------------------------
 #define NTP 512               // threads of the large-front panel kernel (8 waves, <= 256 VGPRs each)
@@ -1665,6 +1896,7 @@ __global__ __launch_bounds__(NTP) void k_panel(DevCtx c, const int *__restrict__
 {
     extern __shared__ double dyn_lds[];
     __shared__ PanelShared ps;
+    __shared__ WaveShared wsh;
     const int f = flist[blockIdx.x];
     const int p = plist[blockIdx.x];                           // every front of a step is at its own panel
     __builtin_amdgcn_s_setprio(3);                             // (critical path: ahead of the side stream's update waves)
@@ -1699,6 +1931,11 @@ __global__ __launch_bounds__(NTP) void k_panel(DevCtx c, const int *__restrict__
             // image, or needs more groups than were launched: more rows than the full-rank estimate)
             // (the groups the PLAN launches for this front -- not the launch's, which other fronts may have raised)
             mode = (was_done || tmax - g1 > STM_TALL_MAX || (nbp + w - 1) / w > min(nsub, stm_tall_launches(s, p, c.tall_min))) ? 0 : 1;
+            // mode 2: a short panel -- this workgroup alone, a wave per 4 columns (dev_wave_panel).  Both conditions belong to
+            // the front: its rows now, and its symbolic row estimate (the host sized the launch's LDS by it)
+            if (mode == 1 && tmax - g1 <= STM_WP_ROWS && stm_panel_rows_est(s, p) <= STM_WP_ROWS && !(c.dbg & 16384) &&
+                STM_NB * 64 * ((tmax - g1 + 63) / 64) <= lds_doubles)
+                mode = 2;
             __syncthreads();
             if (threadIdx.x == 0) {
                 st_agent(&pd->mode, mode); st_agent(&pd->pg1, g1); st_agent(&pd->pt, g1); st_agent(&pd->tmax, tmax);
@@ -1711,6 +1948,15 @@ __global__ __launch_bounds__(NTP) void k_panel(DevCtx c, const int *__restrict__
             if (!wait_progress(&num->hdr, p + 1)) { if (threadIdx.x == 0) st_agent(&num->perr, 1); return; }
             mode = ld_agent(&pd->mode); g1 = ld_agent(&pd->pg1); tmax = ld_agent(&pd->tmax); w = ld_agent(&pd->sw);
             if (mode != 1 || b * w >= nbp) return;
+        }
+        if (mode == 2) {
+            const int rows = tmax - g1;
+#define WAVE_ARGS ps, wsh, s, num, pd, F, St, c.Tau + s.rp, c.Rdead + s.col1, p, g1, tmax, c.tol, c.ntol, T, dyn_lds, Tkeep, defer_ok, c.sig
+            if (rows <= 128) dev_wave_panel<2>(WAVE_ARGS);
+            else if (rows <= 256) dev_wave_panel<4>(WAVE_ARGS);
+            else dev_wave_panel<8>(WAVE_ARGS);
+#undef WAVE_ARGS
+            return;
         }
         if (mode == 1) {
             const int rows = tmax - g1;
