@@ -323,6 +323,55 @@ int ensure_device(int device)
 // contribution block is imported).  For every group the fronts are bucketed by tree level (leaves = 0, counted
 // inside the group), small ones first, large ones by decreasing panel count.  Everything is symbolic.
 // ------------------------------------------------------------------------------------------------
+// Offsets of the fronts (F arena) and of the packed contribution blocks (C arena) for the CURRENT groups: a front gets room
+// in F when it is factorized here (group >= 0), a contribution block when its front is factorized here or arrives here
+// (stmmqr_plan_import_front: a child of one of this plan's fronts).  One rank of a sharded run holds its subtrees and the
+// fronts above them that it owns or shares, not the whole tree.  (Every front keeps its F until the factors are packed at the
+// end of the factorization: stmmqr_factorize_finish.)
+void assign_arenas(stmmqr_plan &P)
+{
+    long long foff = 0, coff = 0;
+    std::vector<char> needc((size_t)std::max(1L, P.nf), 0);
+    for (long f = 0; f < P.nf; f++) {
+        if (P.group[f] < 0) continue;
+        needc[(size_t)f] = 1;
+        for (long q = P.Childp[f]; q < P.Childp[f + 1]; q++) needc[(size_t)P.Child[q]] = 1;
+    }
+    for (long kf = 0; kf < P.nf; kf++) {
+        const long f = P.Post[kf];
+        FrontSym &s = P.fs[f];
+        s.foff = 0; s.coff = 0;
+        if (P.group[f] >= 0) {
+            s.foff = foff;
+            foff += (long long)s.ld * s.fn;
+        }
+        if (needc[(size_t)f]) {
+            const long cn = s.fn - s.fp, fm = s.fm_ub;
+            const long cm = P.do_rank ? std::min(fm, cn) : std::min(std::max(fm - std::min(fm, (long)s.fp), 0L), cn);
+            s.coff = coff;
+            coff += (long long)cm * (cm + 1) / 2 + (long long)cm * (cn - cm);
+            coff = (coff + 1) & ~1LL;
+        }
+    }
+    P.farena = std::max(1LL, foff); P.carena = std::max(1LL, coff);
+}
+
+// the arenas themselves: (re)allocated when their size changed (first factorization of a plan, or after a regrouping)
+int ensure_arenas(stmmqr_plan &P)
+{
+    if (P.d_F.p && P.d_F.n == (size_t)P.farena && P.d_C.p && P.d_C.n == (size_t)P.carena) return 0;
+    HIPCHK(hipStreamSynchronize(P.stream));
+    if (P.d_F.n != (size_t)P.farena) P.d_F.release();
+    if (P.d_C.n != (size_t)P.carena) P.d_C.release();
+    size_t freeb = 0, totalb = 0;
+    HIPCHK(hipMemGetInfo(&freeb, &totalb));
+    const double need = 8.0 * ((P.d_F.p ? 0.0 : (double)P.farena) + (P.d_C.p ? 0.0 : (double)P.carena)) * 1.02;
+    if (need > 0.95 * (double)freeb) return fail(STMMQR_ERR_OUT_OF_MEMORY, "front arena does not fit in free HBM");
+    if (!P.d_F.p) LCHK(P.d_F.alloc((size_t)P.farena));
+    if (!P.d_C.p) LCHK(P.d_C.alloc((size_t)P.carena));
+    return 0;
+}
+
 void build_schedule(stmmqr_plan &P, std::vector<int> &tslot)
 {
     P.sched_gen++;
@@ -712,15 +761,10 @@ int build_plan(stmmqr_plan &P, const stmmqr_symbolic_view &v)
             s.qbig = (fm * fn >= qbig_min && fn >= 1) ? 1 : 0;
         }
         s.parent = (int)parent[f];
-        s.foff = foff;
-        foff += (long long)s.ld * fn;
-        const long cn = fn - fp;
-        const long cm = P.do_rank ? std::min(fm, cn) : std::min(std::max(fm - std::min(fm, fp), 0L), cn);
-        s.coff = coff;
-        coff += (long long)cm * (cm + 1) / 2 + (long long)cm * (cn - cm);
-        coff = (coff + 1) & ~1LL;
+        s.foff = 0; s.coff = 0;                                    // (assign_arenas, once the groups are known)
     }
-    P.farena = foff; P.carena = coff; P.tpanels = tpan_total;
+    (void)foff; (void)coff;
+    P.tpanels = tpan_total;
 
     // ---- relative indices (value independent): child column -> parent column, S entry -> front column ----
     std::vector<int> Rjrel(std::max(1L, v.rjsize), 0), Sjrel(std::max(1L, v.anz), 0), Sj0(std::max(1L, m), -1);
@@ -745,16 +789,18 @@ int build_plan(stmmqr_plan &P, const stmmqr_symbolic_view &v)
 
     // ---- level schedule: one group holding every front (multi-GPU callers regroup with set_groups) ----
     P.group.assign(nf, 0);
+    assign_arenas(P);
     std::vector<int> tslot;
     build_schedule(P, tslot);
 
     // ---- device memory ----------------------------------------------------------------------------
     size_t freeb = 0, totalb = 0;
     HIPCHK(hipMemGetInfo(&freeb, &totalb));
-    const double need = 8.0 * ((double)P.farena + (double)P.carena + 1024.0 * (double)P.tpanels) * 1.05 +
-                        64.0 * (double)(v.rjsize + v.anz);
+    // (the front and contribution-block arenas are allocated by the first factorization, ensure_arenas: a plan that is
+    //  regrouped for one rank of a sharded run never holds the whole tree's fronts)
+    const double need = 8.0 * 1024.0 * (double)P.tpanels * 1.05 + 64.0 * (double)(v.rjsize + v.anz);
     if (need > 0.92 * (double)freeb)
-        return fail(STMMQR_ERR_OUT_OF_MEMORY, "front arena does not fit in free HBM");
+        return fail(STMMQR_ERR_OUT_OF_MEMORY, "the plan's index arrays do not fit in free HBM");
     hipStream_t st = P.stream;
     auto up32 = [&](DevBuf<int> &d, const std::vector<long> &h) {
         std::vector<int> t(h.begin(), h.end());
@@ -763,8 +809,6 @@ int build_plan(stmmqr_plan &P, const stmmqr_symbolic_view &v)
     LCHK(P.d_fs.upload(P.fs, st));
     LCHK(P.d_fnum.alloc(std::max(1L, nf)));
     HIPCHK(hipMemsetAsync(P.d_fnum.p, 0, std::max(1L, nf) * sizeof(FrontNum), st));
-    LCHK(P.d_F.alloc((size_t)P.farena));
-    LCHK(P.d_C.alloc((size_t)P.carena));
     LCHK(P.d_T.alloc((size_t)2 * P.tslots * STM_NB * STM_NB));
     LCHK(P.d_Gp.alloc((size_t)P.tslots * (P.gp_slabs + 1) * STM_NB * STM_NB));
     LCHK(P.d_Tall.alloc((size_t)std::max(1LL, P.tpanels) * STM_NB * STM_NB));
@@ -796,10 +840,10 @@ int build_plan(stmmqr_plan &P, const stmmqr_symbolic_view &v)
     LCHK(P.d_Rhoff.alloc((size_t)v.rjsize));
     LCHK(P.d_Rboff.alloc((size_t)std::max(1L, nf)));
     LCHK(P.d_total.alloc(1));
-    LCHK(P.d_dbg.alloc(16));
+    LCHK(P.d_dbg.alloc(64));
     LCHK(P.d_amax.alloc(1));
     LCHK(P.d_sig.alloc(2));
-    HIPCHK(hipMemsetAsync(P.d_dbg.p, 0, 16 * sizeof(unsigned long long), st));
+    HIPCHK(hipMemsetAsync(P.d_dbg.p, 0, 64 * sizeof(unsigned long long), st));
     LCHK(P.d_Rdead.alloc((size_t)std::max(1L, n)));
     LCHK(P.d_lists.upload(P.lists, st));
     LCHK(P.d_wlists.upload(P.wlists, st));
@@ -838,6 +882,7 @@ int set_pattern(stmmqr_plan &P, const stm_long *Ap, const stm_long *Ai)
 int reset_factorization(stmmqr_plan &P)
 {
     hipStream_t st = P.stream;
+    LCHK(ensure_arenas(P));
     HIPCHK(hipMemsetAsync(P.d_F.p, 0, (size_t)P.farena * sizeof(double), st));
     HIPCHK(hipMemsetAsync(P.d_Rdead.p, 0, (size_t)std::max(1L, P.n), st));
     HIPCHK(hipMemsetAsync(P.d_fnum.p, 0, (size_t)std::max(1L, P.nf) * sizeof(FrontNum), st));
@@ -1420,8 +1465,10 @@ int stmmqr_factorize_finish(stmmqr_plan *plan, stmmqr_stats *stats)
     }
     bytes_asm += 8.0 * (double)P.anz + P.bytes_assemble_idx;
     if (getenv("STMMQR_DBG") && (atoi(getenv("STMMQR_DBG")) & 48)) {
-        unsigned long long hb[16];
+        unsigned long long hb[64];
         HIPCHK(hipMemcpy(hb, P.d_dbg.p, sizeof hb, hipMemcpyDeviceToHost));
+        fprintf(stderr, "[pipeline panels by actual rows] <=128 %llu  <=256 %llu  <=512 %llu  <=1024 %llu  <=2048 %llu  <=4096 %llu  more %llu;  of the <=512: %llu with a row estimate > 512\n",
+                hb[32], hb[33], hb[34], hb[35], hb[36], hb[37], hb[38], hb[39]);
         fprintf(stderr, "[panel cycles, summed over workgroups] stage-in+apply %llu  columns %llu  write-back %llu  - %llu  gram %llu\n",
                 hb[0], hb[1], hb[2], hb[3], hb[4]);
         fprintf(stderr, "[last group of the panel pipeline, cycles] load %llu  waits %llu  apply-loads %llu  applies %llu  factor %llu  gram %llu\n", hb[6],
@@ -1510,6 +1557,9 @@ int stmmqr_plan_set_groups(stmmqr_plan *plan, const int *group)
     // a captured schedule describes the old step lists and workspaces
     if (P.graph_exec) { (void)hipGraphExecDestroy(P.graph_exec); P.graph_exec = nullptr; }
     P.graph_nlaunch = 0;
+    assign_arenas(P);                                        // (the arenas follow at the next stmmqr_factorize_begin)
+    LCHK(P.d_fs.upload(P.fs, P.stream));
+    P.factored = false;                                      // (the factors of the old grouping live at the old offsets)
     std::vector<int> tslot;
     build_schedule(P, tslot);
     // workspaces only grow (a regrouping of the same tree usually needs what it needed before)

@@ -1933,9 +1933,16 @@ __global__ __launch_bounds__(NTP) void k_panel(DevCtx c, const int *__restrict__
             mode = (was_done || tmax - g1 > STM_TALL_MAX || (nbp + w - 1) / w > min(nsub, stm_tall_launches(s, p, c.tall_min))) ? 0 : 1;
             // mode 2: a short panel -- this workgroup alone, a wave per 4 columns (dev_wave_panel).  Both conditions belong to
             // the front: its rows now, and its symbolic row estimate (the host sized the launch's LDS by it)
+            // (the LDS test never fails for a launch sized by the host's rule, STM_NB * STM_WP_ROWS doubles whenever the estimate
+            //  is within STM_WP_ROWS: it keeps a smaller launch safe)
             if (mode == 1 && tmax - g1 <= STM_WP_ROWS && stm_panel_rows_est(s, p) <= STM_WP_ROWS && !(c.dbg & 16384) &&
-                STM_NB * 64 * ((tmax - g1 + 63) / 64) <= lds_doubles)
+                STM_NB * ((tmax - g1 <= 128) ? 128 : (tmax - g1 <= 256) ? 256 : 512) <= lds_doubles)
                 mode = 2;
+            if ((c.dbg & 16) && c.dbgbuf && threadIdx.x == 0 && !was_done) {       // diagnosis: panels by their actual rows
+                const int rws = tmax - g1;
+                atomicAdd(&c.dbgbuf[32 + (rws <= 128 ? 0 : rws <= 256 ? 1 : rws <= 512 ? 2 : rws <= 1024 ? 3 : rws <= 2048 ? 4 : rws <= 4096 ? 5 : 6)], 1ull);
+                if (rws <= 512 && stm_panel_rows_est(s, p) > STM_WP_ROWS) atomicAdd(&c.dbgbuf[39], 1ull);
+            }
             __syncthreads();
             if (threadIdx.x == 0) {
                 st_agent(&pd->mode, mode); st_agent(&pd->pg1, g1); st_agent(&pd->pt, g1); st_agent(&pd->tmax, tmax);

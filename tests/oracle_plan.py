@@ -17,6 +17,7 @@ class OraclePlan:
         self.S, self.orc, self.L = S, orc, orc.lib
         self.nf = S.nf
         self.group = np.zeros(S.nf, np.int32)
+        self.shared = np.zeros(S.nf, bool)
         L = self.L
         L.orc_fsize.restype = C.c_long
         L.orc_fsize.argtypes = [C.c_long] + [c_long_p] * 9
