@@ -57,8 +57,8 @@ struct PanelDesc {
 #define STM_TALL_MAX (16 * STM_TALL_NTH)  // rows a sub-panel can hold in registers (16 per thread)
 #define STM_TALL_WIDE (4 * STM_TALL_NTH)  // more rows than this: 4-column sub-panels (64 doubles of register image)
 #define STM_TALL_XWIDE (8 * STM_TALL_NTH) // more rows than this: 2-column sub-panels
-#define STM_WP_ROWS 512      // panels with at most this many rows (and a row estimate within it: the launch then carries the
-                             // LDS image of the panel, 32 x 512 doubles) are factorized by ONE workgroup, a wave per 4 columns
+#define STM_WP_ROWS 512      // panels whose staircase reaches at most this many rows are factorized by ONE workgroup, a wave per
+                             // 4 columns, with the panel's image in LDS (32 x 512 doubles: every pipeline launch carries it)
 #define STM_PROG 64          // FrontNum::prog advances by this much per panel (2 per column group + 1, <= 16 groups)
 
 // Does panel p of this front take the tall-panel pipeline?  Planned on the host (number of launches) and re-evaluated

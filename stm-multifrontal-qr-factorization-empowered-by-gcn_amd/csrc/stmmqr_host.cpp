@@ -632,8 +632,7 @@ void build_schedule(stmmqr_plan &P, std::vector<int> &tslot)
                 if (!stm_tall_panel(s, p, P.tall_min) && !stm_use_ca(s, p, g_opt.panel_algo, P.ca_min))
                     S.lds_plan = std::max(S.lds_plan, stm_front_lds(s));
                 // a short panel of the pipeline is taken by one workgroup with the panel's image in LDS (dev_wave_panel)
-                if (stm_tall_panel(s, p, P.tall_min) && !stm_use_ca(s, p, g_opt.panel_algo, P.ca_min) &&
-                    stm_panel_rows_est(s, p) <= STM_WP_ROWS)
+                if (stm_tall_panel(s, p, P.tall_min) && !stm_use_ca(s, p, g_opt.panel_algo, P.ca_min))
                     S.lds_plan = std::max(S.lds_plan, STM_NB * STM_WP_ROWS);
             }
             S.lds_big = (int)std::min((long)LDS_CAP_DOUBLES, (((maxfm_big + 63) & ~63L) | 1) * STM_NB + 64);

@@ -1931,11 +1931,13 @@ __global__ __launch_bounds__(NTP) void k_panel(DevCtx c, const int *__restrict__
             // image, or needs more groups than were launched: more rows than the full-rank estimate)
             // (the groups the PLAN launches for this front -- not the launch's, which other fronts may have raised)
             mode = (was_done || tmax - g1 > STM_TALL_MAX || (nbp + w - 1) / w > min(nsub, stm_tall_launches(s, p, c.tall_min))) ? 0 : 1;
-            // mode 2: a short panel -- this workgroup alone, a wave per 4 columns (dev_wave_panel).  Both conditions belong to
-            // the front: its rows now, and its symbolic row estimate (the host sized the launch's LDS by it)
-            // (the LDS test never fails for a launch sized by the host's rule, STM_NB * STM_WP_ROWS doubles whenever the estimate
-            //  is within STM_WP_ROWS: it keeps a smaller launch safe)
-            if (mode == 1 && tmax - g1 <= STM_WP_ROWS && stm_panel_rows_est(s, p) <= STM_WP_ROWS && !(c.dbg & 16384) &&
+            // mode 2: a short panel -- this workgroup alone, a wave per 4 columns (dev_wave_panel).  The condition belongs to
+            // the front: the rows its staircase reaches now (in a sparse front the first panels are far shorter than the front:
+            // 89 % of the pipeline panels of the xenon1 stand-in have at most 512 rows).  Measured and dropped: panels of up
+            // to 1024 rows with 16 rows per lane and a 16-column ring image in LDS (default workload 120.6 -> 154 ms).
+            // (the LDS test never fails for a launch sized by the host's rule, STM_NB * STM_WP_ROWS doubles for every launch with
+            //  a pipeline panel: it keeps a smaller launch safe)
+            if (mode == 1 && tmax - g1 <= STM_WP_ROWS && !(c.dbg & 16384) &&
                 STM_NB * ((tmax - g1 <= 128) ? 128 : (tmax - g1 <= 256) ? 256 : 512) <= lds_doubles)
                 mode = 2;
             if ((c.dbg & 16) && c.dbgbuf && threadIdx.x == 0 && !was_done) {       // diagnosis: panels by their actual rows

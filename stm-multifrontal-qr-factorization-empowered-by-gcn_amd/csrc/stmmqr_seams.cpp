@@ -193,8 +193,7 @@ stm_long stmmqr_front(stm_long m, stm_long n, stm_long npiv, double tol, stm_lon
             if (stm_use_ca(X.s, p, opt.panel_algo)) e = stm_launch_panel_ca(X.c, X.d_flist.p, d_pl.p + p, 1, stm_ca_slabs(X.s), defer_ok, nullptr);
             else {
                 // (as run_schedule: a short panel of the pipeline is taken by one workgroup with the panel's image in LDS)
-                const int lds = (stm_tall_panel(X.s, p, X.c.tall_min) && stm_panel_rows_est(X.s, p) <= STM_WP_ROWS)
-                                    ? std::max(lds_for(m), STM_NB * STM_WP_ROWS) : lds_for(m);
+                const int lds = stm_tall_panel(X.s, p, X.c.tall_min) ? std::max(lds_for(m), STM_NB * STM_WP_ROWS) : lds_for(m);
                 e = stm_launch_panel(X.c, X.d_flist.p, d_pl.p + p, 1, stm_tall_launches(X.s, p, X.c.tall_min), defer_ok, lds, nullptr);
             }
             if (e || ncb <= 0) continue;
