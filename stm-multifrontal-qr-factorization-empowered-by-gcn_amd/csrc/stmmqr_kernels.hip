@@ -1937,7 +1937,7 @@ __global__ __launch_bounds__(NTP) void k_panel(DevCtx c, const int *__restrict__
             // to 1024 rows with 16 rows per lane and a 16-column ring image in LDS (default workload 120.6 -> 154 ms).
             // (the LDS test never fails for a launch sized by the host's rule, STM_NB * STM_WP_ROWS doubles for every launch with
             //  a pipeline panel: it keeps a smaller launch safe)
-            if (mode == 1 && tmax - g1 <= STM_WP_ROWS && !(c.dbg & 16384) &&
+            if (!was_done && tmax - g1 <= STM_WP_ROWS && !(c.dbg & 16384) &&
                 STM_NB * ((tmax - g1 <= 128) ? 128 : (tmax - g1 <= 256) ? 256 : 512) <= lds_doubles)
                 mode = 2;
             if ((c.dbg & 16) && c.dbgbuf && threadIdx.x == 0 && !was_done) {       // diagnosis: panels by their actual rows
