@@ -163,7 +163,10 @@ typedef struct stmmqr_stats {
 typedef struct stmmqr_plan stmmqr_plan;     /* device-resident symbolic plan + arenas; reusable across calls */
 
 /* Build the device plan from the symbolic analysis (host work + one upload).  Returns NULL on error
- * (*status gets the code).  device < 0 selects the current HIP device. */
+ * (*status gets the code).  device < 0 selects the current HIP device.  The front and contribution-block arenas are
+ * sized from the fronts the plan factorizes, shares or imports (all of them until stmmqr_plan_set_groups says otherwise)
+ * and allocated by the first factorization: STMMQR_ERR_OUT_OF_MEMORY then comes from stmmqr_factorize_begin /
+ * stmmqr_factorize_device, and one rank of a sharded run never holds the whole tree. */
 stmmqr_plan *stmmqr_plan_create(const stmmqr_symbolic_view *sym, int device, int *status);
 void stmmqr_plan_destroy(stmmqr_plan *plan);
 
