@@ -236,6 +236,9 @@ int stmmqr_plan_import_front_cols(stmmqr_plan *plan, stm_long f, int part, int n
 /* off[0..fn]: start of each column of front f inside its packed R+H block (after stmmqr_factorize_finish) */
 int stmmqr_plan_front_rhoff(stmmqr_plan *plan, stm_long f, stm_long *off);
 
+/* device memory the plan holds right now, in bytes (what stmmqr_stats.device_bytes reports at the end of a factorization) */
+double stmmqr_plan_device_bytes(const stmmqr_plan *plan);
+
 /* out[0..1] = the reference's flop count of front f (FLOP_COUNT, SparseQR_factorize.c:1571) and the part of it done by
  * trailing updates: every plan of a shared front counts the whole front, the merge keeps one */
 int stmmqr_plan_front_flops(stmmqr_plan *plan, stm_long f, double *out);

@@ -139,6 +139,8 @@ lib.stmmqr_plan_export_front_cols.argtypes = [C.c_void_p, C.c_long, C.c_int, C.c
 lib.stmmqr_plan_import_front_cols.argtypes = [C.c_void_p, C.c_long, C.c_int, C.c_int, C.c_void_p, C.c_int]
 lib.stmmqr_plan_front_rhoff.argtypes = [C.c_void_p, C.c_long, c_long_p]
 lib.stmmqr_plan_front_flops.argtypes = [C.c_void_p, C.c_long, c_double_p]
+lib.stmmqr_plan_device_bytes.argtypes = [C.c_void_p]
+lib.stmmqr_plan_device_bytes.restype = C.c_double
 lib.stmmqr_plan_solve.argtypes = [C.c_void_p, c_double_p, C.c_long, c_double_p, C.c_long, C.c_long]
 lib.stmmqr_get_options.argtypes = [C.POINTER(Options)]
 lib.stmmqr_set_options.argtypes = [C.POINTER(Options)]
@@ -383,6 +385,9 @@ class HipQR:
         off = np.zeros(int(fn) + 1, I64)
         _check(lib.stmmqr_plan_front_rhoff(self._h, int(f), _ip(off)), "stmmqr_plan_front_rhoff")
         return off
+
+    def device_bytes(self) -> float:
+        return float(lib.stmmqr_plan_device_bytes(self._h))
 
     def front_flops(self, f):
         """-> (reference flop count of front f, the part done by trailing updates) of the factorization in progress / held"""

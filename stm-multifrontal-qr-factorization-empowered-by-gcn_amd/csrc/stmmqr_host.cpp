@@ -1786,6 +1786,9 @@ int stmmqr_plan_front_rhoff(stmmqr_plan *plan, stm_long f, stm_long *off)
     return 0;
 }
 
+/* device memory held by the plan right now (bytes): arenas, factors, workspaces, index arrays */
+double stmmqr_plan_device_bytes(const stmmqr_plan *plan) { return plan ? plan->device_bytes() : 0.0; }
+
 /* out[0..1] = flops, flops of the trailing updates of front f (read from the device: valid once its panels are done) */
 int stmmqr_plan_front_flops(stmmqr_plan *plan, stm_long f, double *out)
 {

@@ -287,3 +287,32 @@ def test_step_interface_refusals():
     p.run_group(0)
     p.finish()
     p.close()
+
+
+def test_rank_arenas_hold_only_its_fronts():
+    """the front / contribution-block arenas follow the plan's groups (assign_arenas, allocated by the first
+    stmmqr_factorize_begin): every rank of a 4-way partition of the sme3Dc stand-in holds less device memory than the unsharded
+    plan, and the four together not much more than it (every front once + the imported contribution blocks + per-plan
+    index arrays and workspaces)"""
+    pkg = importlib.import_module(PKG)
+    sh = importlib.import_module(PKG + ".sharded")
+    g = load_golden("sme3dc_standin")
+    S = Symbolic(g)
+    sym = {**S.sc, **{k: v for k, v in S.arr.items() if v is not None}}
+    tol, ntol = scalar(g, "in_tol"), int(scalar(g, "in_ntol"))
+    one = pkg.HipQR(sym)
+    before = one.device_bytes()
+    one.begin(g["in_Ax"], tol, ntol, g["in_Ap"], g["in_Ai"])
+    whole = one.device_bytes()
+    one.close()
+    assert whole > before                                         # the arenas arrive with the first factorization
+    owner, phase = sh.partition(sym, 4)
+    held = []
+    for r in range(4):
+        p = pkg.HipQR(sym)
+        p.set_groups(np.where(owner == r, phase, -1).astype(np.int32))
+        p.begin(g["in_Ax"], tol, ntol, g["in_Ap"], g["in_Ai"])
+        held.append(p.device_bytes())
+        p.close()
+    assert max(held) < 0.8 * whole
+    assert sum(held) < 1.8 * whole
