@@ -245,6 +245,32 @@ def test_shared_fronts_equal_unsharded(name, nranks, small, on_device):
     np.testing.assert_array_equal(G.Stack[:G.rh_total], ref.Stack[:ref.rh_total])
 
 
+@pytest.mark.parametrize("opts", [dict(split_update=0), dict(fused_update=1), dict(lookahead=0), dict(panel_algo=1), dict(panel_algo=2)])
+def test_shared_fronts_under_other_options(opts):
+    """the column-block stride of a shared front in the other update forms (one workgroup per column block: split_update = 0;
+    the fused form must step aside for a stride) and with either panel kernel: still identical to one plan"""
+    pkg = importlib.import_module(PKG)
+    sh = importlib.import_module(PKG + ".sharded")
+    g = load_golden("grid20_standin")
+    S = Symbolic(g)
+    sym = {**S.sc, **{k: v for k, v in S.arr.items() if v is not None}}
+    tol, ntol = scalar(g, "in_tol"), int(scalar(g, "in_ntol"))
+    base = pkg.get_options()
+    pkg.set_options(pair_update=0, big_front_cols=16, **opts)
+    try:
+        ref = pkg.qr_factorize(sym, g["in_Ap"], g["in_Ai"], g["in_Ax"], tol, ntol)
+        owner, phase, span = sh.spread_partition(sym, 2, min_step_flops=0, min_share=0.01, min_cols=32, min_panels_per_rank=1)
+        assert int((span > 1).sum()) >= 1
+        out = _run_ranks(pkg, sh, sym, g, tol, ntol, 2, owner, phase, span, True)
+    finally:
+        pkg.set_options(**{k: base[k] for k in ("pair_update", "big_front_cols", *opts)})
+    G = sh.merge_shards(sym, [o[1] for o in out], ntol)
+    assert sum(o[0]["flops"] for o in out) == ref.stats["flops"]
+    for k in ("Hm", "Hr", "HStair", "HPinv", "Rdead", "Rblock_off", "Hii", "HTau"):
+        np.testing.assert_array_equal(getattr(G, k), getattr(ref, k), err_msg=k)
+    np.testing.assert_array_equal(G.Stack[:G.rh_total], ref.Stack[:ref.rh_total])
+
+
 def test_step_interface_refusals():
     """stmmqr_plan_set_groups refuses a shared front that is not alone in its group or not one of the large fronts;
     stmmqr_factorize_step refuses an unknown step and a zero stride"""
