@@ -1066,7 +1066,32 @@ int run_schedule(stmmqr_plan &P, bool detail, int grp, const StepReq *req = null
         P.stats.nlaunch += nlaunch;
         return e;
     }
+    // a step goes to the side stream when the update beyond block 0 is worth two cross-stream hand-offs (~25 us):
+    // STMMQR_LA_MIN tiles of 256 x 32 (default 2500)
+    const long la_min = getenv("STMMQR_LA_MIN") ? atol(getenv("STMMQR_LA_MIN")) : 2500;
+    // ... and when the panel workgroups of the step fit the compute units the side stream leaves alone (a wide step
+    // fills the GPU with panel workgroups by itself): STMMQR_LA_MAXPWG (default 48)
+    const long la_maxpwg = getenv("STMMQR_LA_MAXPWG") ? atol(getenv("STMMQR_LA_MAXPWG")) : 48;
+    auto worth_it = [&](const Step &S) -> bool {
+        long tiles = 0, pwg = 0;
+        for (int i = 0; i < S.n_act; i++) {
+            const FrontSym &fsym = P.fs[P.lists[S.act_off + i]];
+            const int p = P.lists[S.plist_off + i];
+            const int ncb = stm_upd_ncb(fsym, p);
+            if (ncb > 1) tiles += (long)(ncb - 1) * ((stm_panel_rows_est(fsym, p) + STM_UPD_SLAB - 1) / STM_UPD_SLAB);   // (expected rows, not the bound)
+            pwg += stm_use_ca(fsym, p, P.plan_algo, P.ca_min) ? stm_ca_slabs(fsym) : stm_tall_launches(fsym, p, P.tall_min);
+        }
+        return tiles >= la_min && pwg <= la_maxpwg && S.n_pe + S.n_po == 0;      // (pair-update steps stay on one stream)
+    };
+    // Look-ahead needs the device's side stream (a CU-masked stream, created once per process and released by an atexit
+    // handler): it is only created when some step of this group really goes there -- small matrices never touch it.
     bool la = g_opt.lookahead && !detail && !P.serial_panels && SV.size() > 1;
+    if (la) {
+        bool any = false;
+        for (const Step &S : SV)
+            if (S.n_act > 0 && S.maxcb > 1 && worth_it(S)) { any = true; break; }
+        la = any;
+    }
     if (la && !P.side) P.side = side_stream_for(P.device);
     la = la && P.side;
     if (!la) {
@@ -1095,23 +1120,6 @@ int run_schedule(stmmqr_plan &P, bool detail, int grp, const StepReq *req = null
                 v->push_back(ev);
             }
         hipStream_t sd = P.side;
-        // a step goes to the side stream when the update beyond block 0 is worth two cross-stream hand-offs (~25 us):
-        // STMMQR_LA_MIN tiles of 256 x 32 (default 2500)
-        const long la_min = getenv("STMMQR_LA_MIN") ? atol(getenv("STMMQR_LA_MIN")) : 2500;
-        // ... and when the panel workgroups of the step fit the compute units the side stream leaves alone (a wide step
-        // fills the GPU with panel workgroups by itself): STMMQR_LA_MAXPWG (default 48)
-        const long la_maxpwg = getenv("STMMQR_LA_MAXPWG") ? atol(getenv("STMMQR_LA_MAXPWG")) : 48;
-        auto worth_it = [&](const Step &S) -> bool {
-            long tiles = 0, pwg = 0;
-            for (int i = 0; i < S.n_act; i++) {
-                const FrontSym &fsym = P.fs[P.lists[S.act_off + i]];
-                const int p = P.lists[S.plist_off + i];
-                const int ncb = stm_upd_ncb(fsym, p);
-                if (ncb > 1) tiles += (long)(ncb - 1) * ((stm_panel_rows_est(fsym, p) + STM_UPD_SLAB - 1) / STM_UPD_SLAB);   // (expected rows, not the bound)
-                pwg += stm_use_ca(fsym, p, P.plan_algo, P.ca_min) ? stm_ca_slabs(fsym) : stm_tall_launches(fsym, p, P.tall_min);
-            }
-            return tiles >= la_min && pwg <= la_maxpwg && S.n_pe + S.n_po == 0;      // (pair-update steps stay on one stream)
-        };
         long side_ev = -1;                                     // last side event the main stream has not waited for
         bool prep_on_side = false;                             // prep(t) was issued on the side stream during step t-1
         int e = 0;
