@@ -1476,6 +1476,7 @@ int stmmqr_factorize_finish(stmmqr_plan *plan, stmmqr_stats *stats)
         HIPCHK(hipMemcpy(hb, P.d_dbg.p, sizeof hb, hipMemcpyDeviceToHost));
         fprintf(stderr, "[pipeline panels by actual rows] <=128 %llu  <=256 %llu  <=512 %llu  <=1024 %llu  <=2048 %llu  <=4096 %llu  more %llu;  of the <=512: %llu with a row estimate > 512\n",
                 hb[32], hb[33], hb[34], hb[35], hb[36], hb[37], hb[38], hb[39]);
+        fprintf(stderr, "[k_upd_w workgroups] launched %llu  with work %llu\n", hb[40], hb[41]);
         fprintf(stderr, "[panel cycles, summed over workgroups] stage-in+apply %llu  columns %llu  write-back %llu  - %llu  gram %llu\n",
                 hb[0], hb[1], hb[2], hb[3], hb[4]);
         fprintf(stderr, "[last group of the panel pipeline, cycles] load %llu  waits %llu  apply-loads %llu  applies %llu  factor %llu  gram %llu\n", hb[6],

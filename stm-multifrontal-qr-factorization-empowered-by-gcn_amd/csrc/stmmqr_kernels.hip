@@ -2080,6 +2080,12 @@ __global__ __launch_bounds__(NT) void k_upd_w(DevCtx c, const int *__restrict__ 
     // C = V, partial V'V per slab; the last slab workgroup of a front to arrive sums them in slab order and
     // builds T (dlarft recurrence) for k_upd_c
     const bool gram = with_gram && (cb == (int)gridDim.x - 1);
+    if ((c.dbg & 16) && c.dbgbuf && threadIdx.x == 0) {                  // diagnosis: launched / useful workgroups
+        atomicAdd(&c.dbgbuf[40], 1ull);
+        const int c0d = gram ? pd->pk1 : pd->pc0 + (cb0 + cb * (1 + c.cbskip)) * BN;
+        if (!((gram && !pd->t_deferred) || (!gram && cb0 + cb * (1 + c.cbskip) >= ncbf) || nbp <= 0 || mp <= 0 || c0d >= s.fn || sl * SLAB >= mp))
+            atomicAdd(&c.dbgbuf[41], 1ull);
+    }
     if (gram && !pd->t_deferred) return;
     if (!gram && cb0 + cb * (1 + c.cbskip) >= ncbf) return;
     const int c0 = gram ? pd->pk1 : pd->pc0 + (cb0 + cb * (1 + c.cbskip)) * BN;
