@@ -15,7 +15,7 @@ ROOT = Path(__file__).resolve().parent.parent
 PKG = "stm-multifrontal-qr-factorization-empowered-by-gcn_amd"
 
 
-def _worker(rank, world, port, name, q):
+def _worker(rank, world, port, name, q, spread=False):
     sys.path.insert(0, str(ROOT)); sys.path.insert(0, str(ROOT / "tests"))
     import os
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
@@ -34,8 +34,14 @@ def _worker(rank, world, port, name, q):
         tol, ntol = scalar(g, "in_tol"), int(scalar(g, "in_ntol"))
         plan = pkg.HipQR(sym, device=rank)
         comm = sh.Comm(dist, dev)
-        st, owner, phase = sh.factorize_sharded(plan, sym, g["in_Ax"], tol, ntol, comm, Ap=g["in_Ap"], Ai=g["in_Ai"])
-        G = sh.gather_numeric(plan, sym, comm, owner)
+        sp = None
+        if spread:
+            # heavy top fronts shared by the ranks of their group: panel messages device to device over RCCL
+            pkg.set_options(pair_update=0, big_front_cols=16)
+            owner, phase, span = sh.spread_partition(sym, world, min_step_flops=0, min_share=0.01, min_cols=32, min_panels_per_rank=1)
+            sp = sh.ShardPlan(plan, sym, owner, phase, comm, span)
+        st, owner, phase = sh.factorize_sharded(plan, sym, g["in_Ax"], tol, ntol, comm, Ap=g["in_Ap"], Ai=g["in_Ai"], shard_plan=sp)
+        G = sh.gather_numeric(plan, sym, comm, owner, shard_plan=sp)
         plan.close()
         if rank == 0:
             ref = pkg.qr_factorize(sym, g["in_Ap"], g["in_Ai"], g["in_Ax"], tol, ntol)
@@ -43,14 +49,15 @@ def _worker(rank, world, port, name, q):
             for k in ("Hm", "Hr", "HStair", "HPinv", "Rdead", "Rblock_off", "Hii", "HTau"):
                 ok = ok and np.array_equal(getattr(G, k), getattr(ref, k))
             ok = ok and np.array_equal(G.Stack[:G.rh_total], ref.Stack[:ref.rh_total])
-            q.put((bool(ok), len(sh.cross_edges(sym, owner, phase))))
+            q.put((bool(ok), len(sh.cross_edges(sym, owner, phase)), 0 if sp is None else int((sp.span > 1).sum())))
     finally:
         dist.barrier()
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("name,world", [("epb1", 2), ("grid20_standin", 2), ("grid20_standin", 4)])
-def test_real_hip_plans_over_rccl(name, world):
+@pytest.mark.parametrize("name,world,spread", [("epb1", 2, False), ("grid20_standin", 2, False), ("grid20_standin", 4, False),
+                                               ("grid20_standin", 2, True), ("grid20_standin", 4, True), ("lns_3937", 4, True)])
+def test_real_hip_plans_over_rccl(name, world, spread):
     import torch
     if torch.cuda.device_count() < world:
         pytest.skip(f"needs {world} GPUs")
@@ -58,11 +65,12 @@ def test_real_hip_plans_over_rccl(name, world):
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, name, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, name, q, spread)) for r in range(world)]
     for p in procs:
         p.start()
     for p in procs:
         p.join(600)
         assert p.exitcode == 0
-    ok, ncross = q.get(timeout=5)
+    ok, ncross, nshared = q.get(timeout=5)
     assert ok and ncross >= 1
+    assert nshared >= 1 or not spread
