@@ -307,15 +307,18 @@ double stmmqr_last_seam_ms(void);
  * STMMQR_PAIR_MIN (rows from which a front takes the pair update; 16384), STMMQR_LA_MIN / STMMQR_LA_MAXPWG (look-ahead:
  * tiles of trailing update from which a step is offloaded, 2500, and the most panel workgroups such a step may have, 48;
  * read per factorization), STMMQR_SIDE_RESERVE (compute units the side stream leaves alone; 32), STMMQR_DUMPSTEPS=file
- * (detail runs: one line per step with what ran and how long). */
+ * (detail runs: one line per step with what ran and how long); STMMQR_DBG bits of general use: 16 diagnosis counters printed
+ * by stmmqr_factorize_finish (panels by actual rows, launched / useful update workgroups, refresh rounds), 16384 no
+ * wave-pipelined panels (every short panel through the multi-workgroup pipeline). */
 typedef struct stmmqr_options {
     int panel_width;        /* Householder panel width on device (<= 32); reference FCHUNK = 32                    */
     int big_front_cols;     /* fronts with fn >= this use the multi-workgroup panel/update path                     */
     int verbose;
     int use_graph;          /* replay the level schedule as a hipGraph (captured per plan and tol); 0: no gain measured */
     int panel_algo;         /* panel of the large fronts: 1 the column pipeline (one workgroup reduction per column),
-                               2 the Gram-based panel (one Gram matrix per panel, any height), 0 (default) by panel
-                               height: Gram-based above 2048 rows, where the pipeline's register groups narrow      */
+                               2 the Gram-based panel (one Gram matrix per panel, any height), 0 (default) by the panel's
+                               estimated rows: Gram-based above 4096 (STMMQR_CA_MIN), the column pipeline below -- whose
+                               panels of at most 512 actual rows are taken by ONE workgroup, a wave per 4 columns     */
     int split_update;       /* row-parallel (2-launch) trailing update for fronts of >= 3 row slabs (1)             */
     int tall_min_rows;      /* panels with more rows than this run as a pipeline of column groups (plan time; 0)    */
     int lookahead;          /* 1 (default): the trailing update beyond the next panel's columns, the packing of finished
