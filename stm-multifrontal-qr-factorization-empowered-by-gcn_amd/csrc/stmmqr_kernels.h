@@ -34,7 +34,8 @@ struct DevCtx {
     long long *Rboff;          // [nf] offset of each packed R+H block
     double tol;
     int ntol;
-    unsigned long long *dbgbuf; // [8] phase cycle sums of the panel kernel (STMMQR_DBG bit 4), else unused
+    unsigned long long *dbgbuf; // [64] diagnosis counters (STMMQR_DBG bit 4: phase cycle sums of STAMPS builds, panels by actual rows,
+                                //  launched / useful update workgroups, refresh rounds), else unused
     int *abort;                 // set by the first bounded wait of the fused update that runs out: the others give up at once
     int tall_min;              // stmmqr_options::tall_min_rows at plan time (stm_tall_panel)
     int cbskip;                // update launches: workgroup x takes column block cb0 + x * (1 + cbskip) -- 0 everywhere except
@@ -46,6 +47,7 @@ struct DevCtx {
                                //  512 panel launches in chunks of env STMMQR_CHUNK fronts (default 1),
                                //  2048 column group (dbg >> 20) & 7 of every pipelined panel starts late (tests)
                                //  4096 every column group but the first gives up waiting at once (tests: recovery)
+                               //  16384 no wave-pipelined panels (short panels through the multi-workgroup pipeline too)
 };
 
 int stm_configure_kernels(void);
