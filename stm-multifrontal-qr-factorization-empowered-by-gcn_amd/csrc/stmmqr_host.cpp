@@ -157,6 +157,7 @@ struct stmmqr_plan {
     int gp_slabs = 1;                    // Gram-based panel: max slab workgroups of a front
     long long tpanels = 0;               // panels of all fronts: one kept T each (Q-apply on the resident factors)
     long long wp_doubles = 0;            // workspace of the row-parallel update (partial W blocks)
+    long long wp2_doubles = 0;           // ... of the side stream's copy: steps with pair-update fronts never go there
     bool pattern_set = false;
     double bytes_assemble_idx = 0;       // index bytes of the assembly (symbolic part of SURVEY 8d formula)
 
@@ -405,6 +406,7 @@ void build_schedule(stmmqr_plan &P, std::vector<int> &tslot)
     P.tslots = 1;
     P.gp_slabs = 1;
     P.wp_doubles = 0;
+    P.wp2_doubles = 0;
     for (int grp = 0; grp < ngroups; grp++) {
         // ---- tree levels (leaves = 0, counted inside the group): the order of the solves and of Q ----
         std::vector<int> level(nf, -1), start(nf, 0), end(nf, 0);
@@ -641,6 +643,7 @@ void build_schedule(stmmqr_plan &P, std::vector<int> &tslot)
             // by k_upd_w).  Either form gives the same bits.
             S.split = (S.maxsl >= 3 || ncbsum >= 512) ? 1 : 0;
             P.wp_doubles = std::max(P.wp_doubles, wp);
+            if (S.n_pe + S.n_po == 0) P.wp2_doubles = std::max(P.wp2_doubles, wp);
             // fronts at their last panel: packed at the end of the step, slot released for the next
             S.cpk_off = (int)P.lists.size();
             S.n_cpk = (int)ending[t].size();
@@ -812,7 +815,7 @@ int build_plan(stmmqr_plan &P, const stmmqr_symbolic_view &v)
     LCHK(P.d_Gp.alloc((size_t)P.tslots * (P.gp_slabs + 1) * STM_NB * STM_NB));
     LCHK(P.d_Tall.alloc((size_t)std::max(1LL, P.tpanels) * STM_NB * STM_NB));
     LCHK(P.d_Wp.alloc((size_t)P.wp_doubles));
-    LCHK(P.d_Wp2.alloc((size_t)P.wp_doubles));
+    LCHK(P.d_Wp2.alloc((size_t)std::max(1LL, P.wp2_doubles)));
     P.wcnt_n = (size_t)(P.wp_doubles / (STM_NB * 32) + 1);
     LCHK(P.d_wcnt.alloc(P.wcnt_n));
     LCHK(P.d_wcnt2.alloc(P.wcnt_n));
@@ -1575,7 +1578,7 @@ int stmmqr_plan_set_groups(stmmqr_plan *plan, const int *group)
     LCHK(grow(P.d_T, (size_t)2 * P.tslots * STM_NB * STM_NB));
     LCHK(grow(P.d_Gp, (size_t)P.tslots * (P.gp_slabs + 1) * STM_NB * STM_NB));
     LCHK(grow(P.d_Wp, (size_t)P.wp_doubles));
-    LCHK(grow(P.d_Wp2, (size_t)P.wp_doubles));
+    LCHK(grow(P.d_Wp2, (size_t)std::max(1LL, P.wp2_doubles)));
     P.wcnt_n = std::max(P.wcnt_n, (size_t)(P.wp_doubles / (STM_NB * 32) + 1));
     LCHK(grow(P.d_wcnt, P.wcnt_n));
     LCHK(grow(P.d_wcnt2, P.wcnt_n));
