@@ -1179,7 +1179,7 @@ int run_pack(stmmqr_plan &P)
     HIPCHK(hipMemcpyAsync(&total, P.d_total.p, sizeof(long long), hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
     P.rh_total = total;
-    if ((size_t)total > P.d_RH.n) LCHK(P.d_RH.alloc((size_t)(total + total / 8 + 1024)));
+    if ((size_t)total > P.d_RH.n) LCHK(P.d_RH.alloc((size_t)(total + total / 64 + 1024)));   // (a little room: a refactorization with other dead columns)
     LCHK(stm_launch_rh_copy(c, L0 + P.own_off, L0 + P.rh_parts_off, P.n_own, P.rh_maxparts, P.d_RH.p, st));
     P.stats.nlaunch += 3;
     return 0;
