@@ -87,6 +87,28 @@ def test_gram_panel_everywhere(pkg, oracle, monkeypatch, name, late):
 
 
 @pytest.mark.parametrize("name", NAMES)
+@pytest.mark.parametrize("late", [None, 1])
+def test_column_pipeline_everywhere(pkg, oracle, monkeypatch, name, late):
+    """STMMQR_DBG bit 14: no wave-pipelined panels -- every panel of every large front (fn >= 16 here) goes through the
+    multi-workgroup column pipeline, as before round 3 (the default now sends the short panels, 89 % of them on the xenon1
+    stand-in, to dev_wave_panel, so the small fixtures would hardly reach the pipeline otherwise).  late: column group 1 of every
+    panel starts ~1 ms late."""
+    g = load_golden(name)
+    pkg.set_options(panel_algo=1, big_front_cols=16)
+    monkeypatch.setenv("STMMQR_DBG", str(16384 + (0 if late is None else 2048 + (late << 20))))
+    try:
+        S, G = gpu_run(pkg, g)
+    finally:
+        monkeypatch.delenv("STMMQR_DBG")
+        pkg.set_options(panel_algo=0, big_front_cols=64)
+    N = numeric_from_gpu(S, G)
+    compare_integers(S, N, g)
+    assert G.stats["flops"] == scalar(g, "flopcount") and G.stats["retries"] == 0
+    No = oracle.factorize(S, g["in_Ap"], g["in_Ai"], g["in_Ax"], scalar(g, "in_tol"), int(scalar(g, "in_ntol")))
+    compare_numeric(oracle, S, G, No, g, ftol=1e-10, name=name)
+
+
+@pytest.mark.parametrize("name", NAMES)
 @pytest.mark.parametrize("bfc,algo", [(64, 0), (16, 0), (16, 2), (8, 1)])
 def test_lookahead_schedule_same_bits(pkg, name, bfc, algo):
     """options.lookahead (default 1): the update beyond the next panel's columns, the packing of finished fronts and the
