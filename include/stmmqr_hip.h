@@ -376,7 +376,7 @@ void stmmqr_analysis_free(stmmqr_analysis *a);
  * ordering: the reference's QR_ORDERING_* values (SparseQR_definitions.h:6-21): 0 FIXED, 1 NATURAL, 2 COLAMD, 3 GIVEN (Quser,
  * an extension: the reference's SparseQR has no such argument), 7 DEFAULT (= COLAMD as in the stock build); AMD (5), NESDIS (6),
  * METIS (10, 11) and the best-of strategies (4, 8, 9) are third-party packages in the reference and are refused here.
- * tol < 0: no rank detection.  relax: see stmmqr_analyze.  Bit-identical to the reference's Q1fill / P1inv / R1 / Y / qr_symbolic
+ * tol <= -2 (QR_DEFAULT_TOL): 20 (m + n) eps max_j |A(:,j)|_2 as the reference's qr_tol; -2 < tol < 0: no rank detection.  relax: see stmmqr_analyze.  Bit-identical to the reference's Q1fill / P1inv / R1 / Y / qr_symbolic
  * on the committed fixtures (tests/test_sparseqr_symbolic.py).
  * stmmqr_sparseqr_symbolic is the host half alone (no device), stmmqr_sparseqr_numeric the device half. */
 typedef struct stmmqr_qr stmmqr_qr;

@@ -16,6 +16,7 @@
 #include <sys/time.h>
 
 #include <algorithm>
+#include <cfloat>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
@@ -123,7 +124,24 @@ static int sparseqr_impl(int ordering, double tol, Long m, Long n, const Long *A
     const bool fill_reducing = (ordering == COLAMD);
     std::unique_ptr<stmmqr_qr> QR(new stmmqr_qr());
     QR->m = m; QR->n = n;
-    if (tol < 0) tol = -1;                                                                        // QR_NO_TOL (SparseQR.c:118-127)
+    if (tol <= -2) {
+        // QR_DEFAULT_TOL: 20 (m + n) eps max_j |A(:,j)|_2  (qr_tol / qr_maxcolnorm, SparseQR.c:126-130,1134-1144,1376-1420)
+        double mx = 0;
+        for (Long j = 0; j < n; j++) {
+            // (dnrm2's scaled form: the largest entry carries the magnitude)
+            double scale = 0, ssq = 1;
+            for (Long p = Ap[j]; p < Ap[j + 1]; p++) {
+                const double a = std::fabs(Ax[p]);
+                if (a == 0) continue;
+                if (scale < a) { ssq = 1 + ssq * (scale / a) * (scale / a); scale = a; }
+                else ssq += (a / scale) * (a / scale);
+            }
+            mx = std::max(mx, scale * std::sqrt(ssq));
+        }
+        tol = 20.0 * ((double)m + (double)n) * DBL_EPSILON * mx;
+        tol = std::min(tol, DBL_MAX);
+    }
+    if (tol < 0) tol = -1;                                                                        // QR_NO_TOL (SparseQR.c:131-135)
     QR->tol = tol;
     const double t_start = wall();
 

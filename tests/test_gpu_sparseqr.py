@@ -195,3 +195,33 @@ def test_standalone_driver(tmp_path, name, ordering):
     # an ordering that is not built here is refused with a message, not silently replaced
     out2 = subprocess.run([str(DRIVER), str(mtx), "1", "2"], capture_output=True, text=True, env=env, timeout=60, cwd=tmp_path)
     assert out2.returncode == 2 and "not built here" in out2.stderr
+
+
+def test_default_tolerance_is_the_references():
+    """tol = QR_DEFAULT_TOL (-2): 20 (m + n) eps max column norm (qr_tol, SparseQR.c:126-130,1134-1144), not "no rank
+    detection".  A 160 x 120 matrix with three duplicated columns and a zero column: the rank the compiled reference finds (116,
+    tests/golden/make_rankdef_golden.py), and the least-squares residual of the basic solution equals LAPACK's minimum."""
+    pkg = importlib.import_module(PKG)
+    d = np.load(ROOT / "tests" / "golden" / "api" / "rankdef_default_tol.npz")
+    m, n, Ap, Ai, Ax = int(d["m"]), int(d["n"]), d["Ap"], d["Ai"], d["Ax"]
+    Q = pkg.SparseQR(m, n, Ap, Ai, Ax, ordering=7, tol=-2.0, relax=pkg.relax_for_qr(n, int(Ap[-1])))
+    assert int(Q.info["rank"]) == int(d["ref_rank"]) == int(d["lapack_rank"])
+    import scipy.sparse as sp
+    A = sp.csc_matrix((Ax, Ai, Ap), shape=(m, n))
+    b = np.cos(0.3 * np.arange(m)) + 0.01 * np.arange(m)
+    x = Q.solve(1, Q.qmult(0, b))[:, 0]
+    xr, *_ = np.linalg.lstsq(A.toarray(), b, rcond=None)
+    r, rr = np.linalg.norm(A @ x - b), np.linalg.norm(A.toarray() @ xr - b)
+    assert abs(r - rr) <= 1e-10 * rr
+    Q.close()
+    # -2 < tol < 0 is QR_NO_TOL: no column is declared dead
+    Q = pkg.SparseQR(m, n, Ap, Ai, Ax, ordering=7, tol=-1.0, relax=pkg.relax_for_qr(n, int(Ap[-1])))
+    assert int(Q.info["rank"]) >= n - 1
+    Q.close()
+
+
+def test_random_matrices_against_lapack():
+    """tests/fuzz_sparseqr.py, fixed seed, a dozen small matrices of four kinds: rank, least-squares residual and solution of the
+    whole product path against dense LAPACK"""
+    import fuzz_sparseqr
+    assert fuzz_sparseqr.main(seed=3, iters=3, big=False) == 0
