@@ -227,6 +227,7 @@ struct stmmqr_plan {
         c.Rdead = d_Rdead.p; c.Cmap = d_Cmap.p; c.Cursor = d_Cursor.p; c.Rhoff = d_Rhoff.p; c.Rboff = d_Rboff.p;
         c.tol = last_tol; c.ntol = (int)last_ntol;
         c.dbg = getenv("STMMQR_DBG") ? atoi(getenv("STMMQR_DBG")) : 0;
+        c.tune = getenv("STMMQR_TUNE") ? atoi(getenv("STMMQR_TUNE")) : 0;
         if (serial_panels) c.dbg = (c.dbg & ~(2048 | 4096)) | 256;   // the one-workgroup LDS / in-place panel for every panel
         c.tall_min = tall_min;
         c.cbskip = 0;
@@ -1036,7 +1037,7 @@ int run_schedule(stmmqr_plan &P, bool detail, int grp, const StepReq *req = null
                 if (S.n_po > 0) {
                     LCHK(stm_launch_update_split(c, act + o, pl + o, S.n_po, 0, 1, S.maxsl_po, Wp, wl + o, wcnt, 1, q));
                     LCHK(stm_launch_update_pair(c, act + o, pl + o, S.n_po, S.maxcbp_po, S.maxsl_po, Wp, wl + o, wcnt, q));
-                    nlaunch += 4;
+                    nlaunch += 5;
                 }
             }
             return 0;

@@ -40,6 +40,8 @@ struct DevCtx {
     int tall_min;              // stmmqr_options::tall_min_rows at plan time (stm_tall_panel)
     int cbskip;                // update launches: workgroup x takes column block cb0 + x * (1 + cbskip) -- 0 everywhere except
                                //  when the trailing columns of a front are shared between plans (stmmqr_factorize_step)
+    int tune;                  // env STMMQR_TUNE, measurement sweeps only (0 = the shipped rules): bits 0-3 force 2^(x-1) slabs per
+                               //  workgroup of the pair update's kernels
     int dbg;                   // env STMMQR_DBG, ablations / cross-checks only: 1 no in-panel apply (LDS panel path),
                                //  2 no T, 4 no dlarf in the LDS sub-panel, 16/32 phase timers (-DSTMMQR_STAMPS builds),
                                //  64 in-place panel path, 128 no folded norms, 256 no panel pipeline (LDS panels only),

@@ -2532,6 +2532,12 @@ __device__ __forceinline__ void upd2_chunk_to_lds(const UpdChunk2 &ck, int i, in
 #define VS2 (RB + 4)
 typedef double d2v __attribute__((ext_vector_type(2)));
 
+// slabs of 256 rows one workgroup of the pair kernels takes (the pair's rows in slabs -> 1, 2 or 4)
+__device__ __forceinline__ int stm_pair_spw(int nsl, int tune)
+{
+    if (tune & 15) return 1 << ((tune & 15) - 1);
+    return (nsl >= 32) ? 4 : (nsl >= 16) ? 2 : 1;
+}
 // the two panel descriptions of a pair and what both kernels derive from them (uniform per workgroup)
 struct PairGeom { int g1, mp, mp1, mp2, nb1, nb2, k1a, k1b, pc0; };
 __device__ __forceinline__ bool pair_geom(const FrontNum *num, int p, PairGeom &G)
@@ -2569,6 +2575,12 @@ __global__ __launch_bounds__(NT) void k_upd_w2(DevCtx c, const int *__restrict__
     if (gram && G.nb2 <= 0) return;
     const int c0 = gram ? G.k1a : G.pc0 + cb * BN;
     if (c0 >= s.fn || sl * SLAB >= G.mp) return;
+    // A workgroup takes `spw` consecutive slabs of its column block (a property of the PANEL PAIR, like k_upd_c2's rule): its
+    // life is then 16 chunks instead of 4 behind the same descriptor chain, ticket and partial-W store (at one slab per workgroup
+    // those were most of a workgroup's 25 us for 3.4 us of MFMA work), and there are `spw` times fewer partials to add.
+    const int nsl = (G.mp + SLAB - 1) / SLAB;
+    const int spw = stm_pair_spw(nsl, c.tune);
+    if (sl % spw) return;
     const int nc = gram ? G.nb1 : min(BN, s.fn - c0);
     const long long ld = s.ld;
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, l15 = lane & 15, l4 = lane >> 4;
@@ -2584,7 +2596,7 @@ __global__ __launch_bounds__(NT) void k_upd_w2(DevCtx c, const int *__restrict__
     const double *V1g = Fb + (long long)G.k1a * ld, *V2g = Fb + (long long)G.k1b * ld, *Cg = Fb + (long long)c0 * ld;
     const int mi = wid >> 1, ni = wid & 1;
     d4 acc1 = {0, 0, 0, 0}, acc2 = {0, 0, 0, 0};
-    const int rend = min(G.mp, (sl + 1) * SLAB);
+    const int rend = min(G.mp, (sl + spw) * SLAB);
     UpdChunk2 ck;
     upd2_chunk_load(ck, V1g, V2g, Cg, ld, sl * SLAB + (tid & 63), G.mp, G.nb1, G.nb2, nc, tid >> 6);
     // The K index of an MFMA is a summation index: lane group l4 takes the rows 8 kk + 2 l4 and 8 kk + 2 l4 + 1 of a chunk for
@@ -2608,11 +2620,11 @@ __global__ __launch_bounds__(NT) void k_upd_w2(DevCtx c, const int *__restrict__
         }
         __syncthreads();
     }
-    // slot of (column block, slab): two blocks, W1 then W2; the Gram block is column block ncbp
-    const int nsl = (G.mp + SLAB - 1) / SLAB;
+    // slot of (column block, slab group): two blocks, W1 then W2; the Gram block is column block ncbp
+    const int ngrp = (nsl + spw - 1) / spw;
     double *W0 = Wp + wpoff[fi] + ((long long)(gram ? ncbp : cb) * nslf) * (2 * STM_NB * BN);
-    double *W = W0 + (long long)sl * (2 * STM_NB * BN);
-    if (nsl == 1) {
+    double *W = W0 + (long long)(sl / spw) * (2 * STM_NB * BN);
+    if (ngrp == 1) {
 #pragma unroll
         for (int r = 0; r < 4; r++) {
             W[(16 * mi + l4 + 4 * r) * BN + 16 * ni + l15] = acc1[r];
@@ -2630,26 +2642,92 @@ __global__ __launch_bounds__(NT) void k_upd_w2(DevCtx c, const int *__restrict__
     int *cnt = wcnt + wpoff[fi] / (STM_NB * BN) + (gram ? ncbp : cb);
     if (tid == 0) {
         s_ticket = __hip_atomic_fetch_add(cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (s_ticket == nsl - 1) {
+        if (s_ticket == ngrp - 1) {
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __hip_atomic_store(cnt, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
     __syncthreads();
-    if (s_ticket != nsl - 1) return;
+    if (s_ticket != ngrp - 1) return;
     double v[2 * STM_NB * BN / NT];
 #pragma unroll
-    for (int q = 0; q < 2 * STM_NB * BN / NT; q++) v[q] = stm_ordered_sum<true>(W0 + tid + q * NT, 2 * STM_NB * BN, nsl);   // fixed order
+    for (int q = 0; q < 2 * STM_NB * BN / NT; q++) v[q] = stm_ordered_sum<true>(W0 + tid + q * NT, 2 * STM_NB * BN, ngrp);   // fixed order
 #pragma unroll
     for (int q = 0; q < 2 * STM_NB * BN / NT; q++) W0[tid + q * NT] = v[q];
+}
+
+// Y of a pair, once per column block (between k_upd_w2 and k_upd_c2): Y1 = T1' W1, Y2 = T2' (W2 - G21 Y1) from the summed W of the
+// block, the Gram block G21 of the same launch of k_upd_w2 and the two T factors; the NEGATED 64 x 32 Y replaces W in the block's
+// first slot, in the layout k_upd_c2's lanes read their MFMA operand from.  (It used to be the prologue of EVERY workgroup of
+// k_upd_c2: five 8 KB images through LDS and three 32-step triangular loops, 6-8 us in front of 13 us of MFMA work.)
+__global__ __launch_bounds__(NT) void k_upd_y2(DevCtx c, const int *__restrict__ flist, const int *__restrict__ plist, double *Wp,
+                                               const long long *__restrict__ wpoff)
+{
+    extern __shared__ double dyn_lds[];
+    const int fi = blockIdx.y, f = flist[fi], p = plist[fi];
+    const FrontSym s = c.fs[f];
+    if (p >= s.npanels || !(p & 1)) return;
+    const FrontNum *num = &c.fnum[f];
+    PairGeom G;
+    if (!pair_geom(num, p, G)) return;
+    const int ncbp = stm_upd_ncb(s, p) - 1, nslf = stm_upd_nsl(s);
+    const int cb = blockIdx.x;
+    if (cb >= ncbp || G.pc0 + cb * BN >= s.fn) return;
+    const int tid = threadIdx.x;
+    double *s_W1 = dyn_lds, *s_W2 = s_W1 + STM_NB * WS, *s_T1 = s_W2 + STM_NB * WS, *s_T2 = s_T1 + STM_NB * WS,
+           *s_G = s_T2 + STM_NB * WS, *s_Y1 = s_G + STM_NB * WS;
+    double *W0 = Wp + wpoff[fi] + ((long long)cb * nslf) * (2 * STM_NB * BN);
+    const double *Gr = Wp + wpoff[fi] + ((long long)ncbp * nslf) * (2 * STM_NB * BN) + STM_NB * BN;     // W2 part of the Gram block
+    const double *T1 = c.Tws + (long long)(2 * c.tslot[f] + ((p - 1) & 1)) * STM_NB * STM_NB;
+    const double *T2 = c.Tws + (long long)(2 * c.tslot[f] + (p & 1)) * STM_NB * STM_NB;
+    const bool has2 = G.nb2 > 0;
+    for (int e = tid; e < STM_NB * BN; e += NT) {
+        s_W1[(e / BN) * WS + (e % BN)] = W0[e];
+        s_W2[(e / BN) * WS + (e % BN)] = has2 ? W0[STM_NB * BN + e] : 0.0;
+        s_G[(e / BN) * WS + (e % BN)] = has2 ? Gr[e] : 0.0;                    // G21(a, b) = v2_a' v1_b
+        s_T1[(e / STM_NB) * WS + (e % STM_NB)] = T1[e];                          // s_T[col][row] = T(row, col)
+        s_T2[(e / STM_NB) * WS + (e % STM_NB)] = has2 ? T2[e] : 0.0;
+    }
+    __syncthreads();
+    const int l = tid & 31, cg = tid >> 5;
+    double y[4] = {0, 0, 0, 0};
+    for (int q = 0; q <= l; q++) {                             // Y1 = T1' W1
+        const double tq = s_T1[l * WS + q];
+#pragma unroll
+        for (int x = 0; x < 4; x++) y[x] += tq * s_W1[q * WS + cg * 4 + x];
+    }
+#pragma unroll
+    for (int x = 0; x < 4; x++) s_Y1[l * WS + cg * 4 + x] = y[x];
+    __syncthreads();
+    double z[4];                                               // Z = W2 - G21 Y1  ( = V2'(C - V1 Y1) )
+#pragma unroll
+    for (int x = 0; x < 4; x++) z[x] = s_W2[l * WS + cg * 4 + x];
+    for (int b = 0; b < STM_NB; b++) {
+        const double gq = s_G[l * WS + b];
+#pragma unroll
+        for (int x = 0; x < 4; x++) z[x] -= gq * s_Y1[b * WS + cg * 4 + x];
+    }
+    __syncthreads();                                           // (everyone has read W2 before Z replaces it)
+#pragma unroll
+    for (int x = 0; x < 4; x++) s_W2[l * WS + cg * 4 + x] = z[x];
+    __syncthreads();
+    double y2[4] = {0, 0, 0, 0};
+    for (int q = 0; q <= l; q++) {                             // Y2 = T2' Z
+        const double tq = s_T2[l * WS + q];
+#pragma unroll
+        for (int x = 0; x < 4; x++) y2[x] += tq * s_W2[q * WS + cg * 4 + x];
+    }
+#pragma unroll
+    for (int x = 0; x < 4; x++) {                              // (every thread wrote its W entries into LDS long ago)
+        W0[l * BN + cg * 4 + x] = -y[x];
+        W0[(STM_NB + l) * BN + cg * 4 + x] = -y2[x];
+    }
 }
 
 __global__ __launch_bounds__(NT) void k_upd_c2(DevCtx c, const int *__restrict__ flist, const int *__restrict__ plist,
                                                const double *Wp, const long long *__restrict__ wpoff)
 {
-    extern __shared__ double dyn_lds[];
-    __shared__ int s_pd1[STM_NB], s_pd2[STM_NB];
     const int fi = blockIdx.z, f = flist[fi], p = plist[fi];
     const FrontSym s = c.fs[f];
     if (p >= s.npanels || !(p & 1)) return;
@@ -2662,95 +2740,57 @@ __global__ __launch_bounds__(NT) void k_upd_c2(DevCtx c, const int *__restrict__
     const int c0 = G.pc0 + cb * BN;
     if (c0 >= s.fn || sl * SLAB >= G.mp) return;
     const int nsl_all = (G.mp + SLAB - 1) / SLAB;
-    const int spw = (nsl_all >= 32) ? 4 : (nsl_all >= 16) ? 2 : 1;
+    const int spw = stm_pair_spw(nsl_all, c.tune);
     if (sl % spw) return;
     const int nc = min(BN, s.fn - c0);
     const long long ld = s.ld;
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, l15 = lane & 15, l4 = lane >> 4;
-    double *Vs1 = dyn_lds, *Vs2 = Vs1 + STM_NB * VS, *Cs = Vs2 + STM_NB * VS, *Ws = Cs + BN * VS;     // Ws: [2 * STM_NB][WS]
-    // prologue images in the chunk images (first written after the prologue): 5 x [32][WS] <= 3 x [32][VS]
-    double *s_W1 = dyn_lds, *s_W2 = s_W1 + STM_NB * WS, *s_T1 = s_W2 + STM_NB * WS, *s_T2 = s_T1 + STM_NB * WS,
-           *s_G = s_T2 + STM_NB * WS;
     const PanelDesc *pa = &num->pd[(p - 1) & 1], *pb = &num->pd[p & 1];
-    if (tid < STM_NB) {
-        s_pd1[tid] = (tid < G.nb1) ? pa->pdiag[tid] : STM_BIGROW;
-        s_pd2[tid] = (tid < G.nb2) ? pb->pdiag[tid] : STM_BIGROW;
-    }
     const double *Fb = c.Farena + s.foff + G.g1;
     const double *__restrict__ V1g = Fb + (long long)G.k1a * ld, *__restrict__ V2g = Fb + (long long)G.k1b * ld;
     double *__restrict__ Cg = c.Farena + s.foff + G.g1 + (long long)c0 * ld;
-    {
-        const double *W0 = Wp + wpoff[fi] + ((long long)cb * nslf) * (2 * STM_NB * BN);
-        const double *Gr = Wp + wpoff[fi] + ((long long)ncbp * nslf) * (2 * STM_NB * BN) + STM_NB * BN;     // W2 part of the Gram block
-        const double *T1 = c.Tws + (long long)(2 * c.tslot[f] + ((p - 1) & 1)) * STM_NB * STM_NB;
-        const double *T2 = c.Tws + (long long)(2 * c.tslot[f] + (p & 1)) * STM_NB * STM_NB;
-        const bool has2 = G.nb2 > 0;
-        for (int e = tid; e < STM_NB * BN; e += NT) {
-            s_W1[(e / BN) * WS + (e % BN)] = W0[e];
-            s_W2[(e / BN) * WS + (e % BN)] = has2 ? W0[STM_NB * BN + e] : 0.0;
-            s_G[(e / BN) * WS + (e % BN)] = has2 ? Gr[e] : 0.0;                    // G21(a, b) = v2_a' v1_b
-            s_T1[(e / STM_NB) * WS + (e % STM_NB)] = T1[e];                          // s_T[col][row] = T(row, col)
-            s_T2[(e / STM_NB) * WS + (e % STM_NB)] = has2 ? T2[e] : 0.0;
-        }
-        __syncthreads();
-        const int l = tid & 31, cg = tid >> 5;
-        double y[4] = {0, 0, 0, 0};
-        for (int q = 0; q <= l; q++) {                             // Y1 = T1' W1
-            const double tq = s_T1[l * WS + q];
-#pragma unroll
-            for (int x = 0; x < 4; x++) y[x] += tq * s_W1[q * WS + cg * 4 + x];
-        }
-#pragma unroll
-        for (int x = 0; x < 4; x++) Ws[l * WS + cg * 4 + x] = y[x];
-        __syncthreads();
-        double z[4];                                               // Z = W2 - G21 Y1  ( = V2'(C - V1 Y1) )
-#pragma unroll
-        for (int x = 0; x < 4; x++) z[x] = s_W2[l * WS + cg * 4 + x];
-        for (int b = 0; b < STM_NB; b++) {
-            const double gq = s_G[l * WS + b];
-#pragma unroll
-            for (int x = 0; x < 4; x++) z[x] -= gq * Ws[b * WS + cg * 4 + x];
-        }
-        __syncthreads();                                           // (everyone has read W2 before Z replaces it)
-#pragma unroll
-        for (int x = 0; x < 4; x++) s_W2[l * WS + cg * 4 + x] = z[x];
-        __syncthreads();
-        double y2[4] = {0, 0, 0, 0};
-        for (int q = 0; q <= l; q++) {                             // Y2 = T2' Z
-            const double tq = s_T2[l * WS + q];
-#pragma unroll
-            for (int x = 0; x < 4; x++) y2[x] += tq * s_W2[q * WS + cg * 4 + x];
-        }
-#pragma unroll
-        for (int x = 0; x < 4; x++) Ws[(STM_NB + l) * WS + cg * 4 + x] = y2[x];
-    }
-    __syncthreads();
+    const double *__restrict__ Yn = Wp + wpoff[fi] + ((long long)cb * nslf) * (2 * STM_NB * BN);       // -Y, [64][32] (k_upd_y2)
     // Round 3: the application runs WITHOUT LDS and without barriers.  The product is formed transposed,
     //     D(col, row) = C(row, col) - sum_k Y(k, col) V(row, k),
     // so that (i) C is the accumulator operand the MFMA starts from -- lane (l15, l4) holds D(col l4 + 4 r, row l15): for a
     // fixed r the 64 lanes touch 4 columns x 16 consecutive rows, i.e. four full 128-byte segments of the column-major front,
     // loaded from and stored to global memory directly in that layout -- and (ii) V is the B operand B(k, row): 16 consecutive
-    // rows of 4 reflector columns per load, again whole segments, with the unit-diagonal / zero mask applied in registers.
-    // Y (negated) is the A operand and stays in registers for the whole workgroup.  A wave takes every fourth 16-row tile of
-    // the workgroup's rows; the loads of its next tile are in flight during the 32 MFMAs of the current one.
+    // rows of 4 reflector columns per load, again whole segments.  Y (negated, from k_upd_y2) is the A operand and stays in
+    // registers for the whole workgroup.  A wave takes every fourth 16-row tile of the workgroup's rows.
+    //
+    // Two forms of a tile.  INTERIOR tiles -- every row below all 64 unit diagonals, inside both panels' row ranges, a full
+    // 32-column block: all but the first 64 rows of a pair, its last rows and the front's last column block -- run a pipeline
+    // with NO predication: 24 unconditional loads of the next tile, 32 MFMAs, 8 unconditional stores.  That matters more than
+    // the saved mask arithmetic: with a branch around any load or store of the loop the compiler no longer knows how many
+    // memory operations are outstanding and waits for vmcnt(0) at the top of EVERY tile -- i.e. for the stores it has just
+    // issued (measured: 325 ms per factorization of c5mid for this kernel, 210 ms without its stores, 165 ms with neither
+    // loads nor stores).  The other tiles take the general form (masks, clamped loads, predicated stores), one at a time.
     double yn0[2 * STM_NB / 4], yn1[2 * STM_NB / 4];
 #pragma unroll
     for (int kk = 0; kk < 2 * STM_NB / 4; kk++) {
-        yn0[kk] = -Ws[(4 * kk + l4) * WS + l15];
-        yn1[kk] = -Ws[(4 * kk + l4) * WS + 16 + l15];
+        yn0[kk] = Yn[(4 * kk + l4) * BN + l15];
+        yn1[kk] = Yn[(4 * kk + l4) * BN + 16 + l15];
     }
-    int dv1[STM_NB / 4], dv2[STM_NB / 4];               // row (relative to g1) of the unit diagonal of reflector 4 kk + l4
-#pragma unroll
-    for (int kk = 0; kk < STM_NB / 4; kk++) {
-        const int col = 4 * kk + l4;
-        dv1[kk] = (col < G.nb1) ? s_pd1[col] - G.g1 : STM_BIGROW;
-        dv2[kk] = (col < G.nb2) ? s_pd2[col] - G.g1 : STM_BIGROW;
+    int dmax = -1;                                      // last row (relative to g1) that holds a unit diagonal; BIGROW: a dead reflector
+#pragma unroll 8
+    for (int q = 0; q < STM_NB; q++) {
+        dmax = max(dmax, (q < G.nb1) ? pa->pdiag[q] - G.g1 : STM_BIGROW);
+        dmax = max(dmax, (q < G.nb2) ? pb->pdiag[q] - G.g1 : STM_BIGROW);
     }
     const int rbeg = sl * SLAB, rend = min(G.mp, (sl + spw) * SLAB);
     const int ntile = (rend - rbeg + 15) >> 4;
+    const int rfull = min(min(G.mp1, G.mp2), rend);     // rows below this are inside both panels
+    // tiles [t_lo, t_hi) are interior (nothing if the column block is ragged or some reflector is dead)
+    int t_lo = (dmax >= STM_BIGROW || nc < BN) ? ntile : max(0, (dmax + 1 - rbeg + 15) >> 4);
+    int t_hi = (rfull - rbeg) >> 4;
+    if (t_lo > ntile) t_lo = ntile;
+    if (t_hi < t_lo) t_hi = t_lo;
     struct Tile { double c0[4], c1[4], v1[STM_NB / 4], v2[STM_NB / 4]; };
-    auto load_tile = [&](Tile &t, int tix) {
-        const int row = min(rbeg + 16 * tix + l15, G.mp - 1);                          // (clamped: masked afterwards)
+    // general form of one tile
+    auto general_tile = [&](int tix) {
+        const int i = rbeg + 16 * tix + l15;                                           // my row (relative to g1)
+        const int row = min(i, G.mp - 1);                                              // (clamped: masked afterwards)
+        Tile t;
 #pragma unroll
         for (int r = 0; r < 4; r++) {
             t.c0[r] = Cg[row + (long long)min(l4 + 4 * r, nc - 1) * ld];
@@ -2761,26 +2801,22 @@ __global__ __launch_bounds__(NT) void k_upd_c2(DevCtx c, const int *__restrict__
             t.v1[kk] = V1g[row + (long long)min(4 * kk + l4, G.nb1 - 1) * ld];
             t.v2[kk] = V2g[row + (long long)min(4 * kk + l4, max(G.nb2, 1) - 1) * ld];
         }
-    };
-    Tile cur, nxt;
-    if (wid < ntile) load_tile(cur, wid);
-    for (int tix = wid; tix < ntile; tix += NW) {
-        if (tix + NW < ntile) load_tile(nxt, tix + NW);
-        const int i = rbeg + 16 * tix + l15;                                           // my row (relative to g1)
-        d4 a0 = {cur.c0[0], cur.c0[1], cur.c0[2], cur.c0[3]}, a1 = {cur.c1[0], cur.c1[1], cur.c1[2], cur.c1[3]};
+        d4 a0 = {t.c0[0], t.c0[1], t.c0[2], t.c0[3]}, a1 = {t.c1[0], t.c1[1], t.c1[2], t.c1[3]};
 #pragma unroll
         for (int kk = 0; kk < STM_NB / 4; kk++) {
-            const int d = dv1[kk];
-            const double b = (i < G.mp1 && i >= d) ? ((i == d) ? 1.0 : cur.v1[kk]) : 0.0;
-            a0 = __builtin_amdgcn_mfma_f64_16x16x4f64(yn0[kk], b, a0, 0, 0, 0);
-            a1 = __builtin_amdgcn_mfma_f64_16x16x4f64(yn1[kk], b, a1, 0, 0, 0);
+            const int col = 4 * kk + l4;
+            const int d = (col < G.nb1) ? pa->pdiag[col] - G.g1 : STM_BIGROW;
+            const double bv = (i < G.mp1 && i >= d) ? ((i == d) ? 1.0 : t.v1[kk]) : 0.0;
+            a0 = __builtin_amdgcn_mfma_f64_16x16x4f64(yn0[kk], bv, a0, 0, 0, 0);
+            a1 = __builtin_amdgcn_mfma_f64_16x16x4f64(yn1[kk], bv, a1, 0, 0, 0);
         }
 #pragma unroll
         for (int kk = 0; kk < STM_NB / 4; kk++) {
-            const int d = dv2[kk];
-            const double b = (i < G.mp2 && i >= d) ? ((i == d) ? 1.0 : cur.v2[kk]) : 0.0;
-            a0 = __builtin_amdgcn_mfma_f64_16x16x4f64(yn0[STM_NB / 4 + kk], b, a0, 0, 0, 0);
-            a1 = __builtin_amdgcn_mfma_f64_16x16x4f64(yn1[STM_NB / 4 + kk], b, a1, 0, 0, 0);
+            const int col = 4 * kk + l4;
+            const int d = (col < G.nb2) ? pb->pdiag[col] - G.g1 : STM_BIGROW;
+            const double bv = (i < G.mp2 && i >= d) ? ((i == d) ? 1.0 : t.v2[kk]) : 0.0;
+            a0 = __builtin_amdgcn_mfma_f64_16x16x4f64(yn0[STM_NB / 4 + kk], bv, a0, 0, 0, 0);
+            a1 = __builtin_amdgcn_mfma_f64_16x16x4f64(yn1[STM_NB / 4 + kk], bv, a1, 0, 0, 0);
         }
         if (i < G.mp) {
 #pragma unroll
@@ -2789,8 +2825,80 @@ __global__ __launch_bounds__(NT) void k_upd_c2(DevCtx c, const int *__restrict__
                 if (16 + l4 + 4 * r < nc) Cg[i + (long long)(16 + l4 + 4 * r) * ld] = a1[r];
             }
         }
-        cur = nxt;
+    };
+    int tix = wid;
+    for (; tix < t_lo; tix += NW) general_tile(tix);
+    if (tix < t_hi) {
+        // interior tiles, four per trip: lane addresses advance by 64 rows per tile.  C comes from HBM and is requested THREE
+        // tiles ahead (four register images used in turn -- the trip is unrolled so that none is ever copied: copying the
+        // destination of a load in flight would wait for it), V (L2) one tile ahead and BEFORE the C loads of the same step:
+        // the memory counter retires in order, so the wait for V(t) covers nothing younger -- C(t+2), the stores of tile
+        // t-1, V(t+1) and C(t+3) stay in flight (a counted vmcnt(40)).  The scheduling barriers keep that issue order.
+        // Requests beyond this wave's last tile of the trips are clamped to it (loaded again, never used); the 1-3 interior
+        // tiles left after the last whole trip take the general form.
+        const int nint = (t_hi - 1 - tix) / NW + 1, ntrip = nint >> 2;
+        if (ntrip > 0) {
+            const double *cp = Cg + (rbeg + 16 * tix + l15) + (long long)l4 * ld;
+            const double *v1p = V1g + (rbeg + 16 * tix + l15) + (long long)l4 * ld;
+            const double *v2p = V2g + (rbeg + 16 * tix + l15) + (long long)l4 * ld;
+            const long long ld4 = 4 * ld;
+            struct TC { double c0[4], c1[4]; };
+            struct TV { double v1[STM_NB / 4], v2[STM_NB / 4]; };
+            auto load_c = [&](TC &t, int off) {
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    t.c0[r] = cp[off + r * ld4];
+                    t.c1[r] = cp[off + (4 + r) * ld4];
+                }
+            };
+            auto load_v = [&](TV &t, int off) {
+#pragma unroll
+                for (int kk = 0; kk < STM_NB / 4; kk++) {
+                    t.v1[kk] = v1p[off + kk * ld4];
+                    t.v2[kk] = v2p[off + kk * ld4];
+                }
+            };
+            TC cb4[4];
+            TV vb2[2];
+            const int step = 16 * NW, offlast = step * (4 * ntrip - 1);
+            load_v(vb2[0], 0);
+            load_c(cb4[0], 0);
+            load_c(cb4[1], min(step, offlast));
+            load_c(cb4[2], min(2 * step, offlast));
+            for (int trip = 0; trip < ntrip; trip++) {
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    const int off = step * (4 * trip + q);
+                    load_v(vb2[(q + 1) & 1], min(off + step, offlast));
+                    load_c(cb4[(q + 3) & 3], min(off + 3 * step, offlast));
+                    __builtin_amdgcn_sched_barrier(0);
+                    const TC &tc = cb4[q];
+                    const TV &tv = vb2[q & 1];
+                    d4 a0 = {tc.c0[0], tc.c0[1], tc.c0[2], tc.c0[3]}, a1 = {tc.c1[0], tc.c1[1], tc.c1[2], tc.c1[3]};
+#pragma unroll
+                    for (int kk = 0; kk < STM_NB / 4; kk++) {
+                        a0 = __builtin_amdgcn_mfma_f64_16x16x4f64(yn0[kk], tv.v1[kk], a0, 0, 0, 0);
+                        a1 = __builtin_amdgcn_mfma_f64_16x16x4f64(yn1[kk], tv.v1[kk], a1, 0, 0, 0);
+                    }
+#pragma unroll
+                    for (int kk = 0; kk < STM_NB / 4; kk++) {
+                        a0 = __builtin_amdgcn_mfma_f64_16x16x4f64(yn0[STM_NB / 4 + kk], tv.v2[kk], a0, 0, 0, 0);
+                        a1 = __builtin_amdgcn_mfma_f64_16x16x4f64(yn1[STM_NB / 4 + kk], tv.v2[kk], a1, 0, 0, 0);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                    double *sp = const_cast<double *>(cp) + off;
+#pragma unroll
+                    for (int r = 0; r < 4; r++) {
+                        sp[r * ld4] = a0[r];
+                        sp[(4 + r) * ld4] = a1[r];
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+            tix += 4 * ntrip * NW;
+        }
     }
+    for (; tix < ntile; tix += NW) general_tile(tix);
 }
 
 // T of the LAST panel of a front whose panel kernel left it pending (PanelDesc::t_deferred == 2: the Gram-based panel never
@@ -3719,8 +3827,8 @@ int stm_launch_update_pair(const DevCtx &c, const int *flist, const int *plist, 
     if (nfr <= 0 || ncbp <= 0 || maxsl <= 0) return 0;
     hipLaunchKernelGGL(k_upd_w2, dim3(ncbp + 1, maxsl, nfr), dim3(NT), (size_t)(3 * BN * VS2 + 2) * sizeof(double), st, c, flist, plist, Wp,
                        wpoff, wcnt);
-    hipLaunchKernelGGL(k_upd_c2, dim3(ncbp, maxsl, nfr), dim3(NT), (size_t)(3 * BN * VS + 2 * STM_NB * WS) * sizeof(double), st, c, flist,
-                       plist, (const double *)Wp, wpoff);
+    hipLaunchKernelGGL(k_upd_y2, dim3(ncbp, nfr), dim3(NT), (size_t)(6 * STM_NB * WS) * sizeof(double), st, c, flist, plist, Wp, wpoff);
+    hipLaunchKernelGGL(k_upd_c2, dim3(ncbp, maxsl, nfr), dim3(NT), 0, st, c, flist, plist, (const double *)Wp, wpoff);
     return (int)hipGetLastError();
 }
 int stm_launch_update_notrans(const DevCtx &c, int f, int ncb, hipStream_t st)

@@ -99,6 +99,7 @@ struct OneFront {
         }
         c.Stair = d_St.p; c.Tau = d_Tau.p; c.Rdead = d_Rdead.p; c.Rhoff = d_Rhoff.p; c.Rboff = d_Rboff.p;
         c.dbg = getenv("STMMQR_DBG") ? atoi(getenv("STMMQR_DBG")) : 0;
+        c.tune = getenv("STMMQR_TUNE") ? atoi(getenv("STMMQR_TUNE")) : 0;
         { stmmqr_options o; stmmqr_get_options(&o); c.tall_min = o.tall_min_rows; c.panel_algo = o.panel_algo; c.ca_min_rows = STM_CA_MIN_ROWS; }
 #ifdef STMMQR_STAMPS
         if (!d_dbg.alloc(1024)) return false;
