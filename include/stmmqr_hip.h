@@ -332,6 +332,11 @@ typedef struct stmmqr_options {
     int pair_update;        /* 1 (default): fronts of >= 16384 rows apply the block reflectors of two consecutive panels in
                                one sweep over the columns beyond the next two panels (1.5 instead of 3 passes over the
                                trailing matrix per panel); a property of the front (plan time), it changes rounding only */
+    int mid_front_cols;     /* 0 (default): off.  c > 0: a front with big_front_cols <= fn <= c columns and at most 512 rows is
+                               factorized whole by ONE 512-thread workgroup in one launch (k_front_mid: wave-pipelined panels,
+                               two column blocks of the update side by side) instead of a step of the timeline per panel.
+                               A property of the front (plan time), it changes rounding only; env STMMQR_MID_COLS overrides.
+                               Measured slower on MI355X at every setting, kept as a tested experiment        */
 } stmmqr_options;
 void stmmqr_get_options(stmmqr_options *opt);
 void stmmqr_set_options(const stmmqr_options *opt);

@@ -59,6 +59,11 @@ struct PanelDesc {
 #define STM_TALL_XWIDE (8 * STM_TALL_NTH) // more rows than this: 2-column sub-panels
 #define STM_WP_ROWS 512      // panels whose staircase reaches at most this many rows are factorized by ONE workgroup, a wave per
                              // 4 columns, with the panel's image in LDS (32 x 512 doubles: every pipeline launch carries it)
+#define STM_MID_COLS 0       // default of stmmqr_options::mid_front_cols: fronts of at most this many columns and STM_WP_ROWS rows
+                             // are factorized whole by one workgroup (k_front_mid).  OFF: measured slower at every setting (epb1
+                             // 7.4 ms -> 8.1 / 8.8 / 10.4 ms at 128 / 192 / 256 columns, lns_3937 10.6 -> 11.6 / 12.4 / 13.9 ms): one
+                             // workgroup serialises the column blocks that the step timeline spreads over many
+#define STM_UPD_LDS_HOST (2 * 32 * 66 + 32 * 33)   // = STM_UPD_LDS_DOUBLES of the kernels (one half's chunk images of dev_update_block)
 #define STM_PROG 64          // FrontNum::prog advances by this much per panel (2 per column group + 1, <= 16 groups)
 
 // Does panel p of this front take the tall-panel pipeline?  Planned on the host (number of launches) and re-evaluated

@@ -31,7 +31,7 @@
 namespace {
 
 thread_local std::string g_err;
-stmmqr_options g_opt = {STM_NB, 64, 0, 0, 0, 1, STM_TALL_MIN, 1, 0, 1};      // (panel_algo 0: by panel height)
+stmmqr_options g_opt = {STM_NB, 64, 0, 0, 0, 1, STM_TALL_MIN, 1, 0, 1, STM_MID_COLS};      // (panel_algo 0: by panel height)
 size_t g_chunk[4] = {32, 5000, 4, 4};     // FCHUNK, SMALL, MINCHUNK, MINCHUNK_RATIO (SparseQR.h:16-19)
 
 // offsets inside the reference's sparse_common for the stock LP64 build; verified against the real header
@@ -104,7 +104,8 @@ struct Level {                           // tree level of a group: what the solv
 // tallest front of its tree level: at every step the launches cover all the big fronts that are in flight, each at its
 // own panel.  Everything here is symbolic (lists built once per plan).
 struct Step {
-    int start_off = 0, n_start = 0, n_small = 0;      // fronts starting here (small first): set up + assembled
+    int start_off = 0, n_start = 0, n_small = 0;      // fronts starting here (small first, then mid, then big): set up + assembled
+    int n_mid = 0, lds_mid = 0;                        // mid fronts among them (k_front_mid) and the LDS doubles of their launch
     int asm_parts_off = 0, asm_maxparts = 1, lds_small = 0;
     int act_off = 0, plist_off = 0, n_act = 0;        // big fronts in flight + the panel each is at
     int wp_off = 0;                                   // (index into d_wlists) their slices of the update workspace
@@ -383,9 +384,17 @@ void build_schedule(stmmqr_plan &P, std::vector<int> &tslot)
     const long nf = P.nf;
     int ngroups = 1;
     for (long f = 0; f < nf; f++) ngroups = std::max(ngroups, P.group[f] + 1);
+    // mid fronts: whole front by one 512-thread workgroup (k_front_mid); a property of the front alone.  Scheduled like the small
+    // ones (one launch at the step they start), but they hold a T slot for that step.
+    const int mid_cols = getenv("STMMQR_MID_COLS") ? atoi(getenv("STMMQR_MID_COLS")) : g_opt.mid_front_cols;
+    auto is_mid = [&](int f) {
+        const FrontSym &s = P.fs[f];
+        if ((size_t)f < P.shared.size() && P.shared[f]) return false;
+        return s.fn >= g_opt.big_front_cols && s.fm_ub >= 64 && s.fn <= mid_cols && s.fm_ub <= STM_WP_ROWS;
+    };
     auto is_big = [&](int f) {
         const FrontSym &s = P.fs[f];
-        return s.fn >= g_opt.big_front_cols && s.fm_ub >= 64;
+        return s.fn >= g_opt.big_front_cols && s.fm_ub >= 64 && !is_mid(f);
     };
     // STMMQR_SCHED (experiments): 1 level-synchronous, 2 as soon as possible, 3 envelope rule; unset / 0: chosen per group
     const int sched_policy = getenv("STMMQR_SCHED") ? atoi(getenv("STMMQR_SCHED")) : 0;
@@ -566,12 +575,17 @@ void build_schedule(stmmqr_plan &P, std::vector<int> &tslot)
         int nslots = 0;
         for (int t = 0; t < nstep; t++) {
             Step &S = SV[t];
-            std::vector<int> small, big;
-            for (int f : starting[t]) (is_big(f) ? big : small).push_back(f);
+            std::vector<int> small, mid, big;
+            for (int f : starting[t]) (is_big(f) ? big : is_mid(f) ? mid : small).push_back(f);
             S.start_off = (int)P.lists.size();
-            S.n_small = (int)small.size(); S.n_start = (int)(small.size() + big.size());
+            S.n_small = (int)small.size(); S.n_mid = (int)mid.size(); S.n_start = (int)(small.size() + mid.size() + big.size());
             P.lists.insert(P.lists.end(), small.begin(), small.end());
+            P.lists.insert(P.lists.end(), mid.begin(), mid.end());
             P.lists.insert(P.lists.end(), big.begin(), big.end());
+            for (int f : mid) {
+                const int fm = P.fs[f].fm_ub;
+                S.lds_mid = std::max(S.lds_mid, std::max(STM_NB * (fm <= 128 ? 128 : fm <= 256 ? 256 : 512), 2 * STM_UPD_LDS_HOST));
+            }
             S.asm_parts_off = (int)P.lists.size();
             long maxfm_small = 0;
             for (int i = 0; i < S.n_start; i++) {
@@ -589,6 +603,12 @@ void build_schedule(stmmqr_plan &P, std::vector<int> &tslot)
             for (int f : big) {
                 if (!freeslots.empty()) { tslot[f] = freeslots.back(); freeslots.pop_back(); }
                 else tslot[f] = nslots++;
+            }
+            std::vector<int> midslots;                         // (held for this step's launch only)
+            for (int f : mid) {
+                if (!freeslots.empty()) { tslot[f] = freeslots.back(); freeslots.pop_back(); }
+                else tslot[f] = nslots++;
+                midslots.push_back(tslot[f]);
             }
             active.clear();
             for (const auto &fp : panel_at[t]) { active.push_back(fp.first); pan_now[fp.first] = fp.second; }
@@ -659,6 +679,7 @@ void build_schedule(stmmqr_plan &P, std::vector<int> &tslot)
                 S.cpk_maxparts = std::max(S.cpk_maxparts, parts);
                 freeslots.push_back(tslot[f]);
             }
+            freeslots.insert(freeslots.end(), midslots.begin(), midslots.end());
         }
         P.tslots = std::max(P.tslots, nslots);
     }
@@ -973,6 +994,14 @@ int run_schedule(stmmqr_plan &P, bool detail, int grp, const StepReq *req = null
         if (S.n_small > 0) {
             int e = timed(t_front, [&]() -> int {
                 LCHK(stm_launch_front_wg(c, starting, S.n_small, S.lds_small, q));
+                return 0;
+            });
+            if (e) return e;
+            nlaunch++;
+        }
+        if (S.n_mid > 0) {
+            int e = timed(t_front, [&]() -> int {
+                LCHK(stm_launch_front_mid(c, starting + S.n_small, S.n_mid, S.lds_mid, q));
                 return 0;
             });
             if (e) return e;

@@ -59,6 +59,7 @@ int stm_launch_gather_sx(const double *Ax, const int *smap, double *Sx, int anz,
 int stm_launch_setup(const DevCtx &c, const int *flist, int nfr, hipStream_t st);
 int stm_launch_assemble(const DevCtx &c, const int *flist, const int *nparts, int nfr, int maxparts, hipStream_t st);
 int stm_launch_front_wg(const DevCtx &c, const int *flist, int nfr, int lds_doubles, hipStream_t st);
+int stm_launch_front_mid(const DevCtx &c, const int *flist, int nfr, int lds_doubles, hipStream_t st);
 int stm_launch_panel(const DevCtx &c, const int *flist, const int *plist, int nfr, int nsub, int defer_ok, int lds_doubles, hipStream_t st);
 int stm_configure_capanel(void);
 int stm_launch_panel_ca(const DevCtx &c, const int *flist, const int *plist, int nfr, int nw, int defer_ok, hipStream_t st);

@@ -298,25 +298,34 @@ __device__ __forceinline__ void upd_chunk_v_to_lds(const UpdChunk &ck, int i, in
 // v_mfma_f64_16x16x4_f64 operand maps (cdna_hip_programming.md 3): A[i=l&15][k=l>>4], B[k=l>>4][j=l&15],
 // D[i=(l>>4)+4r][j=l&15].
 // ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ void dev_T_from_gram(double (*G)[STM_NB + 1], double (*T)[STM_NB + 1], const double *tau, int nc);
+__device__ __forceinline__ void dev_T_from_gram(double (*G)[STM_NB + 1], double (*T)[STM_NB + 1], const double *tau, int nc, int tid);
 
 // tau != nullptr: T was left to the update by the panel kernel (PanelDesc::t_deferred) -- G = V'V is accumulated beside
 // W1 (per 256-row slab, slabs added in order: bit-identical to the Gram block of k_upd_w) and T is built here by every
 // workgroup for itself (dev_T_from_gram); Tout / Tkeep (may be null) receive it from the caller's first column block.
 // TN = true (qr_larftb seam, method QR_QX only): C <- (I - V T V') C, i.e. W2 = T W1 instead of T' W1.
-template <bool TN = false>
+// HALVES = true (k_front_mid, 512 threads): the two halves of the workgroup run the update of TWO column blocks side by side,
+// each with its own (c0, nc), its own slice of `lds` (STM_UPD_LDS_DOUBLES apart) and its own T when it is built here; everything
+// that decides a barrier (nbp, mp, tau != nullptr) is the same in both, and a half without a block of its own repeats the other's
+// with `store` = false.  The arithmetic of a column block is the same in both forms.
+#define STM_UPD_LDS_DOUBLES (2 * BN * VS + STM_NB * WS)
+static_assert(STM_UPD_LDS_DOUBLES == STM_UPD_LDS_HOST, "host sizing of k_front_mid's LDS");
+template <bool TN = false, bool HALVES = false>
 __device__ void dev_update_block(double *F, long long ld, int g1, int mp, int k1, int nbp, const int *diag,
                                  const double *T, int c0, int nc, double *lds, const double *tau = nullptr,
-                                 double *Tout = nullptr, double *Tkeep = nullptr)
+                                 double *Tout = nullptr, double *Tkeep = nullptr, bool store = true)
 {
     if (nbp <= 0 || mp <= 0 || nc <= 0) return;
-    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int half = HALVES ? (int)(threadIdx.x >> 8) : 0;
+    const int tid = HALVES ? (int)(threadIdx.x & 255) : (int)threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int l15 = lane & 15, l4 = lane >> 4;
+    if (HALVES) lds += half * STM_UPD_LDS_DOUBLES;
 
     double *Vs = lds;                       // [STM_NB][VS]
     double *Cs = Vs + STM_NB * VS;          // [BN][VS]
     double *Ws = Cs + BN * VS;              // [STM_NB][WS]
-    __shared__ int s_pd[STM_NB];
+    __shared__ int s_pd2[HALVES ? 2 : 1][STM_NB];
+    int *s_pd = s_pd2[half];
 
     __syncthreads();                        // previous users of lds are done
     if (tid < STM_NB) s_pd[tid] = (tid < nbp) ? diag[tid] : STM_BIGROW;
@@ -361,14 +370,15 @@ __device__ void dev_update_block(double *F, long long ld, int g1, int mp, int k1
     double *s_Tm = Cs;                       // T(q, l) at s_Tm[q * WS + l] when it is built here (the chunk images are free)
     if (build_t) {
         double (*Gm)[STM_NB + 1] = reinterpret_cast<double (*)[STM_NB + 1]>(Vs);
-        __shared__ double s_tau_u[STM_NB];
+        __shared__ double s_tau_u2[HALVES ? 2 : 1][STM_NB];
+        double *s_tau_u = s_tau_u2[half];
 #pragma unroll
         for (int r = 0; r < 4; r++) Gm[16 * mi + l4 + 4 * r][16 * ni + l15] = gtot[r];
         if (tid < STM_NB) s_tau_u[tid] = (tid < nbp) ? tau[tid] : 0.0;
         __syncthreads();
-        dev_T_from_gram(Gm, reinterpret_cast<double (*)[STM_NB + 1]>(s_Tm), s_tau_u, nbp);
+        dev_T_from_gram(Gm, reinterpret_cast<double (*)[STM_NB + 1]>(s_Tm), s_tau_u, nbp, tid);
         if (Tout || Tkeep)
-            for (int e = tid; e < STM_NB * STM_NB; e += blockDim.x) {
+            for (int e = tid; e < STM_NB * STM_NB; e += (HALVES ? 256 : (int)blockDim.x)) {
                 const int a = e % STM_NB, b = e / STM_NB;
                 const double tv = (a <= b && a < nbp && b < nbp) ? s_Tm[a * WS + b] : 0.0;
                 if (Tout) Tout[e] = tv;
@@ -422,7 +432,7 @@ __device__ void dev_update_block(double *F, long long ld, int g1, int mp, int k1
             Cs[(16 + l15) * VS + row] -= u1[r];
         }
         __syncthreads();
-        if (i < mp) {
+        if (i < mp && store) {
 #pragma unroll
             for (int q = 0; q < 8; q++) {
                 const int col = lcg * 8 + q;
@@ -450,9 +460,11 @@ __device__ void dev_update_block(double *F, long long ld, int g1, int mp, int k1
 // G, T: LDS, row stride STM_NB + 1; needs >= 256 threads; T is written completely (zeros below the diagonal and for
 // columns >= nc).  Ends with a barrier.
 // ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ void dev_T_from_gram(double (*G)[STM_NB + 1], double (*T)[STM_NB + 1], const double *tau, int nc)
+// tid: index of the thread among the (at least) 256 that work on THIS G / T (threadIdx.x, or threadIdx.x & 255 when the two halves
+// of a 512-thread workgroup each build their own); the barriers are the whole workgroup's either way.
+__device__ __forceinline__ void dev_T_from_gram(double (*G)[STM_NB + 1], double (*T)[STM_NB + 1], const double *tau, int nc, int tid)
 {
-    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int lane = tid & 63, wid = tid >> 6;
     if (wid < 2 && lane < 16) {
         const int o = 16 * wid, a = lane;
         double trow[16];
@@ -570,7 +582,7 @@ __device__ void dev_gram_T(const double *Vg, long long ld, int r0, int r1, int n
     }
     __syncthreads();
     if (tl && tid == 0) tl[2] = wall_clock64();
-    dev_T_from_gram(s_G, s_T, tau, nc);
+    dev_T_from_gram(s_G, s_T, tau, nc, threadIdx.x);
     if (tl && tid == 0) tl[3] = wall_clock64();
     for (int e = tid; e < STM_NB * STM_NB; e += NTH) {
         const int a = e % STM_NB, b = e / STM_NB;
@@ -1888,9 +1900,71 @@ __device__ __forceinline__ void dev_wave_panel(PanelShared &ps, WaveShared &wsh,
 }
 
 // ------------------------------------------------------------------------------------------------
-// large fronts: panel and trailing update are separate launches (many workgroups per update)
+// mid fronts (stm_mid_front: at least big_front_cols but at most mid_front_cols columns, at most STM_WP_ROWS rows): ONE
+// 512-thread workgroup runs the whole front in one launch, like k_front_wg does for the small ones -- every panel is a
+// wave-pipelined panel (dev_wave_panel: the front never has more rows than its LDS image holds), the trailing update
+// runs two column blocks at a time on the two halves of the workgroup (dev_update_block<.., HALVES>, T built from the
+// Gram matrix of the first pair of blocks), then qr_cpack.  As separate launches such a front costs a step of the
+// timeline per panel -- ~45 us each for ~15 us of work (all of epb1's 136 steps were of this kind).
+// LDS: the panel image (32 x 128 / 256 / 512 doubles) and the update's chunk images share the dynamic allocation.
 // ------------------------------------------------------------------------------------------------
 #define NTP 512               // threads of the large-front panel kernel (8 waves, <= 256 VGPRs each)
+__global__ __launch_bounds__(NTP) void k_front_mid(DevCtx c, const int *__restrict__ flist)
+{
+    extern __shared__ double dyn_lds[];
+    __shared__ PanelShared ps;
+    __shared__ WaveShared wsh;
+    const int f = flist[blockIdx.x];
+    const FrontSym s = c.fs[f];
+    FrontNum *num = &c.fnum[f];
+    double *F = c.Farena + s.foff;
+    int *St = c.Stair + s.rp;
+    const int tid = threadIdx.x, half = tid >> 8;
+    for (int p = 0; p < s.npanels; p++) {
+        PanelDesc *pd = &num->pd[p & 1];
+        double *T = c.Tws + (long long)(2 * c.tslot[f] + (p & 1)) * STM_NB * STM_NB;
+        double *Tkeep = c.Tall ? c.Tall + (long long)(s.tpan + p) * STM_NB * STM_NB : nullptr;
+        const int k1 = p * STM_NB, k2 = min(s.fn, k1 + STM_NB), nbp = k2 - k1;
+        // the header of the panel (group 0 of k_panel)
+        const int was_done = num->done, g1 = num->g;
+        const int tmax = min(num->fm, max(St[k2 - 1], g1 + nbp));
+        __syncthreads();                                          // (everyone has read num-> before thread 0 writes the header)
+        if (tid == 0) {
+            pd->mode = 2; pd->pg1 = g1; pd->pt = g1; pd->tmax = tmax; pd->nlive = 0; pd->sw = WP_SW; pd->done_group = -1;
+            if (was_done) { pd->pnb = 0; pd->t_deferred = 0; }
+        }
+        if (was_done) break;                                      // (uniform: the remaining panels have nothing to do either)
+        const int rows = tmax - g1;
+#define WAVE_ARGS ps, wsh, s, num, pd, F, St, c.Tau + s.rp, c.Rdead + s.col1, p, g1, tmax, c.tol, c.ntol, T, dyn_lds, Tkeep, 1, c.sig
+        if (rows <= 128) dev_wave_panel<2>(WAVE_ARGS);
+        else if (rows <= 256) dev_wave_panel<4>(WAVE_ARGS);
+        else dev_wave_panel<8>(WAVE_ARGS);
+#undef WAVE_ARGS
+        __syncthreads();                                          // the panel's columns, Tau, pdiag and pd: visible to every wave
+        const int ncb = (s.fn - k2 + BN - 1) / BN;
+        if (ncb <= 0 || pd->pnb <= 0) continue;
+        const int pg1 = pd->pg1, mp = pd->pt - pd->pg1;
+        const bool deferred = pd->t_deferred != 0;                // (always, with trailing columns -- unless no reflector came out)
+        for (int cb = 0; cb < ncb; cb += 2) {
+            const bool own = (cb + half < ncb);
+            const int mycb = own ? cb + half : cb;
+            const int c0 = k2 + mycb * BN;
+            if (cb == 0 && deferred)
+                dev_update_block<false, true>(F, s.ld, pg1, mp, pd->pk1, pd->pnb, pd->pdiag, nullptr, c0, min(BN, s.fn - c0), dyn_lds,
+                                              c.Tau + s.rp + pd->pk1, half == 0 ? T : nullptr, half == 0 ? Tkeep : nullptr, own);
+            else
+                dev_update_block<false, true>(F, s.ld, pg1, mp, pd->pk1, pd->pnb, pd->pdiag, T, c0, min(BN, s.fn - c0), dyn_lds, nullptr,
+                                              nullptr, nullptr, own);
+            __syncthreads();                                      // (T of the first call: written to its slot before the next reads it)
+        }
+    }
+    __syncthreads();
+    if (tid < NT) dev_cpack(c, s, num, 0, 1);
+}
+
+// ------------------------------------------------------------------------------------------------
+// large fronts: panel and trailing update are separate launches (many workgroups per update)
+// ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(NTP) void k_panel(DevCtx c, const int *__restrict__ flist, const int *__restrict__ plist, int nsub,
                                                int defer_ok, int lds_doubles)
 {
@@ -2183,7 +2257,7 @@ __global__ __launch_bounds__(NT) void k_upd_w(DevCtx c, const int *__restrict__ 
     double *Tout = c.Tws + (long long)(2 * c.tslot[f] + (p & 1)) * STM_NB * STM_NB;
     double *Tkeep = c.Tall ? c.Tall + (long long)(s.tpan + p) * STM_NB * STM_NB : nullptr;
     double (*s_Tb)[STM_NB + 1] = reinterpret_cast<double (*)[STM_NB + 1]>(Cs);            // (the C chunk image is free as well)
-    dev_T_from_gram(reinterpret_cast<double (*)[STM_NB + 1]>(s_G), s_Tb, s_tau, nbp);
+    dev_T_from_gram(reinterpret_cast<double (*)[STM_NB + 1]>(s_G), s_Tb, s_tau, nbp, threadIdx.x);
     for (int e = tid; e < STM_NB * STM_NB; e += NT) {
         const int a = e % STM_NB, b = e / STM_NB;
         const double tv = (a <= b && a < nbp && b < nbp) ? s_Tb[a][b] : 0.0;
@@ -2385,7 +2459,7 @@ __global__ __launch_bounds__(NT, 2) void k_upd_f(DevCtx c, const int *__restrict
         __syncthreads();
         double *Tkeep = c.Tall ? c.Tall + (long long)(s.tpan + p) * STM_NB * STM_NB : nullptr;
         double (*s_Tb)[STM_NB + 1] = reinterpret_cast<double (*)[STM_NB + 1]>(Cs);
-        dev_T_from_gram(reinterpret_cast<double (*)[STM_NB + 1]>(s_G), s_Tb, s_tau, nbp);
+        dev_T_from_gram(reinterpret_cast<double (*)[STM_NB + 1]>(s_G), s_Tb, s_tau, nbp, threadIdx.x);
         for (int e = tid; e < STM_NB * STM_NB; e += NT) {
             const int a = e % STM_NB, b = e / STM_NB;
             const double tv = (a <= b && a < nbp && b < nbp) ? s_Tb[a][b] : 0.0;
@@ -3775,6 +3849,12 @@ int stm_launch_front_wg(const DevCtx &c, const int *flist, int nfr, int lds_doub
     hipLaunchKernelGGL(k_front_wg, dim3(nfr), dim3(NT), bytes, st, c, flist, (int)(bytes / sizeof(double)));
     return (int)hipGetLastError();
 }
+int stm_launch_front_mid(const DevCtx &c, const int *flist, int nfr, int lds_doubles, hipStream_t st)
+{
+    if (nfr <= 0) return 0;
+    hipLaunchKernelGGL(k_front_mid, dim3(nfr), dim3(NTP), (size_t)lds_doubles * sizeof(double), st, c, flist);
+    return (int)hipGetLastError();
+}
 int stm_launch_panel(const DevCtx &c, const int *flist, const int *plist, int nfr, int nsub, int defer_ok, int lds_doubles, hipStream_t st)
 {
     if (nfr <= 0) return 0;
@@ -3927,6 +4007,7 @@ int stm_configure_kernels(void)
     // allow the panel kernels to ask for up to 144 KiB of dynamic LDS (160 KiB per CU on gfx950)
     CK(hipFuncSetAttribute((const void *)k_front_wg, hipFuncAttributeMaxDynamicSharedMemorySize, 122880));
     CK(hipFuncSetAttribute((const void *)k_panel, hipFuncAttributeMaxDynamicSharedMemorySize, 131072));
+    CK(hipFuncSetAttribute((const void *)k_front_mid, hipFuncAttributeMaxDynamicSharedMemorySize, 131072));
     CK(hipFuncSetAttribute((const void *)k_update, hipFuncAttributeMaxDynamicSharedMemorySize, 65536));
     CK(hipFuncSetAttribute((const void *)k_update_n, hipFuncAttributeMaxDynamicSharedMemorySize, 65536));
     CK(hipFuncSetAttribute((const void *)k_qapply, hipFuncAttributeMaxDynamicSharedMemorySize, 131072));

@@ -136,6 +136,31 @@ def test_lookahead_schedule_same_bits(pkg, name, bfc, algo):
 
 
 @pytest.mark.parametrize("name", NAMES)
+@pytest.mark.parametrize("bfc,midc", [(16, 4096), (64, 192), (32, 96)])
+def test_mid_fronts_everywhere(pkg, oracle, name, bfc, midc):
+    """options.mid_front_cols: a front of bfc <= fn <= midc columns and at most 512 rows is factorized whole by ONE 512-thread
+    workgroup (k_front_mid: wave-pipelined panels, the trailing update two column blocks at a time on the halves of the workgroup,
+    T from the Gram matrix of the first pair of blocks, qr_cpack).  (16, 4096) sends every such front of every fixture there --
+    odd and even numbers of column blocks, ragged last blocks, dead columns, fronts whose rows run out inside a panel: integers,
+    flop count, R rows and the factors against the golden vectors and the oracle."""
+    g = load_golden(name)
+    pkg.set_options(big_front_cols=bfc, mid_front_cols=midc)
+    try:
+        S, G = gpu_run(pkg, g)
+    finally:
+        pkg.set_options(big_front_cols=64, mid_front_cols=0)
+    N = numeric_from_gpu(S, G)
+    compare_integers(S, N, g)
+    assert G.stats["flops"] == scalar(g, "flopcount")
+    got, ref = rrow_sig_all(S, N), g["num_rrow_sig"]
+    ftol = ILL_CONDITIONED.get(name, 1e-10)
+    scale = np.max(ref[:, 1], initial=1e-300) if name in ILL_CONDITIONED else np.maximum(ref[:, 1:2], 1e-300)
+    assert np.max(np.abs(got - ref) / scale, initial=0.0) <= ftol
+    No = oracle.factorize(S, g["in_Ap"], g["in_Ai"], g["in_Ax"], scalar(g, "in_tol"), int(scalar(g, "in_ntol")))
+    compare_numeric(oracle, S, G, No, g, ftol=1e-10, name=name)
+
+
+@pytest.mark.parametrize("name", NAMES)
 @pytest.mark.parametrize("bfc", [16, 64])
 def test_pair_update_everywhere(pkg, oracle, monkeypatch, name, bfc):
     """options.pair_update: fronts of >= 16384 rows apply the block reflectors of two consecutive panels in one sweep
