@@ -144,6 +144,16 @@ struct QbDesc {
     int pad;
 };
 
+// Pair update, single-sweep form (stmmqr_options::pair_update = 2): the pair of panels whose application to the columns beyond
+// the NEXT pair's panels is still pending -- it is applied by the sweep that forms W of the next pair (k_upd_f2), which runs after
+// the panel descriptions in FrontNum::pd have been overwritten by that next pair, hence this copy (written by k_upd_y2).
+struct PairPend {
+    int valid;                                   // 0: nothing pending
+    int g1, mp, mp1, mp2, nb1, nb2, k1a, k1b;    // PairGeom of the pending pair
+    int dmax;                                    // last row (relative to g1) holding a unit diagonal, STM_BIGROW if a reflector is missing
+    int diag1[STM_NB], diag2[STM_NB];            // unit-diagonal rows relative to g1 (STM_BIGROW: none)
+};
+
 // numeric, written by the kernels
 struct FrontNum {
     int fm;                  // rows of F                           (qr_fsize)
@@ -163,4 +173,5 @@ struct FrontNum {
     // pending block reflectors, double buffered by panel parity so that the look-ahead schedule can factorize
     // panel p+1 while the tail of update p is still reading the description of panel p
     PanelDesc pd[2];
+    PairPend pend;
 };

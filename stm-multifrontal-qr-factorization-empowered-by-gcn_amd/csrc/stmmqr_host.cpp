@@ -169,6 +169,10 @@ struct stmmqr_plan {
         d_lists, d_smap;
     DevBuf<long long> d_Rhoff;
     DevBuf<long long> d_wlists;
+    DevBuf<double> d_Ypend;                    // -Y of the pair-update fronts, by absolute column block (DevCtx::Ypend)
+    DevBuf<long long> d_ypoff;                 // [nf] offsets into it (-1: not a pair-update front)
+    std::vector<long long> ypoff;
+    long long yp_doubles = 0;
     DevBuf<int> d_wcnt, d_wcnt2;         // per column block of the update workspaces: slab tickets (zero between launches)
     DevBuf<int> d_wflag, d_wflag2;       // ... fused update: step + 1 once W2 of the column block is in its slot
     DevBuf<int> d_abort;
@@ -214,7 +218,7 @@ struct stmmqr_plan {
         add(d_fs); add(d_fnum); add(d_F); add(d_C); add(d_T); add(d_Gp); add(d_Tall); add(d_Sx); add(d_Ax); add(d_Tau); add(d_RH);
         add(d_Wp); add(d_Wp2); add(d_tslot); add(d_Sp); add(d_Sjrel); add(d_Sj0); add(d_Sleft); add(d_Child); add(d_Rjrel);
         add(d_Stair); add(d_Hii); add(d_Cmap); add(d_Cursor); add(d_lists); add(d_smap); add(d_Rhoff); add(d_wlists);
-        add(d_wcnt); add(d_wcnt2); add(d_wflag); add(d_wflag2); add(d_Rboff); add(d_Rdead);
+        add(d_wcnt); add(d_wcnt2); add(d_wflag); add(d_wflag2); add(d_Rboff); add(d_Rdead); add(d_Ypend); add(d_ypoff);
         return b;
     }
     DevCtx ctx() const
@@ -229,6 +233,7 @@ struct stmmqr_plan {
         c.tol = last_tol; c.ntol = (int)last_ntol;
         c.dbg = getenv("STMMQR_DBG") ? atoi(getenv("STMMQR_DBG")) : 0;
         c.tune = getenv("STMMQR_TUNE") ? atoi(getenv("STMMQR_TUNE")) : 0;
+        c.Ypend = d_Ypend.p; c.ypoff = d_ypoff.p;
         if (serial_panels) c.dbg = (c.dbg & ~(2048 | 4096)) | 256;   // the one-workgroup LDS / in-place panel for every panel
         c.tall_min = tall_min;
         c.cbskip = 0;
@@ -408,6 +413,13 @@ void build_schedule(stmmqr_plan &P, std::vector<int> &tslot)
     };
     P.pair_front.assign(std::max(1L, nf), 0);
     for (long f = 0; f < nf; f++) P.pair_front[f] = (P.group[f] >= 0 && is_pair((int)f)) ? 1 : 0;
+    P.ypoff.assign(std::max(1L, nf), -1);
+    P.yp_doubles = 0;
+    for (long f = 0; f < nf; f++)
+        if (P.pair_front[f]) {
+            P.ypoff[f] = P.yp_doubles;
+            P.yp_doubles += (long long)((P.fs[f].fn + 31) / 32) * (2 * STM_NB * 32);
+        }
     tslot.assign(std::max(1L, nf), 0);
     P.glevels.assign(ngroups, std::vector<Level>());
     P.gsteps.assign(ngroups, std::vector<Step>());
@@ -837,6 +849,8 @@ int build_plan(stmmqr_plan &P, const stmmqr_symbolic_view &v)
     LCHK(P.d_Gp.alloc((size_t)P.tslots * (P.gp_slabs + 1) * STM_NB * STM_NB));
     LCHK(P.d_Tall.alloc((size_t)std::max(1LL, P.tpanels) * STM_NB * STM_NB));
     LCHK(P.d_Wp.alloc((size_t)P.wp_doubles));
+    LCHK(P.d_Ypend.alloc((size_t)std::max(1LL, P.yp_doubles)));
+    LCHK(P.d_ypoff.upload(P.ypoff, st));
     LCHK(P.d_Wp2.alloc((size_t)std::max(1LL, P.wp2_doubles)));
     P.wcnt_n = (size_t)(P.wp_doubles / (STM_NB * 32) + 1);
     LCHK(P.d_wcnt.alloc(P.wcnt_n));
@@ -1065,8 +1079,8 @@ int run_schedule(stmmqr_plan &P, bool detail, int grp, const StepReq *req = null
                 o += S.n_pe;
                 if (S.n_po > 0) {
                     LCHK(stm_launch_update_split(c, act + o, pl + o, S.n_po, 0, 1, S.maxsl_po, Wp, wl + o, wcnt, 1, q));
-                    LCHK(stm_launch_update_pair(c, act + o, pl + o, S.n_po, S.maxcbp_po, S.maxsl_po, Wp, wl + o, wcnt, q));
-                    nlaunch += 5;
+                    LCHK(stm_launch_update_pair(c, act + o, pl + o, S.n_po, S.maxcbp_po, S.maxsl_po, Wp, wl + o, wcnt, g_opt.pair_update >= 2 ? 1 : 0, q));
+                    nlaunch += (g_opt.pair_update >= 2) ? 6 : 5;
                 }
             }
             return 0;
@@ -1608,6 +1622,8 @@ int stmmqr_plan_set_groups(stmmqr_plan *plan, const int *group)
     LCHK(grow(P.d_T, (size_t)2 * P.tslots * STM_NB * STM_NB));
     LCHK(grow(P.d_Gp, (size_t)P.tslots * (P.gp_slabs + 1) * STM_NB * STM_NB));
     LCHK(grow(P.d_Wp, (size_t)P.wp_doubles));
+    LCHK(grow(P.d_Ypend, (size_t)std::max(1LL, P.yp_doubles)));
+    LCHK(P.d_ypoff.upload(P.ypoff, P.stream));
     LCHK(grow(P.d_Wp2, (size_t)std::max(1LL, P.wp2_doubles)));
     P.wcnt_n = std::max(P.wcnt_n, (size_t)(P.wp_doubles / (STM_NB * 32) + 1));
     LCHK(grow(P.d_wcnt, P.wcnt_n));
