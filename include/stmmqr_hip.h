@@ -331,7 +331,10 @@ typedef struct stmmqr_options {
                                sums: DESIGN.md 5), kept as an experiment.                                            */
     int pair_update;        /* 1 (default): fronts of >= 16384 rows apply the block reflectors of two consecutive panels in
                                one sweep over the columns beyond the next two panels (1.5 instead of 3 passes over the
-                               trailing matrix per panel); a property of the front (plan time), it changes rounding only */
+                               trailing matrix per panel); a property of the front (plan time), it changes rounding only.
+                               2: the same pairs in ONE sweep each (k_upd_f2: the application beyond the next pair's panels is
+                               delayed to the sweep that forms W of that next pair; 16 instead of 24 bytes per entry and pair);
+                               measured slower on MI355X (one wave per SIMD), kept as a tested experiment        */
     int mid_front_cols;     /* 0 (default): off.  c > 0: a front with big_front_cols <= fn <= c columns and at most 512 rows is
                                factorized whole by ONE 512-thread workgroup in one launch (k_front_mid: wave-pipelined panels,
                                two column blocks of the update side by side) instead of a step of the timeline per panel.

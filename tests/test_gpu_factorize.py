@@ -162,18 +162,21 @@ def test_mid_fronts_everywhere(pkg, oracle, name, bfc, midc):
 
 @pytest.mark.parametrize("name", NAMES)
 @pytest.mark.parametrize("bfc", [16, 64])
-def test_pair_update_everywhere(pkg, oracle, monkeypatch, name, bfc):
+@pytest.mark.parametrize("mode", [1, 2])
+def test_pair_update_everywhere(pkg, oracle, monkeypatch, name, bfc, mode):
     """options.pair_update: fronts of >= 16384 rows apply the block reflectors of two consecutive panels in one sweep
-    (k_upd_w2 / k_upd_c2) on the columns beyond the next two panels.  STMMQR_PAIR_MIN=1 gives that path to every large
+    (k_upd_w2 / k_upd_c2; mode 2: k_upd_f2) on the columns beyond the next two panels.  STMMQR_PAIR_MIN=1 gives that path to every large
     front with at least four panels (here: fn >= 16 / 64): integers, R rows and the factors against the golden vectors and
     the oracle, exactly as for the one-panel-at-a-time update (different rounding, same tolerances)."""
     g = load_golden(name)
     monkeypatch.setenv("STMMQR_PAIR_MIN", "1")
-    pkg.set_options(big_front_cols=bfc)
+    # mode 2: ONE sweep per pair (k_upd_f2: the application of a pair beyond the next pair's panels is delayed to the sweep that
+    # forms W of that next pair) -- pending pairs across fronts that run out of rows, ragged blocks, dead columns, last pairs
+    pkg.set_options(big_front_cols=bfc, pair_update=mode)
     try:
         S, G = gpu_run(pkg, g)
     finally:
-        pkg.set_options(big_front_cols=64)
+        pkg.set_options(big_front_cols=64, pair_update=1)
     N = numeric_from_gpu(S, G)
     compare_integers(S, N, g)
     assert G.stats["flops"] == scalar(g, "flopcount")
