@@ -282,6 +282,7 @@ def main():
     ap.add_argument("--lookahead", type=int, default=None)
     ap.add_argument("--tall-min", type=int, default=None)
     ap.add_argument("--fused-update", type=int, default=None)
+    ap.add_argument("--use-graph", type=int, default=None)
     ap.add_argument("--pair-update", type=int, default=None)
     ap.add_argument("--mode", choices=["replicas", "sharded"], default=None,
                     help="N>1: sharded (default) = ONE matrix, subtrees on the ranks, contribution blocks up a tree of joins "
@@ -328,6 +329,8 @@ def main():
         pkg.set_options(pair_update=args.pair_update)
     if args.fused_update is not None:
         pkg.set_options(fused_update=args.fused_update)
+    if args.use_graph is not None:
+        pkg.set_options(use_graph=args.use_graph)
     if args.tall_min is not None:
         pkg.set_options(tall_min_rows=args.tall_min)
     name = args.workload
