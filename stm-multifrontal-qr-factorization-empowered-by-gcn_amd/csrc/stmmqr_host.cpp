@@ -962,6 +962,15 @@ int reset_group(stmmqr_plan &P, int grp)
 // cb_first, cb_first + cb_stride, ... (at most cb_count of them when cb_count >= 0) of the step's fronts.
 struct StepReq { int step, what, cb_first, cb_stride, cb_count; };
 
+// Events of the look-ahead schedule order two streams of ONE device: no timing, and no system-scope fence when they are recorded
+// (the host never inspects them; the kernels' own agent-scope release / acquire at their boundaries is what the other stream needs).
+// STMMQR_LA_SYSFENCE=1 brings the default (system-scope) events back.
+static unsigned la_event_flags()
+{
+    const bool sysfence = getenv("STMMQR_LA_SYSFENCE") && atoi(getenv("STMMQR_LA_SYSFENCE")) != 0;
+    return hipEventDisableTiming | (sysfence ? 0u : (unsigned)hipEventDisableSystemFence);
+}
+
 int run_schedule(stmmqr_plan &P, bool detail, int grp, const StepReq *req = nullptr)
 {
     hipStream_t st = P.stream;
@@ -1086,6 +1095,19 @@ int run_schedule(stmmqr_plan &P, bool detail, int grp, const StepReq *req = null
             return 0;
         });
     };
+    // T and block 0 of a step's update in ONE launch (k_upd_f: the slab workgroups of the block meet through global memory; the
+    // Gram block of the same launch builds T) -- the look-ahead chain panel(t) -> block 0 -> panel(t+1) then has one launch between
+    // two panels instead of three (T, k_upd_w, k_upd_c).  Same bits as the other forms.
+    auto update_b0_fused = [&](const Step &S, hipStream_t q) -> int {
+        const int *act = L0 + S.act_off, *pl = L0 + S.plist_off;
+        const long long *wl = P.d_wlists.p + S.wp_off;
+        const int epoch = (int)(&S - SV.data()) + 1 + grp * (1 << 20);
+        nlaunch++;
+        return timed(t_upd, [&]() -> int {
+            LCHK(stm_launch_update_fused(c, act, pl, S.n_norm, 0, 1, S.maxsl, P.d_Wp.p, wl, P.d_wcnt.p, P.d_wflag.p, epoch, 1, q));
+            return 0;
+        });
+    };
     auto post = [&](const Step &S, hipStream_t q) -> int {
         if (S.n_cpk <= 0) return 0;
         nlaunch++;
@@ -1118,6 +1140,18 @@ int run_schedule(stmmqr_plan &P, bool detail, int grp, const StepReq *req = null
     const long la_min = getenv("STMMQR_LA_MIN") ? atol(getenv("STMMQR_LA_MIN")) : 2500;
     // ... and when the panel workgroups of the step fit the compute units the side stream leaves alone (a wide step
     // fills the GPU with panel workgroups by itself): STMMQR_LA_MAXPWG (default 48)
+    // T + block 0 of an offloaded step in ONE launch (update_b0_fused) where the step's panels are expected to reach at most
+    // STMMQR_LA_FUSED_ROWS rows (default 5120; 0: never): one launch between two panels of the chain instead of three, and look-ahead then
+    // pays from STMMQR_LA_MIN_FUSED tiles (default 1500).  Measured: sme3Dc stand-in 87.2 -> 84.3 ms, default workload 121.4 ->
+    // 119.4-120.9; on the 7818-row fronts of c5mini (31 slabs) the fused launch is the slower one (43.5 -> 48.9 ms).
+    const int la_fused_rows = getenv("STMMQR_LA_FUSED_ROWS") ? atoi(getenv("STMMQR_LA_FUSED_ROWS")) : 5120;
+    const long la_min_fused = getenv("STMMQR_LA_MIN_FUSED") ? atol(getenv("STMMQR_LA_MIN_FUSED")) : 1500;
+    auto b0_fused = [&](const Step &S) -> bool {
+        if (la_fused_rows <= 0 || !S.split || !g_opt.split_update || S.maxsl > 256 || S.n_pe + S.n_po > 0 || c.cbskip != 0) return false;
+        for (int i = 0; i < S.n_act; i++)                          // (the rows the panels are expected to reach, not the bound)
+            if (stm_panel_rows_est(P.fs[P.lists[S.act_off + i]], P.lists[S.plist_off + i]) > la_fused_rows) return false;
+        return true;
+    };
     const long la_maxpwg = getenv("STMMQR_LA_MAXPWG") ? atol(getenv("STMMQR_LA_MAXPWG")) : 48;
     auto worth_it = [&](const Step &S) -> bool {
         long tiles = 0, pwg = 0;
@@ -1128,7 +1162,7 @@ int run_schedule(stmmqr_plan &P, bool detail, int grp, const StepReq *req = null
             if (ncb > 1) tiles += (long)(ncb - 1) * ((stm_panel_rows_est(fsym, p) + STM_UPD_SLAB - 1) / STM_UPD_SLAB);   // (expected rows, not the bound)
             pwg += stm_use_ca(fsym, p, P.plan_algo, P.ca_min) ? stm_ca_slabs(fsym) : stm_tall_launches(fsym, p, P.tall_min);
         }
-        return tiles >= la_min && pwg <= la_maxpwg && S.n_pe + S.n_po == 0;      // (pair-update steps stay on one stream)
+        return tiles >= (b0_fused(S) ? std::min(la_min, la_min_fused) : la_min) && pwg <= la_maxpwg && S.n_pe + S.n_po == 0;      // (pair-update steps stay on one stream)
     };
     // Look-ahead needs the device's side stream (a CU-masked stream, created once per process and released by an atexit
     // handler): it is only created when some step of this group really goes there -- small matrices never touch it.
@@ -1163,7 +1197,7 @@ int run_schedule(stmmqr_plan &P, bool detail, int grp, const StepReq *req = null
         for (auto *v : {&P.ev_main, &P.ev_prep, &P.ev_side})
             while (v->size() < ns + 1) {
                 hipEvent_t ev = nullptr;
-                HIPCHK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+                HIPCHK(hipEventCreateWithFlags(&ev, la_event_flags()));
                 v->push_back(ev);
             }
         hipStream_t sd = P.side;
@@ -1189,10 +1223,16 @@ int run_schedule(stmmqr_plan &P, bool detail, int grp, const StepReq *req = null
                 if ((e = post(S, st))) return e;
                 continue;
             }
-            if ((e = update(S, 0, 0, true, P.d_Wp.p, st))) return e;                                   // T
-            HIPCHK(hipEventRecord(P.ev_main[t], st));
-            if (side_ev >= 0) { HIPCHK(hipStreamWaitEvent(st, P.ev_side[side_ev], 0)); side_ev = -1; }
-            if ((e = update(S, 0, 1, false, P.d_Wp.p, st))) return e;                                  // block 0
+            if (b0_fused(S)) {
+                if (side_ev >= 0) { HIPCHK(hipStreamWaitEvent(st, P.ev_side[side_ev], 0)); side_ev = -1; }
+                if ((e = update_b0_fused(S, st))) return e;                                            // T + block 0
+                HIPCHK(hipEventRecord(P.ev_main[t], st));
+            } else {
+                if ((e = update(S, 0, 0, true, P.d_Wp.p, st))) return e;                               // T
+                HIPCHK(hipEventRecord(P.ev_main[t], st));
+                if (side_ev >= 0) { HIPCHK(hipStreamWaitEvent(st, P.ev_side[side_ev], 0)); side_ev = -1; }
+                if ((e = update(S, 0, 1, false, P.d_Wp.p, st))) return e;                              // block 0
+            }
             HIPCHK(hipStreamWaitEvent(sd, P.ev_main[t], 0));
             if ((e = post(S, sd))) return e;
             if (t + 1 < ns && SV[t + 1].n_start > 0) {
@@ -1391,7 +1431,7 @@ int stmmqr_factorize_group(stmmqr_plan *plan, int group, int detail)
                 for (auto *v : {&P.ev_main, &P.ev_prep, &P.ev_side})
                     while (v->size() < P.gsteps[0].size() + 1) {
                         hipEvent_t ev = nullptr;
-                        HIPCHK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+                        HIPCHK(hipEventCreateWithFlags(&ev, la_event_flags()));
                         v->push_back(ev);
                     }
             }
