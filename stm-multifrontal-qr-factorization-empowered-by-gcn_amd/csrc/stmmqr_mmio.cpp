@@ -106,6 +106,9 @@ static int read_mm(const char *path, stm_long *m_out, stm_long *n_out, stm_long 
     const double int_max = 9223372036854775807.0;
     if (!(l1 <= int_max) || !(l2 <= int_max)) { fclose(f); return bad("bad size line"); }
     if (!(l3 >= 0) || !(l3 <= int_max) || l3 > 4.0e12) { fclose(f); g_mm_err = "problem too large"; return STMMQR_ERR_TOO_LARGE; }
+    // (dimensions beyond what the library factorizes -- m, n < 2^31 here, < 2^30 on the device -- are refused before the column
+    //  pointers are allocated: the reference gets there too, by a failed malloc of ncol + 1 Longs)
+    if (l1 > 2147483646.0 || l2 > 2147483646.0) { fclose(f); g_mm_err = "problem too large"; return STMMQR_ERR_TOO_LARGE; }
     const long nrow = (long)l1, ncol = (long)l2, nnz = (long)l3;
     // (:311-315) a rectangular matrix is unsymmetric whatever the banner or the size line says: no other triangle
     if (nrow != ncol) stype = UNSYM;
