@@ -225,3 +225,25 @@ def test_random_matrices_against_lapack():
     whole product path against dense LAPACK"""
     import fuzz_sparseqr
     assert fuzz_sparseqr.main(seed=3, iters=3, big=False) == 0
+
+
+@pytest.mark.parametrize("name,opts,env", [
+    ("pair update on every large front, two sweeps", dict(pair_update=1, big_front_cols=16), {"STMMQR_PAIR_MIN": "1"}),
+    ("pair update on every large front, one sweep", dict(pair_update=2, big_front_cols=16), {"STMMQR_PAIR_MIN": "1"}),
+    ("every front of at most 512 rows whole in one workgroup", dict(big_front_cols=16, mid_front_cols=4096), {}),
+    ("Gram-based panel everywhere", dict(panel_algo=2, big_front_cols=16), {}),
+    ("look-ahead on every step", dict(), {"STMMQR_LA_MIN": "0", "STMMQR_LA_MIN_FUSED": "0"}),
+])
+def test_random_matrices_through_the_other_paths(monkeypatch, name, opts, env):
+    """The same randomized end-to-end check (rank, least-squares residual and solution against dense LAPACK) with the kernels that
+    the defaults only give to large fronts -- or to nothing: the two tested experiments -- forced onto matrices no fixture holds."""
+    import fuzz_sparseqr
+    pkg = importlib.import_module(PKG)
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    base = pkg.get_options()
+    pkg.set_options(**opts)
+    try:
+        assert fuzz_sparseqr.main(seed=29, iters=2, big=False) == 0
+    finally:
+        pkg.set_options(**{k: base[k] for k in opts})
