@@ -469,3 +469,61 @@ def numeric_from_gpu(S: Symbolic, G) -> Numeric:
     c.rank = G.rank; c.rank1 = G.rank1; c.maxfrank = G.maxfrank; c.maxfm = G.maxfm; c.rh_total = G.rh_total
     N.c = c
     return N
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# multi-process tests: every child is ended whatever happens (a hung rank must not be left holding a GPU or a port)
+def run_ranks(target, world: int, args: tuple, timeout: float):
+    """Start `world` spawned processes `target(rank, world, port, *args, q)`, wait for all of them until ONE common deadline,
+    and return what rank 0 put into the queue.  In a `finally` every child still alive is terminated, then killed; a rank that
+    failed or did not finish is reported with its exit code (never a bare hang, never a left-over process)."""
+    import socket
+    import time
+    import torch.multiprocessing as mp
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=target, args=(r, world, port) + tuple(args) + (q,)) for r in range(world)]
+    deadline = time.monotonic() + timeout
+    try:
+        for p in procs:
+            p.start()
+        result = None
+        while time.monotonic() < deadline:
+            if result is None:
+                try:
+                    result = q.get(timeout=0.2)            # drain early: a child blocks in exit while its queue item is unread
+                except Exception:
+                    pass
+            codes = [p.exitcode for p in procs]
+            if any(c not in (None, 0) for c in codes):      # one rank died: the others would wait for it for ever
+                break
+            if all(c == 0 for c in codes):
+                break
+        codes = [p.exitcode for p in procs]
+        assert all(c == 0 for c in codes), f"rank exit codes {codes} (None = still running after {timeout:.0f} s or ended early)"
+        if result is None:
+            result = q.get(timeout=5)
+        return result
+    finally:
+        for p in procs:
+            if p.is_alive():
+                p.terminate()
+        for p in procs:
+            p.join(5)
+            if p.is_alive():
+                p.kill()
+                p.join(5)
+
+
+def finish_ranks(dist, ok: bool):
+    """End of a rank's work: the ranks meet once more only when THIS rank succeeded (a barrier in a `finally` turns one rank's
+    exception into everybody's hang); the process group is destroyed either way."""
+    try:
+        if ok:
+            dist.barrier()
+    finally:
+        try:
+            dist.destroy_process_group()
+        except Exception:
+            pass
