@@ -61,21 +61,26 @@ def host_cores():
     return n
 
 
-def _refdump_run(refdump, mtx, ordering, reps, threads, timeout):
-    """one refdump process: `reps` qr_factorize runs of the compiled reference, best time; threads = MKL threads
-    (the reference's second parallel mode, BLAS-internal threading, STMMQR/README.md:94; SPQR_grain = 1 so that the TPSM
-    pool -- which deadlocks on small pools, SURVEY.md 3.3 -- stays out of it)"""
-    env = dict(os.environ, MKL_NUM_THREADS=str(threads), OMP_NUM_THREADS=str(threads),
-               MKL_THREADING_LAYER="SEQUENTIAL" if threads == 1 else "GNU", MKL_DYNAMIC="FALSE")
-    print(f"[bench] cpu baseline: reference on {threads} core(s), {reps} run(s) ...", file=sys.stderr, flush=True)
+def _refdump_run(refdump, mtx, ordering, reps, threads, timeout, grain=1, pool=None):
+    """one refdump process: `reps` SparseQR runs of the compiled reference, best qr_factorize time.
+    grain = 1: serial qr_kernel(0) with `threads` MKL threads (the reference's BLAS-internal threading, STMMQR/README.md:94).
+    grain > 1: the reference's own tree parallelism -- TPSM pool of `pool` threads, SPQR_grain = grain
+    (SparseQR_multithreads.c:86-115), MKL sequential inside the tasks.  Returns a dict, or {"error": ...}."""
+    mkl = threads if grain <= 1 else 1
+    env = dict(os.environ, MKL_NUM_THREADS=str(mkl), OMP_NUM_THREADS=str(mkl),
+               MKL_THREADING_LAYER="SEQUENTIAL" if mkl == 1 else "GNU", MKL_DYNAMIC="FALSE")
+    if pool:
+        env["REFDUMP_POOL"] = str(pool)
+    what = f"{threads} core(s), {reps} run(s)" + (f", TPSM pool {pool}, SPQR_grain {grain}" if grain > 1 else "")
+    print(f"[bench] cpu baseline: reference on {what} ...", file=sys.stderr, flush=True)
     try:
-        out = subprocess.run([str(refdump), str(mtx), ordering, "1", "d", "-", str(reps)], capture_output=True, text=True, env=env,
-                             timeout=timeout).stdout
+        pr = subprocess.run([str(refdump), str(mtx), ordering, str(grain), "d", "-", str(reps)], capture_output=True, text=True, env=env,
+                            timeout=timeout)
     except subprocess.TimeoutExpired:
-        print(f"[bench] cpu baseline: the {threads}-core leg exceeded {timeout:.0f} s and was dropped", file=sys.stderr, flush=True)
-        return None
+        print(f"[bench] cpu baseline: the leg on {what} exceeded {timeout:.0f} s and was dropped", file=sys.stderr, flush=True)
+        return {"error": f"no result within {timeout:.0f} s (killed)"}
     res = {}
-    for line in out.splitlines():
+    for line in pr.stdout.splitlines():
         if line.startswith("REF factorize seconds"):
             res["seconds"] = float(line.split(":")[1].split()[0])
         elif line.startswith("nf ="):
@@ -83,16 +88,31 @@ def _refdump_run(refdump, mtx, ordering, reps, threads, timeout):
         elif line.startswith("REF qmult(QTX) seconds"):
             t = line.replace(":", " ").split()
             res["qmult_qtx_seconds"] = float(t[3]); res["solve_seconds"] = float(t[6])
-    return res if "seconds" in res and "flops" in res else None
+    if "seconds" in res and "flops" in res:
+        return res
+    tail = (pr.stderr.strip().splitlines() or pr.stdout.strip().splitlines() or [""])
+    return {"error": f"exit code {pr.returncode}: " + " | ".join(tail[:4])[:300]}
 
 
-def cpu_baseline(name, g, budget_s=30.0):
-    """The REAL reference (oracle/_ref/refdump, built by oracle/Makefile) timed on this host in two legs -- 1 core
-    (SPQR_grain = 1, MKL sequential: STMMQR/README.md:71-72) and all cores (MKL threads = nproc) --, best of `reps` runs each,
-    reps sized so that both legs together stay within ~budget_s seconds of CPU work.  `value` is the faster leg.
+def _write_mtx(path, m, n, Ap, Ai, Ax):
+    cols = np.repeat(np.arange(n), np.diff(Ap))
+    with open(path, "w") as f:
+        f.write("%%%%MatrixMarket matrix coordinate real general\n%d %d %d\n" % (m, n, len(Ax)))
+        np.savetxt(f, np.c_[Ai + 1, cols + 1, Ax], fmt="%d %d %.17g")
+
+
+def cpu_baseline(name, g, budget_s=30.0, mtx_path=None, flops=None):
+    """The REAL reference (oracle/_ref/refdump, built by oracle/Makefile) timed on this host, three legs:
+      1. 1 core (SPQR_grain = 1, MKL sequential: STMMQR/README.md:71-72),
+      2. all cores through MKL threads (SPQR_grain = 1, MKL_NUM_THREADS = nproc),
+      3. all cores through the reference's own TPSM tree parallelism (pool of 4 x nproc threads, SPQR_grain = 2 x nproc), under a
+         time limit because the pool can deadlock; a leg that fails is reported with its error, never dropped
+         silently.
+    Repetitions are sized from THIS host's first run of each leg, not from the fixture: a leg whose first run took < 20 s is
+    run twice more (best of 3), a longer one stands as best of 1.  `value` is the fastest leg.
     Falls back to the CPU restatement (kind "port") when the reference build is not present."""
     refdump = ROOT / "oracle" / "_ref" / "refdump"
-    ref_s = float(g["fac_seconds"][0])                 # seconds in the build container: sizing hint only
+    ref_s = float(g["fac_seconds"][0]) if "fac_seconds" in g else 0.0     # seconds in the build container: guard for the huge ones only
     nproc = host_cores()
     if ref_s > 150.0:
         # one run of the reference is minutes to most of an hour (c5mid / c5 stand-ins): not repeated inside a bench run;
@@ -104,34 +124,52 @@ def cpu_baseline(name, g, budget_s=30.0):
     if refdump.exists():
         try:
             with tempfile.TemporaryDirectory() as td:
-                mtx = Path(td) / "a.mtx"
-                if "A_p" in g:
-                    Ap, Ai, Ax = g["A_p"], g["A_i"], g["A_x"]
-                    m, n = int(g["A_m"][0]), int(g["A_n"][0])
+                if mtx_path is not None:
+                    mtx = Path(mtx_path)
                 else:
-                    Ap, Ai, Ax = g["in_Ap"], g["in_Ai"], g["in_Ax"]
-                    m, n = int(g["in_m"][0]), int(g["in_n"][0])
-                cols = np.repeat(np.arange(n), np.diff(Ap))
-                with open(mtx, "w") as f:
-                    f.write("%%MatrixMarket matrix coordinate real general\n%d %d %d\n" % (m, n, len(Ax)))
-                    np.savetxt(f, np.c_[Ai + 1, cols + 1, Ax], fmt="%d %d %.17g")
-                # best of 3 for legs under ~15 s (box-to-box spread of one run: 11.6-15.8 s on the default workload), one run above
-                reps = 3 if ref_s < 15.0 else int(max(1, min(3, budget_s / 2 / max(ref_s * 1.3, 1e-3))))
+                    mtx = Path(td) / "a.mtx"
+                    if "A_p" in g:
+                        _write_mtx(mtx, int(g["A_m"][0]), int(g["A_n"][0]), g["A_p"], g["A_i"], g["A_x"])
+                    else:
+                        _write_mtx(mtx, int(g["in_m"][0]), int(g["in_n"][0]), g["in_Ap"], g["in_Ai"], g["in_Ax"])
                 ordering = str(int(g["ordering"][0])) if "ordering" in g else "-1"
                 omap = {"5": "0", "2": "1", "11": "2", "6": "3"}      # QR_ORDERING_* -> refdump selector
+                osel = omap.get(ordering, "-1")
+                fl_known = float(flops if flops is not None else g["flopcount"][0])
                 legs = []
-                for threads in ([1, nproc] if nproc > 1 else [1]):
-                    r = _refdump_run(refdump, mtx, omap.get(ordering, "-1"), reps, threads, timeout=max(60.0, 6 * reps * ref_s))
-                    if r:
-                        legs.append({"cores": threads, "value": r["flops"] / r["seconds"] * 1e-9, "unit": "GFLOP/s",
-                                     "seconds": r["seconds"], "best_of": reps,
-                                     **({k: r[k] for k in ("qmult_qtx_seconds", "solve_seconds") if k in r})})
-                if legs:
-                    best = max(legs, key=lambda l: l["value"])
+                plan = [dict(threads=1, grain=1, pool=None, mode="serial qr_kernel, MKL sequential")]
+                if nproc > 1:
+                    plan.append(dict(threads=nproc, grain=1, pool=None, mode="serial qr_kernel, MKL threads = nproc"))
+                    plan.append(dict(threads=nproc, grain=2 * nproc, pool=4 * nproc,
+                                     mode="TPSM tree parallelism: pool 4 x nproc, SPQR_grain 2 x nproc, MKL sequential"))
+                for leg in plan:
+                    tpsm = leg["grain"] > 1
+                    first_to = 300.0 if tpsm else max(120.0, 12 * max(ref_s, 1.0))
+                    r = _refdump_run(refdump, mtx, osel, 1, leg["threads"], first_to, leg["grain"], leg["pool"])
+                    rec = {"cores": leg["threads"], "mode": leg["mode"]}
+                    if "error" in r:
+                        rec["error"] = r["error"]
+                        legs.append(rec)
+                        continue
+                    best, reps = r, 1
+                    if r["seconds"] < 20.0:
+                        r2 = _refdump_run(refdump, mtx, osel, 2, leg["threads"], max(120.0, 8 * r["seconds"] + 60.0), leg["grain"], leg["pool"])
+                        if "error" not in r2:
+                            reps = 3
+                            if r2["seconds"] < best["seconds"]:
+                                best = r2
+                    fl = best["flops"] if best["flops"] > 0 else fl_known    # (the reference counts flops in serial mode only)
+                    rec.update({"value": fl / best["seconds"] * 1e-9, "unit": "GFLOP/s", "seconds": best["seconds"], "best_of": reps,
+                                **({k: best[k] for k in ("qmult_qtx_seconds", "solve_seconds") if k in best})})
+                    legs.append(rec)
+                good = [l for l in legs if "value" in l]
+                if good:
+                    best = max(good, key=lambda l: l["value"])
                     return {"value": best["value"], "unit": "GFLOP/s", "cores": best["cores"], "kind": "reference",
-                            "sample": f"{name}: qr_factorize of the compiled reference on this host, best of {reps} per leg; "
-                                      f"legs: " + "; ".join(f"{l['cores']} core(s) {l['seconds'] * 1e3:.1f} ms" for l in legs) +
-                                      " (SPQR_grain=1; 1 core = MKL sequential, all cores = MKL_NUM_THREADS=nproc)",
+                            "sample": f"{name}: qr_factorize of the compiled reference on this host ({nproc} cores); "
+                                      f"legs: " + "; ".join(
+                                          (f"{l['cores']} core(s) [{l['mode']}] {l['seconds'] * 1e3:.1f} ms best of {l['best_of']}" if "value" in l
+                                           else f"{l['cores']} core(s) [{l['mode']}] FAILED: {l['error']}") for l in legs),
                             "seconds": best["seconds"], "legs": legs, "host_cores": nproc}
         except Exception as e:  # fall through to the port
             print(f"[bench] reference baseline failed: {e}", file=sys.stderr)
@@ -254,6 +292,43 @@ def run_micro(pkg, args):
 
 
 DEFAULT_WORKLOAD = {1: "xenon1_colamd_standin", 2: "xenon1_standin", 4: "sme3dc_standin", 8: "c5_standin"}
+# the BASELINE matrices that are absent from the reference checkout (.MISSING_LARGE_BLOBS) are read from
+# $STMMQR_DATA_DIR when somebody put them there; otherwise the labelled stand-in fixture runs
+REAL_FILE_OF = {"xenon1_colamd_standin": "xenon1.mtx", "sme3dc_standin": "sme3Dc.mtx", "c5_standin": "3D_51448_3D.mtx"}
+DRIVER_ORDERINGS = {"default": 7, "colamd": 2}        # qrtest.c:155-169; AMD / METIS / NESDIS are third-party packages of the reference
+
+
+def matrix_workload(pkg, path, ordering_name):
+    """--matrix F.mtx: the driver's flow on a file (qrtest.c:112-169) with this library alone -- reader, the driver's default
+    tolerance 20 (m + n) eps max-column-norm (qrtest.c:135-142), singletons + COLAMD + symbolic analysis on the host -- and a
+    fixture-shaped dict for the numeric factorization that is then timed: the matrix handed to qr_factorize (Y when singletons
+    were removed, SparseQR.c:349,371), tol, ntol = its column count, the qr_symbolic."""
+    if ordering_name not in DRIVER_ORDERINGS:
+        raise SystemExit(f"--ordering {ordering_name}: only {sorted(DRIVER_ORDERINGS)} are computed by this library (AMD / METIS / NESDIS are "
+                         "third-party packages of the reference; run stmmqr_qrtest --reflib for those)")
+    t0 = time.perf_counter()
+    m, n, Ap, Ai, Ax = pkg.read_matrix_market(path)
+    t_read = time.perf_counter() - t0
+    cn = np.sqrt(np.add.reduceat(Ax * Ax, Ap[:-1][np.diff(Ap) > 0])) if len(Ax) else np.zeros(1)
+    mx = float(cn.max(initial=0.0)) or 1.0
+    tol = 20.0 * (m + n) * np.finfo(np.float64).eps * mx
+    t0 = time.perf_counter()
+    sq = pkg.SparseQR(m, n, Ap, Ai, Ax, ordering=DRIVER_ORDERINGS[ordering_name], tol=tol, relax=pkg.relax_for_qr(n, len(Ax)),
+                      symbolic_only=True)
+    t_sym = time.perf_counter() - t0
+    sym = sq.symbolic()
+    info = sq.info
+    Y = sq.Y()
+    inA = Y if Y is not None else (Ap, Ai, Ax)
+    g = {"sym_" + k: (np.asarray([v]) if np.isscalar(v) else v) for k, v in sym.items() if k != "info"}
+    g.update({"in_Ap": np.ascontiguousarray(inA[0]), "in_Ai": np.ascontiguousarray(inA[1]), "in_Ax": np.ascontiguousarray(inA[2]),
+              "in_m": np.asarray([sym["m"]]), "in_n": np.asarray([sym["n"]]), "in_tol": np.asarray([tol]),
+              "in_ntol": np.asarray([sym["n"]]), "ordering": np.asarray([DRIVER_ORDERINGS[ordering_name]]),
+              "A_m": np.asarray([m]), "A_n": np.asarray([n]), "A_p": Ap, "A_i": Ai, "A_x": Ax})
+    meta = {"file": str(path), "read_ms": t_read * 1e3, "own_symbolic_ms": t_sym * 1e3, "n1rows": int(info["n1rows"]),
+            "n1cols": int(info["n1cols"]), "flop_bound": float(info["flop_bound"])}
+    sq.close()
+    return g, meta
 
 
 def spawn_ranks(args):
@@ -276,6 +351,10 @@ def main():
                     help="fixture name or 'micro'; default by --gpus: 1 the xenon1 stand-in in the driver's default (COLAMD) "
                          "ordering, 2 the METIS-ordered xenon1 stand-in, 4 the sme3Dc stand-in, 8 the configs[4] stand-in at full size "
                          "(n = 52 022; c5mid_standin / c5mini_standin are the same structure at n = 27 000 / 8000)")
+    ap.add_argument("--matrix", default=None,
+                    help="a Matrix Market file instead of a fixture: reader -> singletons + COLAMD + symbolic analysis of this library -> "
+                         "timed numeric factorization; CPU leg = the compiled reference on the same file")
+    ap.add_argument("--ordering", default="default", help="with --matrix: default | colamd (qrtest's third argument absent / 1)")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--big-front-cols", type=int, default=None)
     ap.add_argument("--panel-algo", type=int, default=None)
@@ -336,7 +415,17 @@ def main():
     name = args.workload
     if name == "micro":
         return run_micro(pkg, args)
-    g = load_golden(name)
+    mtx_path, mtx_meta = args.matrix, None
+    ddir = os.environ.get("STMMQR_DATA_DIR")
+    if mtx_path is None and ddir and name in REAL_FILE_OF and (Path(ddir) / REAL_FILE_OF[name]).exists():
+        mtx_path = str(Path(ddir) / REAL_FILE_OF[name])       # the real BASELINE matrix instead of its stand-in
+    if mtx_path is not None:
+        if not Path(mtx_path).exists() and ddir and (Path(ddir) / mtx_path).exists():
+            mtx_path = str(Path(ddir) / mtx_path)
+        g, mtx_meta = matrix_workload(pkg, mtx_path, args.ordering)
+        name = Path(mtx_path).stem
+    else:
+        g = load_golden(name)
     S = Symbolic(g)
     sym = {**S.sc, **{k: v for k, v in S.arr.items() if v is not None}}
     tol, ntol = scalar(g, "in_tol"), int(scalar(g, "in_ntol"))
@@ -394,7 +483,8 @@ def main():
         total_flops = float(tsum[1].item())          # replicas: world x flops; sharded: the shards add up to one matrix
     else:
         total_flops = st["flops"]
-    flops = scalar(g, "flopcount")
+    # (a fixture carries the reference's own count; for a file the device's count stands and the CPU leg's must equal it)
+    flops = scalar(g, "flopcount") if "flopcount" in g else (total_flops if (sharded or world == 1) else total_flops / world)
     assert int(round(total_flops)) == int(round(flops if (sharded or world == 1) else world * flops)), (total_flops, flops)
     # a step that silently ran twice (a bounded panel wait ran out and the factorization was repeated with one-workgroup
     # panels) is not a measurement
@@ -460,9 +550,11 @@ def main():
         roof["update_kernels"] = upd_obj
         roof["traffic_source"] = (str(pmc_file.relative_to(ROOT)) + f"; FETCH_SIZE x {FETCH_CORRECTION:.3f} (gfx950 half-counting, "
                                   "calibrated on k_rh_copy / k_cpack)") if pmc_ok else None
-        roof["whole_factorization"] = {"bound": "mfma", "achieved": flops / max(det["ms_total"], 1e-9) * 1e-9,
+        # (from the TIMED steps -- value itself --, not from the detail pass, whose event pairs make it ~15 % slower)
+        roof["whole_factorization"] = {"bound": "mfma", "achieved": value * 1e-3 / max(world if not sharded else 1, 1),
                                        "peak": PEAK_FP64_MFMA_TFLOPS, "unit": "TFLOP/s",
-                                       "frac": flops / max(det["ms_total"], 1e-9) * 1e-9 / PEAK_FP64_MFMA_TFLOPS}
+                                       "frac": value * 1e-3 / max(world if not sharded else 1, 1) / PEAK_FP64_MFMA_TFLOPS,
+                                       "note": "flops of one factorization / ms_per_step of the timed region, per GPU"}
         roof["assembly"] = {"bound": "hbm", "achieved": det["bytes_assemble"] / max(det["ms_assemble"], 1e-9) * 1e-6,
                             "peak": PEAK_HBM_GBS, "unit": "GB/s",
                             "frac": det["bytes_assemble"] / max(det["ms_assemble"], 1e-9) * 1e-6 / PEAK_HBM_GBS}
@@ -472,7 +564,9 @@ def main():
                       "c5_": "3D_51448_3D.mtx (SURVEY 8d generator at full size, n = 52 022)"}
         sof = next((v for k, v in standin_of.items() if name.startswith(k)), None)
         wl = (f"{name}: m={S.m} n={S.n} nnz={S.anz} fronts={S.nf} flops/step={flops:.4g}, ordering {oname}" +
-              (f" (stand-in for {sof}, absent from the reference checkout)" if "standin" in name and sof else ""))
+              (f" (stand-in for {sof}, absent from the reference checkout)" if "standin" in name and sof else "") +
+              (f" (Matrix Market file {mtx_meta['file']}: {mtx_meta['n1cols']} column singletons removed first, own reader + COLAMD + "
+               f"symbolic analysis)" if mtx_meta else ""))
         out = {
             "metric": "numerical-factorization GFLOP/s", "value": value, "unit": "GFLOP/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": wall / args.steps * 1e3,
@@ -485,7 +579,7 @@ def main():
                                         if sharded else f"replica x{world}") +
                                        (" -- REHEARSAL: all ranks on ONE GPU, gloo, blocks through the host (not a measurement)"
                                         if rehearsal else "")),
-                       "device_ms_per_step": dev_ms / args.steps, "launches_per_step": st["nlaunch"],
+                       "flops_per_step": flops, "device_ms_per_step": dev_ms / args.steps, "launches_per_step": st["nlaunch"],
                        "levels": st["nlevels"], "timeline_steps": st["nsteps"], "retries": retries,
                        "device_bytes": det.get("device_bytes", 0.0)},
             "roofline": roof,
@@ -500,6 +594,8 @@ def main():
             out["config"]["shared_fronts"] = 0 if span is None else int((np.asarray(span) > 1).sum())
             # ... and if every heavy top front were shared regardless of the per-step latency threshold of spread_partition
             out["config"]["strong_scaling_bound_all_heavy_fronts_shared"] = crit_all[1] / max(crit_all[0], 1.0)
+        if mtx_meta:
+            out["config"]["matrix_file"] = mtx_meta
         # SURVEY 8 (f1), outside the timed region: Q'b and the least-squares solve on the factors still resident in HBM
         # (wall time including the copies of the vectors), with the residual the reference's driver prints
         try:
@@ -535,7 +631,11 @@ def main():
         except Exception as e:
             out["dropin_seam_error"] = str(e)
         if not args.no_cpu and world == 1:             # (the CPU baseline is reported at N = 1 only)
-            cb = cpu_baseline(name, g)
+            cb = cpu_baseline(name, g, mtx_path=mtx_path, flops=flops)
+            if mtx_path is not None and cb.get("kind") == "reference":
+                fl_ref = [l for l in cb.get("legs", []) if l.get("mode", "").startswith("serial") and "value" in l]
+                if fl_ref:      # the reference's own flop count on the same file must be the device's
+                    cb["flops_match_device"] = bool(int(round(fl_ref[0]["value"] * 1e9 * fl_ref[0]["seconds"])) == int(round(flops)))
             out["cpu_baseline"] = cb
         print(json.dumps(out))
     plan.close()

@@ -214,8 +214,22 @@ static double solve_residual(sparse_csc *A, SparseQR_factorization *QR, sparse_c
     return sqrt(d) / (double)n;
 }
 
+#include <execinfo.h>
+#include <signal.h>
+static void on_segv(int sig)
+{
+    /* say where: the TPSM mode (grain > 1) of the reference as built here dies inside the pool set-up on hosts that do not look
+     * like the machine its checked-in include/tpsm/Numainfo.h describes (2 sockets, 4 NUMA nodes, 128 cores) */
+    void *bt[48];
+    int n = backtrace(bt, 48);
+    fprintf(stderr, "refdump: signal %d\n", sig);
+    backtrace_symbols_fd(bt, n, 2);
+    _exit(128 + sig);
+}
+
 int main(int argc, char **argv)
 {
+    signal(SIGSEGV, on_segv);
     if (argc < 6) {
         fprintf(stderr, "usage: %s <matrix.mtx> <ordering> <grain> <tolmode d|n> <out.bin|-> [reps]\n", argv[0]);
         return 1;

@@ -170,11 +170,16 @@ SYNTH = {
     "syn_rankdef_grid": syn_rankdef_grid,
 }
 # (fixture name, source, ordering, tolmode)
+# every matrix of the reference's own test list (STMMQR/test.txt:1-16) that is present under Data/ (9 of 16; the other seven are
+# in .MISSING_LARGE_BLOBS and have stand-ins, gen3d.py).  Their values cannot be regenerated, so the fixture keeps the matrix.
 REAL = [("bcsstk14", "bcsstk14.mtx", -1, "d"), ("epb1", "epb1.mtx", -1, "d"),
-        ("lns_3937", "lns_3937.mtx", -1, "d")]
+        ("lns_3937", "lns_3937.mtx", -1, "d"),
+        ("dwt_992", "dwt_992.mtx", -1, "d"), ("reorientation_8", "reorientation_8.mtx", -1, "d"),
+        ("cvxqp3", "cvxqp3.mtx", -1, "d"), ("t2d_q9", "t2d_q9.mtx", -1, "d"), ("bayer10", "bayer10.mtx", -1, "d"),
+        ("ex18", "ex18.mtx", -1, "d")]
 
 
-def compact(name, d):
+def compact(name, d, keep_values=False):
     """dump dict -> fixture dict (ints to int32 where they fit, stacks -> sketches when large)."""
     out = {}
     ns = int(d["num_ns"][0])
@@ -195,7 +200,7 @@ def compact(name, d):
     out["num_rrow_sig"] = np.concatenate([sigs[f] for f in range(nf)]) if nf else np.zeros((0, 3))
     out["num_rh_sketch"] = sk
     out["num_rh_size"] = rsize
-    big = d["in_Ax"].size > VALUES_LIMIT
+    big = d["in_Ax"].size > VALUES_LIMIT and not keep_values
     for k, a in d.items():
         if k.startswith("num_Stack_"):
             if len(a) <= FULL_STACK_LIMIT:
@@ -209,7 +214,7 @@ def compact(name, d):
     return out
 
 
-def run(name, mtx, ordering, tolmode):
+def run(name, mtx, ordering, tolmode, keep_values=False):
     with tempfile.TemporaryDirectory() as td:
         binp = Path(td) / "dump.bin"
         env = {"MKL_THREADING_LAYER": "SEQUENTIAL", "PATH": "/usr/bin:/bin"}
@@ -218,7 +223,7 @@ def run(name, mtx, ordering, tolmode):
         if r.returncode != 0:
             raise RuntimeError(f"{name}: refdump failed\n{r.stdout}\n{r.stderr}")
         d = parse_dump(binp)
-    fx = compact(name, d)
+    fx = compact(name, d, keep_values)
     np.savez_compressed(HERE / f"{name}.npz", **fx)
     sz = (HERE / f"{name}.npz").stat().st_size
     print(f"{name:18s} m={d['in_m'][0]:6d} n={d['in_n'][0]:6d} nf={d['sym_nf'][0]:5d} rank={d['num_rank'][0]:6d} "
@@ -259,7 +264,7 @@ def main():
     for name, fn, ordering, tolmode in REAL:
         if only and name not in only:
             continue
-        run(name, REFDATA / fn, ordering, tolmode)
+        run(name, REFDATA / fn, ordering, tolmode, keep_values=True)
 
 
 if __name__ == "__main__":

@@ -8,11 +8,10 @@ What "identical to the reference" means for this path (see tests/test_oracle_gol
 """
 import numpy as np
 
-from stmmqr_testlib import (aqr_probe_error, front_R, numeric_from_gpu, rrow_signature, rrow_signature_of_block, scalar)
+from stmmqr_testlib import (ILL_CONDITIONED, aqr_probe_error, front_R, numeric_from_gpu, rrow_signature, rrow_signature_of_block, scalar)
 
 ELEMENTWISE = ("syn_dense6x4", "syn_wide5x8", "syn_dupcol", "syn_emptycol", "syn_chain", "syn_star",
                "syn_rand60x40")
-ILL_CONDITIONED = {"bcsstk14": 1e-6, "lns_3937": 1e-6}
 
 
 def rrow_sig_all(S, N):

@@ -46,8 +46,18 @@ SYM_SCALARS = ["m", "n", "anz", "nf", "maxfn", "rjsize", "do_rank_detection", "m
 BIG_FIXTURES = ("xenon1_standin", "xenon1_colamd_standin", "sme3dc_standin", "c5mini_standin", "c5mid_standin", "c5_standin")      # full BASELINE size: too slow for the scalar CPU oracle, GPU tests only
 
 
+# The reference's own test list (STMMQR/test.txt:1-16) as far as its files are present under /root/reference/Data: 9 of 16.
+REFERENCE_TEST_MATRICES = ("dwt_992", "lns_3937", "bcsstk14", "epb1", "reorientation_8", "cvxqp3", "t2d_q9", "bayer10", "ex18")
+# ... two of them are too heavy for the scalar CPU oracle inside every parametrized test (2e10 / 1.9e11 flops: 7 s / 100 s per oracle
+# run): they have their own tests (tests/test_oracle_golden.py once each on the CPU, tests/test_gpu_factorize.py::test_reference_inputs)
+HEAVY_REAL = ("reorientation_8", "cvxqp3")
+# R rows of these are only determined relative to ||A|| (pivots near tol, condition numbers of 1e10 and more: the reference's own
+# driver prints res = 1e0 ... 1e3 for them); the tolerance applies to |difference| / max row norm
+ILL_CONDITIONED = {"bcsstk14": 1e-6, "lns_3937": 1e-6, "bayer10": 1e-9, "ex18": 1e-6, "reorientation_8": 1e-9, "cvxqp3": 1e-8}
+
+
 def golden_names(include_big: bool = False):
-    return sorted(p.stem for p in GOLDEN.glob("*.npz") if include_big or p.stem not in BIG_FIXTURES)
+    return sorted(p.stem for p in GOLDEN.glob("*.npz") if include_big or (p.stem not in BIG_FIXTURES and p.stem not in HEAVY_REAL))
 
 
 def load_golden(name: str) -> dict:
