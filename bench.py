@@ -160,6 +160,7 @@ def cpu_baseline(name, g, budget_s=30.0, mtx_path=None, flops=None):
                                 best = r2
                     fl = best["flops"] if best["flops"] > 0 else fl_known    # (the reference counts flops in serial mode only)
                     rec.update({"value": fl / best["seconds"] * 1e-9, "unit": "GFLOP/s", "seconds": best["seconds"], "best_of": reps,
+                                "flops": fl,
                                 **({k: best[k] for k in ("qmult_qtx_seconds", "solve_seconds") if k in best})})
                     legs.append(rec)
                 good = [l for l in legs if "value" in l]
@@ -635,7 +636,7 @@ def main():
             if mtx_path is not None and cb.get("kind") == "reference":
                 fl_ref = [l for l in cb.get("legs", []) if l.get("mode", "").startswith("serial") and "value" in l]
                 if fl_ref:      # the reference's own flop count on the same file must be the device's
-                    cb["flops_match_device"] = bool(int(round(fl_ref[0]["value"] * 1e9 * fl_ref[0]["seconds"])) == int(round(flops)))
+                    cb["flops_match_device"] = bool(int(round(fl_ref[0]["flops"])) == int(round(flops)))
             out["cpu_baseline"] = cb
         print(json.dumps(out))
     plan.close()

@@ -305,7 +305,7 @@ int main(int argc, char **argv)
     double bwd = 0;
     double res = solve_residual(A, QR, cc, &bwd);
     put_d("res", res); put_d("backward_err", bwd);
-    printf("nf = %ld ntasks = %ld rank = %ld flops = %.6g (bound %.6g)\n", (long)QR->QRsym->nf,
+    printf("nf = %ld ntasks = %ld rank = %ld flops = %.17g (bound %.17g)\n", (long)QR->QRsym->nf,
            (long)QR->QRnum->ntasks, (long)QR->rank, g_flops, cc->SPQR_flopcount_bound);
     printf("REF factorize seconds (best of %d): %.6f   GFLOP/s: %.3f\n", reps, best,
            g_flops > 0 ? g_flops / best * 1e-9 : 0.0);

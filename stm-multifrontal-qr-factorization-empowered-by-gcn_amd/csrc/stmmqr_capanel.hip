@@ -256,7 +256,7 @@ __global__ __launch_bounds__(CA_NT) void k_panel_ca(DevCtx c, const int *__restr
     if (!owner) {
         // ---- slab workgroup: wait for the owner's rounds ----
         for (;;) {
-            if (!ca_wait_ge(&num->prog, STM_PROG * p + 1 + round, &s_ok)) { if (tid == 0) st_agent(&num->perr, 1); return; }
+            if (!ca_wait_ge(&num->prog, STM_PROG * p + 1 + round, &s_ok)) { if (tid == 0) STM_SET_PERR(c, num); return; }
             const int final = ld_agent(&pd->sw);        // (stored before the flag of this round; sw: 0 refresh round, 1 final)
             const double *Mg = Gp + (long long)c.gp_slabs * (STM_NB * STM_NB);
             for (int e = tid; e < STM_NB * STM_NB; e += CA_NT) cs.M[e >> 5][e & 31] = ld_agent(&Mg[e]);
@@ -363,7 +363,7 @@ __global__ __launch_bounds__(CA_NT) void k_panel_ca(DevCtx c, const int *__restr
                     ca_publish_block(cs.G, Gp + (long long)w * (STM_NB * STM_NB));
                 }
                 const int others = nwact - (nr > 0 ? 1 : 0);
-                if (!ca_wait_ge(&num->gcnt, others, &s_ok)) { if (tid == 0) st_agent(&num->perr, 1); return; }
+                if (!ca_wait_ge(&num->gcnt, others, &s_ok)) { if (tid == 0) STM_SET_PERR(c, num); return; }
                 if (tid == 0) st_agent(&num->gcnt, 0);
                 for (int e = tid; e < STM_NB * STM_NB; e += CA_NT) {
                     cs.G[e >> 5][e & 31] = stm_ordered_sum<true>(Gp + e, STM_NB * STM_NB, nwact);

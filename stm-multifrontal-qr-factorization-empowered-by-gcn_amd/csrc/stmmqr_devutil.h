@@ -94,3 +94,9 @@ __device__ __forceinline__ bool stm_wait_ge(const int *flag, int target, int *ab
     __syncthreads();
     return *s_ok != 0;
 }
+
+// A bounded wait ran out: recorded on the front (which panel chain failed) AND in the plan-wide word abort[1], so that the host
+// learns it from four bytes instead of a copy of every FrontNum (stmmqr_factorize_group of the phased interface).
+// (abort is null in the single-front seams of stmmqr_seams.cpp: they read the front's own perr)
+#define STM_SET_PERR(c, num) do { st_agent(&(num)->perr, 1); if ((c).abort) st_agent((c).abort + 1, 1); } while (0)
+

@@ -150,6 +150,9 @@ struct stmmqr_plan {
     std::vector<int> h_tslot;                  // host copy of d_tslot
     std::vector<char> shared;                  // per front: STMMQR_GROUP_SHARED -- alone in its group, driven step by step
                                                //  (stmmqr_factorize_step), its trailing column blocks shared with other plans
+    std::vector<char> has_c;                   // per front: its packed contribution block has a slot in the C arena of this plan
+                                               //  (the front is factorized here, or it is a child of one that is: assign_arenas)
+    std::vector<long long> c_slot;             // ... and the size of that slot in doubles (the symbolic bound of csize)
     int own_off = 0, n_own = 0;
     std::vector<int> lists;              // host copy of d_lists
     int post_off = 0, rh_parts_off = 0, rh_maxparts = 1;
@@ -340,6 +343,7 @@ void assign_arenas(stmmqr_plan &P)
 {
     long long foff = 0, coff = 0;
     std::vector<char> needc((size_t)std::max(1L, P.nf), 0);
+    P.c_slot.assign((size_t)std::max(1L, P.nf), 0);
     for (long f = 0; f < P.nf; f++) {
         if (P.group[f] < 0) continue;
         needc[(size_t)f] = 1;
@@ -357,10 +361,12 @@ void assign_arenas(stmmqr_plan &P)
             const long cn = s.fn - s.fp, fm = s.fm_ub;
             const long cm = P.do_rank ? std::min(fm, cn) : std::min(std::max(fm - std::min(fm, (long)s.fp), 0L), cn);
             s.coff = coff;
-            coff += (long long)cm * (cm + 1) / 2 + (long long)cm * (cn - cm);
+            P.c_slot[(size_t)f] = (long long)cm * (cm + 1) / 2 + (long long)cm * (cn - cm);
+            coff += P.c_slot[(size_t)f];
             coff = (coff + 1) & ~1LL;
         }
     }
+    P.has_c.swap(needc);
     P.farena = std::max(1LL, foff); P.carena = std::max(1LL, coff);
 }
 
@@ -856,7 +862,7 @@ int build_plan(stmmqr_plan &P, const stmmqr_symbolic_view &v)
     LCHK(P.d_wcnt.alloc(P.wcnt_n));
     LCHK(P.d_wcnt2.alloc(P.wcnt_n));
     LCHK(P.d_wflag.alloc(P.wcnt_n));
-    if (!P.d_abort.p) LCHK(P.d_abort.alloc(1));
+    if (!P.d_abort.p) LCHK(P.d_abort.alloc(2));
     LCHK(P.d_wflag2.alloc(P.wcnt_n));
     HIPCHK(hipMemset(P.d_wcnt.p, 0, P.wcnt_n * sizeof(int)));
     HIPCHK(hipMemset(P.d_wcnt2.p, 0, P.wcnt_n * sizeof(int)));
@@ -929,7 +935,7 @@ int reset_factorization(stmmqr_plan &P)
     HIPCHK(hipMemsetAsync(P.d_wcnt2.p, 0, P.wcnt_n * sizeof(int), st));
     HIPCHK(hipMemsetAsync(P.d_wflag.p, 0, P.wcnt_n * sizeof(int), st));
     HIPCHK(hipMemsetAsync(P.d_wflag2.p, 0, P.wcnt_n * sizeof(int), st));
-    HIPCHK(hipMemsetAsync(P.d_abort.p, 0, sizeof(int), st));
+    HIPCHK(hipMemsetAsync(P.d_abort.p, 0, 2 * sizeof(int), st));
     LCHK(stm_launch_sigma(P.d_Ax.p, (int)P.anz, P.d_amax.p, P.d_sig.p, st));
     LCHK(stm_launch_gather_sx(P.d_Ax.p, P.d_smap.p, P.d_Sx.p, (int)P.anz, st));
     P.stats.nlaunch += 6;
@@ -953,7 +959,7 @@ int reset_group(stmmqr_plan &P, int grp)
     HIPCHK(hipMemsetAsync(P.d_wcnt2.p, 0, P.wcnt_n * sizeof(int), st));
     HIPCHK(hipMemsetAsync(P.d_wflag.p, 0, P.wcnt_n * sizeof(int), st));
     HIPCHK(hipMemsetAsync(P.d_wflag2.p, 0, P.wcnt_n * sizeof(int), st));
-    HIPCHK(hipMemsetAsync(P.d_abort.p, 0, sizeof(int), st));
+    HIPCHK(hipMemsetAsync(P.d_abort.p, 0, 2 * sizeof(int), st));
     HIPCHK(hipStreamSynchronize(st));                       // (`zero` lives on this stack frame)
     return 0;
 }
@@ -1463,11 +1469,10 @@ int stmmqr_factorize_group(stmmqr_plan *plan, int group, int detail)
     // HERE and the group is run again with one-workgroup panels (no inter-workgroup waits), exactly as
     // stmmqr_factorize_device does for the whole factorization -- the other groups and the imported fronts are not touched.
     if (!e && !P.whole_call && !P.serial_panels) {
+        // (four bytes: the kernels raise abort[1] beside the front's own perr -- not a copy of every FrontNum per phase)
+        int failed = 0;
+        HIPCHK(hipMemcpyAsync(&failed, P.d_abort.p + 1, sizeof(int), hipMemcpyDeviceToHost, P.stream));
         HIPCHK(hipStreamSynchronize(P.stream));
-        P.h_fnum.resize((size_t)std::max(1L, P.nf));
-        if (P.nf > 0) HIPCHK(hipMemcpy(P.h_fnum.data(), P.d_fnum.p, (size_t)P.nf * sizeof(FrontNum), hipMemcpyDeviceToHost));
-        bool failed = false;
-        for (long f = 0; f < P.nf && !failed; f++) failed = (P.group[f] == group && P.h_fnum[f].perr != 0);
         if (failed) {
             if (g_opt.verbose) fprintf(stderr, "[stmmqr_hip] a panel wait ran out in group %d: running it again with one-workgroup panels\n", group);
             P.stats.retries++;
@@ -1669,7 +1674,7 @@ int stmmqr_plan_set_groups(stmmqr_plan *plan, const int *group)
     LCHK(grow(P.d_wcnt, P.wcnt_n));
     LCHK(grow(P.d_wcnt2, P.wcnt_n));
     LCHK(grow(P.d_wflag, P.wcnt_n));
-    if (!P.d_abort.p) LCHK(P.d_abort.alloc(1));
+    if (!P.d_abort.p) LCHK(P.d_abort.alloc(2));
     LCHK(grow(P.d_wflag2, P.wcnt_n));
     HIPCHK(hipMemset(P.d_wcnt.p, 0, P.wcnt_n * sizeof(int)));
     HIPCHK(hipMemset(P.d_wcnt2.p, 0, P.wcnt_n * sizeof(int)));
@@ -1677,6 +1682,23 @@ int stmmqr_plan_set_groups(stmmqr_plan *plan, const int *group)
     LCHK(P.d_lists.upload(P.lists, P.stream));
     LCHK(P.d_wlists.upload(P.wlists, P.stream));
     HIPCHK(hipStreamSynchronize(P.stream));
+    return 0;
+}
+
+// Does front f have a contribution-block slot on this plan, allocated, that holds `csize` doubles?  A front that is neither
+// factorized here nor a child of a front that is has NO slot (its coff is 0: the first resident block's), and the arenas exist
+// only between the first stmmqr_factorize_begin after a (re)grouping and the next regrouping.
+static int check_c_slot(const stmmqr_plan &P, stm_long f, long long csize, const char *what)
+{
+    if (f < 0 || f >= P.nf) return fail(STMMQR_ERR_INVALID, std::string(what) + ": no such front");
+    if ((size_t)f >= P.has_c.size() || !P.has_c[(size_t)f])
+        return fail(STMMQR_ERR_INVALID, std::string(what) + ": the front has no contribution-block slot on this plan (it is neither "
+                                        "factorized here nor a child of a front that is)");
+    if (!P.d_C.p || P.d_C.n != (size_t)P.carena)
+        return fail(STMMQR_ERR_INVALID, std::string(what) + ": the arenas of the current grouping are not allocated yet "
+                                        "(stmmqr_factorize_begin comes first)");
+    if (csize < 0 || csize > P.c_slot[(size_t)f])
+        return fail(STMMQR_ERR_INVALID, std::string(what) + ": the block exceeds the front's slot");
     return 0;
 }
 
@@ -1702,6 +1724,7 @@ int stmmqr_plan_export_front(stmmqr_plan *plan, stm_long f, double *C, stm_long 
     int e = stmmqr_plan_front_info(plan, f, info);
     if (e) return e;
     stmmqr_plan &P = *plan;
+    if ((e = check_c_slot(P, f, info[3], "stmmqr_plan_export_front"))) return e;
     if (info[3] > 0 && C)
         HIPCHK(hipMemcpy(C, P.d_C.p + P.fs[f].coff, (size_t)info[3] * sizeof(double),
                          c_on_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost));
@@ -1724,6 +1747,9 @@ int stmmqr_plan_import_front(stmmqr_plan *plan, stm_long f, stm_long fm, stm_lon
     if (cm < 0 || cm > cn || rank < 0 || rank + cm > P.fs[f].fm_ub)
         return fail(STMMQR_ERR_INVALID, "imported front does not fit the symbolic bounds");
     const long csize = cm * (cm + 1) / 2 + cm * (cn - cm);
+    if (!P.begun) return fail(STMMQR_ERR_INVALID, "stmmqr_plan_import_front outside factorize_begin / factorize_finish (begin resets every front's state)");
+    if (int e = check_c_slot(P, f, csize, "stmmqr_plan_import_front")) return e;
+    if ((cm > 0 && !rows) || (csize > 0 && !C)) return fail(STMMQR_ERR_INVALID, "stmmqr_plan_import_front: null block / row ids");
     HIPCHK(hipStreamSynchronize(P.stream));
     FrontNum nm;
     memset(&nm, 0, sizeof nm);
@@ -1796,6 +1822,8 @@ static int panel_copy(stmmqr_plan &P, stm_long f, stm_long p, double *buf, int o
     const FrontSym &s = P.fs[f];
     if (p < 0 || p >= s.npanels) return fail(STMMQR_ERR_INVALID, "no such panel");
     if (P.group[f] < 0) return fail(STMMQR_ERR_INVALID, "the front is not factorized by this plan");
+    if (!P.begun || !P.d_F.p || P.d_F.n != (size_t)P.farena)
+        return fail(STMMQR_ERR_INVALID, "panel messages move between factorize_begin and factorize_finish (the front arena of the current grouping must exist)");
     HIPCHK(hipSetDevice(P.device));
     const PanelMsg m = panel_msg(s, p);
     const hipMemcpyKind kind = on_device ? hipMemcpyDeviceToDevice : (out ? hipMemcpyDeviceToHost : hipMemcpyHostToDevice);
@@ -1834,11 +1862,14 @@ static int front_cols_copy(stmmqr_plan &P, stm_long f, int part, int nparts, dou
 {
     if (f < 0 || f >= P.nf || nparts < 1 || part < 0 || part >= nparts) return fail(STMMQR_ERR_INVALID, "bad front / part");
     HIPCHK(hipSetDevice(P.device));
+    if (int e = check_c_slot(P, f, 0, out ? "stmmqr_plan_export_front_cols" : "stmmqr_plan_import_front_cols")) return e;
     HIPCHK(hipStreamSynchronize(P.stream));
     FrontNum nm;
     HIPCHK(hipMemcpy(&nm, P.d_fnum.p + f, sizeof nm, hipMemcpyDeviceToHost));
     const FrontSym &s = P.fs[f];
     const long cn = s.fn - s.fp, cm = nm.cm;
+    if (cm < 0 || cm > cn || (long long)cm * (cm + 1) / 2 + (long long)cm * (cn - cm) > P.c_slot[(size_t)f])
+        return fail(STMMQR_ERR_INVALID, "front_cols: the front's contribution block does not fit its slot");
     auto coff = [&](long j) -> long long { return j < cm ? (long long)j * (j + 1) / 2 : (long long)cm * (cm + 1) / 2 + (long long)(j - cm) * cm; };
     const hipMemcpyKind kind = on_device ? hipMemcpyDeviceToDevice : (out ? hipMemcpyDeviceToHost : hipMemcpyHostToDevice);
     long long pos = 0;

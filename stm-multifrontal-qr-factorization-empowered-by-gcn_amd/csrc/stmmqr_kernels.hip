@@ -1207,7 +1207,7 @@ __device__ __forceinline__ void dev_tall_group(PanelShared &ps, const FrontSym &
                                                int *St, double *Tau, char *Rdead, int p, int b, int g1, int tmax,
                                                double tol, int ntol_global, double *Tout, double *lds, int dbg = 0,
                                                unsigned long long *dbgbuf = nullptr, double *Tkeep = nullptr, int defer_ok = 0,
-                                               const double *sigp = nullptr)
+                                               const double *sigp = nullptr, int *abortp = nullptr)
 {
     const int tid = threadIdx.x;
     const int m = num->fm, n = s.fn, npiv = s.fp;              // (fm is fixed before the panel kernels run)
@@ -1265,7 +1265,10 @@ __device__ __forceinline__ void dev_tall_group(PanelShared &ps, const FrontSym &
     double ch_ls = 0, ch_fl = 0;
     for (int sp = 0; sp < b && !prev_done; sp++)
     for (int half = 0; half < 2; half++) {
-        if (!wait_progress(&num->prog, STM_PROG * p + 2 * sp + 1 + half, seen)) { if (tid == 0) st_agent(&num->perr, 1); return; }
+        if (!wait_progress(&num->prog, STM_PROG * p + 2 * sp + 1 + half, seen)) {
+            if (tid == 0) { st_agent(&num->perr, 1); if (abortp) st_agent(abortp + 1, 1); }      // (= STM_SET_PERR)
+            return;
+        }
         TSTAMP(7);
         TL(2 + 3 * tl_h);
         const int pc0 = SWT * sp + half * (SWT / 2);
@@ -1987,7 +1990,7 @@ __global__ __launch_bounds__(NTP) void k_panel(DevCtx c, const int *__restrict__
         for (int it = 0; it < 4000; it++) __builtin_amdgcn_s_sleep(100);
     }
     if ((c.dbg & 4096) && b > 0) {                              // tests: every column group but the first gives up at once
-        if (threadIdx.x == 0) st_agent(&num->perr, 1);
+        if (threadIdx.x == 0) STM_SET_PERR(c, num);
         return;
     }
     bool tall = stm_tall_panel(s, p, c.tall_min) && !(c.dbg & 256);
@@ -2028,7 +2031,7 @@ __global__ __launch_bounds__(NTP) void k_panel(DevCtx c, const int *__restrict__
             publish_progress(&num->hdr, p + 1);
             if (was_done) return;
         } else {
-            if (!wait_progress(&num->hdr, p + 1)) { if (threadIdx.x == 0) st_agent(&num->perr, 1); return; }
+            if (!wait_progress(&num->hdr, p + 1)) { if (threadIdx.x == 0) STM_SET_PERR(c, num); return; }
             mode = ld_agent(&pd->mode); g1 = ld_agent(&pd->pg1); tmax = ld_agent(&pd->tmax); w = ld_agent(&pd->sw);
             if (mode != 1 || b * w >= nbp) return;
         }
@@ -2043,7 +2046,7 @@ __global__ __launch_bounds__(NTP) void k_panel(DevCtx c, const int *__restrict__
         }
         if (mode == 1) {
             const int rows = tmax - g1;
-#define TALL_ARGS ps, s, num, pd, F, St, c.Tau + s.rp, c.Rdead + s.col1, p, b, g1, tmax, c.tol, c.ntol, T, dyn_lds, c.dbg, c.dbgbuf, Tkeep, defer_ok, c.sig
+#define TALL_ARGS ps, s, num, pd, F, St, c.Tau + s.rp, c.Rdead + s.col1, p, b, g1, tmax, c.tol, c.ntol, T, dyn_lds, c.dbg, c.dbgbuf, Tkeep, defer_ok, c.sig, c.abort
             if (w == 2) dev_tall_group<NTP, 16, 2>(TALL_ARGS);
             else if (w == 4) dev_tall_group<NTP, 8, 4>(TALL_ARGS);
             else if (rows <= NTP) dev_tall_group<NTP, 1, 8>(TALL_ARGS);
@@ -2490,7 +2493,7 @@ __global__ __launch_bounds__(NT, 2) void k_upd_f(DevCtx c, const int *__restrict
     double *s_W1 = Vs, *s_T = Cs;                                  // (the chunk images are free between the phases)
     if (last) {
         // (>=: with look-ahead the T of the NEXT panel may be announced while the side stream still applies this one)
-        if (pd->t_deferred && !stm_wait_ge(&num->tready, epoch, c.abort, &s_ok)) { if (tid == 0) st_agent(&num->perr, 1); return; }
+        if (pd->t_deferred && !stm_wait_ge(&num->tready, epoch, c.abort, &s_ok)) { if (tid == 0) STM_SET_PERR(c, num); return; }
         for (int e = tid; e < STM_NB * BN; e += NT) {
             const double v = stm_ordered_sum<true>(Wslot + e, STM_NB * BN, nsl);        // fixed order: deterministic
             s_W1[(e / BN) * WS + (e % BN)] = v;
@@ -2516,7 +2519,7 @@ __global__ __launch_bounds__(NT, 2) void k_upd_f(DevCtx c, const int *__restrict
         } else
             __syncthreads();
     } else {
-        if (!stm_wait_ge(flag, epoch, c.abort, &s_ok)) { if (tid == 0) st_agent(&num->perr, 1); return; }
+        if (!stm_wait_ge(flag, epoch, c.abort, &s_ok)) { if (tid == 0) STM_SET_PERR(c, num); return; }
         for (int e = tid; e < STM_NB * BN; e += NT) Ws[(e / BN) * WS + (e % BN)] = ld_agent(&Wslot[e]);
         __syncthreads();
     }

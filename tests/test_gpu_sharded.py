@@ -342,3 +342,50 @@ def test_rank_arenas_hold_only_its_fronts():
         p.close()
     assert max(held) < 0.8 * whole
     assert sum(held) < 1.8 * whole
+
+
+def test_fronts_without_a_slot_are_refused():
+    """ADVICE round 3 (memory safety of the public C ABI): after a regrouping a plan's contribution-block arena holds only the
+    fronts it factorizes and their children.  Importing / exporting any OTHER front used to write to offset 0 of the arena (the first
+    resident block) or past its end; it is refused now, as is an import before stmmqr_factorize_begin (no arenas yet, and begin
+    resets every front), a block larger than the front's slot, and a panel message outside begin / finish."""
+    pkg = importlib.import_module(PKG)
+    sh = importlib.import_module(PKG + ".sharded")
+    g = load_golden("grid20_standin")
+    S = Symbolic(g)
+    sym = {**S.sc, **{k: v for k, v in S.arr.items() if v is not None}}
+    tol, ntol = scalar(g, "in_tol"), int(scalar(g, "in_ntol"))
+    owner, phase = sh.partition(sym, 2)
+    mine = np.where(owner == 0, phase, -1).astype(np.int32)
+    par = np.full(S.nf, -1)
+    for f in range(S.nf):
+        for q in range(sym["Childp"][f], sym["Childp"][f + 1]):
+            par[sym["Child"][q]] = f
+    # a front of rank 1 whose parent is ALSO on rank 1: rank 0 has no slot for it
+    foreign = [f for f in range(S.nf) if mine[f] < 0 and par[f] >= 0 and mine[par[f]] < 0]
+    # ... and one that rank 0 receives (a child of one of its fronts)
+    incoming = [f for f in range(S.nf) if mine[f] < 0 and par[f] >= 0 and mine[par[f]] >= 0]
+    assert foreign and incoming
+    p = pkg.HipQR(sym)
+    p.set_groups(mine)
+    f_in, f_no = incoming[0], foreign[0]
+    cn = int(sym["Rp"][f_in + 1] - sym["Rp"][f_in] - (sym["Super"][f_in + 1] - sym["Super"][f_in]))
+    rows = np.arange(max(cn, 1), dtype=np.int64)
+    with pytest.raises(pkg.StmmqrError, match="factorize_begin"):
+        p.import_front(f_in, 1, 0, 1, np.zeros(1), rows[:1])                      # before begin
+    p.begin(g["in_Ax"], tol, ntol, g["in_Ap"], g["in_Ai"])
+    with pytest.raises(pkg.StmmqrError, match="no contribution-block slot"):
+        p.import_front(f_no, 1, 0, 1, np.ones(1), rows[:1])
+    with pytest.raises(pkg.StmmqrError, match="no contribution-block slot"):
+        p.export_front(f_no)
+    with pytest.raises(pkg.StmmqrError, match="symbolic bounds"):
+        p.import_front(f_in, 10 ** 6, 0, cn + 1, np.ones(1), rows[:1])           # cm beyond the front's columns
+    with pytest.raises(pkg.StmmqrError, match="not factorized by this plan"):
+        p.export_panel(f_no, 0)
+    p.close()
+    # panel messages outside begin / finish
+    q = pkg.HipQR(sym)
+    own_big = [f for f in range(S.nf) if sym["Rp"][f + 1] - sym["Rp"][f] >= 64]
+    with pytest.raises(pkg.StmmqrError, match="between factorize_begin and factorize_finish"):
+        q.export_panel(own_big[0], 0)
+    q.close()
