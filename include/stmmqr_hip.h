@@ -297,7 +297,9 @@ double stmmqr_last_seam_ms(void);
 /* ================================================================================================
  * 3. Configuration / introspection
  * ================================================================================================ */
-/* Defaults: {32, 64, 0, 0, 0, 1, 0, 1, 0, 1}.  Read when a plan is created (or a seam is called); the numerical results do not
+/* Defaults: {32, 64, 0, 0, 0, 1, 0, 1, 0, 1}.  (Two options of round 3 were removed in round 4 with the kernels behind them, both
+ * measured slower at every setting: mid_front_cols = whole mid-size fronts in one workgroup, pair_update = 2 = the single-sweep pair
+ * update; profiles/EXPERIMENTS.md.)   Read when a plan is created (or a seam is called); the numerical results do not
  * depend on them beyond rounding.
  * Environment (diagnosis, tests and experiments only; read at plan time unless noted): STMMQR_DBG (bit mask,
  * csrc/stmmqr_kernels.h), STMMQR_QBIG_MIN (entries of a front from which Q-apply / back substitution split its rows over
@@ -328,18 +330,16 @@ typedef struct stmmqr_options {
                                1: ONE launch that keeps its tiles of C in registers between V'C and the application
                                (C read once, written once per panel).  Same bits either way; measured 1.1x - 2.5x slower
                                on MI355X (the slab workgroups of a column block idle while one of them adds the partial
-                               sums: DESIGN.md 5), kept as an experiment.                                            */
+                               sums: DESIGN.md 5), kept as an experiment.  ONE exception to "0 = two launches": an offloaded
+                               look-ahead step applies T + column block 0 in one fused launch when every workgroup of that launch
+                               fits the compute units the side stream leaves alone (counted with the fronts' row BOUNDS) and the
+                               panels are expected to reach at most STMMQR_LA_FUSED_ROWS rows (5120; 0 turns it off).      */
     int pair_update;        /* 1 (default): fronts of >= 16384 rows apply the block reflectors of two consecutive panels in
                                one sweep over the columns beyond the next two panels (1.5 instead of 3 passes over the
                                trailing matrix per panel); a property of the front (plan time), it changes rounding only.
-                               2: the same pairs in ONE sweep each (k_upd_f2: the application beyond the next pair's panels is
-                               delayed to the sweep that forms W of that next pair; 16 instead of 24 bytes per entry and pair);
-                               measured slower on MI355X (one wave per SIMD), kept as a tested experiment        */
-    int mid_front_cols;     /* 0 (default): off.  c > 0: a front with big_front_cols <= fn <= c columns and at most 512 rows is
-                               factorized whole by ONE 512-thread workgroup in one launch (k_front_mid: wave-pipelined panels,
-                               two column blocks of the update side by side) instead of a step of the timeline per panel.
-                               A property of the front (plan time), it changes rounding only; env STMMQR_MID_COLS overrides.
-                               Measured slower on MI355X at every setting, kept as a tested experiment        */
+                               0: every front panel by panel.  (A single-sweep form, 16 instead of 24 bytes per entry and pair, was
+                               built in round 3, measured slower at one wave per SIMD and removed in round 4:
+                               profiles/EXPERIMENTS.md.)                                                                    */
 } stmmqr_options;
 void stmmqr_get_options(stmmqr_options *opt);
 void stmmqr_set_options(const stmmqr_options *opt);

@@ -75,7 +75,7 @@ class Stats(C.Structure):
 class Options(C.Structure):
     _fields_ = [("panel_width", C.c_int), ("big_front_cols", C.c_int), ("verbose", C.c_int), ("use_graph", C.c_int),
                 ("panel_algo", C.c_int), ("split_update", C.c_int), ("tall_min_rows", C.c_int),
-                ("lookahead", C.c_int), ("fused_update", C.c_int), ("pair_update", C.c_int), ("mid_front_cols", C.c_int)]
+                ("lookahead", C.c_int), ("fused_update", C.c_int), ("pair_update", C.c_int)]
 
 
 def _ip(a):

@@ -59,10 +59,6 @@ struct PanelDesc {
 #define STM_TALL_XWIDE (8 * STM_TALL_NTH) // more rows than this: 2-column sub-panels
 #define STM_WP_ROWS 512      // panels whose staircase reaches at most this many rows are factorized by ONE workgroup, a wave per
                              // 4 columns, with the panel's image in LDS (32 x 512 doubles: every pipeline launch carries it)
-#define STM_MID_COLS 0       // default of stmmqr_options::mid_front_cols: fronts of at most this many columns and STM_WP_ROWS rows
-                             // are factorized whole by one workgroup (k_front_mid).  OFF: measured slower at every setting (epb1
-                             // 7.4 ms -> 8.1 / 8.8 / 10.4 ms at 128 / 192 / 256 columns, lns_3937 10.6 -> 11.6 / 12.4 / 13.9 ms): one
-                             // workgroup serialises the column blocks that the step timeline spreads over many
 #define STM_UPD_LDS_HOST (2 * 32 * 66 + 32 * 33)   // = STM_UPD_LDS_DOUBLES of the kernels (one half's chunk images of dev_update_block)
 #define STM_PROG 64          // FrontNum::prog advances by this much per panel (2 per column group + 1, <= 16 groups)
 
@@ -144,16 +140,6 @@ struct QbDesc {
     int pad;
 };
 
-// Pair update, single-sweep form (stmmqr_options::pair_update = 2): the pair of panels whose application to the columns beyond
-// the NEXT pair's panels is still pending -- it is applied by the sweep that forms W of the next pair (k_upd_f2), which runs after
-// the panel descriptions in FrontNum::pd have been overwritten by that next pair, hence this copy (written by k_upd_y2).
-struct PairPend {
-    int valid;                                   // 0: nothing pending
-    int g1, mp, mp1, mp2, nb1, nb2, k1a, k1b;    // PairGeom of the pending pair
-    int dmax;                                    // last row (relative to g1) holding a unit diagonal, STM_BIGROW if a reflector is missing
-    int diag1[STM_NB], diag2[STM_NB];            // unit-diagonal rows relative to g1 (STM_BIGROW: none)
-};
-
 // numeric, written by the kernels
 struct FrontNum {
     int fm;                  // rows of F                           (qr_fsize)
@@ -173,5 +159,4 @@ struct FrontNum {
     // pending block reflectors, double buffered by panel parity so that the look-ahead schedule can factorize
     // panel p+1 while the tail of update p is still reading the description of panel p
     PanelDesc pd[2];
-    PairPend pend;
 };

@@ -31,7 +31,7 @@
 namespace {
 
 thread_local std::string g_err;
-stmmqr_options g_opt = {STM_NB, 64, 0, 0, 0, 1, STM_TALL_MIN, 1, 0, 1, STM_MID_COLS};      // (panel_algo 0: by panel height)
+stmmqr_options g_opt = {STM_NB, 64, 0, 0, 0, 1, STM_TALL_MIN, 1, 0, 1};      // (panel_algo 0: by panel height)
 size_t g_chunk[4] = {32, 5000, 4, 4};     // FCHUNK, SMALL, MINCHUNK, MINCHUNK_RATIO (SparseQR.h:16-19)
 
 // offsets inside the reference's sparse_common for the stock LP64 build; verified against the real header
@@ -104,8 +104,7 @@ struct Level {                           // tree level of a group: what the solv
 // tallest front of its tree level: at every step the launches cover all the big fronts that are in flight, each at its
 // own panel.  Everything here is symbolic (lists built once per plan).
 struct Step {
-    int start_off = 0, n_start = 0, n_small = 0;      // fronts starting here (small first, then mid, then big): set up + assembled
-    int n_mid = 0, lds_mid = 0;                        // mid fronts among them (k_front_mid) and the LDS doubles of their launch
+    int start_off = 0, n_start = 0, n_small = 0;      // fronts starting here (small first, then big): set up + assembled
     int asm_parts_off = 0, asm_maxparts = 1, lds_small = 0;
     int act_off = 0, plist_off = 0, n_act = 0;        // big fronts in flight + the panel each is at
     int wp_off = 0;                                   // (index into d_wlists) their slices of the update workspace
@@ -204,7 +203,7 @@ struct stmmqr_plan {
     DevBuf<int> d_Rm;                               // rows of R (live pivots) of the split fronts of a level (k_rbig_*)
     std::vector<QbLevel> level_qbig;               // descriptors (d_qb) of the fronts of each level that take the split Q-apply
     hipGraphExec_t graph_exec = nullptr;           // options.use_graph: the captured schedule of group 0
-    double graph_tol = 0; int graph_ntol = 0, graph_dbg = 0, graph_opt = 0; long graph_nlaunch = 0;
+    double graph_tol = 0; int graph_ntol = 0, graph_dbg = 0; long long graph_opt = 0; long graph_nlaunch = 0;
     long sched_gen = 0, graph_gen = -1;            // schedule generation (bumped by every build_schedule) / the captured one
     bool rowmap_ready = false;         // d_Wmap belongs to the factorization currently held
     std::vector<int> level_lds_qa, level_lds_qa_all, level_lds_rs;   // dynamic LDS of k_qapply(_t) / k_rsolve per level of group 0
@@ -395,17 +394,9 @@ void build_schedule(stmmqr_plan &P, std::vector<int> &tslot)
     const long nf = P.nf;
     int ngroups = 1;
     for (long f = 0; f < nf; f++) ngroups = std::max(ngroups, P.group[f] + 1);
-    // mid fronts: whole front by one 512-thread workgroup (k_front_mid); a property of the front alone.  Scheduled like the small
-    // ones (one launch at the step they start), but they hold a T slot for that step.
-    const int mid_cols = getenv("STMMQR_MID_COLS") ? atoi(getenv("STMMQR_MID_COLS")) : g_opt.mid_front_cols;
-    auto is_mid = [&](int f) {
-        const FrontSym &s = P.fs[f];
-        if ((size_t)f < P.shared.size() && P.shared[f]) return false;
-        return s.fn >= g_opt.big_front_cols && s.fm_ub >= 64 && s.fn <= mid_cols && s.fm_ub <= STM_WP_ROWS;
-    };
     auto is_big = [&](int f) {
         const FrontSym &s = P.fs[f];
-        return s.fn >= g_opt.big_front_cols && s.fm_ub >= 64 && !is_mid(f);
+        return s.fn >= g_opt.big_front_cols && s.fm_ub >= 64;
     };
     // STMMQR_SCHED (experiments): 1 level-synchronous, 2 as soon as possible, 3 envelope rule; unset / 0: chosen per group
     const int sched_policy = getenv("STMMQR_SCHED") ? atoi(getenv("STMMQR_SCHED")) : 0;
@@ -593,17 +584,12 @@ void build_schedule(stmmqr_plan &P, std::vector<int> &tslot)
         int nslots = 0;
         for (int t = 0; t < nstep; t++) {
             Step &S = SV[t];
-            std::vector<int> small, mid, big;
-            for (int f : starting[t]) (is_big(f) ? big : is_mid(f) ? mid : small).push_back(f);
+            std::vector<int> small, big;
+            for (int f : starting[t]) (is_big(f) ? big : small).push_back(f);
             S.start_off = (int)P.lists.size();
-            S.n_small = (int)small.size(); S.n_mid = (int)mid.size(); S.n_start = (int)(small.size() + mid.size() + big.size());
+            S.n_small = (int)small.size(); S.n_start = (int)(small.size() + big.size());
             P.lists.insert(P.lists.end(), small.begin(), small.end());
-            P.lists.insert(P.lists.end(), mid.begin(), mid.end());
             P.lists.insert(P.lists.end(), big.begin(), big.end());
-            for (int f : mid) {
-                const int fm = P.fs[f].fm_ub;
-                S.lds_mid = std::max(S.lds_mid, std::max(STM_NB * (fm <= 128 ? 128 : fm <= 256 ? 256 : 512), 2 * STM_UPD_LDS_HOST));
-            }
             S.asm_parts_off = (int)P.lists.size();
             long maxfm_small = 0;
             for (int i = 0; i < S.n_start; i++) {
@@ -621,12 +607,6 @@ void build_schedule(stmmqr_plan &P, std::vector<int> &tslot)
             for (int f : big) {
                 if (!freeslots.empty()) { tslot[f] = freeslots.back(); freeslots.pop_back(); }
                 else tslot[f] = nslots++;
-            }
-            std::vector<int> midslots;                         // (held for this step's launch only)
-            for (int f : mid) {
-                if (!freeslots.empty()) { tslot[f] = freeslots.back(); freeslots.pop_back(); }
-                else tslot[f] = nslots++;
-                midslots.push_back(tslot[f]);
             }
             active.clear();
             for (const auto &fp : panel_at[t]) { active.push_back(fp.first); pan_now[fp.first] = fp.second; }
@@ -697,7 +677,6 @@ void build_schedule(stmmqr_plan &P, std::vector<int> &tslot)
                 S.cpk_maxparts = std::max(S.cpk_maxparts, parts);
                 freeslots.push_back(tslot[f]);
             }
-            freeslots.insert(freeslots.end(), midslots.begin(), midslots.end());
         }
         P.tslots = std::max(P.tslots, nslots);
     }
@@ -1028,14 +1007,6 @@ int run_schedule(stmmqr_plan &P, bool detail, int grp, const StepReq *req = null
             if (e) return e;
             nlaunch++;
         }
-        if (S.n_mid > 0) {
-            int e = timed(t_front, [&]() -> int {
-                LCHK(stm_launch_front_mid(c, starting + S.n_small, S.n_mid, S.lds_mid, q));
-                return 0;
-            });
-            if (e) return e;
-            nlaunch++;
-        }
         return 0;
     };
     // which kernel takes a panel is a property of the front (stm_use_ca); a step with both kinds gets both launches (each
@@ -1094,8 +1065,8 @@ int run_schedule(stmmqr_plan &P, bool detail, int grp, const StepReq *req = null
                 o += S.n_pe;
                 if (S.n_po > 0) {
                     LCHK(stm_launch_update_split(c, act + o, pl + o, S.n_po, 0, 1, S.maxsl_po, Wp, wl + o, wcnt, 1, q));
-                    LCHK(stm_launch_update_pair(c, act + o, pl + o, S.n_po, S.maxcbp_po, S.maxsl_po, Wp, wl + o, wcnt, g_opt.pair_update >= 2 ? 1 : 0, q));
-                    nlaunch += (g_opt.pair_update >= 2) ? 6 : 5;
+                    LCHK(stm_launch_update_pair(c, act + o, pl + o, S.n_po, S.maxcbp_po, S.maxsl_po, Wp, wl + o, wcnt, q));
+                    nlaunch += 5;
                 }
             }
             return 0;
@@ -1152,8 +1123,16 @@ int run_schedule(stmmqr_plan &P, bool detail, int grp, const StepReq *req = null
     // 119.4-120.9; on the 7818-row fronts of c5mini (31 slabs) the fused launch is the slower one (43.5 -> 48.9 ms).
     const int la_fused_rows = getenv("STMMQR_LA_FUSED_ROWS") ? atoi(getenv("STMMQR_LA_FUSED_ROWS")) : 5120;
     const long la_min_fused = getenv("STMMQR_LA_MIN_FUSED") ? atol(getenv("STMMQR_LA_MIN_FUSED")) : 1500;
+    // Forward progress of that launch: the slab workgroups of block 0 and of the Gram block wait for each other (bounded), so all
+    // of them must be resident at once.  What is guaranteed while the side stream fills the rest of the GPU are the reserved
+    // compute units, two k_upd_f workgroups each (248 VGPRs) -- counted with the row BOUND of every front of the step (a rank-
+    // deficient front can have more rows than its estimate), not with the estimate the 5120-row rule uses.
+    const long la_slots = 2 * (getenv("STMMQR_SIDE_RESERVE") ? std::max(0L, atol(getenv("STMMQR_SIDE_RESERVE"))) : 32L);
     auto b0_fused = [&](const Step &S) -> bool {
         if (la_fused_rows <= 0 || !S.split || !g_opt.split_update || S.maxsl > 256 || S.n_pe + S.n_po > 0 || c.cbskip != 0) return false;
+        long wgs = 0;
+        for (int i = 0; i < S.n_norm; i++) wgs += 2L * stm_upd_nsl(P.fs[P.lists[S.act_off + i]]);
+        if (wgs > la_slots) return false;
         for (int i = 0; i < S.n_act; i++)                          // (the rows the panels are expected to reach, not the bound)
             if (stm_panel_rows_est(P.fs[P.lists[S.act_off + i]], P.lists[S.plist_off + i]) > la_fused_rows) return false;
         return true;
@@ -1207,6 +1186,12 @@ int run_schedule(stmmqr_plan &P, bool detail, int grp, const StepReq *req = null
                 v->push_back(ev);
             }
         hipStream_t sd = P.side;
+        // STMMQR_X_NOWAIT (timing experiments ONLY, results are wrong): 1 the main stream never waits for the side stream inside the
+        // loop, 2 the side stream never waits for the main stream either, 4 no event records at all
+        const int x_nowait = getenv("STMMQR_X_NOWAIT") ? atoi(getenv("STMMQR_X_NOWAIT")) : 0;
+#define XWAIT_MAIN(call) do { if (!(x_nowait & 1)) HIPCHK(call); } while (0)
+#define XWAIT_SIDE(call) do { if (!(x_nowait & 2)) HIPCHK(call); } while (0)
+#define XRECORD(call) do { if (!(x_nowait & 4)) HIPCHK(call); } while (0)
         long side_ev = -1;                                     // last side event the main stream has not waited for
         bool prep_on_side = false;                             // prep(t) was issued on the side stream during step t-1
         int e = 0;
@@ -1230,16 +1215,16 @@ int run_schedule(stmmqr_plan &P, bool detail, int grp, const StepReq *req = null
                 continue;
             }
             if (b0_fused(S)) {
-                if (side_ev >= 0) { HIPCHK(hipStreamWaitEvent(st, P.ev_side[side_ev], 0)); side_ev = -1; }
+                if (side_ev >= 0) { XWAIT_MAIN(hipStreamWaitEvent(st, P.ev_side[side_ev], 0)); side_ev = -1; }
                 if ((e = update_b0_fused(S, st))) return e;                                            // T + block 0
-                HIPCHK(hipEventRecord(P.ev_main[t], st));
+                XRECORD(hipEventRecord(P.ev_main[t], st));
             } else {
                 if ((e = update(S, 0, 0, true, P.d_Wp.p, st))) return e;                               // T
-                HIPCHK(hipEventRecord(P.ev_main[t], st));
-                if (side_ev >= 0) { HIPCHK(hipStreamWaitEvent(st, P.ev_side[side_ev], 0)); side_ev = -1; }
+                XRECORD(hipEventRecord(P.ev_main[t], st));
+                if (side_ev >= 0) { XWAIT_MAIN(hipStreamWaitEvent(st, P.ev_side[side_ev], 0)); side_ev = -1; }
                 if ((e = update(S, 0, 1, false, P.d_Wp.p, st))) return e;                              // block 0
             }
-            HIPCHK(hipStreamWaitEvent(sd, P.ev_main[t], 0));
+            XWAIT_SIDE(hipStreamWaitEvent(sd, P.ev_main[t], 0));
             if ((e = post(S, sd))) return e;
             if (t + 1 < ns && SV[t + 1].n_start > 0) {
                 if ((e = prep(SV[t + 1], sd))) return e;
@@ -1247,7 +1232,7 @@ int run_schedule(stmmqr_plan &P, bool detail, int grp, const StepReq *req = null
                 prep_on_side = true;
             }
             if ((e = update(S, 1, S.maxcb - 1, false, P.d_Wp2.p, sd))) return e;
-            HIPCHK(hipEventRecord(P.ev_side[t], sd));
+            XRECORD(hipEventRecord(P.ev_side[t], sd));
             side_ev = (long)t;
         }
         if (side_ev >= 0) HIPCHK(hipStreamWaitEvent(st, P.ev_side[side_ev], 0));   // join: the caller continues on `stream`
@@ -1425,7 +1410,15 @@ int stmmqr_factorize_group(stmmqr_plan *plan, int group, int detail)
         // kernel arguments or decides what is launched: (tol, ntol, debug mask), the schedule generation (set_groups
         // rebuilds the lists and may move the workspaces) and the run-time options
         const DevCtx c = P.ctx();
-        const int optkey = (g_opt.lookahead ? 1 : 0) | (g_opt.split_update ? 2 : 0) | (g_opt.fused_update ? 4 : 0) | (P.serial_panels ? 8 : 0);
+        // (everything run_schedule reads at capture time and that decides WHAT is launched or travels in the kernel arguments: the
+        //  run-time options incl. pair_update, STMMQR_TUNE, and the look-ahead thresholds of the environment)
+        auto envl = [](const char *k, long dflt) { return getenv(k) ? atol(getenv(k)) : dflt; };
+        long long optkey = 1469598103934665603LL;
+        for (long long v : {(long long)g_opt.lookahead, (long long)g_opt.split_update, (long long)g_opt.fused_update, (long long)g_opt.pair_update,
+                            (long long)P.serial_panels, (long long)c.tune, (long long)envl("STMMQR_LA_MIN", 2500), (long long)envl("STMMQR_LA_MIN_FUSED", 1500),
+                            (long long)envl("STMMQR_LA_FUSED_ROWS", 5120), (long long)envl("STMMQR_LA_MAXPWG", 48), (long long)envl("STMMQR_LA_SYSFENCE", 0),
+                            (long long)envl("STMMQR_SIDE_RESERVE", 32)})
+            optkey = (optkey ^ v) * 1099511628211LL;
         if (!P.graph_exec || P.graph_tol != c.tol || P.graph_ntol != c.ntol || P.graph_dbg != c.dbg || P.graph_gen != P.sched_gen ||
             P.graph_opt != optkey) {
             if (P.graph_exec) { (void)hipGraphExecDestroy(P.graph_exec); P.graph_exec = nullptr; }

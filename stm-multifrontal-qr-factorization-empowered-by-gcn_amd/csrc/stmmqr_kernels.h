@@ -40,7 +40,8 @@ struct DevCtx {
     int tall_min;              // stmmqr_options::tall_min_rows at plan time (stm_tall_panel)
     int cbskip;                // update launches: workgroup x takes column block cb0 + x * (1 + cbskip) -- 0 everywhere except
                                //  when the trailing columns of a front are shared between plans (stmmqr_factorize_step)
-    double *Ypend;             // pair update: -Y (64 x 32 per column block) of every pair-update front, by ABSOLUTE column block (column >> 5)
+    double *Ypend;             // pair update: -Y (64 x 32 per column block) of every pair-update front, by ABSOLUTE column block (column >> 5):
+                               //  written by k_upd_y2, read by k_upd_c2 of the same step
     const long long *ypoff;    // [nf] offset (doubles) of a front's blocks in Ypend (-1: not a pair-update front)
     int tune;                  // env STMMQR_TUNE, measurement sweeps only (0 = the shipped rules): bits 0-3 force 2^(x-1) slabs per
                                //  workgroup of the pair update's kernels
@@ -61,7 +62,6 @@ int stm_launch_gather_sx(const double *Ax, const int *smap, double *Sx, int anz,
 int stm_launch_setup(const DevCtx &c, const int *flist, int nfr, hipStream_t st);
 int stm_launch_assemble(const DevCtx &c, const int *flist, const int *nparts, int nfr, int maxparts, hipStream_t st);
 int stm_launch_front_wg(const DevCtx &c, const int *flist, int nfr, int lds_doubles, hipStream_t st);
-int stm_launch_front_mid(const DevCtx &c, const int *flist, int nfr, int lds_doubles, hipStream_t st);
 int stm_launch_panel(const DevCtx &c, const int *flist, const int *plist, int nfr, int nsub, int defer_ok, int lds_doubles, hipStream_t st);
 int stm_configure_capanel(void);
 int stm_launch_panel_ca(const DevCtx &c, const int *flist, const int *plist, int nfr, int nw, int defer_ok, hipStream_t st);
@@ -69,7 +69,7 @@ int stm_launch_update(const DevCtx &c, const int *flist, const int *plist, int n
 int stm_launch_update_fused(const DevCtx &c, const int *flist, const int *plist, int nfr, int cb0, int ncb, int maxsl, double *Wp,
                             const long long *wpoff, int *wcnt, int *wflag, int epoch, int with_gram, hipStream_t st);
 int stm_launch_update_pair(const DevCtx &c, const int *flist, const int *plist, int nfr, int ncbp, int maxsl, double *Wp,
-                           const long long *wpoff, int *wcnt, int fused, hipStream_t st);
+                           const long long *wpoff, int *wcnt, hipStream_t st);
 int stm_launch_update_split(const DevCtx &c, const int *flist, const int *plist, int nfr, int cb0, int ncb, int maxsl, double *Wp,
                             const long long *wpoff, int *wcnt, int with_gram, hipStream_t st);
 int stm_launch_larft(const DevCtx &c, int f, hipStream_t st);

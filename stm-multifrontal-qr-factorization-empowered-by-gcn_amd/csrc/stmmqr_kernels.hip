@@ -304,28 +304,21 @@ __device__ __forceinline__ void dev_T_from_gram(double (*G)[STM_NB + 1], double 
 // W1 (per 256-row slab, slabs added in order: bit-identical to the Gram block of k_upd_w) and T is built here by every
 // workgroup for itself (dev_T_from_gram); Tout / Tkeep (may be null) receive it from the caller's first column block.
 // TN = true (qr_larftb seam, method QR_QX only): C <- (I - V T V') C, i.e. W2 = T W1 instead of T' W1.
-// HALVES = true (k_front_mid, 512 threads): the two halves of the workgroup run the update of TWO column blocks side by side,
-// each with its own (c0, nc), its own slice of `lds` (STM_UPD_LDS_DOUBLES apart) and its own T when it is built here; everything
-// that decides a barrier (nbp, mp, tau != nullptr) is the same in both, and a half without a block of its own repeats the other's
-// with `store` = false.  The arithmetic of a column block is the same in both forms.
 #define STM_UPD_LDS_DOUBLES (2 * BN * VS + STM_NB * WS)
-static_assert(STM_UPD_LDS_DOUBLES == STM_UPD_LDS_HOST, "host sizing of k_front_mid's LDS");
-template <bool TN = false, bool HALVES = false>
+static_assert(STM_UPD_LDS_DOUBLES == STM_UPD_LDS_HOST, "host sizing of the update kernels' LDS");
+template <bool TN = false>
 __device__ void dev_update_block(double *F, long long ld, int g1, int mp, int k1, int nbp, const int *diag,
                                  const double *T, int c0, int nc, double *lds, const double *tau = nullptr,
-                                 double *Tout = nullptr, double *Tkeep = nullptr, bool store = true)
+                                 double *Tout = nullptr, double *Tkeep = nullptr)
 {
     if (nbp <= 0 || mp <= 0 || nc <= 0) return;
-    const int half = HALVES ? (int)(threadIdx.x >> 8) : 0;
-    const int tid = HALVES ? (int)(threadIdx.x & 255) : (int)threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int tid = (int)threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int l15 = lane & 15, l4 = lane >> 4;
-    if (HALVES) lds += half * STM_UPD_LDS_DOUBLES;
 
     double *Vs = lds;                       // [STM_NB][VS]
     double *Cs = Vs + STM_NB * VS;          // [BN][VS]
     double *Ws = Cs + BN * VS;              // [STM_NB][WS]
-    __shared__ int s_pd2[HALVES ? 2 : 1][STM_NB];
-    int *s_pd = s_pd2[half];
+    __shared__ int s_pd[STM_NB];
 
     __syncthreads();                        // previous users of lds are done
     if (tid < STM_NB) s_pd[tid] = (tid < nbp) ? diag[tid] : STM_BIGROW;
@@ -370,15 +363,14 @@ __device__ void dev_update_block(double *F, long long ld, int g1, int mp, int k1
     double *s_Tm = Cs;                       // T(q, l) at s_Tm[q * WS + l] when it is built here (the chunk images are free)
     if (build_t) {
         double (*Gm)[STM_NB + 1] = reinterpret_cast<double (*)[STM_NB + 1]>(Vs);
-        __shared__ double s_tau_u2[HALVES ? 2 : 1][STM_NB];
-        double *s_tau_u = s_tau_u2[half];
+        __shared__ double s_tau_u[STM_NB];
 #pragma unroll
         for (int r = 0; r < 4; r++) Gm[16 * mi + l4 + 4 * r][16 * ni + l15] = gtot[r];
         if (tid < STM_NB) s_tau_u[tid] = (tid < nbp) ? tau[tid] : 0.0;
         __syncthreads();
         dev_T_from_gram(Gm, reinterpret_cast<double (*)[STM_NB + 1]>(s_Tm), s_tau_u, nbp, tid);
         if (Tout || Tkeep)
-            for (int e = tid; e < STM_NB * STM_NB; e += (HALVES ? 256 : (int)blockDim.x)) {
+            for (int e = tid; e < STM_NB * STM_NB; e += (int)blockDim.x) {
                 const int a = e % STM_NB, b = e / STM_NB;
                 const double tv = (a <= b && a < nbp && b < nbp) ? s_Tm[a * WS + b] : 0.0;
                 if (Tout) Tout[e] = tv;
@@ -432,7 +424,7 @@ __device__ void dev_update_block(double *F, long long ld, int g1, int mp, int k1
             Cs[(16 + l15) * VS + row] -= u1[r];
         }
         __syncthreads();
-        if (i < mp && store) {
+        if (i < mp) {
 #pragma unroll
             for (int q = 0; q < 8; q++) {
                 const int col = lcg * 8 + q;
@@ -1902,68 +1894,7 @@ __device__ __forceinline__ void dev_wave_panel(PanelShared &ps, WaveShared &wsh,
         }
 }
 
-// ------------------------------------------------------------------------------------------------
-// mid fronts (stm_mid_front: at least big_front_cols but at most mid_front_cols columns, at most STM_WP_ROWS rows): ONE
-// 512-thread workgroup runs the whole front in one launch, like k_front_wg does for the small ones -- every panel is a
-// wave-pipelined panel (dev_wave_panel: the front never has more rows than its LDS image holds), the trailing update
-// runs two column blocks at a time on the two halves of the workgroup (dev_update_block<.., HALVES>, T built from the
-// Gram matrix of the first pair of blocks), then qr_cpack.  As separate launches such a front costs a step of the
-// timeline per panel -- ~45 us each for ~15 us of work (all of epb1's 136 steps were of this kind).
-// LDS: the panel image (32 x 128 / 256 / 512 doubles) and the update's chunk images share the dynamic allocation.
-// ------------------------------------------------------------------------------------------------
 #define NTP 512               // threads of the large-front panel kernel (8 waves, <= 256 VGPRs each)
-__global__ __launch_bounds__(NTP) void k_front_mid(DevCtx c, const int *__restrict__ flist)
-{
-    extern __shared__ double dyn_lds[];
-    __shared__ PanelShared ps;
-    __shared__ WaveShared wsh;
-    const int f = flist[blockIdx.x];
-    const FrontSym s = c.fs[f];
-    FrontNum *num = &c.fnum[f];
-    double *F = c.Farena + s.foff;
-    int *St = c.Stair + s.rp;
-    const int tid = threadIdx.x, half = tid >> 8;
-    for (int p = 0; p < s.npanels; p++) {
-        PanelDesc *pd = &num->pd[p & 1];
-        double *T = c.Tws + (long long)(2 * c.tslot[f] + (p & 1)) * STM_NB * STM_NB;
-        double *Tkeep = c.Tall ? c.Tall + (long long)(s.tpan + p) * STM_NB * STM_NB : nullptr;
-        const int k1 = p * STM_NB, k2 = min(s.fn, k1 + STM_NB), nbp = k2 - k1;
-        // the header of the panel (group 0 of k_panel)
-        const int was_done = num->done, g1 = num->g;
-        const int tmax = min(num->fm, max(St[k2 - 1], g1 + nbp));
-        __syncthreads();                                          // (everyone has read num-> before thread 0 writes the header)
-        if (tid == 0) {
-            pd->mode = 2; pd->pg1 = g1; pd->pt = g1; pd->tmax = tmax; pd->nlive = 0; pd->sw = WP_SW; pd->done_group = -1;
-            if (was_done) { pd->pnb = 0; pd->t_deferred = 0; }
-        }
-        if (was_done) break;                                      // (uniform: the remaining panels have nothing to do either)
-        const int rows = tmax - g1;
-#define WAVE_ARGS ps, wsh, s, num, pd, F, St, c.Tau + s.rp, c.Rdead + s.col1, p, g1, tmax, c.tol, c.ntol, T, dyn_lds, Tkeep, 1, c.sig
-        if (rows <= 128) dev_wave_panel<2>(WAVE_ARGS);
-        else if (rows <= 256) dev_wave_panel<4>(WAVE_ARGS);
-        else dev_wave_panel<8>(WAVE_ARGS);
-#undef WAVE_ARGS
-        __syncthreads();                                          // the panel's columns, Tau, pdiag and pd: visible to every wave
-        const int ncb = (s.fn - k2 + BN - 1) / BN;
-        if (ncb <= 0 || pd->pnb <= 0) continue;
-        const int pg1 = pd->pg1, mp = pd->pt - pd->pg1;
-        const bool deferred = pd->t_deferred != 0;                // (always, with trailing columns -- unless no reflector came out)
-        for (int cb = 0; cb < ncb; cb += 2) {
-            const bool own = (cb + half < ncb);
-            const int mycb = own ? cb + half : cb;
-            const int c0 = k2 + mycb * BN;
-            if (cb == 0 && deferred)
-                dev_update_block<false, true>(F, s.ld, pg1, mp, pd->pk1, pd->pnb, pd->pdiag, nullptr, c0, min(BN, s.fn - c0), dyn_lds,
-                                              c.Tau + s.rp + pd->pk1, half == 0 ? T : nullptr, half == 0 ? Tkeep : nullptr, own);
-            else
-                dev_update_block<false, true>(F, s.ld, pg1, mp, pd->pk1, pd->pnb, pd->pdiag, T, c0, min(BN, s.fn - c0), dyn_lds, nullptr,
-                                              nullptr, nullptr, own);
-            __syncthreads();                                      // (T of the first call: written to its slot before the next reads it)
-        }
-    }
-    __syncthreads();
-    if (tid < NT) dev_cpack(c, s, num, 0, 1);
-}
 
 // ------------------------------------------------------------------------------------------------
 // large fronts: panel and trailing update are separate launches (many workgroups per update)
@@ -2734,299 +2665,12 @@ __global__ __launch_bounds__(NT) void k_upd_w2(DevCtx c, const int *__restrict__
     for (int q = 0; q < 2 * STM_NB * BN / NT; q++) W0[tid + q * NT] = v[q];
 }
 
-// ------------------------------------------------------------------------------------------------
-// Pair update in ONE sweep per pair (stmmqr_options::pair_update = 2).  The two-sweep form reads C twice and writes it once per pair
-// of panels: 24 bytes per entry, and both sweeps run within 1.5x of their memory floors.  Here the application of
-// pair t to the columns beyond the NEXT pair's panels is delayed until the sweep that forms W of pair t+1:
-//   k_upd_f2 (odd panel p; new pair (p-1, p), pending pair (p-3, p-2) = FrontNum::pend, its -Y in DevCtx::Ypend):
-//       for every 16-row tile of a column block beyond panel p+1:   C <- C - V_old Y_old   (as k_upd_c2: C is the accumulator,
-//       stored back), then the SAME registers are the operand of    W_new += V_new' C     -- 16 bytes per entry and pair, the MFMA
-//       work of both kernels behind one set of loads.  The summation index of the second product is the row, which an MFMA
-//       operand carries on its 4 lane groups, while the tile holds its rows on 16 lanes: the updated tile and the new pair's V
-//       tile go through a per-wave LDS scratch (written and read by the same wave: no barrier).
-//   k_upd_w2 (Gram block only), k_upd_y2 (Y_new; the pair becomes the pending one), k_upd_c2 on the FIRST TWO column blocks only:
-//       the columns of the next pair's panels are brought up to date at once (the panel-by-panel updates and the panel
-//       factorizations need them); everything beyond them waits for the next pair's sweep.
-// A front's last pair steps: with at most two column blocks beyond panel p+1 k_upd_c2 covers everything; with more, the step of
-// panel p+2 exists and its sweep applies the pending pair even if the front has run out of rows meanwhile (no new pair).
-// One wave per SIMD (~390 registers: -Y_old 64, W_new 64, four C tiles, two tiles of each V pair).
-// ------------------------------------------------------------------------------------------------
-#define F2_S 17                                                  // column stride (doubles) of the scratch images: conflict-free
-#define F2_WAVE_DOUBLES ((BN + 2 * STM_NB) * F2_S)               // C tile (32 columns) + new V tile (64 columns) of 16 rows
-#define F2_LDS_DOUBLES (NW * 2 * STM_NB * BN)                    // (>= NW * F2_WAVE_DOUBLES: the cross-wave sum of W needs more)
-__global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(1, 1)))
-void k_upd_f2(DevCtx c, const int *__restrict__ flist, const int *__restrict__ plist, double *Wp, const long long *__restrict__ wpoff, int *wcnt)
-{
-    extern __shared__ double dyn_lds[];
-    __shared__ int s_ticket;
-    const int fi = blockIdx.z, f = flist[fi], p = plist[fi];
-    const FrontSym s = c.fs[f];
-    if (p >= s.npanels || !(p & 1)) return;
-    FrontNum *num = &c.fnum[f];
-    PairGeom G;
-    const bool has_new = pair_geom(num, p, G);
-    const PairPend *pe = &num->pend;
-    const bool pend = pe->valid != 0;
-    if (!has_new && !pend) return;
-    const int ncbp = stm_upd_ncb(s, p) - 1, nslf = stm_upd_nsl(s);
-    const int cb = blockIdx.x, sl = blockIdx.y;
-    if (cb >= ncbp) return;
-    const int c0 = STM_NB * (p + 2) + cb * BN;                   // (= G.pc0 + cb * BN; also without a new pair)
-    if (c0 >= s.fn) return;
-    const int nc = min(BN, s.fn - c0);
-    // rows relative to `base`: the pending pair's first row when there is one (the new pair starts `offn` rows below it)
-    const int og1 = pe->g1, omp = pe->mp, omp1 = pe->mp1, omp2 = pe->mp2, onb1 = pe->nb1, onb2 = pe->nb2;
-    const int base = pend ? og1 : G.g1, offn = has_new ? G.g1 - base : 0;
-    const int mpT = max(pend ? omp : 0, has_new ? G.mp + offn : 0);
-    if (sl * SLAB >= mpT) return;
-    const int nsl = (mpT + SLAB - 1) / SLAB, spw = stm_pair_spw(nsl, c.tune);
-    if (sl % spw) return;
-    const long long ld = s.ld;
-    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, l15 = lane & 15, l4 = lane >> 4;
-    double *F = c.Farena + s.foff;
-    double *__restrict__ Cg = F + base + (long long)c0 * ld;
-    const double *__restrict__ V1o = F + og1 + (long long)pe->k1a * ld, *__restrict__ V2o = F + og1 + (long long)pe->k1b * ld;
-    const double *__restrict__ V1n = F + G.g1 + (long long)G.k1a * ld, *__restrict__ V2n = F + G.g1 + (long long)G.k1b * ld;
-    const PanelDesc *pa = &num->pd[(p - 1) & 1], *pb = &num->pd[p & 1];
-    double *Cs = dyn_lds + wid * F2_WAVE_DOUBLES, *Vs = Cs + BN * F2_S;        // this wave's scratch: [col][row]
-    // -Y of the pending pair (A operand of the application), by absolute column block
-    double yn0[2 * STM_NB / 4], yn1[2 * STM_NB / 4];
-    if (pend) {
-        const double *__restrict__ Yn = c.Ypend + c.ypoff[f] + (long long)(c0 >> 5) * (2 * STM_NB * BN);
-#pragma unroll
-        for (int kk = 0; kk < 2 * STM_NB / 4; kk++) {
-            yn0[kk] = Yn[(4 * kk + l4) * BN + l15];
-            yn1[kk] = Yn[(4 * kk + l4) * BN + 16 + l15];
-        }
-    } else {
-#pragma unroll
-        for (int kk = 0; kk < 2 * STM_NB / 4; kk++) yn0[kk] = yn1[kk] = 0.0;
-    }
-    d4 w[4][2];                                                  // W_new: [k group: V1 0-15, V1 16-31, V2 0-15, V2 16-31][column half]
-#pragma unroll
-    for (int m = 0; m < 4; m++) w[m][0] = w[m][1] = d4{0, 0, 0, 0};
-    const int rbeg = sl * SLAB, rend = min(mpT, (sl + spw) * SLAB);
-    const int ntile = (rend - rbeg + 15) >> 4;
-    // W_new += V_new(tile)' C(tile) from this wave's scratch: row quad q is the summation index of one MFMA
-    auto accumulate = [&]() {
-#pragma unroll
-        for (int q = 0; q < 4; q++) {
-            const double b0 = Cs[l15 * F2_S + 4 * q + l4], b1 = Cs[(16 + l15) * F2_S + 4 * q + l4];
-#pragma unroll
-            for (int m = 0; m < 4; m++) {
-                const double a = Vs[(16 * m + l15) * F2_S + 4 * q + l4];
-                w[m][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b0, w[m][0], 0, 0, 0);
-                w[m][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b1, w[m][1], 0, 0, 0);
-            }
-        }
-    };
-    // general form of one tile: clamped loads, masks, predicated stores
-    auto general_tile = [&](int tix) {
-        const int i = rbeg + 16 * tix + l15;                     // my row, relative to base
-        const int rowc = min(i, mpT - 1);
-        d4 a0, a1;
-#pragma unroll
-        for (int r = 0; r < 4; r++) {
-            a0[r] = Cg[rowc + (long long)min(l4 + 4 * r, nc - 1) * ld];
-            a1[r] = Cg[rowc + (long long)min(16 + l4 + 4 * r, nc - 1) * ld];
-        }
-        if (pend) {
-            const int rowo = min(i, omp - 1);
-#pragma unroll
-            for (int kk = 0; kk < STM_NB / 4; kk++) {
-                const int col = 4 * kk + l4;
-                const int d = (col < onb1) ? pe->diag1[col] : STM_BIGROW;
-                const double v = V1o[rowo + (long long)min(col, onb1 - 1) * ld];
-                const double bv = (i < omp1 && i >= d) ? ((i == d) ? 1.0 : v) : 0.0;
-                a0 = __builtin_amdgcn_mfma_f64_16x16x4f64(yn0[kk], bv, a0, 0, 0, 0);
-                a1 = __builtin_amdgcn_mfma_f64_16x16x4f64(yn1[kk], bv, a1, 0, 0, 0);
-            }
-#pragma unroll
-            for (int kk = 0; kk < STM_NB / 4; kk++) {
-                const int col = 4 * kk + l4;
-                const int d = (col < onb2) ? pe->diag2[col] : STM_BIGROW;
-                const double v = V2o[rowo + (long long)min(col, max(onb2, 1) - 1) * ld];
-                const double bv = (i < omp2 && i >= d) ? ((i == d) ? 1.0 : v) : 0.0;
-                a0 = __builtin_amdgcn_mfma_f64_16x16x4f64(yn0[STM_NB / 4 + kk], bv, a0, 0, 0, 0);
-                a1 = __builtin_amdgcn_mfma_f64_16x16x4f64(yn1[STM_NB / 4 + kk], bv, a1, 0, 0, 0);
-            }
-            if (i < omp) {
-#pragma unroll
-                for (int r = 0; r < 4; r++) {
-                    if (l4 + 4 * r < nc) Cg[i + (long long)(l4 + 4 * r) * ld] = a0[r];
-                    if (16 + l4 + 4 * r < nc) Cg[i + (long long)(16 + l4 + 4 * r) * ld] = a1[r];
-                }
-            }
-        }
-        if (has_new) {
-            const int in = i - offn;                             // my row, relative to the new pair's first row
-            const bool rok = (in >= 0 && in < G.mp);
-#pragma unroll
-            for (int r = 0; r < 4; r++) {
-                Cs[(l4 + 4 * r) * F2_S + l15] = (rok && l4 + 4 * r < nc) ? a0[r] : 0.0;
-                Cs[(16 + l4 + 4 * r) * F2_S + l15] = (rok && 16 + l4 + 4 * r < nc) ? a1[r] : 0.0;
-            }
-            const int rown = min(max(in, 0), G.mp - 1);
-#pragma unroll
-            for (int kk = 0; kk < STM_NB / 4; kk++) {
-                const int col = 4 * kk + l4;
-                const int d1 = (col < G.nb1) ? pa->pdiag[col] - G.g1 : STM_BIGROW, d2 = (col < G.nb2) ? pb->pdiag[col] - G.g1 : STM_BIGROW;
-                const double v1 = V1n[rown + (long long)min(col, G.nb1 - 1) * ld];
-                const double v2 = V2n[rown + (long long)min(col, max(G.nb2, 1) - 1) * ld];
-                Vs[col * F2_S + l15] = (in >= 0 && in < G.mp1 && in >= d1) ? ((in == d1) ? 1.0 : v1) : 0.0;
-                Vs[(STM_NB + col) * F2_S + l15] = (in >= 0 && in < G.mp2 && in >= d2) ? ((in == d2) ? 1.0 : v2) : 0.0;
-            }
-            accumulate();
-        }
-    };
-    // interior tiles: below every unit diagonal of both pairs, inside all four panels' rows, a full column block, no dead reflector
-    int t_lo = ntile, t_hi = ntile;
-    if (pend && has_new && nc == BN) {
-        int dmaxn = -1;
-#pragma unroll 8
-        for (int q = 0; q < STM_NB; q++) {
-            dmaxn = max(dmaxn, (q < G.nb1) ? pa->pdiag[q] - G.g1 : STM_BIGROW);
-            dmaxn = max(dmaxn, (q < G.nb2) ? pb->pdiag[q] - G.g1 : STM_BIGROW);
-        }
-        const int dmaxo = pe->dmax;
-        if (dmaxn < STM_BIGROW && dmaxo < STM_BIGROW) {
-            const int lo = max(dmaxo + 1, dmaxn + 1 + offn), hi = min(min(min(omp1, omp2), min(G.mp1, G.mp2) + offn), rend);
-            t_lo = min(ntile, max(0, (lo - rbeg + 15) >> 4));
-            t_hi = max(t_lo, min(ntile, (hi - rbeg) >> 4));
-        }
-    }
-    int tix = wid;
-    for (; tix < t_lo; tix += NW) general_tile(tix);
-    if (tix < t_hi) {
-        // four tiles per trip as in k_upd_c2: C three tiles ahead, both V pairs one tile ahead and before the C loads of the step
-        const int nint = (t_hi - 1 - tix) / NW + 1, ntrip = nint >> 2;
-        if (ntrip > 0) {
-            const int r0 = rbeg + 16 * tix + l15;
-            const double *cp = Cg + r0 + (long long)l4 * ld;
-            const double *v1op = V1o + r0 + (long long)l4 * ld, *v2op = V2o + r0 + (long long)l4 * ld;
-            const double *v1np = V1n + (r0 - offn) + (long long)l4 * ld, *v2np = V2n + (r0 - offn) + (long long)l4 * ld;
-            const long long ld4 = 4 * ld;
-            struct TC { double c0[4], c1[4]; };
-            struct TV { double v1[STM_NB / 4], v2[STM_NB / 4]; };
-            auto load_c = [&](TC &t, int off) {
-#pragma unroll
-                for (int r = 0; r < 4; r++) {
-                    t.c0[r] = cp[off + r * ld4];
-                    t.c1[r] = cp[off + (4 + r) * ld4];
-                }
-            };
-            auto load_v = [&](TV &t, const double *p1, const double *p2, int off) {
-#pragma unroll
-                for (int kk = 0; kk < STM_NB / 4; kk++) {
-                    t.v1[kk] = p1[off + kk * ld4];
-                    t.v2[kk] = p2[off + kk * ld4];
-                }
-            };
-            TC cb4[4];
-            TV vo2[2], vn2[2];
-            const int step = 16 * NW, offlast = step * (4 * ntrip - 1);
-            load_v(vo2[0], v1op, v2op, 0);
-            load_v(vn2[0], v1np, v2np, 0);
-            load_c(cb4[0], 0);
-            load_c(cb4[1], min(step, offlast));
-            load_c(cb4[2], min(2 * step, offlast));
-            for (int trip = 0; trip < ntrip; trip++) {
-#pragma unroll
-                for (int q = 0; q < 4; q++) {
-                    const int off = step * (4 * trip + q);
-                    load_v(vo2[(q + 1) & 1], v1op, v2op, min(off + step, offlast));
-                    load_v(vn2[(q + 1) & 1], v1np, v2np, min(off + step, offlast));
-                    load_c(cb4[(q + 3) & 3], min(off + 3 * step, offlast));
-                    __builtin_amdgcn_sched_barrier(0);
-                    const TC &tc = cb4[q];
-                    const TV &to = vo2[q & 1], &tn = vn2[q & 1];
-#pragma unroll
-                    for (int kk = 0; kk < STM_NB / 4; kk++) {      // the new pair's V tile does not wait for the application
-                        Vs[(4 * kk + l4) * F2_S + l15] = tn.v1[kk];
-                        Vs[(STM_NB + 4 * kk + l4) * F2_S + l15] = tn.v2[kk];
-                    }
-                    d4 a0 = {tc.c0[0], tc.c0[1], tc.c0[2], tc.c0[3]}, a1 = {tc.c1[0], tc.c1[1], tc.c1[2], tc.c1[3]};
-#pragma unroll
-                    for (int kk = 0; kk < STM_NB / 4; kk++) {
-                        a0 = __builtin_amdgcn_mfma_f64_16x16x4f64(yn0[kk], to.v1[kk], a0, 0, 0, 0);
-                        a1 = __builtin_amdgcn_mfma_f64_16x16x4f64(yn1[kk], to.v1[kk], a1, 0, 0, 0);
-                    }
-#pragma unroll
-                    for (int kk = 0; kk < STM_NB / 4; kk++) {
-                        a0 = __builtin_amdgcn_mfma_f64_16x16x4f64(yn0[STM_NB / 4 + kk], to.v2[kk], a0, 0, 0, 0);
-                        a1 = __builtin_amdgcn_mfma_f64_16x16x4f64(yn1[STM_NB / 4 + kk], to.v2[kk], a1, 0, 0, 0);
-                    }
-                    double *sp = const_cast<double *>(cp) + off;
-#pragma unroll
-                    for (int r = 0; r < 4; r++) {
-                        sp[r * ld4] = a0[r];
-                        sp[(4 + r) * ld4] = a1[r];
-                        Cs[(l4 + 4 * r) * F2_S + l15] = a0[r];
-                        Cs[(16 + l4 + 4 * r) * F2_S + l15] = a1[r];
-                    }
-                    accumulate();
-                    __builtin_amdgcn_sched_barrier(0);
-                }
-            }
-            tix += 4 * ntrip * NW;
-        }
-    }
-    for (; tix < ntile; tix += NW) general_tile(tix);
-    if (!has_new) return;
-    // ---- W_new of this workgroup: the four waves' sums added in wave order, then the slot / ticket protocol of k_upd_w2 ----
-    __syncthreads();                                             // (every wave is done with its scratch)
-    {
-        double *Wl = dyn_lds + wid * (2 * STM_NB * BN);
-#pragma unroll
-        for (int m = 0; m < 4; m++)
-#pragma unroll
-            for (int h = 0; h < 2; h++)
-#pragma unroll
-                for (int r = 0; r < 4; r++)
-                    Wl[(m >> 1) * STM_NB * BN + (16 * (m & 1) + l4 + 4 * r) * BN + 16 * h + l15] = w[m][h][r];
-    }
-    __syncthreads();
-    double v[2 * STM_NB * BN / NT];
-#pragma unroll
-    for (int q = 0; q < 2 * STM_NB * BN / NT; q++) {
-        const int e = tid + q * NT;
-        v[q] = ((dyn_lds[e] + dyn_lds[2 * STM_NB * BN + e]) + dyn_lds[2 * (2 * STM_NB * BN) + e]) + dyn_lds[3 * (2 * STM_NB * BN) + e];
-    }
-    const int ngrp = (nsl + spw - 1) / spw;
-    double *W0 = Wp + wpoff[fi] + ((long long)cb * nslf) * (2 * STM_NB * BN);
-    double *W = W0 + (long long)(sl / spw) * (2 * STM_NB * BN);
-    if (ngrp == 1) {
-#pragma unroll
-        for (int q = 0; q < 2 * STM_NB * BN / NT; q++) W[tid + q * NT] = v[q];
-        return;
-    }
-#pragma unroll
-    for (int q = 0; q < 2 * STM_NB * BN / NT; q++) st_agent(&W[tid + q * NT], v[q]);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    int *cnt = wcnt + wpoff[fi] / (STM_NB * BN) + cb;
-    if (tid == 0) {
-        s_ticket = __hip_atomic_fetch_add(cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (s_ticket == ngrp - 1) {
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __hip_atomic_store(cnt, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-    }
-    __syncthreads();
-    if (s_ticket != ngrp - 1) return;
-#pragma unroll
-    for (int q = 0; q < 2 * STM_NB * BN / NT; q++) v[q] = stm_ordered_sum<true>(W0 + tid + q * NT, 2 * STM_NB * BN, ngrp);   // fixed order
-#pragma unroll
-    for (int q = 0; q < 2 * STM_NB * BN / NT; q++) W0[tid + q * NT] = v[q];
-}
-
 // Y of a pair, once per column block (between k_upd_w2 and k_upd_c2): Y1 = T1' W1, Y2 = T2' (W2 - G21 Y1) from the summed W of the
 // block, the Gram block G21 of the same launch of k_upd_w2 and the two T factors; the NEGATED 64 x 32 Y goes to the front's Y area
 // (DevCtx::Ypend, by absolute column block), in the layout k_upd_c2's lanes read their MFMA operand from.  (It used to be the prologue of EVERY workgroup of
 // k_upd_c2: five 8 KB images through LDS and three 32-step triangular loops, 6-8 us in front of 13 us of MFMA work.)
 __global__ __launch_bounds__(NT) void k_upd_y2(DevCtx c, const int *__restrict__ flist, const int *__restrict__ plist, double *Wp,
-                                               const long long *__restrict__ wpoff, int fused)
+                                               const long long *__restrict__ wpoff)
 {
     extern __shared__ double dyn_lds[];
     const int fi = blockIdx.y, f = flist[fi], p = plist[fi];
@@ -3038,26 +2682,6 @@ __global__ __launch_bounds__(NT) void k_upd_y2(DevCtx c, const int *__restrict__
     const int ncbp = stm_upd_ncb(s, p) - 1, nslf = stm_upd_nsl(s);
     const int cb = blockIdx.x;
     const int tid = threadIdx.x;
-    if (cb == 0) {
-        // single-sweep form: this pair is now the pending one (k_upd_f2 of the next pair applies it beyond that pair's panels)
-        PairPend *pe = &num->pend;
-        const PanelDesc *pa = &num->pd[(p - 1) & 1], *pb = &num->pd[p & 1];
-        if (tid == 0) {
-            pe->valid = (fused && live) ? 1 : 0;
-            pe->g1 = G.g1; pe->mp = G.mp; pe->mp1 = G.mp1; pe->mp2 = G.mp2; pe->nb1 = G.nb1; pe->nb2 = G.nb2; pe->k1a = G.k1a; pe->k1b = G.k1b;
-            int dmax = -1;
-            if (live)
-                for (int q = 0; q < STM_NB; q++) {
-                    dmax = max(dmax, (q < G.nb1) ? pa->pdiag[q] - G.g1 : STM_BIGROW);
-                    dmax = max(dmax, (q < G.nb2) ? pb->pdiag[q] - G.g1 : STM_BIGROW);
-                }
-            pe->dmax = dmax;
-        }
-        if (live && tid < STM_NB) {
-            pe->diag1[tid] = (tid < G.nb1) ? pa->pdiag[tid] - G.g1 : STM_BIGROW;
-            pe->diag2[tid] = (tid < G.nb2) ? pb->pdiag[tid] - G.g1 : STM_BIGROW;
-        }
-    }
     if (!live) return;
     if (cb >= ncbp || G.pc0 + cb * BN >= s.fn) return;
     double *s_W1 = dyn_lds, *s_W2 = s_W1 + STM_NB * WS, *s_T1 = s_W2 + STM_NB * WS, *s_T2 = s_T1 + STM_NB * WS,
@@ -4161,12 +3785,6 @@ int stm_launch_front_wg(const DevCtx &c, const int *flist, int nfr, int lds_doub
     hipLaunchKernelGGL(k_front_wg, dim3(nfr), dim3(NT), bytes, st, c, flist, (int)(bytes / sizeof(double)));
     return (int)hipGetLastError();
 }
-int stm_launch_front_mid(const DevCtx &c, const int *flist, int nfr, int lds_doubles, hipStream_t st)
-{
-    if (nfr <= 0) return 0;
-    hipLaunchKernelGGL(k_front_mid, dim3(nfr), dim3(NTP), (size_t)lds_doubles * sizeof(double), st, c, flist);
-    return (int)hipGetLastError();
-}
 int stm_launch_panel(const DevCtx &c, const int *flist, const int *plist, int nfr, int nsub, int defer_ok, int lds_doubles, hipStream_t st)
 {
     if (nfr <= 0) return 0;
@@ -4214,23 +3832,12 @@ int stm_launch_update_fused(const DevCtx &c, const int *flist, const int *plist,
     return (int)hipGetLastError();
 }
 int stm_launch_update_pair(const DevCtx &c, const int *flist, const int *plist, int nfr, int ncbp, int maxsl, double *Wp,
-                           const long long *wpoff, int *wcnt, int fused, hipStream_t st)
+                           const long long *wpoff, int *wcnt, hipStream_t st)
 {
     if (nfr <= 0 || ncbp <= 0 || maxsl <= 0) return 0;
-    if (fused) {
-        // one sweep per pair: the Gram block alone, then apply-the-pending-pair + W of the new one, Y, and the application of the new
-        // pair to the first two column blocks (the next pair's panel columns)
-        hipLaunchKernelGGL(k_upd_w2, dim3(1, maxsl, nfr), dim3(NT), (size_t)(3 * BN * VS2 + 2) * sizeof(double), st, c, flist, plist, Wp,
-                           wpoff, wcnt);
-        hipLaunchKernelGGL(k_upd_f2, dim3(ncbp, maxsl, nfr), dim3(NT), (size_t)F2_LDS_DOUBLES * sizeof(double), st, c, flist, plist, Wp,
-                           wpoff, wcnt);
-        hipLaunchKernelGGL(k_upd_y2, dim3(ncbp, nfr), dim3(NT), (size_t)(6 * STM_NB * WS) * sizeof(double), st, c, flist, plist, Wp, wpoff, 1);
-        hipLaunchKernelGGL(k_upd_c2, dim3(ncbp < 2 ? ncbp : 2, maxsl, nfr), dim3(NT), 0, st, c, flist, plist, (const double *)Wp, wpoff);
-        return (int)hipGetLastError();
-    }
     hipLaunchKernelGGL(k_upd_w2, dim3(ncbp + 1, maxsl, nfr), dim3(NT), (size_t)(3 * BN * VS2 + 2) * sizeof(double), st, c, flist, plist, Wp,
                        wpoff, wcnt);
-    hipLaunchKernelGGL(k_upd_y2, dim3(ncbp, nfr), dim3(NT), (size_t)(6 * STM_NB * WS) * sizeof(double), st, c, flist, plist, Wp, wpoff, 0);
+    hipLaunchKernelGGL(k_upd_y2, dim3(ncbp, nfr), dim3(NT), (size_t)(6 * STM_NB * WS) * sizeof(double), st, c, flist, plist, Wp, wpoff);
     hipLaunchKernelGGL(k_upd_c2, dim3(ncbp, maxsl, nfr), dim3(NT), 0, st, c, flist, plist, (const double *)Wp, wpoff);
     return (int)hipGetLastError();
 }
@@ -4330,9 +3937,7 @@ int stm_configure_kernels(void)
     // allow the panel kernels to ask for up to 144 KiB of dynamic LDS (160 KiB per CU on gfx950)
     CK(hipFuncSetAttribute((const void *)k_front_wg, hipFuncAttributeMaxDynamicSharedMemorySize, 122880));
     CK(hipFuncSetAttribute((const void *)k_panel, hipFuncAttributeMaxDynamicSharedMemorySize, 131072));
-    CK(hipFuncSetAttribute((const void *)k_front_mid, hipFuncAttributeMaxDynamicSharedMemorySize, 131072));
     CK(hipFuncSetAttribute((const void *)k_update, hipFuncAttributeMaxDynamicSharedMemorySize, 65536));
-    CK(hipFuncSetAttribute((const void *)k_upd_f2, hipFuncAttributeMaxDynamicSharedMemorySize, 65536));
     CK(hipFuncSetAttribute((const void *)k_update_n, hipFuncAttributeMaxDynamicSharedMemorySize, 65536));
     CK(hipFuncSetAttribute((const void *)k_qapply, hipFuncAttributeMaxDynamicSharedMemorySize, 131072));
     CK(hipFuncSetAttribute((const void *)k_qapply_t, hipFuncAttributeMaxDynamicSharedMemorySize, 131072));

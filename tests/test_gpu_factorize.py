@@ -124,6 +124,7 @@ def test_lookahead_schedule_same_bits(pkg, name, bfc, algo):
         for la, fused in ((0, 0), (1, 0), (0, 1), (1, 1)):
             pkg.set_options(lookahead=la, fused_update=fused, big_front_cols=bfc, panel_algo=algo)
             S, G = gpu_run(pkg, g)
+            assert G.stats["retries"] == 0            # (rank-deficient fixtures too: no bounded wait of the fused block-0 launch runs out)
             out.append((G.Stack[:G.rh_total].copy(), G.HTau.copy(), G.HStair.copy(), G.Rdead.copy(), G.rank))
     finally:
         del os.environ["STMMQR_LA_MIN"]
@@ -135,44 +136,43 @@ def test_lookahead_schedule_same_bits(pkg, name, bfc, algo):
             assert np.array_equal(x, y, equal_nan=True)
 
 
-@pytest.mark.parametrize("name", NAMES)
-@pytest.mark.parametrize("bfc,midc", [(16, 4096), (64, 192), (32, 96)])
-def test_mid_fronts_everywhere(pkg, oracle, name, bfc, midc):
-    """options.mid_front_cols: a front of bfc <= fn <= midc columns and at most 512 rows is factorized whole by ONE 512-thread
-    workgroup (k_front_mid: wave-pipelined panels, the trailing update two column blocks at a time on the halves of the workgroup,
-    T from the Gram matrix of the first pair of blocks, qr_cpack).  (16, 4096) sends every such front of every fixture there --
-    odd and even numbers of column blocks, ragged last blocks, dead columns, fronts whose rows run out inside a panel: integers,
-    flop count, R rows and the factors against the golden vectors and the oracle."""
+@pytest.mark.parametrize("name", ["c5mini_standin", "xenon1_standin"])
+def test_lookahead_events_without_system_fence_same_bits(pkg, monkeypatch, name):
+    """The events that order the plan's stream and the side stream are created with hipEventDisableSystemFence (they order two queues
+    of ONE device; the host never inspects them).  HIP documents that flag for events the HOST does not synchronise with; the
+    device-side ordering rests on the agent-scope release / acquire of the barrier packets.  Checked here on workloads that really
+    offload steps at the default thresholds (ROCm 7.2.0, MI355X: recorded in DESIGN.md): one stream, two streams with the default
+    (fenced) events, two streams without the system fence -- the same bits."""
     g = load_golden(name)
-    pkg.set_options(big_front_cols=bfc, mid_front_cols=midc)
-    try:
-        S, G = gpu_run(pkg, g)
-    finally:
-        pkg.set_options(big_front_cols=64, mid_front_cols=0)
-    N = numeric_from_gpu(S, G)
-    compare_integers(S, N, g)
-    assert G.stats["flops"] == scalar(g, "flopcount")
-    got, ref = rrow_sig_all(S, N), g["num_rrow_sig"]
-    ftol = ILL_CONDITIONED.get(name, 1e-10)
-    scale = np.max(ref[:, 1], initial=1e-300) if name in ILL_CONDITIONED else np.maximum(ref[:, 1:2], 1e-300)
-    assert np.max(np.abs(got - ref) / scale, initial=0.0) <= ftol
-    No = oracle.factorize(S, g["in_Ap"], g["in_Ai"], g["in_Ax"], scalar(g, "in_tol"), int(scalar(g, "in_ntol")))
-    compare_numeric(oracle, S, G, No, g, ftol=1e-10, name=name)
+    out = []
+    for la, fence in ((0, None), (1, "1"), (1, "0")):
+        if fence is not None:
+            monkeypatch.setenv("STMMQR_LA_SYSFENCE", fence)
+        pkg.set_options(lookahead=la)
+        try:
+            S, G = gpu_run(pkg, g)
+        finally:
+            pkg.set_options(lookahead=1)
+            monkeypatch.delenv("STMMQR_LA_SYSFENCE", raising=False)
+        assert G.stats["retries"] == 0
+        out.append((G.Stack[:G.rh_total].copy(), G.HTau.copy(), G.HStair.copy(), G.rank))
+        del G
+    for b in out[1:]:
+        assert out[0][3] == b[3]
+        for x, y in zip(out[0][:3], b[:3]):
+            assert np.array_equal(x, y, equal_nan=True)
 
 
 @pytest.mark.parametrize("name", NAMES)
 @pytest.mark.parametrize("bfc", [16, 64])
-@pytest.mark.parametrize("mode", [1, 2])
-def test_pair_update_everywhere(pkg, oracle, monkeypatch, name, bfc, mode):
+def test_pair_update_everywhere(pkg, oracle, monkeypatch, name, bfc):
     """options.pair_update: fronts of >= 16384 rows apply the block reflectors of two consecutive panels in one sweep
-    (k_upd_w2 / k_upd_c2; mode 2: k_upd_f2) on the columns beyond the next two panels.  STMMQR_PAIR_MIN=1 gives that path to every large
+    (k_upd_w2 / k_upd_y2 / k_upd_c2) on the columns beyond the next two panels.  STMMQR_PAIR_MIN=1 gives that path to every large
     front with at least four panels (here: fn >= 16 / 64): integers, R rows and the factors against the golden vectors and
     the oracle, exactly as for the one-panel-at-a-time update (different rounding, same tolerances)."""
     g = load_golden(name)
     monkeypatch.setenv("STMMQR_PAIR_MIN", "1")
-    # mode 2: ONE sweep per pair (k_upd_f2: the application of a pair beyond the next pair's panels is delayed to the sweep that
-    # forms W of that next pair) -- pending pairs across fronts that run out of rows, ragged blocks, dead columns, last pairs
-    pkg.set_options(big_front_cols=bfc, pair_update=mode)
+    pkg.set_options(big_front_cols=bfc, pair_update=1)
     try:
         S, G = gpu_run(pkg, g)
     finally:
