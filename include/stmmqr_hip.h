@@ -97,6 +97,17 @@ void stmmqr_get_common_layout(stm_common_layout *layout);
 stm_qr_numeric *qr_factorize(stm_sparse_csc **Ahandle, stm_long freeA, double tol, stm_long ntol,
                              stm_qr_symbolic *QRsym, stm_sparse_common *cc);
 
+/* The seam keeps the plan of the last qr_symbolic it factorized (symbolic upload, schedule, workspaces, front arenas: about as
+ * expensive to build as one factorization of the BASELINE matrices): a later call with an EQUAL qr_symbolic -- compared by a hash of
+ * its scalars and arrays, the options and the plan-time environment -- and the same device reuses it, and skips the value map
+ * (qr_stranspose2) too when A's pattern is unchanged.  A cached plan keeps its device memory until stmmqr_plan_cache_clear() /
+ * stmmqr_shutdown(); env STMMQR_PLAN_CACHE = 0 turns the cache off, = n keeps the n most recent plans (default 1).
+ * STMMQR_SEAM_TIMING=1 prints where a call spent its time.  Match: the interval SparseQR.c:346-377 brackets ("Factorize time"). */
+void stmmqr_plan_cache_clear(void);
+/* releases a qr_numeric returned by qr_factorize with the reference's accounting (= qr_freenum, SparseQR.c:1225-1272), for hosts
+ * that link this library without the reference */
+void stmmqr_free_numeric(stm_qr_numeric **QRnum, stm_sparse_common *cc);
+
 /* SparseQR.h:137-143 ; globals FCHUNK/SMALL/MINCHUNK/MINCHUNK_RATIO (SparseQR.h:16-19) become library state */
 int chunk_getSettings(size_t fchunk, size_t small_, size_t minchunk, size_t minchunk_ratio);
 

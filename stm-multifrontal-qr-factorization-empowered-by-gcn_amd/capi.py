@@ -389,6 +389,12 @@ class HipQR:
     def device_bytes(self) -> float:
         return float(lib.stmmqr_plan_device_bytes(self._h))
 
+    def result_sizes(self):
+        """-> (entries of the packed R+H, rank) of the factorization held"""
+        rh, rk = C.c_long(0), C.c_long(0)
+        _check(lib.stmmqr_plan_result_sizes(self._h, C.byref(rh), C.byref(rk)), "stmmqr_plan_result_sizes")
+        return int(rh.value), int(rk.value)
+
     def front_flops(self, f):
         """-> (reference flop count of front f, the part done by trailing updates) of the factorization in progress / held"""
         v = np.zeros(2)
@@ -452,6 +458,70 @@ def qr_factorize(sym: dict, Ap, Ai, Ax, tol, ntol) -> QRNumeric:
         return N
     finally:
         plan.close()
+
+
+class SeamNumeric:
+    """What the exported qr_factorize (the drop-in seam with the reference's structs) returned: a view of the qr_numeric; the
+    arrays are copied out on demand, close() releases it through stmmqr_free_numeric."""
+
+    def __init__(self, ptr, nf, n, m, rjsize, hisize):
+        self._p, self.nf, self.n, self.m, self.rjsize, self.hisize = ptr, nf, n, m, rjsize, hisize
+        c = ptr.contents
+        self.rank, self.rank1, self.maxfrank, self.maxfm = c.rank, c.rank1, c.maxfrank, c.maxfm
+        self.rh_total = int(c.Stack_size[0])
+
+    def arrays(self) -> dict:
+        c = self._p.contents
+        take = lambda ptr, cnt, ty: np.ctypeslib.as_array(C.cast(ptr, C.POINTER(ty)), shape=(max(cnt, 1),))[:cnt].copy()
+        stacks = C.cast(c.Stacks, C.POINTER(c_double_p))
+        base = C.cast(stacks[0], C.c_void_p).value
+        rb = C.cast(c.Rblock, C.POINTER(C.c_void_p))
+        return {"Stack": take(stacks[0], self.rh_total, C.c_double), "Rdead": take(c.Rdead, self.n, C.c_int8),
+                "HStair": take(c.HStair, self.rjsize, C.c_long), "HTau": take(c.HTau, self.rjsize, C.c_double),
+                "Hii": take(c.Hii, self.hisize, C.c_long), "HPinv": take(c.HPinv, self.m, C.c_long),
+                "Hm": take(c.Hm, self.nf, C.c_long), "Hr": take(c.Hr, self.nf, C.c_long),
+                "Rblock_off": np.array([((rb[f] or base) - base) // 8 for f in range(self.nf)], I64)}
+
+    def close(self):
+        if self._p:
+            pp = C.POINTER(QrNumericC)(self._p.contents)
+            lib.stmmqr_free_numeric(C.byref(pp), None)
+            self._p = None
+
+    __del__ = close
+
+
+def qr_factorize_seam(sym: dict, Ap, Ai, Ax, tol, ntol) -> SeamNumeric:
+    """ONE call of the exported qr_factorize -- the drop-in seam itself, with the reference's structs (sparse_csc **, freeA = 0,
+    qr_symbolic *, cc = NULL), exactly what SparseQR.c:349 calls: plan (built or from the seam's cache), H2D, factorization, host
+    allocation of the qr_numeric, D2H of the packed factors."""
+    keep = {}
+    S = QrSymbolicC()
+    for k in ("m", "n", "anz", "nf", "maxfn", "rjsize", "do_rank_detection", "maxstack", "hisize", "keepH", "ntasks", "ns"):
+        setattr(S, k, int(sym.get(k, 1 if k in ("keepH", "ntasks", "ns") else 0)))
+    for k in ("Sp", "Sj", "Qfill", "PLinv", "Sleft", "Parent", "Child", "Childp", "Super", "Rp", "Rj", "Post", "Hip", "Fm", "Cm"):
+        a = sym.get(k)
+        if a is not None and len(a):
+            keep[k] = np.ascontiguousarray(a, I64)
+            setattr(S, k, _ip(keep[k]))
+    keep["Ap"], keep["Ai"], keep["Ax"] = np.ascontiguousarray(Ap, I64), np.ascontiguousarray(Ai, I64), np.ascontiguousarray(Ax, np.float64)
+    A = SparseCsc()
+    A.nrow, A.ncol, A.nzmax = S.m, S.n, len(keep["Ax"])
+    A.p, A.i, A.x = keep["Ap"].ctypes.data, keep["Ai"].ctypes.data, keep["Ax"].ctypes.data
+    A.stype, A.itype, A.xtype, A.dtype, A.sorted, A.packed = 0, 2, 1, 0, 1, 1
+    Ah = C.pointer(A)
+    lib.qr_factorize.restype = C.POINTER(QrNumericC)
+    lib.qr_factorize.argtypes = [C.POINTER(C.POINTER(SparseCsc)), C.c_long, C.c_double, C.c_long, C.POINTER(QrSymbolicC), C.c_void_p]
+    lib.stmmqr_free_numeric.restype = None
+    lib.stmmqr_free_numeric.argtypes = [C.POINTER(C.POINTER(QrNumericC)), C.c_void_p]
+    N = lib.qr_factorize(C.byref(Ah), 0, float(tol), int(ntol), C.byref(S), None)
+    if not N:
+        raise StmmqrError("qr_factorize (seam) returned NULL: " + last_error())
+    return SeamNumeric(N, S.nf, S.n, S.m, S.rjsize, S.hisize)
+
+
+def plan_cache_clear():
+    lib.stmmqr_plan_cache_clear()
 
 
 def qr_front(m, n, npiv, tol, ntol, F, Stair):

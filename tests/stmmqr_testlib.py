@@ -56,6 +56,11 @@ HEAVY_REAL = ("reorientation_8", "cvxqp3")
 ILL_CONDITIONED = {"bcsstk14": 1e-6, "lns_3937": 1e-6, "bayer10": 1e-9, "ex18": 1e-6, "reorientation_8": 1e-9, "cvxqp3": 1e-8}
 
 
+# ... and a triangular solve amplifies the rounding differences of two correct Q'b by cond(R): the tolerance of solution-against-
+# solution comparisons on those inputs (measured differences x 100; the residual checks stay tight)
+SOLVE_TOL = {"bcsstk14": 1e-6, "lns_3937": 1e-6, "bayer10": 1e-5, "ex18": 1e-2, "reorientation_8": 1e-5, "cvxqp3": 1e-5}
+
+
 def golden_names(include_big: bool = False):
     return sorted(p.stem for p in GOLDEN.glob("*.npz") if include_big or (p.stem not in BIG_FIXTURES and p.stem not in HEAVY_REAL))
 

@@ -8,6 +8,7 @@ import numpy as np
 import pytest
 
 from parity import ILL_CONDITIONED
+from stmmqr_testlib import SOLVE_TOL
 from stmmqr_testlib import Symbolic, csc_matvec, golden_names, load_golden, numeric_from_gpu, scalar
 
 pytestmark = pytest.mark.gpu
@@ -75,7 +76,9 @@ def test_solve_residual_and_oracle(pkg, oracle, name):
             np.testing.assert_array_equal(x == 0.0, xo == 0.0)
             assert int(np.sum(x == 0.0)) >= S.n - G.rank
             # (the triangular solve amplifies the rounding differences of the two Q'b by cond(R))
-            assert np.linalg.norm(x - xo) <= ILL_CONDITIONED.get(name, 1e-9) * max(np.linalg.norm(xo), 1.0)
+            d = np.linalg.norm(x - xo) / max(np.linalg.norm(xo), 1.0)
+            print(f"[solve diff] {name} {d:.3e}")
+            assert d <= SOLVE_TOL.get(name, 1e-9)
             if "solve_x" in g and int(scalar(g, "n1rows")) == 0 and int(scalar(g, "n1cols")) == 0:
                 ref = g["solve_x"][:S.n]
                 assert np.linalg.norm(x - ref) <= 1e-8 * max(np.linalg.norm(ref), 1.0)
@@ -89,7 +92,9 @@ def test_solve_residual_and_oracle(pkg, oracle, name):
             y = oracle.qmult(0, S, N, B[:, j])[:S.n]
             xo = np.zeros(S.n)
             xo[q] = oracle.rsolve(S, N, y)
-            assert np.linalg.norm(X[:, j] - xo) <= ILL_CONDITIONED.get(name, 1e-9) * max(np.linalg.norm(xo), 1e-300)
+            d = np.linalg.norm(X[:, j] - xo) / max(np.linalg.norm(xo), 1e-300)
+            print(f"[solve diff] {name} {d:.3e}")
+            assert d <= SOLVE_TOL.get(name, 1e-9)
         # the driver's check (qrtest.c:11-53): res = ||A x - b|| / (||A|| ||x|| + ||b||) for a consistent system
         r = csc_matvec(S.m, Ap, Ai, Ax, X[:, 0]) - B[:, 0]
         res = np.linalg.norm(r) / (np.linalg.norm(Ax) * np.linalg.norm(X[:, 0]) + np.linalg.norm(B[:, 0]))
