@@ -141,6 +141,8 @@ typedef struct stmmqr_symbolic_view {
     stm_long m, n, anz, nf, maxfn, rjsize, hisize, do_rank_detection;
     const stm_long *Sp, *Sj, *Qfill, *PLinv, *Sleft;
     const stm_long *Child, *Childp, *Super, *Rp, *Rj, *Post, *Hip, *Fm;
+    stm_long maxstack;          /* QRsym->maxstack: the analysis' bound for the reference's one stack, hence for all of R+H; sizes the
+                                   R+H arena of the slab recycling.  0 = unknown (the arena then holds all recycled slabs)          */
 } stmmqr_symbolic_view;
 
 /* per-call measurements (all times in milliseconds, HIP events on the library's own stream) */

@@ -58,7 +58,7 @@ lib = C.CDLL(str(lib_path))
 class SymbolicView(C.Structure):
     _fields_ = [(k, C.c_long) for k in ["m", "n", "anz", "nf", "maxfn", "rjsize", "hisize", "do_rank_detection"]] + \
                [(k, c_long_p) for k in ["Sp", "Sj", "Qfill", "PLinv", "Sleft", "Child", "Childp", "Super", "Rp", "Rj",
-                                        "Post", "Hip", "Fm"]]
+                                        "Post", "Hip", "Fm"]] + [("maxstack", C.c_long)]
 
 
 class Stats(C.Structure):
@@ -229,6 +229,7 @@ class HipQR:
                 a = np.ascontiguousarray(a, dtype=I64)
                 self._keep[k] = a
             setattr(v, k, _ip(a))
+        v.maxstack = int(sym.get("maxstack", 0) or 0)
         self.sym = {k: int(sym[k]) for k in ["m", "n", "anz", "nf", "maxfn", "rjsize", "hisize"]}
         st = C.c_int(0)
         self._h = lib.stmmqr_plan_create(C.byref(v), device, C.byref(st))

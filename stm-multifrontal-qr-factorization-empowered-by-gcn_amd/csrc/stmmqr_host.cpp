@@ -121,6 +121,9 @@ struct Step {
     int n_norm = 0, n_pe = 0, n_po = 0;
     int maxsl_pe = 0, maxsl_po = 0, maxcbp_po = 0;
     int cpk_off = 0, cpk_parts_off = 0, n_cpk = 0, cpk_maxparts = 1;   // big fronts whose last panel runs here
+    // slab recycling: the fronts whose packed R+H block is staged at the end of this step (the small fronts that started here and
+    // the big fronts packed here, kept fronts excluded) + copy parts
+    int rhp_off = 0, rhp_parts_off = 0, n_rhp = 0, rhp_maxparts = 1;
 };
 
 }  // namespace
@@ -157,6 +160,23 @@ struct stmmqr_plan {
                                                //  (the front is factorized here, or it is a child of one that is: assign_arenas)
     std::vector<long long> c_slot;             // ... and the size of that slot in doubles (the symbolic bound of csize)
     int own_off = 0, n_own = 0;
+    // ---- slab recycling (the reference's stack discipline, SparseQR_factorize.c:405-422,925-933, re-cast for a timeline of steps):
+    // a front's slab lives from the step it starts to the step its contribution block is packed and its R+H block staged into the
+    // R+H arena; a contribution block from there to the step its parent starts.  Offsets are assigned by an address-ordered
+    // first-fit over that timeline (assign_arenas_timeline), all symbolic.  Fronts in `kept` keep their slab (never staged: their
+    // packed block is produced on the fly when the factors are downloaded) -- chosen where that makes the peak smaller (a root
+    // front that IS most of the factors).  Only plans that hold the whole tree in one group recycle (sharded plans: as before).
+    bool recycle = false;
+    long maxstack = 0;                   // QRsym->maxstack (0: unknown)
+    std::vector<char> kept;              // per front
+    std::vector<int> f_t0, f_t1, c_t1;   // slab: [f_t0, f_t1]; contribution block: [f_t1, c_t1]  (steps of group 0)
+    long long rh_cap = 0;                // capacity of the R+H arena (doubles)
+    long long rh_est_total = 0;          // all packed R+H blocks if no pivot column dies (symbolic; exact for full-rank input)
+    int rh_grow = 0;                     // 0: the arena is sized from that estimate; 1: from the hard bounds (it overflowed once)
+    long long scr_doubles = 0;           // scratch of the resident-factor operations: the widest tree level in front form
+    std::vector<FrontSym> fs_scr;        // FrontSym with foff into that scratch (kept fronts: their own slab, relative to it)
+    bool overflowed = false;             // a factorization did not fit the R+H arena at its hard bound: this plan does not recycle
+    bool arena_overflow = false;         // the last factorization did not fit the arena (it is repeated with a larger one / without)
     std::vector<int> lists;              // host copy of d_lists
     int post_off = 0, rh_parts_off = 0, rh_maxparts = 1;
     long long farena = 0, carena = 0;
@@ -184,6 +204,10 @@ struct stmmqr_plan {
     DevBuf<int> d_abort;
     size_t wcnt_n = 1;
     DevBuf<long long> d_Rboff, d_total;
+    DevBuf<long long> d_rhtop, d_fin;    // slab recycling: {bump pointer, overflow word}; Post-order offsets of the packed blocks
+    DevBuf<char> d_kept;
+    DevBuf<double> d_scr, d_bounce;      // resident-factor scratch (one tree level in front form); download window
+    DevBuf<FrontSym> d_fs_scr;
     DevBuf<unsigned long long> d_dbg, d_amax;
     DevBuf<double> d_sig;                           // {sg, 1/sg}: magnitude guard of the panel kernels
     DevBuf<char> d_Rdead;
@@ -225,6 +249,7 @@ struct stmmqr_plan {
         add(d_Wp); add(d_Wp2); add(d_tslot); add(d_Sp); add(d_Sjrel); add(d_Sj0); add(d_Sleft); add(d_Child); add(d_Rjrel);
         add(d_Stair); add(d_Hii); add(d_Cmap); add(d_Cursor); add(d_lists); add(d_smap); add(d_Rhoff); add(d_wlists);
         add(d_wcnt); add(d_wcnt2); add(d_wflag); add(d_wflag2); add(d_Rboff); add(d_Rdead); add(d_Ypend); add(d_ypoff);
+        add(d_rhtop); add(d_fin); add(d_kept); add(d_scr); add(d_bounce); add(d_fs_scr);
         return b;
     }
     DevCtx ctx() const
@@ -240,6 +265,7 @@ struct stmmqr_plan {
         c.dbg = getenv("STMMQR_DBG") ? atoi(getenv("STMMQR_DBG")) : 0;
         c.tune = getenv("STMMQR_TUNE") ? atoi(getenv("STMMQR_TUNE")) : 0;
         c.Ypend = d_Ypend.p; c.ypoff = d_ypoff.p;
+        c.rh_top = recycle ? d_rhtop.p : nullptr; c.rh_cap = rh_cap;
         if (serial_panels) c.dbg = (c.dbg & ~(2048 | 4096)) | 256;   // the one-workgroup LDS / in-place panel for every panel
         c.tall_min = tall_min;
         c.cbskip = 0;
@@ -376,17 +402,103 @@ void assign_arenas(stmmqr_plan &P)
 // the arenas themselves: (re)allocated when their size changed (first factorization of a plan, or after a regrouping)
 int ensure_arenas(stmmqr_plan &P)
 {
-    if (P.d_F.p && P.d_F.n == (size_t)P.farena && P.d_C.p && P.d_C.n == (size_t)P.carena) return 0;
+    if (P.d_F.p && P.d_F.n == (size_t)P.farena && P.d_C.p && P.d_C.n == (size_t)P.carena &&
+        (!P.recycle || (P.d_RH.p && P.d_RH.n == (size_t)P.rh_cap)))
+        return 0;
     HIPCHK(hipStreamSynchronize(P.stream));
     if (P.d_F.n != (size_t)P.farena) P.d_F.release();
     if (P.d_C.n != (size_t)P.carena) P.d_C.release();
     size_t freeb = 0, totalb = 0;
     HIPCHK(hipMemGetInfo(&freeb, &totalb));
-    const double need = 8.0 * ((P.d_F.p ? 0.0 : (double)P.farena) + (P.d_C.p ? 0.0 : (double)P.carena)) * 1.02;
+    const double need = 8.0 * ((P.d_F.p ? 0.0 : (double)P.farena) + (P.d_C.p ? 0.0 : (double)P.carena) +
+                               ((P.recycle && P.d_RH.n != (size_t)P.rh_cap) ? (double)P.rh_cap : 0.0)) * 1.02;
     if (need > 0.95 * (double)freeb) return fail(STMMQR_ERR_OUT_OF_MEMORY, "front arena does not fit in free HBM");
     if (!P.d_F.p) LCHK(P.d_F.alloc((size_t)P.farena));
     if (!P.d_C.p) LCHK(P.d_C.alloc((size_t)P.carena));
+    if (P.recycle && P.d_RH.n != (size_t)P.rh_cap) LCHK(P.d_RH.alloc((size_t)P.rh_cap));
     return 0;
+}
+
+// ---- timeline allocator (slab recycling) ----------------------------------------------------------------------------------
+// Objects with a size and a lifetime [t0, t1] in steps; an address may be given to another object from step t1 + 1 on.  Objects
+// are placed in order of their first step (larger first inside a step) at the lowest address that holds them (address-ordered
+// first fit, free blocks coalesced).  Returns the peak address.  Everything is symbolic, so the offsets are part of the plan.
+struct TlObj { long long size; int t0, t1; long long *out; };
+long long timeline_first_fit(std::vector<TlObj> &objs, long long base, int nstep)
+{
+    std::vector<std::vector<int>> at0((size_t)nstep + 1), at1((size_t)nstep + 2);
+    for (size_t i = 0; i < objs.size(); i++) {
+        objs[i].size = (objs[i].size + 1) & ~1LL;
+        if (objs[i].size <= 0) { *objs[i].out = base; continue; }
+        at0[(size_t)objs[i].t0].push_back((int)i);
+        at1[(size_t)objs[i].t1 + 1].push_back((int)i);
+    }
+    std::vector<std::pair<long long, long long>> freeb;            // (offset, size), sorted by offset, never adjacent
+    long long top = base;
+    auto release = [&](long long off, long long sz) {
+        size_t i = (size_t)(std::lower_bound(freeb.begin(), freeb.end(), std::make_pair(off, 0LL)) - freeb.begin());
+        freeb.insert(freeb.begin() + (long)i, {off, sz});
+        if (i + 1 < freeb.size() && freeb[i].first + freeb[i].second == freeb[i + 1].first) {
+            freeb[i].second += freeb[i + 1].second;
+            freeb.erase(freeb.begin() + (long)i + 1);
+        }
+        if (i > 0 && freeb[i - 1].first + freeb[i - 1].second == freeb[i].first) {
+            freeb[i - 1].second += freeb[i].second;
+            freeb.erase(freeb.begin() + (long)i);
+        }
+        if (!freeb.empty() && freeb.back().first + freeb.back().second == top) {      // (no free block ever touches the top)
+            top = freeb.back().first;
+            freeb.pop_back();
+        }
+    };
+    long long peak = base;
+    for (int t = 0; t <= nstep; t++) {
+        for (int i : at1[(size_t)t]) release(*objs[(size_t)i].out, objs[(size_t)i].size);
+        if (t == nstep) break;
+        std::vector<int> &now = at0[(size_t)t];
+        std::stable_sort(now.begin(), now.end(), [&](int a, int b) { return objs[(size_t)a].size > objs[(size_t)b].size; });
+        for (int i : now) {
+            const long long sz = objs[(size_t)i].size;
+            long long at = -1;
+            for (auto it = freeb.begin(); it != freeb.end(); ++it)
+                if (it->second >= sz) {
+                    at = it->first;
+                    if (it->second == sz) freeb.erase(it);
+                    else { it->first += sz; it->second -= sz; }
+                    break;
+                }
+            if (at < 0) { at = top; top = at + sz; }             // nothing fits: the arena grows
+            *objs[(size_t)i].out = at;
+            peak = std::max(peak, top);
+        }
+    }
+    return peak;
+}
+
+// Front and contribution-block offsets of a plan that holds the whole tree in ONE group, from the step timeline of that group
+// (P.f_t0 / f_t1 / c_t1, filled by build_schedule).  `kept` fronts sit at the bottom of the front arena for good.
+// Returns {front arena, contribution arena} in doubles.
+std::pair<long long, long long> timeline_offsets(stmmqr_plan &P, const std::vector<char> &kept, int nstep, bool apply)
+{
+    const long nf = P.nf;
+    std::vector<long long> foff((size_t)std::max(1L, nf), 0), coff((size_t)std::max(1L, nf), 0);
+    long long base = 0;
+    for (long f = 0; f < nf; f++)
+        if (kept[(size_t)f]) { foff[(size_t)f] = base; base += (long long)P.fs[f].ld * P.fs[f].fn; }
+    std::vector<TlObj> fo, co;
+    for (long f = 0; f < nf; f++) {
+        const FrontSym &s = P.fs[f];
+        if (!kept[(size_t)f]) fo.push_back({(long long)s.ld * s.fn, P.f_t0[f], P.f_t1[f], &foff[(size_t)f]});
+        const long cn = s.fn - s.fp, fm = s.fm_ub;
+        const long cm = P.do_rank ? std::min(fm, cn) : std::min(std::max(fm - std::min(fm, (long)s.fp), 0L), cn);
+        const long long csz = (long long)cm * (cm + 1) / 2 + (long long)cm * (cn - cm);
+        if (apply) P.c_slot[(size_t)f] = csz;
+        co.push_back({csz, P.f_t1[f], std::max(P.f_t1[f], P.c_t1[f]), &coff[(size_t)f]});
+    }
+    const long long fpeak = timeline_first_fit(fo, base, nstep), cpeak = timeline_first_fit(co, 0, nstep);
+    if (apply)
+        for (long f = 0; f < nf; f++) { P.fs[f].foff = foff[(size_t)f]; P.fs[f].coff = coff[(size_t)f]; }
+    return {std::max(1LL, fpeak), std::max(1LL, cpeak)};
 }
 
 void build_schedule(stmmqr_plan &P, std::vector<int> &tslot)
@@ -398,6 +510,19 @@ void build_schedule(stmmqr_plan &P, std::vector<int> &tslot)
     const long nf = P.nf;
     int ngroups = 1;
     for (long f = 0; f < nf; f++) ngroups = std::max(ngroups, P.group[f] + 1);
+    {
+        // slab recycling: plans that hold the whole tree in one group (STMMQR_RECYCLE=0: every front keeps its slab, as sharded
+        // plans do); a plan whose last factorization overflowed the R+H arena stays without it
+        bool whole = (ngroups == 1) && nf > 0;
+        for (long f = 0; f < nf && whole; f++) whole = (P.group[f] == 0) && !((size_t)f < P.shared.size() && P.shared[(size_t)f]);
+        // (STMMQR_RECYCLE: 0 never, 2 always, unset / 1: when the slabs of all fronts exceed 256 MB -- below that the three extra
+        //  launches per step cost more than the memory is worth: epb1 holds 70 MB either way and took 7.4 -> 7.7 ms)
+        const char *ev = getenv("STMMQR_RECYCLE");
+        const int mode = ev ? atoi(ev) : 1;
+        long long slabs = 0;
+        for (long f = 0; f < nf; f++) slabs += (long long)P.fs[f].ld * P.fs[f].fn;
+        P.recycle = whole && !P.overflowed && (mode == 2 || (mode == 1 && slabs >= (32LL << 20)));
+    }
     auto is_big = [&](int f) {
         const FrontSym &s = P.fs[f];
         return s.fn >= g_opt.big_front_cols && s.fm_ub >= 64;
@@ -683,6 +808,82 @@ void build_schedule(stmmqr_plan &P, std::vector<int> &tslot)
             }
         }
         P.tslots = std::max(P.tslots, nslots);
+        // ---- slab recycling: lifetimes of the slabs and contribution blocks on this timeline, the fronts that keep their slab,
+        // the offsets, and per step the fronts whose packed R+H block is staged at its end ----
+        if (P.recycle && grp == 0) {
+            P.f_t0.assign((size_t)std::max(1L, nf), 0); P.f_t1.assign((size_t)std::max(1L, nf), 0); P.c_t1.assign((size_t)std::max(1L, nf), 0);
+            for (int t = 0; t < nstep; t++) {
+                for (int f : starting[t]) { P.f_t0[(size_t)f] = t; if (!is_big(f)) P.f_t1[(size_t)f] = t; }
+                for (int f : ending[t]) P.f_t1[(size_t)f] = t;
+            }
+            for (long f = 0; f < nf; f++) {
+                const int par = P.fs[f].parent;
+                P.c_t1[(size_t)f] = (par >= 0) ? P.f_t0[(size_t)par] : P.f_t1[(size_t)f];
+            }
+            // which fronts keep their slab: none, or the 1-3 largest -- whatever makes fronts + contribution blocks + R+H arena
+            // smallest (the arena holds min(maxstack, all recycled slabs) doubles: the reference's bound for all of R+H)
+            std::vector<int> bysize((size_t)nf);
+            for (long f = 0; f < nf; f++) bysize[(size_t)f] = (int)f;
+            std::stable_sort(bysize.begin(), bysize.end(), [&](int a, int b) {
+                return (long long)P.fs[a].ld * P.fs[a].fn > (long long)P.fs[b].ld * P.fs[b].fn; });
+            long long best = -1;
+            int bestk = 0;
+            for (int k = 0; k <= std::min(3L, nf); k++) {
+                std::vector<char> kp((size_t)std::max(1L, nf), 0);
+                long long rec = 0;
+                for (int q = 0; q < k; q++) kp[(size_t)bysize[(size_t)q]] = 1;
+                for (long f = 0; f < nf; f++) if (!kp[(size_t)f]) rec += (long long)P.fs[f].ld * P.fs[f].fn;
+                const auto pk = timeline_offsets(P, kp, nstep, false);
+                const long long cap = (P.maxstack > 0) ? std::min((long long)P.maxstack, rec) : rec;
+                const long long tot = pk.first + pk.second + cap;
+                if (best < 0 || tot < best - best / 50) { best = tot; bestk = k; }      // (a kept front must buy at least 2 %)
+            }
+            P.kept.assign((size_t)std::max(1L, nf), 0);
+            long long rec = 0;
+            for (int q = 0; q < bestk; q++) P.kept[(size_t)bysize[(size_t)q]] = 1;
+            for (long f = 0; f < nf; f++) if (!P.kept[(size_t)f]) rec += (long long)P.fs[f].ld * P.fs[f].fn;
+            P.rh_cap = std::max(1LL, (P.maxstack > 0) ? std::min((long long)P.maxstack, rec) : rec);
+            // (the estimate + 12.5 % where that is less: dead columns move rows into later fronts and can make the factors
+            //  larger than the full-rank pattern says; an arena that overflows is regrown to the hard bound and the factorization
+            //  repeated once -- stats.retries says so)
+            if (!P.rh_grow && P.rh_est_total > 0) {
+                // (STMMQR_RH_EST_SCALE: tests shrink the estimate to drive the overflow path)
+                const double sc = getenv("STMMQR_RH_EST_SCALE") ? atof(getenv("STMMQR_RH_EST_SCALE")) : 1.0;
+                const long long est = (long long)((double)P.rh_est_total * sc);
+                P.rh_cap = std::max(1LL, std::min(P.rh_cap, est + est / 8 + 4096));
+            }
+            const auto pk = timeline_offsets(P, P.kept, nstep, true);
+            P.farena = pk.first; P.carena = pk.second;
+            P.has_c.assign((size_t)std::max(1L, nf), 1);
+            for (int t = 0; t < nstep; t++) {
+                Step &S = SV[t];
+                std::vector<int> rhp;
+                for (int f : starting[t]) if (!is_big(f) && !P.kept[(size_t)f]) rhp.push_back(f);
+                for (int f : ending[t]) if (!P.kept[(size_t)f]) rhp.push_back(f);
+                S.rhp_off = (int)P.lists.size();
+                S.n_rhp = (int)rhp.size();
+                P.lists.insert(P.lists.end(), rhp.begin(), rhp.end());
+                S.rhp_parts_off = (int)P.lists.size();
+                for (int f : rhp) {
+                    const int parts = std::min(256, std::max(1, P.fs[f].fn / 16));
+                    P.lists.push_back(parts);
+                    S.rhp_maxparts = std::max(S.rhp_maxparts, parts);
+                }
+            }
+            // scratch of the resident-factor operations: every tree level in front form, one level at a time
+            P.fs_scr = P.fs;
+            P.scr_doubles = 1;
+            for (size_t l = 0; l < LV.size(); l++) {
+                long long o = 0;
+                for (int q = 0; q < LV[l].n_all; q++) {
+                    const int f = P.lists[(size_t)(LV[l].all_off + q)];
+                    if (P.kept[(size_t)f]) continue;
+                    P.fs_scr[(size_t)f].foff = o;
+                    o += (long long)P.fs[f].ld * P.fs[f].fn;
+                }
+                P.scr_doubles = std::max(P.scr_doubles, o);
+            }
+        }
     }
     // fronts factorized on this device, in Post order, + their R+H copy parts; then ALL fronts in Post order
     P.own_off = (int)P.lists.size();
@@ -705,6 +906,20 @@ void build_schedule(stmmqr_plan &P, std::vector<int> &tslot)
     P.h_tslot = tslot;
 }
 
+// device side of the slab recycling of the current schedule (after build_schedule): kept flags, scratch layout, bump words
+int upload_recycle(stmmqr_plan &P)
+{
+    if (!P.d_rhtop.p) LCHK(P.d_rhtop.alloc(2));
+    if (!P.d_fin.p || P.d_fin.n < (size_t)std::max(1L, P.nf)) LCHK(P.d_fin.alloc((size_t)std::max(1L, P.nf)));
+    HIPCHK(hipMemsetAsync(P.d_rhtop.p, 0, 2 * sizeof(long long), P.stream));
+    if (!P.recycle) return 0;
+    LCHK(P.d_kept.upload(P.kept, P.stream));
+    HIPCHK(hipStreamSynchronize(P.stream));
+    P.d_scr.release();                                        // (allocated by the first resident-factor operation: ensure_scratch)
+    P.d_RH.release();                                         // (the arena follows with the front arenas: ensure_arenas)
+    return 0;
+}
+
 // ------------------------------------------------------------------------------------------------
 // planner: everything that depends only on the symbolic analysis
 // ------------------------------------------------------------------------------------------------
@@ -712,6 +927,7 @@ int build_plan(stmmqr_plan &P, const stmmqr_symbolic_view &v)
 {
     P.m = v.m; P.n = v.n; P.anz = v.anz; P.nf = v.nf; P.maxfn = v.maxfn; P.rjsize = v.rjsize;
     P.hisize = v.hisize; P.do_rank = v.do_rank_detection ? 1 : 0;
+    P.maxstack = v.maxstack > 0 ? v.maxstack : 0;
     const long m = v.m, n = v.n, nf = v.nf;
     if (m < 0 || n < 0 || nf < 0) return fail(STMMQR_ERR_INVALID, "negative dimension");
     if (v.anz >= (1L << 31) - 1 || v.rjsize >= (1L << 31) - 1 || v.hisize >= (1L << 31) - 1 || m >= (1L << 30) ||
@@ -811,6 +1027,37 @@ int build_plan(stmmqr_plan &P, const stmmqr_symbolic_view &v)
             if (P.Sp[r + 1] > P.Sp[r]) Sj0[r] = (int)P.Sj[P.Sp[r]];
         P.bytes_assemble_idx += 4.0 * (double)v.anz;
     }
+    // ---- size of every packed R+H block if no pivot column dies (exact for full-rank input): the symbolic staircase of the front
+    // (qr_fsize: rows of S by leftmost column + the children's contribution rows, whose leftmost columns are the columns of their
+    // C) run through qr_front's row bookkeeping (:1434-1609) and qr_rhpack's column lengths (:1691-1784).  Sizes the R+H arena of
+    // the slab recycling (with a margin; QRsym->maxstack is the hard bound the arena falls back to) ----
+    P.rh_est_total = 0;
+    {
+        std::vector<long> stair;
+        for (long kf = 0; kf < nf; kf++) {
+            const long f = P.Post[kf];
+            const long fp = P.fs[f].fp, fn = P.fs[f].fn, fm = fmest[f];
+            stair.assign((size_t)fn + 1, 0);
+            for (long j = 0; j < fp; j++) stair[(size_t)j] = P.Sleft[P.Super[f] + j + 1] - P.Sleft[P.Super[f] + j];
+            for (long q = P.Childp[f]; q < P.Childp[f + 1]; q++) {
+                const long c = P.Child[q];
+                const long fpc = P.Super[c + 1] - P.Super[c], pc = P.Rp[c] + fpc;
+                for (long i = 0; i < cmest[c]; i++) stair[(size_t)Rjrel[(size_t)(pc + i)]]++;
+            }
+            long run = 0;
+            for (long j = 0; j < fn; j++) { run += stair[(size_t)j]; stair[(size_t)j] = run; }       // rows with leftmost column <= j
+            long g = 0, rm = 0;
+            long long sz = 0;
+            for (long k = 0; k < fn; k++) {
+                long t;
+                if (g >= fm) t = (k < fp) ? 0 : fm;                       // rows ran out
+                else { t = std::min(fm, std::max(g + 1, stair[(size_t)k])); g++; }
+                if (k < fp) { if (t > 0) rm++; sz += (t > 0) ? t : rm; }
+                else { const long h = std::min(rm + (k - fp) + 1, fm); sz += rm + std::max(t - h, 0L); }
+            }
+            P.rh_est_total += sz;
+        }
+    }
 
     // ---- level schedule: one group holding every front (multi-GPU callers regroup with set_groups) ----
     P.group.assign(nf, 0);
@@ -875,6 +1122,7 @@ int build_plan(stmmqr_plan &P, const stmmqr_symbolic_view &v)
     LCHK(P.d_lists.upload(P.lists, st));
     LCHK(P.d_wlists.upload(P.wlists, st));
     HIPCHK(hipStreamSynchronize(st));
+    LCHK(upload_recycle(P));
     return 0;
 }
 
@@ -910,7 +1158,9 @@ int reset_factorization(stmmqr_plan &P)
 {
     hipStream_t st = P.stream;
     LCHK(ensure_arenas(P));
-    HIPCHK(hipMemsetAsync(P.d_F.p, 0, (size_t)P.farena * sizeof(double), st));
+    // (with slab recycling every front's slab is zeroed when the front starts: k_zero_slabs in prep)
+    if (!P.recycle) HIPCHK(hipMemsetAsync(P.d_F.p, 0, (size_t)P.farena * sizeof(double), st));
+    HIPCHK(hipMemsetAsync(P.d_rhtop.p, 0, 2 * sizeof(long long), st));
     HIPCHK(hipMemsetAsync(P.d_Rdead.p, 0, (size_t)std::max(1L, P.n), st));
     HIPCHK(hipMemsetAsync(P.d_fnum.p, 0, (size_t)std::max(1L, P.nf) * sizeof(FrontNum), st));
     // (tickets are back at zero after every launch unless a wait ran out; the flags carry step numbers)
@@ -996,6 +1246,7 @@ int run_schedule(stmmqr_plan &P, bool detail, int grp, const StepReq *req = null
         const int *starting = L0 + S.start_off;
         if (S.n_start > 0) {
             int e = timed(t_asm, [&]() -> int {
+                if (P.recycle) { LCHK(stm_launch_zero_slabs(c, starting, S.n_start, S.asm_maxparts, q)); nlaunch++; }
                 LCHK(stm_launch_setup(c, starting, S.n_start, q));
                 LCHK(stm_launch_assemble(c, starting, L0 + S.asm_parts_off, S.n_start, S.asm_maxparts, q));
                 return 0;
@@ -1090,10 +1341,16 @@ int run_schedule(stmmqr_plan &P, bool detail, int grp, const StepReq *req = null
         });
     };
     auto post = [&](const Step &S, hipStream_t q) -> int {
-        if (S.n_cpk <= 0) return 0;
-        nlaunch++;
+        if (S.n_cpk <= 0 && !(P.recycle && S.n_rhp > 0)) return 0;
         return timed(t_cpk, [&]() -> int {
-            LCHK(stm_launch_cpack(c, L0 + S.cpk_off, L0 + S.cpk_parts_off, S.n_cpk, S.cpk_maxparts, q));
+            if (S.n_cpk > 0) { LCHK(stm_launch_cpack(c, L0 + S.cpk_off, L0 + S.cpk_parts_off, S.n_cpk, S.cpk_maxparts, q)); nlaunch++; }
+            if (P.recycle && S.n_rhp > 0) {
+                // slab recycling: the packed R+H blocks of the fronts that are finished now go to the arena (sizes and places on the
+                // device: k_rh_count bumps the arena's pointer); their slabs are free from the next step on
+                LCHK(stm_launch_rh_count(c, L0 + S.rhp_off, S.n_rhp, q));
+                LCHK(stm_launch_rh_copy(c, L0 + S.rhp_off, L0 + S.rhp_parts_off, S.n_rhp, S.rhp_maxparts, P.d_RH.p, q));
+                nlaunch += 2;
+            }
             return 0;
         });
     };
@@ -1252,8 +1509,36 @@ int run_pack(stmmqr_plan &P)
     hipStream_t st = P.stream;
     const DevCtx c = P.ctx();
     const int *L0 = P.d_lists.p;
+    if (P.recycle) {
+        // the blocks were staged front by front (run_schedule: post); what is left are the kept fronts' column offsets, the
+        // reference's layout of all blocks (Post order: d_fin, used by the download) and the check that the arena held everything
+        std::vector<int> kl;
+        for (long f = 0; f < P.nf; f++) if (P.kept[(size_t)f]) kl.push_back((int)f);
+        if (!kl.empty()) {
+            DevBuf<int> d_kl;
+            LCHK(d_kl.upload(kl, st));
+            DevCtx ck = c;
+            ck.rh_top = nullptr;                                  // (no place in the arena: packed on the fly by the download)
+            LCHK(stm_launch_rh_count(ck, d_kl.p, (int)kl.size(), st));
+            HIPCHK(hipStreamSynchronize(st));
+        }
+        LCHK(stm_launch_rh_scan(c, L0 + P.post_off, (int)P.nf, P.d_total.p, P.d_fin.p, st));
+        long long total = 0, top[2] = {0, 0};
+        HIPCHK(hipMemcpyAsync(&total, P.d_total.p, sizeof(long long), hipMemcpyDeviceToHost, st));
+        HIPCHK(hipMemcpyAsync(top, P.d_rhtop.p, 2 * sizeof(long long), hipMemcpyDeviceToHost, st));
+        HIPCHK(hipStreamSynchronize(st));
+        P.rh_total = total;
+        P.stats.nlaunch += 2;
+        if (top[1] != 0) {
+            if (!P.rh_grow) P.rh_grow = 1;                            // next: the hard bound (QRsym->maxstack / all recycled slabs)
+            else P.overflowed = true;                                 // that too: no recycling for this plan
+            P.arena_overflow = true;
+            return fail(STMMQR_ERR_OUT_OF_MEMORY, "the packed factors exceed the R+H arena of the slab recycling");
+        }
+        return 0;
+    }
     LCHK(stm_launch_rh_count(c, L0 + P.own_off, P.n_own, st));
-    LCHK(stm_launch_rh_scan(c, L0 + P.post_off, (int)P.nf, P.d_total.p, st));
+    LCHK(stm_launch_rh_scan(c, L0 + P.post_off, (int)P.nf, P.d_total.p, P.d_Rboff.p, st));
     long long total = 0;
     HIPCHK(hipMemcpyAsync(&total, P.d_total.p, sizeof(long long), hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
@@ -1582,6 +1867,14 @@ int stmmqr_factorize_finish(stmmqr_plan *plan, stmmqr_stats *stats)
     P.stats.bytes_assemble = bytes_asm;
     P.stats.bytes_pack = bytes_pack;
     P.stats.device_bytes = P.device_bytes();
+    if (getenv("STMMQR_MEMDUMP")) {
+        auto gb = [](const auto &b) { return (double)b.n * sizeof(*b.p) * 1e-9; };
+        fprintf(stderr, "[stmmqr_hip] device memory (GB): fronts %.3f  contribution blocks %.3f  R+H %.3f  update workspaces %.3f + %.3f  "
+                        "kept T %.3f  pair -Y %.3f  Sx/Ax/smap %.3f  per-column arrays %.3f  total %.3f  (recycle %d, kept fronts %d, maxstack %.3f)\n",
+                gb(P.d_F), gb(P.d_C), gb(P.d_RH), gb(P.d_Wp), gb(P.d_Wp2), gb(P.d_Tall), gb(P.d_Ypend), gb(P.d_Sx) + gb(P.d_Ax) + gb(P.d_smap),
+                gb(P.d_Stair) + gb(P.d_Tau) + gb(P.d_Hii) + gb(P.d_Cmap) + gb(P.d_Cursor) + gb(P.d_Rhoff) + gb(P.d_Rjrel) + gb(P.d_Sjrel),
+                P.stats.device_bytes * 1e-9, (int)P.recycle, (int)std::count(P.kept.begin(), P.kept.end(), (char)1), 8e-9 * (double)P.maxstack);
+    }
     P.factored = true;
     P.begun = false;
     if (stats) *stats = P.stats;
@@ -1597,15 +1890,32 @@ int stmmqr_factorize_device(stmmqr_plan *plan, const stm_long *Ap, const stm_lon
     // (the workgroups of a launch are not guaranteed to run together: a GPU shared with another job), the factorization is
     // not lost: it is run once more with every panel factorized by ONE workgroup (dev_panel: no inter-workgroup wait
     // anywhere), slower but independent of co-residency.
+    int arena_retries = 0;
     for (int attempt = 0; attempt < 2; attempt++) {
         plan->serial_panels = (attempt == 1);
         plan->panel_wait_failed = false;
         plan->whole_call = true;
         int e = stmmqr_factorize_begin(plan, Ap, Ai, Ax, ax_on_device, tol, ntol);
-        if (!e && attempt == 1) plan->stats.retries = 1;            // (visible in stmmqr_stats: bench.py asserts 0)
+        if (!e) plan->stats.retries = (attempt == 1 ? 1 : 0) + arena_retries;   // (visible in stmmqr_stats: bench.py asserts 0)
         for (int g = 0; g < (int)plan->glevels.size() && !e; g++) e = stmmqr_factorize_group(plan, g, detail);
         if (!e) e = stmmqr_factorize_finish(plan, stats);
         plan->whole_call = false;
+        if (e && plan->arena_overflow && plan->recycle) {
+            // the packed factors did not fit the arena: sized from the full-rank estimate -> once more with the hard bound
+            // (QRsym->maxstack); at the hard bound (never seen) -> once more with every front in a slab of its own and the packed
+            // blocks placed at the end, as sharded plans always run
+            plan->arena_overflow = false;
+            if (g_opt.verbose) fprintf(stderr, "[stmmqr_hip] R+H arena overflow: factorizing again %s\n", plan->overflowed ? "without slab recycling" : "with the arena at its hard bound");
+            plan->begun = false;
+            std::vector<int> grp(plan->group.begin(), plan->group.end());
+            for (size_t f = 0; f < grp.size(); f++) if ((size_t)f < plan->shared.size() && plan->shared[f]) grp[f] |= STMMQR_GROUP_SHARED;
+            int e2 = stmmqr_plan_set_groups(plan, grp.data());        // (rh_grow / overflowed: build_schedule sizes the arena anew)
+            if (e2) return e2;
+            arena_retries++;
+            attempt = -1;                                             // (both attempts again)
+            Ap = nullptr; Ai = nullptr;
+            continue;
+        }
         const bool retry = e && plan->panel_wait_failed && attempt == 0;
         plan->serial_panels = false;
         if (!retry) return e;
@@ -1657,10 +1967,11 @@ int stmmqr_plan_set_groups(stmmqr_plan *plan, const int *group)
     if (P.graph_exec) { (void)hipGraphExecDestroy(P.graph_exec); P.graph_exec = nullptr; }
     P.graph_nlaunch = 0;
     assign_arenas(P);                                        // (the arenas follow at the next stmmqr_factorize_begin)
-    LCHK(P.d_fs.upload(P.fs, P.stream));
     P.factored = false;                                      // (the factors of the old grouping live at the old offsets)
     std::vector<int> tslot;
-    build_schedule(P, tslot);
+    build_schedule(P, tslot);                                // (a plan that holds the whole tree again recycles its slabs: new offsets)
+    LCHK(P.d_fs.upload(P.fs, P.stream));
+    LCHK(upload_recycle(P));
     // workspaces only grow (a regrouping of the same tree usually needs what it needed before)
     auto grow = [](auto &buf, size_t n) -> int { return buf.n >= n && buf.p ? 0 : buf.alloc(n); };
     LCHK(grow(P.d_T, (size_t)2 * P.tslots * STM_NB * STM_NB));
@@ -1690,6 +2001,9 @@ int stmmqr_plan_set_groups(stmmqr_plan *plan, const int *group)
 static int check_c_slot(const stmmqr_plan &P, stm_long f, long long csize, const char *what)
 {
     if (f < 0 || f >= P.nf) return fail(STMMQR_ERR_INVALID, std::string(what) + ": no such front");
+    if (P.recycle)
+        return fail(STMMQR_ERR_INVALID, std::string(what) + ": this plan holds the whole tree and recycles its contribution blocks "
+                                        "(nothing to exchange; regroup with stmmqr_plan_set_groups first)");
     if ((size_t)f >= P.has_c.size() || !P.has_c[(size_t)f])
         return fail(STMMQR_ERR_INVALID, std::string(what) + ": the front has no contribution-block slot on this plan (it is neither "
                                         "factorized here nor a child of a front that is)");
@@ -1945,8 +2259,10 @@ int stmmqr_plan_result_sizes(const stmmqr_plan *plan, stm_long *rh_total, stm_lo
 namespace {
 // host half of qr_hpinv for the device: Wmap[S-row id] = position in the permuted row order (same rule as in
 // stmmqr_plan_download); uploaded once per factorization together with the static maps
+int ensure_scratch(stmmqr_plan &P);
 int ensure_rowmap(stmmqr_plan &P)
 {
+    LCHK(ensure_scratch(P));
     if (P.rowmap_ready) return 0;
     hipStream_t st = P.stream;
     const long nf = P.nf, m = P.m, n = P.n;
@@ -2055,16 +2371,47 @@ int check_device_err(stmmqr_plan &P, const char *what)
     return 0;
 }
 
+// Slab recycling: the resident-factor kernels read fronts in front form.  A front whose slab was recycled is put back into
+// that form, level by level, in a scratch that holds the widest tree level (res_ctx: the FrontSym array whose offsets point into
+// the scratch; level_to_front_form: zeros + the inverse of k_rh_copy for the level's fronts).  Kept fronts are read where they are
+// (their offset is taken relative to the scratch's base: one flat device address space).
+int ensure_scratch(stmmqr_plan &P)
+{
+    if (!P.recycle || (P.d_scr.p && P.d_fs_scr.p)) return 0;
+    LCHK(P.d_scr.alloc((size_t)std::max(1LL, P.scr_doubles)));
+    std::vector<FrontSym> t = P.fs_scr;
+    for (long f = 0; f < P.nf; f++)
+        if (P.kept[(size_t)f]) t[(size_t)f].foff = (long long)((P.d_F.p + P.fs[f].foff) - P.d_scr.p);
+    LCHK(P.d_fs_scr.upload(t, P.stream));
+    HIPCHK(hipStreamSynchronize(P.stream));
+    return 0;
+}
+DevCtx res_ctx(stmmqr_plan &P)
+{
+    DevCtx c = P.ctx();
+    if (P.recycle) { c.fs = P.d_fs_scr.p; c.Farena = P.d_scr.p; }
+    return c;
+}
+int level_to_front_form(stmmqr_plan &P, size_t l)
+{
+    if (!P.recycle) return 0;
+    const auto &LV = P.glevels[0];
+    if (LV[l].n_all <= 0) return 0;
+    const DevCtx c = P.ctx();
+    return stm_launch_rh_unpack(c, P.d_fs_scr.p, P.d_lists.p + LV[l].all_off, LV[l].n_all, 64, P.d_kept.p, P.d_RH.p, P.d_scr.p, P.stream);
+}
+
 // W (device, S-row order) <- Q' W or Q W
 int run_qapply(stmmqr_plan &P, int method)
 {
-    DevCtx c = P.ctx();
+    DevCtx c = res_ctx(P);
     const int *L0 = P.d_lists.p;
     const auto &LV = P.glevels[0];
     // blocked form with the kept T factors; STMMQR_DBG bit 13 selects the reflector-by-reflector kernel (same result up
     // to rounding: used by the tests to cross-check the two)
     const bool blocked = c.Tall && !(c.dbg & 8192);
     auto launch = [&](size_t l, int m) -> int {
+        LCHK(level_to_front_form(P, l));
         if (blocked) {
             LCHK(stm_launch_qapply_t(c, L0 + LV[l].all_off, LV[l].n_all, m, P.d_W.p, P.level_lds_qa[l], P.stream));
             // the large fronts of the level (independent of the others): rows split over workgroups, a launch per panel
@@ -2122,11 +2469,12 @@ int qapply_vector(stmmqr_plan &P, int method, const double *in, double *out)
 // back substitution R x = y on the device work vector W (internal row order) -> d_Xs (R's column order)
 int rsolve_vector(stmmqr_plan &P)
 {
-    DevCtx c = P.ctx();
+    DevCtx c = res_ctx(P);
     const int *L0 = P.d_lists.p;
     const auto &LV = P.glevels[0];
     hipStream_t st = P.stream;
     for (size_t l = LV.size(); l-- > 0;) {
+        LCHK(level_to_front_form(P, l));
         LCHK(stm_launch_rsolve(c, L0 + LV[l].all_off, LV[l].n_all, P.d_Rj.p, P.d_W.p, P.d_Xs.p, P.level_lds_rs[l], P.d_err.p, st));
         const auto &Q = P.level_qbig[l];         // the large fronts of the level: rows split over workgroups
         LCHK(stm_launch_rsolve_big(c, P.d_qb.p + Q.off, Q.n, Q.max_rsteps, Q.max_nslab, P.d_Rj.p, P.d_W.p, P.d_Xs.p, P.d_Xf.p,
@@ -2197,7 +2545,7 @@ int stmmqr_plan_rsolve(stmmqr_plan *plan, int system, const double *B, stm_long 
             LCHK(stm_launch_perm(P.d_Xs.p, (system == 1 && P.has_qfill) ? P.d_Qfill.p : nullptr, P.d_Yall.p + j * n, (int)n, 1, st));
         }
     } else {
-        DevCtx c = P.ctx();
+        DevCtx c = res_ctx(P);
         const int *L0 = P.d_lists.p;
         const auto &LV = P.glevels[0];
         if (!P.d_U.p) { LCHK(P.d_U.alloc((size_t)std::max(1L, P.rjsize))); LCHK(P.d_Xr.alloc((size_t)std::max(1L, m))); }
@@ -2207,9 +2555,11 @@ int stmmqr_plan_rsolve(stmmqr_plan *plan, int system, const double *B, stm_long 
             // b in R's column order: E'B gathers through Qfill
             LCHK(stm_launch_perm(P.d_Xall.p + j * n, (system == 3 && P.has_qfill) ? P.d_Qfill.p : nullptr, P.d_Xs.p, (int)n, 0, st));
             HIPCHK(hipMemsetAsync(P.d_Xr.p, 0, (size_t)std::max(1L, m) * sizeof(double), st));
-            for (size_t l = 0; l < LV.size(); l++)
+            for (size_t l = 0; l < LV.size(); l++) {
+                LCHK(level_to_front_form(P, l));
                 LCHK(stm_launch_rtsolve(c, L0 + LV[l].all_off, LV[l].n_all, P.d_Xs.p, P.d_U.p, P.d_Xr.p, P.d_rowbase.p,
                                         P.level_lds_rt[l], st));
+            }
             HIPCHK(hipMemcpyAsync(P.d_Yall.p + j * m, P.d_Xr.p, (size_t)m * sizeof(double), hipMemcpyDeviceToDevice, st));
         }
     }
@@ -2253,7 +2603,28 @@ int stmmqr_plan_download(stmmqr_plan *plan, double *Stack, stm_long *Rblock_off,
     hipStream_t st = P.stream;
     const long nf = P.nf, m = P.m, n = P.n;
     HIPCHK(hipEventRecord(P.ev[6], st));
-    if (Stack && P.rh_total > 0)
+    if (Stack && P.rh_total > 0 && P.recycle) {
+        // slab recycling: the blocks lie in the arena in the order the fronts finished (kept fronts: still in front form); the
+        // reference's layout is produced window by window in a bounce buffer (k_rh_window) and copied out, two windows in flight
+        const long long win = std::min<long long>(P.rh_total, 32LL << 20);            // 256 MB windows
+        if (P.d_bounce.n < (size_t)(2 * win)) LCHK(P.d_bounce.alloc((size_t)(2 * win)));
+        const DevCtx c = P.ctx();
+        const int parts = (int)std::min<long long>(64, std::max<long long>(1, win / (64 * 1024)));
+        hipEvent_t evw[2] = {nullptr, nullptr};
+        for (auto &e : evw) HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        int rc = 0;
+        for (long long w0 = 0, i = 0; w0 < P.rh_total && !rc; w0 += win, i++) {
+            const long long w1 = std::min(P.rh_total, w0 + win);
+            double *out = P.d_bounce.p + (i & 1) * win;
+            if (i >= 2 && hipEventSynchronize(evw[i & 1]) != hipSuccess) rc = 1;       // (the copy that last read this half is done)
+            if (!rc && stm_launch_rh_window(c, P.d_lists.p + P.own_off, P.n_own, parts, P.d_fin.p, P.d_kept.p, P.d_RH.p, w0, w1, out, st)) rc = 1;
+            if (!rc && hipMemcpyAsync(Stack + w0, out, (size_t)(w1 - w0) * sizeof(double), hipMemcpyDeviceToHost, st) != hipSuccess) rc = 1;
+            if (!rc && hipEventRecord(evw[i & 1], st) != hipSuccess) rc = 1;
+        }
+        if (hipStreamSynchronize(st) != hipSuccess) rc = 1;
+        for (auto &e : evw) (void)hipEventDestroy(e);
+        if (rc) return fail(STMMQR_ERR_DEVICE, "download of the packed factors failed");
+    } else if (Stack && P.rh_total > 0)
         HIPCHK(hipMemcpyAsync(Stack, P.d_RH.p, (size_t)P.rh_total * sizeof(double), hipMemcpyDeviceToHost, st));
     std::vector<int> stair32((size_t)std::max(1L, P.rjsize)), hii32((size_t)std::max(1L, P.hisize));
     std::vector<long long> rboff((size_t)std::max(1L, nf));
@@ -2265,7 +2636,7 @@ int stmmqr_plan_download(stmmqr_plan *plan, double *Stack, stm_long *Rblock_off,
         HIPCHK(hipMemcpyAsync(HTau, P.d_Tau.p, (size_t)P.rjsize * sizeof(double), hipMemcpyDeviceToHost, st));
     if (Rdead && n > 0) HIPCHK(hipMemcpyAsync(Rdead, P.d_Rdead.p, (size_t)n, hipMemcpyDeviceToHost, st));
     if (nf > 0)
-        HIPCHK(hipMemcpyAsync(rboff.data(), P.d_Rboff.p, (size_t)nf * sizeof(long long), hipMemcpyDeviceToHost, st));
+        HIPCHK(hipMemcpyAsync(rboff.data(), P.recycle ? P.d_fin.p : P.d_Rboff.p, (size_t)nf * sizeof(long long), hipMemcpyDeviceToHost, st));
     HIPCHK(hipEventRecord(P.ev[7], st));
     HIPCHK(hipStreamSynchronize(st));
     float ms = 0;
@@ -2562,7 +2933,7 @@ stm_qr_numeric *qr_factorize(stm_sparse_csc **Ahandle, stm_long freeA, double to
     v.hisize = S->hisize; v.do_rank_detection = S->do_rank_detection;
     v.Sp = S->Sp; v.Sj = S->Sj; v.Qfill = S->Qfill; v.PLinv = S->PLinv; v.Sleft = S->Sleft;
     v.Child = S->Child; v.Childp = S->Childp; v.Super = S->Super; v.Rp = S->Rp; v.Rj = S->Rj; v.Post = S->Post;
-    v.Hip = S->Hip; v.Fm = S->Fm;
+    v.Hip = S->Hip; v.Fm = S->Fm; v.maxstack = S->maxstack;
 
     int st = 0;
     // the plan: from the cache when an equal qr_symbolic was factorized before (same options), else built now

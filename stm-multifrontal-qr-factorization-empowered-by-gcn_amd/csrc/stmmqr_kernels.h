@@ -43,6 +43,9 @@ struct DevCtx {
     double *Ypend;             // pair update: -Y (64 x 32 per column block) of every pair-update front, by ABSOLUTE column block (column >> 5):
                                //  written by k_upd_y2, read by k_upd_c2 of the same step
     const long long *ypoff;    // [nf] offset (doubles) of a front's blocks in Ypend (-1: not a pair-update front)
+    long long *rh_top;         // slab recycling: {bump pointer of the R+H arena (doubles), overflow word}; nullptr = the packed blocks are
+                               //  placed by k_rh_scan at the end (Post order), every front keeps its slab until then
+    long long rh_cap;          // ... capacity of that arena (doubles)
     int tune;                  // env STMMQR_TUNE, measurement sweeps only (0 = the shipped rules): bits 0-3 force 2^(x-1) slabs per
                                //  workgroup of the pair update's kernels
     int dbg;                   // env STMMQR_DBG, ablations / cross-checks only: 1 no in-panel apply (LDS panel path),
@@ -76,7 +79,13 @@ int stm_launch_larft(const DevCtx &c, int f, hipStream_t st);
 int stm_launch_update_notrans(const DevCtx &c, int f, int ncb, hipStream_t st);   // qr_larftb seam, QR_QX
 int stm_launch_cpack(const DevCtx &c, const int *flist, const int *nparts, int nfr, int maxparts, hipStream_t st);
 int stm_launch_rh_count(const DevCtx &c, const int *flist, int nfr, hipStream_t st);
-int stm_launch_rh_scan(const DevCtx &c, const int *post, int nf, long long *rh_total, hipStream_t st);
+int stm_launch_rh_scan(const DevCtx &c, const int *post, int nf, long long *rh_total, long long *outoff, hipStream_t st);
+// slab recycling (stmmqr_host.cpp, timeline allocator)
+int stm_launch_zero_slabs(const DevCtx &c, const int *flist, int nfr, int maxparts, hipStream_t st);
+int stm_launch_rh_unpack(const DevCtx &c, const FrontSym *cs, const int *flist, int nfr, int maxparts, const char *kept, const double *RH,
+                         double *scratch, hipStream_t st);
+int stm_launch_rh_window(const DevCtx &c, const int *flist, int nfr, int maxparts, const long long *fin, const char *kept, const double *RH,
+                         long long w0, long long w1, double *out, hipStream_t st);
 int stm_launch_rh_copy(const DevCtx &c, const int *flist, const int *nparts, int nfr, int maxparts, double *RH,
                        hipStream_t st);
 // Q-apply / triangular solve on the resident factors

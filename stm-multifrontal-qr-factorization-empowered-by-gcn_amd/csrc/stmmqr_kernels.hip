@@ -3004,11 +3004,122 @@ __global__ __launch_bounds__(NT) void k_rh_count(DevCtx c, const int *__restrict
         if (k < n) off[k] = carry + incl - len;
         carry += tot;
     }
-    if (tid == 0) num->rsize = carry;
+    if (tid == 0) {
+        num->rsize = carry;
+        if (c.rh_top) {
+            // slab recycling (stmmqr_host.cpp, "timeline allocator"): the block gets its place in the R+H arena NOW, by a device-side
+            // bump pointer -- its size depends on the numerical rank, the host never learns it before the end.  The arena holds
+            // QRsym->maxstack doubles, the reference's own bound for all of R+H (SparseQR_analyze.c:1061-1161); should a block
+            // not fit all the same, the overflow word is raised and nothing is copied (the host repeats without recycling).
+            const long long at = (long long)atomicAdd((unsigned long long *)c.rh_top, (unsigned long long)carry);
+            if (at + carry > c.rh_cap) { c.Rboff[f] = -1; atomicExch((int *)(c.rh_top + 1), 1); }
+            else c.Rboff[f] = at;
+        }
+    }
+}
+// Slab recycling: the fronts that start at a step get their (reused) slabs zeroed before the assembly scatters into them
+// (k_assemble writes every entry of S and of the children's contribution blocks exactly once and relies on zeros elsewhere;
+// without recycling ONE memset of the whole arena does this).  grid (parts, fronts); 16-byte stores.
+__global__ __launch_bounds__(256) void k_zero_slabs(DevCtx c, const int *__restrict__ flist)
+{
+    const int f = flist[blockIdx.y];
+    const FrontSym s = c.fs[f];
+    const long long n2 = ((long long)s.ld * s.fn) >> 1;             // ld is even: whole double2's
+    double2 *F2 = reinterpret_cast<double2 *>(c.Farena + s.foff);
+    const double2 z = {0.0, 0.0};
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n2; i += (long long)gridDim.x * 256) F2[i] = z;
+}
+
+// Slab recycling, resident-factor operations (Q-apply, solves): a front whose slab was given to another front after its packed
+// R+H block had been staged is put back into front form in a scratch slab (zeros + the inverse of k_rh_copy); the kernels of
+// SURVEY 8 (f1) then read it exactly as they read a front that was never packed.  `cs`: the FrontSym array of the scratch layout
+// (foff = where this front lives in the scratch of its level).  grid (parts, fronts); phase 0 zero-fill, phase 1 scatter.
+__global__ __launch_bounds__(NT) void k_rh_unpack(DevCtx c, const FrontSym *__restrict__ cs, const int *__restrict__ flist,
+                                                  const char *__restrict__ kept, const double *__restrict__ RH, double *__restrict__ scratch,
+                                                  int phase)
+{
+    const int f = flist[blockIdx.y];
+    if (kept[f]) return;                                       // (still in front form in its own slab)
+    const FrontSym s = cs[f];
+    const FrontNum *num = &c.fnum[f];
+    const int fm = num->fm, n = s.fn, fp = s.fp, rm = num->rank;
+    double *F = scratch + s.foff;
+    const long long ld = s.ld;
+    if (phase == 0) {
+        const long long n2 = (ld * n) >> 1;
+        double2 *F2 = reinterpret_cast<double2 *>(F);
+        const double2 z = {0.0, 0.0};
+        for (long long i = (long long)blockIdx.x * NT + threadIdx.x; i < n2; i += (long long)gridDim.x * NT) F2[i] = z;
+        return;
+    }
+    if (fm <= 0 || n <= 0 || c.Rboff[f] < 0) return;
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const int *St = c.Stair + s.rp;
+    const long long *off = c.Rhoff + s.rp;
+    const double *R = RH + c.Rboff[f];
+    for (int k = blockIdx.x * NW + wid; k < n; k += gridDim.x * NW) {
+        double *Fk = F + k * ld;
+        const double *Rk = R + off[k];
+        if (k < fp) {
+            const int len = (int)(((k + 1 < n) ? off[k + 1] : num->rsize) - off[k]);
+            for (int i = lane; i < len; i += 64) Fk[i] = Rk[i];
+        } else {
+            const int h = min(rm + (k - fp) + 1, fm);
+            const int t = St[k];
+            for (int i = lane; i < rm; i += 64) Fk[i] = Rk[i];
+            for (int i = lane; i < t - h; i += 64) Fk[h + i] = Rk[rm + i];
+        }
+    }
+}
+
+// Slab recycling, download: the packed blocks sit in the arena in the order the fronts finished; the host wants the reference's
+// layout (Post order, Rblock offsets = exclusive sums of the block sizes: `fin`).  One launch copies the part of every block that
+// falls into the window [w0, w1) of that final layout into `out` (a bounce buffer the host then reads); fronts that kept their
+// slab (`kept`: never packed on the device) are packed on the fly, column by column, with the same clipping.
+__global__ __launch_bounds__(NT) void k_rh_window(DevCtx c, const int *__restrict__ flist, const long long *__restrict__ fin,
+                                                  const char *__restrict__ kept, const double *__restrict__ RH, long long w0, long long w1,
+                                                  double *__restrict__ out)
+{
+    const int f = flist[blockIdx.y];
+    const FrontSym s = c.fs[f];
+    const FrontNum *num = &c.fnum[f];
+    const long long b0 = fin[f], b1 = b0 + num->rsize;
+    if (b1 <= w0 || b0 >= w1 || num->rsize <= 0) return;
+    if (!kept[f]) {
+        if (c.Rboff[f] < 0) return;
+        const double *src = RH + c.Rboff[f];
+        const long long a = max(w0, b0), b = min(w1, b1);
+        for (long long i = a + (long long)blockIdx.x * NT + threadIdx.x; i < b; i += (long long)gridDim.x * NT) out[i - w0] = src[i - b0];
+        return;
+    }
+    const int fm = num->fm, n = s.fn, fp = s.fp, rm = num->rank;
+    if (fm <= 0 || n <= 0) return;
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const long long ld = s.ld;
+    const double *F = c.Farena + s.foff;
+    const int *St = c.Stair + s.rp;
+    const long long *off = c.Rhoff + s.rp;
+    auto copy = [&](long long dst0, const double *src, int len) {        // dst0: position in the final layout
+        if (dst0 + len <= w0 || dst0 >= w1) return;
+        const int i0 = (int)max(0LL, w0 - dst0), i1 = (int)min((long long)len, w1 - dst0);
+        for (int i = i0 + lane; i < i1; i += 64) out[dst0 + i - w0] = src[i];
+    };
+    for (int k = blockIdx.x * NW + wid; k < n; k += gridDim.x * NW) {
+        const double *Fk = F + k * ld;
+        const long long d = b0 + off[k];
+        if (k < fp) {
+            const int len = (int)(((k + 1 < n) ? off[k + 1] : num->rsize) - off[k]);
+            copy(d, Fk, len);
+        } else {
+            const int h = min(rm + (k - fp) + 1, fm);
+            copy(d, Fk, rm);
+            copy(d + rm, Fk + h, St[k] - h);
+        }
+    }
 }
 
 // single workgroup: Rboff[f] = offset of front f's block in Post order; total in *rh_total
-__global__ __launch_bounds__(NT) void k_rh_scan(DevCtx c, const int *__restrict__ post, int nf, long long *rh_total)
+__global__ __launch_bounds__(NT) void k_rh_scan(DevCtx c, const int *__restrict__ post, int nf, long long *rh_total, long long *outoff)
 {
     __shared__ long long s_part[NT];
     const int tid = threadIdx.x;
@@ -3027,7 +3138,7 @@ __global__ __launch_bounds__(NT) void k_rh_scan(DevCtx c, const int *__restrict_
     long long run = s_part[tid];
     for (int q = a; q < b; q++) {
         const int f = post[q];
-        c.Rboff[f] = run;
+        outoff[f] = run;
         run += c.fnum[f].rsize;
     }
 }
@@ -3048,6 +3159,7 @@ __global__ __launch_bounds__(NT) void k_rh_copy(DevCtx c, const int *__restrict_
     const double *F = c.Farena + s.foff;
     const int *St = c.Stair + s.rp;
     const long long *off = c.Rhoff + s.rp;
+    if (c.Rboff[f] < 0) return;                              // (arena overflow: flagged by k_rh_count, the host repeats)
     double *R = RH + c.Rboff[f];
     // one wave per column; eight loads of a lane in flight before their stores (a plain copy loop waits for every load:
     // 0.85 TB/s on the default workload's 1.2 GB of factors)
@@ -3865,9 +3977,30 @@ int stm_launch_rh_count(const DevCtx &c, const int *flist, int nfr, hipStream_t 
     hipLaunchKernelGGL(k_rh_count, dim3(nfr), dim3(NT), 0, st, c, flist);
     return (int)hipGetLastError();
 }
-int stm_launch_rh_scan(const DevCtx &c, const int *post, int nf, long long *rh_total, hipStream_t st)
+int stm_launch_rh_scan(const DevCtx &c, const int *post, int nf, long long *rh_total, long long *outoff, hipStream_t st)
 {
-    hipLaunchKernelGGL(k_rh_scan, dim3(1), dim3(NT), 0, st, c, post, nf, rh_total);
+    hipLaunchKernelGGL(k_rh_scan, dim3(1), dim3(NT), 0, st, c, post, nf, rh_total, outoff);
+    return (int)hipGetLastError();
+}
+int stm_launch_zero_slabs(const DevCtx &c, const int *flist, int nfr, int maxparts, hipStream_t st)
+{
+    if (nfr <= 0) return 0;
+    hipLaunchKernelGGL(k_zero_slabs, dim3(maxparts, nfr), dim3(256), 0, st, c, flist);
+    return (int)hipGetLastError();
+}
+int stm_launch_rh_unpack(const DevCtx &c, const FrontSym *cs, const int *flist, int nfr, int maxparts, const char *kept, const double *RH,
+                         double *scratch, hipStream_t st)
+{
+    if (nfr <= 0) return 0;
+    hipLaunchKernelGGL(k_rh_unpack, dim3(maxparts, nfr), dim3(NT), 0, st, c, cs, flist, kept, RH, scratch, 0);
+    hipLaunchKernelGGL(k_rh_unpack, dim3(maxparts, nfr), dim3(NT), 0, st, c, cs, flist, kept, RH, scratch, 1);
+    return (int)hipGetLastError();
+}
+int stm_launch_rh_window(const DevCtx &c, const int *flist, int nfr, int maxparts, const long long *fin, const char *kept, const double *RH,
+                         long long w0, long long w1, double *out, hipStream_t st)
+{
+    if (nfr <= 0 || w1 <= w0) return 0;
+    hipLaunchKernelGGL(k_rh_window, dim3(maxparts, nfr), dim3(NT), 0, st, c, flist, fin, kept, RH, w0, w1, out);
     return (int)hipGetLastError();
 }
 int stm_launch_rh_copy(const DevCtx &c, const int *flist, const int *nparts, int nfr, int maxparts, double *RH,

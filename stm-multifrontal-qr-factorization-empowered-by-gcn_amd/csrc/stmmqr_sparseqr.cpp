@@ -318,7 +318,7 @@ static int numeric_impl(stmmqr_qr *QR, int device)
     V.m = S->m; V.n = S->n; V.anz = S->anz; V.nf = S->nf; V.maxfn = S->maxfn; V.rjsize = S->rjsize; V.hisize = S->hisize;
     V.do_rank_detection = S->do_rank_detection;
     V.Sp = S->Sp; V.Sj = S->Sj; V.Qfill = S->Qfill; V.PLinv = S->PLinv; V.Sleft = S->Sleft; V.Child = S->Child; V.Childp = S->Childp;
-    V.Super = S->Super; V.Rp = S->Rp; V.Rj = S->Rj; V.Post = S->Post; V.Hip = S->Hip; V.Fm = S->Fm;
+    V.Super = S->Super; V.Rp = S->Rp; V.Rj = S->Rj; V.Post = S->Post; V.Hip = S->Hip; V.Fm = S->Fm; V.maxstack = S->maxstack;
     int st = 0;
     QR->plan = stmmqr_plan_create(&V, device, &st);
     if (!QR->plan) return st ? st : STMMQR_ERR_DEVICE;

@@ -326,7 +326,12 @@ def test_rank_arenas_hold_only_its_fronts():
     S = Symbolic(g)
     sym = {**S.sc, **{k: v for k, v in S.arr.items() if v is not None}}
     tol, ntol = scalar(g, "in_tol"), int(scalar(g, "in_ntol"))
-    one = pkg.HipQR(sym)
+    import os
+    os.environ["STMMQR_RECYCLE"] = "0"        # (the yardstick: a whole-tree plan WITHOUT slab recycling, like the ranks' plans)
+    try:
+        one = pkg.HipQR(sym)
+    finally:
+        del os.environ["STMMQR_RECYCLE"]
     before = one.device_bytes()
     one.begin(g["in_Ax"], tol, ntol, g["in_Ap"], g["in_Ai"])
     whole = one.device_bytes()
