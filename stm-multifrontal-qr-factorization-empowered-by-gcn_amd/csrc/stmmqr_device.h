@@ -128,6 +128,14 @@ static inline __host__ __device__ int stm_upd_ncb(const FrontSym &s, int p)
 }
 static inline __host__ __device__ int stm_upd_nsl(const FrontSym &s) { return (s.fm_ub + STM_UPD_SLAB - 1) / STM_UPD_SLAB; }
 
+// Pair update: a workgroup of k_upd_w2 / k_upd_c2 takes 1, 2 or 4 slabs of the pair's rows (stm_pair_spw), so a column block has
+// at most this many partial sums: the stride of its slots in the workspace (host sizing = device indexing; nslf = slabs of the
+// front's row bound; `tune` -- env STMMQR_TUNE at plan time, measurement sweeps -- may force one slab per workgroup: full stride)
+static inline __host__ __device__ int stm_pair_slots(int nslf, int tune)
+{
+    if (tune & 15) return nslf;
+    return nslf < 16 ? nslf : (nslf + 3) / 4 > 16 ? (nslf + 3) / 4 : 16;
+}
 #define STM_PAIR_MIN_ROWS 16384  // fronts with at least this many (estimated) rows take the pair update (stmmqr_options::pair_update);
                                  // measured: 27 000 rows -12 %, 7818 rows +17 % (and no look-ahead for pair steps)
 

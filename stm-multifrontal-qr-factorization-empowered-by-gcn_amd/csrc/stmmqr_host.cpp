@@ -145,6 +145,7 @@ struct stmmqr_plan {
     int ca_min = STM_CA_MIN_ROWS;                      // (env STMMQR_CA_MIN at plan time: experiments)
     int plan_algo = 0;                                 // g_opt.panel_algo when the schedule was built
     int tall_min = STM_TALL_MIN;                       // g_opt.tall_min_rows when the schedule was built
+    int tune = 0;                                      // env STMMQR_TUNE when the schedule was built (measurement sweeps)
     std::vector<long> Sp, Sj, Qfill, PLinv, Sleft, Child, Childp, Super, Rp, Rj, Post, Hip, Fm;
     bool has_qfill = false;
     std::vector<FrontSym> fs;
@@ -263,7 +264,7 @@ struct stmmqr_plan {
         c.Rdead = d_Rdead.p; c.Cmap = d_Cmap.p; c.Cursor = d_Cursor.p; c.Rhoff = d_Rhoff.p; c.Rboff = d_Rboff.p;
         c.tol = last_tol; c.ntol = (int)last_ntol;
         c.dbg = getenv("STMMQR_DBG") ? atoi(getenv("STMMQR_DBG")) : 0;
-        c.tune = getenv("STMMQR_TUNE") ? atoi(getenv("STMMQR_TUNE")) : 0;
+        c.tune = tune;                                            // (env STMMQR_TUNE when the schedule was built)
         c.Ypend = d_Ypend.p; c.ypoff = d_ypoff.p;
         c.rh_top = recycle ? d_rhtop.p : nullptr; c.rh_cap = rh_cap;
         if (serial_panels) c.dbg = (c.dbg & ~(2048 | 4096)) | 256;   // the one-workgroup LDS / in-place panel for every panel
@@ -504,6 +505,7 @@ std::pair<long long, long long> timeline_offsets(stmmqr_plan &P, const std::vect
 void build_schedule(stmmqr_plan &P, std::vector<int> &tslot)
 {
     P.sched_gen++;
+    P.tune = getenv("STMMQR_TUNE") ? atoi(getenv("STMMQR_TUNE")) : 0;
     P.tall_min = g_opt.tall_min_rows;
     P.plan_algo = g_opt.panel_algo;
     P.ca_min = getenv("STMMQR_CA_MIN") ? atoi(getenv("STMMQR_CA_MIN")) : STM_CA_MIN_ROWS;
@@ -758,8 +760,13 @@ void build_schedule(stmmqr_plan &P, std::vector<int> &tslot)
                 const int p = pan_now[f];
                 const int ncb = stm_upd_ncb(s, p), nsl = stm_upd_nsl(s);
                 P.wlists.push_back(wp);
-                // (+1: Gram block; pair-update fronts: two blocks per partial)
-                wp += (long long)(ncb + 1) * nsl * (STM_NB * 32) * (is_pair(f) ? 2 : 1);
+                // (+1: Gram block.  Pair-update fronts: two blocks per partial, at most stm_pair_slots partials per column block in the
+                //  sweep of an odd panel -- a workgroup takes up to four slabs --, and the panel-by-panel updates of the next panels'
+                //  columns use the first 2 + 1 column blocks with the full slab count)
+                if (is_pair(f))
+                    wp += std::max((long long)(ncb + 1) * stm_pair_slots(nsl, P.tune) * (2 * STM_NB * 32), 3LL * nsl * (STM_NB * 32));
+                else
+                    wp += (long long)(ncb + 1) * nsl * (STM_NB * 32);
                 const int k = cls(f);
                 if (k == 0) {
                     S.n_norm++;

@@ -2123,7 +2123,11 @@ __global__ __launch_bounds__(NT) void k_upd_w(DevCtx c, const int *__restrict__ 
         }
         __syncthreads();
     }
-    double *W = Wp + wpoff[fi] + ((long long)(gram ? ncbf : cb) * nslf + sl) * (STM_NB * BN);
+    // (the Gram block's slot comes after the front's last column block; a pair-update front only ever brings column blocks 0 and 1
+    //  here -- everything beyond goes through k_upd_w2, whose slots are packed more tightly: stm_pair_slots -- so its Gram block
+    //  sits right behind those two)
+    const int gslot = (c.ypoff && c.ypoff[f] >= 0) ? min(ncbf, 2) : ncbf;
+    double *W = Wp + wpoff[fi] + ((long long)(gram ? gslot : cb) * nslf + sl) * (STM_NB * BN);
     __shared__ int s_ticket;
     const int nsl = (mp + SLAB - 1) / SLAB;
     if (!gram) {
@@ -2181,7 +2185,7 @@ __global__ __launch_bounds__(NT) void k_upd_w(DevCtx c, const int *__restrict__ 
     if (s_ticket != nsl - 1) return;
     double *s_G = Vs;                                          // [row * WS + col] (the chunk images are free now)
     __shared__ double s_tau[STM_NB];
-    const double *G0 = Wp + wpoff[fi] + ((long long)ncbf * nslf) * (STM_NB * BN);
+    const double *G0 = Wp + wpoff[fi] + ((long long)gslot * nslf) * (STM_NB * BN);
     if (tid < STM_NB) s_tau[tid] = (tid < nbp) ? c.Tau[s.rp + pd->pk1 + tid] : 0.0;
     for (int e = tid; e < STM_NB * BN; e += NT) {
         const double gsum = stm_ordered_sum<false>(G0 + e, STM_NB * BN, nsl);      // fixed order: deterministic
@@ -2364,7 +2368,8 @@ __global__ __launch_bounds__(NT, 2) void k_upd_f(DevCtx c, const int *__restrict
         }
     }
     const int nsl = (mp + SLAB - 1) / SLAB;
-    double *Wslot = Wp + wpoff[fi] + ((long long)(gram ? ncbf : cb) * nslf) * (STM_NB * BN);      // slot 0 of the column block
+    const int gslot = (c.ypoff && c.ypoff[f] >= 0) ? min(ncbf, 2) : ncbf;                         // (as in k_upd_w)
+    double *Wslot = Wp + wpoff[fi] + ((long long)(gram ? gslot : cb) * nslf) * (STM_NB * BN);     // slot 0 of the column block
     double *W = Wslot + (long long)sl * (STM_NB * BN);
 #pragma unroll
     for (int r = 0; r < 4; r++) st_agent(&W[(16 * mi + l4 + 4 * r) * BN + 16 * ni + l15], acc[r]);
@@ -2630,7 +2635,7 @@ __global__ __launch_bounds__(NT) void k_upd_w2(DevCtx c, const int *__restrict__
     }
     // slot of (column block, slab group): two blocks, W1 then W2; the Gram block is column block ncbp
     const int ngrp = (nsl + spw - 1) / spw;
-    double *W0 = Wp + wpoff[fi] + ((long long)(gram ? ncbp : cb) * nslf) * (2 * STM_NB * BN);
+    double *W0 = Wp + wpoff[fi] + ((long long)(gram ? ncbp : cb) * stm_pair_slots(nslf, c.tune)) * (2 * STM_NB * BN);
     double *W = W0 + (long long)(sl / spw) * (2 * STM_NB * BN);
     if (ngrp == 1) {
 #pragma unroll
@@ -2686,8 +2691,9 @@ __global__ __launch_bounds__(NT) void k_upd_y2(DevCtx c, const int *__restrict__
     if (cb >= ncbp || G.pc0 + cb * BN >= s.fn) return;
     double *s_W1 = dyn_lds, *s_W2 = s_W1 + STM_NB * WS, *s_T1 = s_W2 + STM_NB * WS, *s_T2 = s_T1 + STM_NB * WS,
            *s_G = s_T2 + STM_NB * WS, *s_Y1 = s_G + STM_NB * WS;
-    double *W0 = Wp + wpoff[fi] + ((long long)cb * nslf) * (2 * STM_NB * BN);
-    const double *Gr = Wp + wpoff[fi] + ((long long)ncbp * nslf) * (2 * STM_NB * BN) + STM_NB * BN;     // W2 part of the Gram block
+    const int nslp = stm_pair_slots(nslf, c.tune);
+    double *W0 = Wp + wpoff[fi] + ((long long)cb * nslp) * (2 * STM_NB * BN);
+    const double *Gr = Wp + wpoff[fi] + ((long long)ncbp * nslp) * (2 * STM_NB * BN) + STM_NB * BN;     // W2 part of the Gram block
     const double *T1 = c.Tws + (long long)(2 * c.tslot[f] + ((p - 1) & 1)) * STM_NB * STM_NB;
     const double *T2 = c.Tws + (long long)(2 * c.tslot[f] + (p & 1)) * STM_NB * STM_NB;
     const bool has2 = G.nb2 > 0;
