@@ -88,6 +88,11 @@ typedef struct stm_common_layout {
 } stm_common_layout;
 void stmmqr_set_common_layout(const stm_common_layout *layout);
 void stmmqr_get_common_layout(stm_common_layout *layout);
+/* SparseCore_malloc / SparseCore_free / cc->status through that layout (src/core/SparseCore_common.c:603-655): what a host-side
+ * companion of this library hands to code that releases it with the reference's allocator (libstmmqr_hip_api.so does) */
+void *stmmqr_cc_malloc(size_t n, size_t size, stm_sparse_common *cc);
+void stmmqr_cc_free(size_t n, size_t size, void *p, stm_sparse_common *cc);
+void stmmqr_cc_set_status(stm_sparse_common *cc, int code);
 
 /* ================================================================================================
  * 1. Drop-in seam (reference names; prototypes STMMQR/include/SparseQR.h:127-268)

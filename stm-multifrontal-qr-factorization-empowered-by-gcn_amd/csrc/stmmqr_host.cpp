@@ -2744,6 +2744,11 @@ static void *cc_malloc(size_t n, size_t size, stm_sparse_common *cc, bool zero =
 static void cc_free(size_t n, size_t size, void *p, stm_sparse_common *cc);
 void *stm_cc_malloc(size_t n, size_t size, stm_sparse_common *cc) { return cc_malloc(n, size, cc, false); }
 void stm_cc_free(size_t n, size_t size, void *p, stm_sparse_common *cc) { cc_free(n, size, p, cc); }
+// ... and exported for libstmmqr_hip_api.so (csrc/stmmqr_api.cpp): what it returns is released by the reference's own
+// SparseCore_free_dense / SparseCore_free and must be counted the same way
+void *stmmqr_cc_malloc(size_t n, size_t size, stm_sparse_common *cc) { return cc_malloc(n, size, cc, false); }
+void stmmqr_cc_free(size_t n, size_t size, void *p, stm_sparse_common *cc) { cc_free(n, size, p, cc); }
+void stmmqr_cc_set_status(stm_sparse_common *cc, int code) { stm_cc_set_status(cc, code); }
 
 // SparseCore_malloc semantics (src/core/SparseCore_common.c:603-655): malloc(max(1,n)*size) + counters
 static void *cc_malloc(size_t n, size_t size, stm_sparse_common *cc, bool zero)
