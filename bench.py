@@ -343,6 +343,40 @@ def spawn_ranks(args):
     return subprocess.call(cmd, env=env)
 
 
+def _failure_line(args, world, why):
+    """the contract's ONE JSON line also when the run did not finish: value null, the reason in `error` (never a hang, never silence)"""
+    return json.dumps({"metric": "numerical-factorization GFLOP/s", "value": None, "unit": "GFLOP/s", "n_gpus": world,
+                       "steps": args.steps, "warmup": args.warmup, "ms_per_step": None, "higher_is_better": True,
+                       "scaling": "strong" if (world > 1 and (args.mode or "sharded") == "sharded") else "weak", "vs_baseline": None,
+                       "dtype": "f64", "data": "synthetic", "config": {"workload": args.workload or args.matrix}, "error": why})
+
+
+def _install_guards(args, rank, world):
+    """N > 1: (i) a rank that is terminated by the launcher because ANOTHER rank failed (torch.distributed.run sends SIGTERM to the
+    survivors) still prints the line on rank 0; (ii) a watchdog ends a run that makes no progress (a lost message, a rank that
+    never arrived) after STMMQR_BENCH_DEADLINE seconds (default 1500) with the line and a non-zero exit instead of hanging the
+    node.  The multi-GPU path has never run on hardware (one-GPU build box): its first contact must fail loudly, not hang."""
+    import signal
+    import threading
+    state = {"done": False}
+
+    def bail(why, code):
+        if state["done"]:
+            return
+        state["done"] = True
+        if rank == 0:
+            print(_failure_line(args, world, why), flush=True)
+        os._exit(code)
+
+    if world > 1:
+        signal.signal(signal.SIGTERM, lambda sig, frm: bail("terminated by the launcher (another rank failed)", 143))
+        deadline = float(os.environ.get("STMMQR_BENCH_DEADLINE", "1500"))
+        t = threading.Timer(deadline, lambda: bail(f"no result after {deadline:.0f} s (deadline of bench.py: a rank or a message is missing)", 124))
+        t.daemon = True
+        t.start()
+    return state
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -378,6 +412,21 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    guard = _install_guards(args, rank, world)
+    try:
+        return _run(args, torch, rank, world, local, guard)
+    except BaseException as e:                       # (SystemExit of argparse etc. included: the line comes first)
+        if world > 1 and not guard["done"] and not isinstance(e, SystemExit):
+            guard["done"] = True
+            import traceback
+            traceback.print_exc()
+            if rank == 0:
+                print(_failure_line(args, world, f"rank 0: {type(e).__name__}: {e}"), flush=True)
+            os._exit(1)                              # (no destructors of a half-initialised process group: they can hang)
+        raise
+
+
+def _run(args, torch, rank, world, local, guard):
     # STMMQR_BENCH_REHEARSAL=1 (a one-GPU box): every rank on device 0, gloo, contribution blocks through the host -- the
     # whole multi-process protocol (spawn, rendezvous, partition, phases, exchange, timing) without RCCL / a second GPU
     rehearsal = world > 1 and os.environ.get("STMMQR_BENCH_REHEARSAL") == "1"
@@ -386,10 +435,14 @@ def main():
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        import datetime
+        to = datetime.timedelta(seconds=float(os.environ.get("STMMQR_BENCH_PG_TIMEOUT", "600")))
         if rehearsal:
-            dist.init_process_group(backend="gloo")
+            dist.init_process_group(backend="gloo", timeout=to)
         else:
-            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local))
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local), timeout=to)
+    if world > 1 and os.environ.get("STMMQR_BENCH_FAIL_RANK") == str(rank):        # (tests: one rank dies after the rendezvous)
+        raise RuntimeError("injected failure of this rank (STMMQR_BENCH_FAIL_RANK)")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if args.mode is None:
@@ -655,6 +708,7 @@ def main():
                     cb["flops_match_device"] = bool(int(round(fl_ref[0]["flops"])) == int(round(flops)))
             out["cpu_baseline"] = cb
         print(json.dumps(out))
+    guard["done"] = True                                # (the line is out: a late SIGTERM / deadline prints nothing more)
     if plan is not None:
         plan.close()
     if world > 1:
