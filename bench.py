@@ -500,7 +500,20 @@ def _run(args, torch, rank, world, local, guard):
     crit = None
     if sharded:
         sh = importlib.import_module(PKG + ".sharded")
-        comm = sh.Comm(dist, None if rehearsal else dev)
+        # the panel loop of shared fronts: native (C++ loop, RCCL point-to-point on a comm stream) unless STMMQR_NATIVE_LOOP=0 or RCCL
+        # cannot be set up -- then the step-by-step loop over torch.distributed, which moves the same bytes
+        native, native_note = None, "python loop over torch.distributed"
+        if not rehearsal and os.environ.get("STMMQR_NATIVE_LOOP", "1") != "0":
+            try:
+                native = pkg.RcclTransport(dist, dev)
+                native_note = "native loop (stmmqr_factorize_shared_front), RCCL ncclSend / ncclRecv on a comm stream"
+            except Exception as e:                      # noqa: BLE001 (every rank takes the same branch: the id broadcast is collective)
+                print(f"[bench] rank {rank}: RCCL transport not available ({e}); python loop", file=sys.stderr, flush=True)
+        ok = torch.tensor([1 if native is not None else 0], dtype=torch.int64, device=dev if not rehearsal else "cpu")
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        if int(ok.item()) == 0:
+            native, native_note = None, "python loop over torch.distributed"
+        comm = sh.Comm(dist, None if rehearsal else dev, native=native)
         owner0, phase0 = sh.partition(sym, world)
         crit_sub = sh.critical_path_flops(sym, owner0, phase0, world)
         if args.spread:
@@ -649,6 +662,9 @@ def _run(args, torch, rank, world, local, guard):
             out["config"]["strong_scaling_bound"] = crit[1] / max(crit[0], 1.0)
             out["config"]["strong_scaling_bound_subtrees_only"] = crit_sub[1] / max(crit_sub[0], 1.0)
             out["config"]["shared_fronts"] = 0 if span is None else int((np.asarray(span) > 1).sum())
+            out["config"]["shared_front_loop"] = native_note
+            out["config"]["hardware_scaling_note"] = ("no multi-GPU node was available to the build: this line is the FIRST hardware run of the "
+                                                      "RCCL path unless parallelism says REHEARSAL")
             # ... and if every heavy top front were shared regardless of the per-step latency threshold of spread_partition
             out["config"]["strong_scaling_bound_all_heavy_fronts_shared"] = crit_all[1] / max(crit_all[0], 1.0)
         if mtx_meta:

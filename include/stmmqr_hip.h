@@ -251,6 +251,33 @@ int stmmqr_plan_import_panel(stmmqr_plan *plan, stm_long f, stm_long p, const do
 int stmmqr_plan_export_front_cols(stmmqr_plan *plan, stm_long f, int part, int nparts, double *buf, int on_device,
                                   stm_long *ndoubles);
 int stmmqr_plan_import_front_cols(stmmqr_plan *plan, stm_long f, int part, int nparts, const double *buf, int on_device);
+/* The panel loop of a shared front, native (round 4): ONE call per rank and shared front does what the step-by-step interface
+ * above does from a host loop -- PREP, then for every panel the owner's block 0 / PANEL / export / send / rest of its update and
+ * the others' posted receive / update / import -- with everything enqueued on the plan's stream and a comm stream ordered by
+ * events: no stream synchronisation and no interpreter between two steps; the send of panel t overlaps the owner's update of step
+ * t - 1, a receiver posts the receive of panel t before its update of step t - 1.  This rank is tr->rank, the group is the ranks
+ * [first_rank, first_rank + nranks).  Returns when the device has finished the front.
+ * The transport is a table of callbacks on DEVICE buffers, enqueued on the stream they are given:
+ *   stmmqr_rccl_transport_create   RCCL point-to-point (ncclSend / ncclRecv in a group) -- the xGMI path of a multi-GPU node;
+ *                                  librccl is loaded at run time; the 128-byte id comes from stmmqr_rccl_unique_id on one rank
+ *                                  and reaches the others by any means (bench.py: a torch.distributed broadcast)
+ *   a caller's own table           tests play the ranks of a group on ONE GPU this way (tests/test_gpu_sharded.py) */
+typedef struct stmmqr_transport {
+    void *ctx;
+    int (*send)(void *ctx, const void *dev_buf, size_t bytes, int peer, void *hip_stream);
+    int (*recv)(void *ctx, void *dev_buf, size_t bytes, int peer, void *hip_stream);
+    int (*group_begin)(void *ctx);          /* may be NULL */
+    int (*group_end)(void *ctx);            /* may be NULL */
+    int rank, size;
+} stmmqr_transport;
+int stmmqr_factorize_shared_front(stmmqr_plan *plan, int group, stm_long f, int first_rank, int nranks, const stmmqr_transport *tr);
+int stmmqr_device_copy(void *dst, const void *src, size_t bytes, void *hip_stream);   /* D2D, complete on return, after the stream's work */
+int stmmqr_rccl_unique_id(char id[128]);
+int stmmqr_rccl_transport_create(int world, int rank, const char id[128], stmmqr_transport **out);
+void stmmqr_rccl_transport_destroy(stmmqr_transport *tr);
+int stmmqr_transport_sendrecv(const stmmqr_transport *tr, const void *sendbuf, size_t sendbytes, int dst, void *recvbuf, size_t recvbytes,
+                              int src, void *hip_stream);
+
 /* off[0..fn]: start of each column of front f inside its packed R+H block (after stmmqr_factorize_finish) */
 int stmmqr_plan_front_rhoff(stmmqr_plan *plan, stm_long f, stm_long *off);
 

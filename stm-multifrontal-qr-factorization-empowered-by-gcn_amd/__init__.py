@@ -8,4 +8,4 @@ code and no CPU fallback: importing :mod:`capi` raises if the HIP library has no
 from .capi import (HipQR, Relax, SparseQR, analyze, relax_for_qr, QRNumeric, StmmqrError, device_alloc, device_count, device_free, device_name, get_options,  # noqa: F401
                    last_seam_ms, lib,
                    lib_path, qr_assemble, qr_cpack, qr_factorize, qr_fcsize, qr_front, qr_fsize, qr_hpinv, qr_larftb, qr_rhpack,
-                   qr_stranspose2, read_matrix_market, set_options, qr_factorize_seam, plan_cache_clear, SeamNumeric)
+                   qr_stranspose2, read_matrix_market, set_options, qr_factorize_seam, plan_cache_clear, SeamNumeric, RcclTransport, CallbackTransport, device_copy)

@@ -146,6 +146,75 @@ lib.stmmqr_get_options.argtypes = [C.POINTER(Options)]
 lib.stmmqr_set_options.argtypes = [C.POINTER(Options)]
 
 
+class TransportC(C.Structure):
+    """stmmqr_transport (include/stmmqr_hip.h): callbacks on device buffers, enqueued on the HIP stream they are given"""
+    SEND = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p)
+    RECV = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p)
+    GRP = C.CFUNCTYPE(C.c_int, C.c_void_p)
+    _fields_ = [("ctx", C.c_void_p), ("send", SEND), ("recv", RECV), ("group_begin", GRP), ("group_end", GRP), ("rank", C.c_int),
+                ("size", C.c_int)]
+
+
+lib.stmmqr_factorize_shared_front.argtypes = [C.c_void_p, C.c_int, C.c_long, C.c_int, C.c_int, C.POINTER(TransportC)]
+lib.stmmqr_rccl_unique_id.argtypes = [C.c_char_p]
+lib.stmmqr_rccl_transport_create.argtypes = [C.c_int, C.c_int, C.c_char_p, C.POINTER(C.POINTER(TransportC))]
+lib.stmmqr_rccl_transport_destroy.restype = None
+lib.stmmqr_rccl_transport_destroy.argtypes = [C.POINTER(TransportC)]
+lib.stmmqr_transport_sendrecv.argtypes = [C.POINTER(TransportC), C.c_void_p, C.c_size_t, C.c_int, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p]
+lib.stmmqr_device_copy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
+
+
+class RcclTransport:
+    """RCCL point-to-point transport of the native shared-front loop (stmmqr_rccl_transport_create).  `dist`: an initialised
+    torch.distributed (any backend) that carries the 128-byte id from rank 0 to the others; the communicator itself is this
+    library's own (ncclCommInitRank on the copy of librccl the process already holds)."""
+
+    def __init__(self, dist, device=None):
+        import torch
+        rank, world = dist.get_rank(), dist.get_world_size()
+        ident = C.create_string_buffer(128)
+        if rank == 0:
+            _check(lib.stmmqr_rccl_unique_id(ident), "stmmqr_rccl_unique_id")
+        t = torch.frombuffer(bytearray(ident.raw), dtype=torch.uint8).clone()
+        if device is not None and dist.get_backend() == "nccl":
+            t = t.to(device)
+        dist.broadcast(t, 0)
+        raw = bytes(t.cpu().numpy().tobytes())
+        self._p = C.POINTER(TransportC)()
+        _check(lib.stmmqr_rccl_transport_create(world, rank, raw, C.byref(self._p)), "stmmqr_rccl_transport_create")
+        self.rank, self.size = rank, world
+
+    @property
+    def ptr(self):
+        return self._p
+
+    def sendrecv(self, send_ptr, send_bytes, dst, recv_ptr, recv_bytes, src, stream=None):
+        _check(lib.stmmqr_transport_sendrecv(self._p, send_ptr, send_bytes, dst, recv_ptr, recv_bytes, src, stream), "stmmqr_transport_sendrecv")
+
+    def close(self):
+        if self._p:
+            lib.stmmqr_rccl_transport_destroy(self._p)
+            self._p = C.POINTER(TransportC)()
+
+
+class CallbackTransport:
+    """A stmmqr_transport whose send / receive are Python callables (tests: the ranks of a group as threads on one GPU)"""
+
+    def __init__(self, rank, size, send, recv):
+        self._send = TransportC.SEND(lambda ctx, buf, nbytes, peer, stream: int(send(buf, nbytes, peer, stream) or 0))
+        self._recv = TransportC.RECV(lambda ctx, buf, nbytes, peer, stream: int(recv(buf, nbytes, peer, stream) or 0))
+        self._t = TransportC(None, self._send, self._recv, TransportC.GRP(), TransportC.GRP(), rank, size)
+        self.rank, self.size = rank, size
+
+    @property
+    def ptr(self):
+        return C.pointer(self._t)
+
+
+def device_copy(dst: int, src: int, nbytes: int, stream=None):
+    _check(lib.stmmqr_device_copy(C.c_void_p(dst), C.c_void_p(src), nbytes, stream), "stmmqr_device_copy")
+
+
 def last_error() -> str:
     return lib.stmmqr_last_error().decode()
 
@@ -332,6 +401,12 @@ class HipQR:
     def run_step(self, g, step, what, cb_first=0, cb_stride=1, cb_count=-1):
         _check(lib.stmmqr_factorize_step(self._h, int(g), int(step), int(what), int(cb_first), int(cb_stride), int(cb_count)),
                "stmmqr_factorize_step")
+
+    def shared_front_native(self, group, f, first_rank, nranks, transport):
+        """the whole panel loop of a shared front in ONE native call (stmmqr_factorize_shared_front); transport: RcclTransport or
+        CallbackTransport"""
+        _check(lib.stmmqr_factorize_shared_front(self._h, int(group), int(f), int(first_rank), int(nranks), transport.ptr),
+               "stmmqr_factorize_shared_front")
 
     def panel_doubles(self, f) -> int:
         n = np.zeros(1, I64)

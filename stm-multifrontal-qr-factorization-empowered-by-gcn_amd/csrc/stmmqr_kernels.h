@@ -99,4 +99,5 @@ int stm_launch_rsolve(const DevCtx &c, const int *flist, int nfr, const int *Rj,
                       int *err, hipStream_t st);
 int stm_launch_rtsolve(const DevCtx &c, const int *flist, int nfr, const double *Bp, double *U, double *Xr, const int *rowbase,
                        int lds_bytes, hipStream_t st);
+int stm_launch_panel_msg(void *const homes[6], const long long offs[6], const long long bytes[6], void *buf, int out, hipStream_t st);
 int stm_launch_perm(const double *in, const int *perm, double *out, int n, int scatter, hipStream_t st);

@@ -4064,6 +4064,30 @@ int stm_launch_rtsolve(const DevCtx &c, const int *flist, int nfr, const double 
     hipLaunchKernelGGL(k_rtsolve, dim3(nfr), dim3(RS_NT), (size_t)lds_bytes, st, c, flist, Bp, U, Xr, rowbase);
     return (int)hipGetLastError();
 }
+// One panel message of a shared front (stmmqr_host.cpp: panel_msg) packed / unpacked on the device in ONE launch: six byte ranges
+// (the panel's columns, T, the front's Tau / Stair / Rdead ranges, its FrontNum) between their homes and a contiguous buffer.
+// Six hipMemcpyAsync cost 6 x 5-8 us of device time per panel step; this is one kernel bound by the 2-13 MB of the columns.
+struct MsgSeg { char *home; long long off, bytes; };
+struct MsgSegs { MsgSeg s[6]; };
+__global__ __launch_bounds__(256) void k_panel_msg(MsgSegs g, char *__restrict__ buf, int out)
+{
+    const MsgSeg sg = g.s[blockIdx.y];
+    char *a = out ? buf + sg.off : sg.home;                   // destination
+    const char *b = out ? sg.home : buf + sg.off;             // source
+    const long long n16 = ((((uintptr_t)a | (uintptr_t)b) & 15) == 0) ? sg.bytes >> 4 : 0;
+    const long long t0 = (long long)blockIdx.x * 256 + threadIdx.x, nt = (long long)gridDim.x * 256;
+    for (long long i = t0; i < n16; i += nt) reinterpret_cast<float4 *>(a)[i] = reinterpret_cast<const float4 *>(b)[i];
+    for (long long i = (n16 << 4) + t0; i < sg.bytes; i += nt) a[i] = b[i];
+}
+int stm_launch_panel_msg(void *const homes[6], const long long offs[6], const long long bytes[6], void *buf, int out, hipStream_t st)
+{
+    MsgSegs g;
+    long long mx = 0;
+    for (int q = 0; q < 6; q++) { g.s[q].home = (char *)homes[q]; g.s[q].off = offs[q]; g.s[q].bytes = bytes[q]; mx = bytes[q] > mx ? bytes[q] : mx; }
+    const int gx = (int)((mx / 16 + 255) / 256 < 1 ? 1 : ((mx / 16 + 255) / 256 > 1024 ? 1024 : (mx / 16 + 255) / 256));
+    hipLaunchKernelGGL(k_panel_msg, dim3(gx, 6), dim3(256), 0, st, g, (char *)buf, out);
+    return (int)hipGetLastError();
+}
 int stm_launch_perm(const double *in, const int *perm, double *out, int n, int scatter, hipStream_t st)
 {
     if (n <= 0) return 0;

@@ -163,12 +163,16 @@ def front_flop_split(sym: dict):
 
 
 def spread_partition(sym: dict, nranks: int, oversub: int = 4, min_share: float = 0.02, min_panels_per_rank: int = 4,
-                     min_cols: int = 256, min_flops: float = 0.0, min_step_flops: float = 2e10):
+                     min_cols: int = 256, min_flops: float = 0.0, min_step_flops: float = 6e9):
     """-> (owner[nf], phase[nf], span[nf]).  partition() plus shared fronts: a front of the top set of a group of R = 2^k
     ranks whose flop bound is at least `min_share` of the whole tree's and `min_flops`, and at least `min_step_flops` per
-    panel step (every step costs a message, a stream synchronisation and a handful of launches -- a few hundred
-    microseconds through torch.distributed -- while a 5000-column front updates in ~150 us per step on one GPU: sharing pays
-    from roughly 25 000 columns upwards, i.e. for configs[4]'s root front, not for the xenon1 / sme3Dc stand-ins), with at
+    panel step -- round 4, measured with the native loop (stmmqr_factorize_shared_front, tools/shared_step_cost.py on one MI355X):
+    a shared step costs its owner +38 us (5976-column front) to +60 us (7818 columns) over the unshared step (block 0 as a launch
+    pair of its own, the panel message packed and unpacked), plus the message itself on a real link (2-13 MB: ~50-250 us over one
+    xGMI link, hidden behind the update only on the ranks that do not wait for it); splitting the update R ways must save more
+    than that: at the 10-15 TFLOP/s these updates run at, 6e9 flops are ~400-600 us of update per step.  The round-3 value, 2e10,
+    was sized for the Python loop (hundreds of microseconds of host time per step).  The xenon1 / sme3Dc stand-ins' top fronts
+    carry ~1e9 flops per step -- 40 us of update: sharing them cannot pay, whatever the loop costs --, with at
     least `min_cols` columns and `min_panels_per_rank` panels per rank, is shared by the ranks [owner, owner + R) (span = R, else 1).  A shared front is
     alone in its phase: inside a group's top set the fronts are numbered in postorder and every shared front closes the
     stage before it, so children still never run later than their parents."""
@@ -247,9 +251,11 @@ def critical_path_flops(sym: dict, owner, phase, nranks, span=None):
 # communication (torch.distributed point-to-point, batched per phase; a None comm = single process)
 # --------------------------------------------------------------------------------------------------
 class Comm:
-    def __init__(self, dist=None, device=None):
+    def __init__(self, dist=None, device=None, native=None):
         self.dist = dist
         self.device = device            # torch device of this rank (None: host tensors, gloo)
+        self.native = native            # a stmmqr_transport (capi.RcclTransport): the panel loop of a shared front then runs as ONE
+                                        #  native call (stmmqr_factorize_shared_front) instead of the step-by-step loop below
         self.rank = dist.get_rank() if dist else 0
         self.size = dist.get_world_size() if dist else 1
 
@@ -363,10 +369,15 @@ def run_shared_front(plan, sp: ShardPlan, f, comm: Comm):
     g, r0, R = int(sp.phase[f]), int(sp.owner[f]), int(sp.span[f])
     i = comm.rank - r0
     nsteps = plan.group_steps(g)
-    ring = sp.panel_ring(plan, f, comm)
+    native = getattr(comm, "native", None) is not None and hasattr(plan, "shared_front_native")
+    if native:
+        # the same loop in C++ (csrc/stmmqr_host.cpp): panels, updates and messages enqueued without a host round trip per step
+        plan.shared_front_native(g, f, r0, R, comm.native)
+    ring = None if native else sp.panel_ring(plan, f, comm)
     dev = _use_dev(plan, comm, "export_panel_dev")
-    plan.run_step(g, 0, PREP)
-    for t in range(nsteps):
+    if not native:
+        plan.run_step(g, 0, PREP)
+    for t in range(0 if native else nsteps):
         o = t % R
         first = (i - t) % R                                   # my first column block of step t - 1
         buf = ring[o]
@@ -390,8 +401,9 @@ def run_shared_front(plan, sp: ShardPlan, f, comm: Comm):
                 plan.import_panel_dev(f, t, buf.data_ptr())
             else:
                 plan.import_panel(f, t, buf.cpu().numpy())
-    plan.run_step(g, nsteps - 1, UPDATE | GRAM, (i - nsteps) % R, R, -1)
-    plan.run_step(g, nsteps - 1, POST)
+    if not native:
+        plan.run_step(g, nsteps - 1, UPDATE | GRAM, (i - nsteps) % R, R, -1)
+        plan.run_step(g, nsteps - 1, POST)
     # the packed contribution block is complete in my columns only: the group's first rank collects the others' columns
     if sp.parent[f] >= 0 and R > 1:
         devc = _use_dev(plan, comm, "export_front_cols_dev")

@@ -164,6 +164,7 @@ class LocalComm:
 
     def __init__(self, rank, size, queues, device):
         self.rank, self.size, self.queues, self.device, self.dist = rank, size, queues, device, None
+        self.native = None
 
     def tensor(self, a):
         import torch
@@ -182,17 +183,39 @@ class LocalComm:
             t.copy_(self.queues[(src, self.rank)].get(timeout=180))
 
 
-def _run_ranks(pkg, sh, sym, g, tol, ntol, nranks, owner, phase, span, on_device):
+def _thread_transport(pkg, rank, size, boxes):
+    """a stmmqr_transport for ranks that are threads on ONE GPU (TEST INFRASTRUCTURE): send = wait for the stream, copy the buffer
+    to a staging buffer on the device, post it; receive = take it, copy it in (device to device), free the staging buffer"""
+    def send(buf, nbytes, peer, stream):
+        stage = pkg.device_alloc(max(nbytes, 8))
+        pkg.device_copy(stage, buf, nbytes, stream)
+        boxes[(rank, peer)].put((stage, nbytes))
+        return 0
+
+    def recv(buf, nbytes, peer, stream):
+        stage, n = boxes[(peer, rank)].get(timeout=180)
+        assert n == nbytes
+        pkg.device_copy(buf, stage, nbytes, stream)
+        pkg.device_free(stage)
+        return 0
+
+    return pkg.CallbackTransport(rank, size, send, recv)
+
+
+def _run_ranks(pkg, sh, sym, g, tol, ntol, nranks, owner, phase, span, on_device, native=False):
     import queue
     import threading
     import torch
     dev = torch.device("cuda:0") if on_device else None
     queues = {(a, b): queue.Queue() for a in range(nranks) for b in range(nranks)}
+    boxes = {(a, b): queue.Queue() for a in range(nranks) for b in range(nranks)}
     out, errs = [None] * nranks, []
 
     def work(r):
         try:
             comm = LocalComm(r, nranks, queues, dev)
+            if native:
+                comm.native = _thread_transport(pkg, r, nranks, boxes)
             plan = pkg.HipQR(sym)
             sp = sh.ShardPlan(plan, sym, owner, phase, comm, span)
             st, _, _ = sh.factorize_sharded(plan, sym, g["in_Ax"], tol, ntol, comm, Ap=g["in_Ap"], Ai=g["in_Ai"], shard_plan=sp)
@@ -243,6 +266,60 @@ def test_shared_fronts_equal_unsharded(name, nranks, small, on_device):
     for k in ("Hm", "Hr", "HStair", "HPinv", "Rdead", "Rblock_off", "Hii", "HTau"):
         np.testing.assert_array_equal(getattr(G, k), getattr(ref, k), err_msg=k)
     np.testing.assert_array_equal(G.Stack[:G.rh_total], ref.Stack[:ref.rh_total])
+
+
+@pytest.mark.parametrize("name,nranks,small", [("grid20_standin", 2, True), ("lns_3937", 4, True), ("epb1", 2, True),
+                                               ("syn_rankdef_grid", 2, True), ("sme3dc_standin", 4, False), ("c5mini_standin", 8, False)])
+def test_native_shared_front_loop_equals_unsharded(name, nranks, small):
+    """round-3 verdict item 7: the panel loop of a shared front as ONE native call per rank (stmmqr_factorize_shared_front: panels,
+    updates and messages enqueued on the plan's stream and a comm stream, ordered by events, no host round trip per step).  The
+    ranks are threads on this GPU with a callback transport; on a multi-GPU node the transport is RCCL.  Merged result identical
+    to one plan's, exactly like the step-by-step Python loop."""
+    pkg = importlib.import_module(PKG)
+    sh = importlib.import_module(PKG + ".sharded")
+    g = load_golden(name)
+    S = Symbolic(g)
+    sym = {**S.sc, **{k: v for k, v in S.arr.items() if v is not None}}
+    tol, ntol = scalar(g, "in_tol"), int(scalar(g, "in_ntol"))
+    pkg.set_options(pair_update=0, big_front_cols=16 if small else 64)
+    try:
+        ref = pkg.qr_factorize(sym, g["in_Ap"], g["in_Ai"], g["in_Ax"], tol, ntol)
+        kw = dict(min_step_flops=0, min_share=0.01, min_cols=32, min_panels_per_rank=1) if small else dict(min_step_flops=0)
+        owner, phase, span = sh.spread_partition(sym, nranks, **kw)
+        assert int((span > 1).sum()) >= 1
+        out = _run_ranks(pkg, sh, sym, g, tol, ntol, nranks, owner, phase, span, True, native=True)
+    finally:
+        pkg.set_options(pair_update=1, big_front_cols=64)
+    G = sh.merge_shards(sym, [o[1] for o in out], ntol)
+    assert sum(o[0]["flops"] for o in out) == ref.stats["flops"]
+    assert sum(o[0]["retries"] for o in out) == 0
+    assert (G.rank, G.rank1, G.maxfrank, G.maxfm, G.rh_total) == (ref.rank, ref.rank1, ref.maxfrank, ref.maxfm, ref.rh_total)
+    for k in ("Hm", "Hr", "HStair", "HPinv", "Rdead", "Rblock_off", "Hii", "HTau"):
+        np.testing.assert_array_equal(getattr(G, k), getattr(ref, k), err_msg=k)
+    np.testing.assert_array_equal(G.Stack[:G.rh_total], ref.Stack[:ref.rh_total])
+
+
+def test_rccl_transport_single_rank_loopback():
+    """the RCCL transport on the one GPU this box has: librccl found and loaded at run time, ncclGetUniqueId / ncclCommInitRank with a
+    world of one, a send to and a receive from itself in one group on a stream -- the calls, their signatures and the stream
+    plumbing of the path that carries panels over xGMI on a multi-GPU node (which no box of this build could run)"""
+    import torch
+    import torch.distributed as dist
+    import socket
+    pkg = importlib.import_module(PKG)
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1)
+    try:
+        tr = pkg.RcclTransport(dist, torch.device("cuda:0"))
+        a = torch.arange(4096, dtype=torch.float64, device="cuda:0")
+        b = torch.zeros_like(a)
+        torch.cuda.synchronize()
+        tr.sendrecv(a.data_ptr(), a.numel() * 8, 0, b.data_ptr(), b.numel() * 8, 0, None)
+        torch.cuda.synchronize()
+        assert torch.equal(a, b)
+        tr.close()
+    finally:
+        dist.destroy_process_group()
 
 
 @pytest.mark.parametrize("opts", [dict(split_update=0), dict(fused_update=1), dict(lookahead=0), dict(panel_algo=1), dict(panel_algo=2)])
