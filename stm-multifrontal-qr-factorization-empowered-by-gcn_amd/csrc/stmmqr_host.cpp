@@ -177,6 +177,7 @@ struct stmmqr_plan {
     int rh_grow = 0;                     // 0: the arena is sized from that estimate; 1: from the hard bounds (it overflowed once)
     long long scr_doubles = 0;           // scratch of the resident-factor operations: the widest tree level in front form
     std::vector<FrontSym> fs_scr;        // FrontSym with foff into that scratch (kept fronts: their own slab, relative to it)
+    bool scr_all = false, scr_valid = false;   // the scratch holds every front (rebuilt once per factorization) / is up to date
     bool overflowed = false;             // a factorization did not fit the R+H arena at its hard bound: this plan does not recycle
     bool arena_overflow = false;         // the last factorization did not fit the arena (it is repeated with a larger one / without)
     std::vector<int> lists;              // host copy of d_lists
@@ -1696,6 +1697,7 @@ int stmmqr_factorize_begin(stmmqr_plan *plan, const stm_long *Ap, const stm_long
     P.stats.ms_host = host_ms_plan;
     P.factored = false;
     P.rowmap_ready = false;
+    P.scr_valid = false;
     P.evused = 0;
     P.begun = true;
     P.first_group = true;
@@ -2641,7 +2643,23 @@ int check_device_err(stmmqr_plan &P, const char *what)
 int ensure_scratch(stmmqr_plan &P)
 {
     if (!P.recycle || (P.d_scr.p && P.d_fs_scr.p)) return 0;
-    LCHK(P.d_scr.alloc((size_t)std::max(1LL, P.scr_doubles)));
+    // Two layouts.  Where HBM has room (all recycled slabs within a quarter of what is free; STMMQR_RESIDENT_CACHE=0 / 1 forces) the
+    // scratch holds EVERY front in front form, rebuilt once per factorization at the first Q-apply / solve and kept for the
+    // following ones: the memory comes back only while the factors are being used, never during the factorization.  Otherwise it
+    // holds the widest tree level and every level is rebuilt whenever a kernel walks it.
+    size_t freeb = 0, totalb = 0;
+    HIPCHK(hipMemGetInfo(&freeb, &totalb));
+    long long all = 0;
+    for (long f = 0; f < P.nf; f++) if (!P.kept[(size_t)f]) all += (long long)P.fs[f].ld * P.fs[f].fn;
+    const char *ev = getenv("STMMQR_RESIDENT_CACHE");
+    P.scr_all = ev ? atoi(ev) != 0 : (8.0 * (double)all <= 0.25 * (double)freeb);
+    if (P.scr_all) {
+        long long o = 0;
+        for (long f = 0; f < P.nf; f++)
+            if (!P.kept[(size_t)f]) { P.fs_scr[(size_t)f].foff = o; o += (long long)P.fs[f].ld * P.fs[f].fn; }
+    }
+    P.scr_valid = false;
+    LCHK(P.d_scr.alloc((size_t)std::max(1LL, P.scr_all ? all : P.scr_doubles)));
     std::vector<FrontSym> t = P.fs_scr;
     for (long f = 0; f < P.nf; f++)
         if (P.kept[(size_t)f]) t[(size_t)f].foff = (long long)((P.d_F.p + P.fs[f].foff) - P.d_scr.p);
@@ -2659,8 +2677,13 @@ int level_to_front_form(stmmqr_plan &P, size_t l)
 {
     if (!P.recycle) return 0;
     const auto &LV = P.glevels[0];
-    if (LV[l].n_all <= 0) return 0;
     const DevCtx c = P.ctx();
+    if (P.scr_all) {
+        if (P.scr_valid) return 0;
+        P.scr_valid = true;                                       // every front at once, kept until the next factorization
+        return stm_launch_rh_unpack(c, P.d_fs_scr.p, P.d_lists.p + P.own_off, P.n_own, 64, P.d_kept.p, P.d_RH.p, P.d_scr.p, P.stream);
+    }
+    if (LV[l].n_all <= 0) return 0;
     return stm_launch_rh_unpack(c, P.d_fs_scr.p, P.d_lists.p + LV[l].all_off, LV[l].n_all, 64, P.d_kept.p, P.d_RH.p, P.d_scr.p, P.stream);
 }
 

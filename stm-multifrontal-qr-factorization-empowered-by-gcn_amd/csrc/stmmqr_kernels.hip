@@ -3052,10 +3052,15 @@ __global__ __launch_bounds__(NT) void k_rh_unpack(DevCtx c, const FrontSym *__re
     double *F = scratch + s.foff;
     const long long ld = s.ld;
     if (phase == 0) {
-        const long long n2 = (ld * n) >> 1;
-        double2 *F2 = reinterpret_cast<double2 *>(F);
+        // zeros where the kernels may look: the front's ACTUAL rows (the slab's leading dimension is the symbolic bound under rank
+        // detection, often twice as many), column by column
+        const int rows2 = (min(fm, (int)ld) + 1) >> 1;
         const double2 z = {0.0, 0.0};
-        for (long long i = (long long)blockIdx.x * NT + threadIdx.x; i < n2; i += (long long)gridDim.x * NT) F2[i] = z;
+        const long long tot = (long long)rows2 * n;
+        for (long long e = (long long)blockIdx.x * NT + threadIdx.x; e < tot; e += (long long)gridDim.x * NT) {
+            const int k = (int)(e / rows2), i2 = (int)(e - (long long)k * rows2);
+            reinterpret_cast<double2 *>(F + k * ld)[i2] = z;
+        }
         return;
     }
     if (fm <= 0 || n <= 0 || c.Rboff[f] < 0) return;

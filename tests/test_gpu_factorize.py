@@ -511,8 +511,9 @@ def test_seam_plan_cache(pkg, name, monkeypatch):
     assert np.array_equal(N.Stack[:N.c.rh_total], ref["Stack"]) and np.array_equal(N.HPinv[:S.m], ref["HPinv"])
 
 
+@pytest.mark.parametrize("cache", ["0", "1"])
 @pytest.mark.parametrize("name", NAMES + ["cvxqp3", "xenon1_standin", "c5mini_standin"])
-def test_slab_recycling_same_bits_and_less_memory(pkg, monkeypatch, name):
+def test_slab_recycling_same_bits_and_less_memory(pkg, monkeypatch, name, cache):
     """Round-3 verdict item 5 (the reference's stack discipline, SparseQR_factorize.c:405-422,925-933): a plan that holds the whole
     tree gives a front's slab to later fronts once its contribution block is packed and its R+H block staged, and a contribution
     block's place once the parent has assembled it (offsets by a first fit over the step timeline).  Same kernels on the same data:
@@ -523,6 +524,8 @@ def test_slab_recycling_same_bits_and_less_memory(pkg, monkeypatch, name):
     sym = sym_dict(S)
     tol, ntol = scalar(g, "in_tol"), int(scalar(g, "in_ntol"))
     out, mem = [], []
+    # (cache: the front form of the recycled fronts rebuilt once per factorization and kept / rebuilt level by level at every use)
+    monkeypatch.setenv("STMMQR_RESIDENT_CACHE", cache)
     for rec in ("0", "1"):
         monkeypatch.setenv("STMMQR_RECYCLE", "2" if rec == "1" else "0")
         plan = pkg.HipQR(sym)
