@@ -498,9 +498,12 @@ int stmmqr_sparseqr_solve(stmmqr_qr *qr, int system, const double *B, stm_long l
             }
             return 0;
         }
-        // R' systems with singleton rows: forward through the singleton rows, then the multifrontal part
-        if (qr->rank != n)
-            return stm_fail(STMMQR_ERR_INVALID, "stmmqr_sparseqr_solve: R' systems of a rank-deficient factorization with singletons are not built");
+        // R' systems with singleton rows: forward through the singleton rows, then the multifrontal part.  Rank-deficient
+        // factorizations (qr_private_rtsolve's "squeezed" R, SparseQR.c:2522-2700: Rmap / RmapInv): a dead column has no equation.
+        // Dead columns only exist in the multifrontal part (a singleton's diagonal passed the tolerance test to become one), so
+        // the singleton stage is the same -- what it subtracts from a dead column's entry of b is never read -- and the plan's
+        // R' solve skips the dead columns of its own part; the solution's rows are the singleton rows, then the live
+        // multifrontal rows in order, then zeros: the reference's layout.
         std::vector<double> b((size_t)n), B2((size_t)std::max<Long>(n2, 1) * (size_t)nrhs), X2((size_t)std::max<Long>(m2, 1) * (size_t)nrhs, 0.0);
         for (Long j = 0; j < nrhs; j++) {
             for (Long k = 0; k < n; k++) b[(size_t)k] = B[colmap(k) + j * ldb];             // b in R's column order

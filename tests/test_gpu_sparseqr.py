@@ -75,7 +75,7 @@ def test_sparseqr_api_against_reference(name):
     Bm = np.asfortranarray(np.stack([entry(np.arange(m) + 5, j + 2) for j in range(nr)], axis=1))
     Bn = np.asfortranarray(np.stack([entry(np.arange(n) + 5, j + 2) for j in range(nr)], axis=1))
     S0, S1 = Q.solve(0, Bm), Q.solve(1, Bm)
-    can_rt = int(info["n1cols"]) == 0 or int(info["rank"]) == n
+    can_rt = True          # (round 4: R' systems of rank-deficient factorizations with singletons too -- lns_3937 is one)
     if name in EXACT:
         for got, k in ((Y0, "qmult_0"), (Y1, "qmult_1"), (S0, "solve_0"), (S1, "solve_1")):
             assert rel(np.asarray(got).ravel(order="F"), ref[k]) < 1e-8, k
@@ -84,8 +84,16 @@ def test_sparseqr_api_against_reference(name):
             assert rel(Q.solve(2, Bn).ravel(order="F"), ref["solve_2"]) < 1e-8
             assert rel(Q.solve(3, Bn).ravel(order="F"), ref["solve_3"]) < 1e-8
     elif can_rt:
-        # R' X = B, then R (R' ...) round trip is not available without R; at least the solves run and are finite
-        assert np.isfinite(Q.solve(2, Bn)).all() and np.isfinite(Q.solve(3, Bn)).all()
+        X2, X3 = Q.solve(2, Bn), Q.solve(3, Bn)
+        assert np.isfinite(X2).all() and np.isfinite(X3).all()
+        # against the reference's own QR_solve output.  R is unique up to the sign of each row, and in R'x = b the sign of row i of R
+        # is the sign of x_i: on inputs with rounding-noise pivots (where two correct implementations differ in those signs) the
+        # entries agree in absolute value; the tolerance is cond(R) eps on the ill-conditioned ones
+        r2, r3 = rel(np.abs(X2.ravel(order="F")), np.abs(ref["solve_2"])), rel(np.abs(X3.ravel(order="F")), np.abs(ref["solve_3"]))
+        print(f"[rt solve vs reference] {name} {r2:.2e} {r3:.2e}")
+        assert r2 < 1e-5 and r3 < 1e-5
+        rank = int(info["rank"])
+        assert not np.any(X2[rank:]) and not np.any(X3[rank:])          # rows beyond the rank: exactly zero
     Q.close()
 
 
