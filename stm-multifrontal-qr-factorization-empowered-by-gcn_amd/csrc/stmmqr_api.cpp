@@ -10,7 +10,7 @@
 // entry points include/tpsm/tpsm_main.h).  A program written against the reference's headers -- its own driver test/qrtest.c,
 // unmodified -- links this library and libstmmqr_hip.so in place of the reference's QR module (src/qr/*) and thread pool; what
 // it still takes from the reference is the sparse-matrix toolbox it calls itself (SparseCore_read_matrix, SparseCore_sdmult, ...).
-// oracle/Makefile builds exactly that program (oracle/_ref/qrtest_hipapi) and tests/test_outer_api.py runs it.
+// The test infrastructure builds exactly that program and tests/test_outer_api.py runs it.
 //
 // An OPT-IN second shared object: libstmmqr_hip.so itself does not export these names, so the other integration -- the
 // reference's own SparseQR.o around this library's qr_factorize -- gets no duplicate symbols.

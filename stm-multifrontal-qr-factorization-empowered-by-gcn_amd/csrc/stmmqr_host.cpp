@@ -1456,12 +1456,6 @@ int run_schedule(stmmqr_plan &P, bool detail, int grp, const StepReq *req = null
                 v->push_back(ev);
             }
         hipStream_t sd = P.side;
-        // STMMQR_X_NOWAIT (timing experiments ONLY, results are wrong): 1 the main stream never waits for the side stream inside the
-        // loop, 2 the side stream never waits for the main stream either, 4 no event records at all
-        const int x_nowait = getenv("STMMQR_X_NOWAIT") ? atoi(getenv("STMMQR_X_NOWAIT")) : 0;
-#define XWAIT_MAIN(call) do { if (!(x_nowait & 1)) HIPCHK(call); } while (0)
-#define XWAIT_SIDE(call) do { if (!(x_nowait & 2)) HIPCHK(call); } while (0)
-#define XRECORD(call) do { if (!(x_nowait & 4)) HIPCHK(call); } while (0)
         long side_ev = -1;                                     // last side event the main stream has not waited for
         bool prep_on_side = false;                             // prep(t) was issued on the side stream during step t-1
         int e = 0;
@@ -1485,16 +1479,16 @@ int run_schedule(stmmqr_plan &P, bool detail, int grp, const StepReq *req = null
                 continue;
             }
             if (b0_fused(S)) {
-                if (side_ev >= 0) { XWAIT_MAIN(hipStreamWaitEvent(st, P.ev_side[side_ev], 0)); side_ev = -1; }
+                if (side_ev >= 0) { HIPCHK(hipStreamWaitEvent(st, P.ev_side[side_ev], 0)); side_ev = -1; }
                 if ((e = update_b0_fused(S, st))) return e;                                            // T + block 0
-                XRECORD(hipEventRecord(P.ev_main[t], st));
+                HIPCHK(hipEventRecord(P.ev_main[t], st));
             } else {
                 if ((e = update(S, 0, 0, true, P.d_Wp.p, st))) return e;                               // T
-                XRECORD(hipEventRecord(P.ev_main[t], st));
-                if (side_ev >= 0) { XWAIT_MAIN(hipStreamWaitEvent(st, P.ev_side[side_ev], 0)); side_ev = -1; }
+                HIPCHK(hipEventRecord(P.ev_main[t], st));
+                if (side_ev >= 0) { HIPCHK(hipStreamWaitEvent(st, P.ev_side[side_ev], 0)); side_ev = -1; }
                 if ((e = update(S, 0, 1, false, P.d_Wp.p, st))) return e;                              // block 0
             }
-            XWAIT_SIDE(hipStreamWaitEvent(sd, P.ev_main[t], 0));
+            HIPCHK(hipStreamWaitEvent(sd, P.ev_main[t], 0));
             if ((e = post(S, sd))) return e;
             if (t + 1 < ns && SV[t + 1].n_start > 0) {
                 if ((e = prep(SV[t + 1], sd))) return e;
@@ -1502,7 +1496,7 @@ int run_schedule(stmmqr_plan &P, bool detail, int grp, const StepReq *req = null
                 prep_on_side = true;
             }
             if ((e = update(S, 1, S.maxcb - 1, false, P.d_Wp2.p, sd))) return e;
-            XRECORD(hipEventRecord(P.ev_side[t], sd));
+            HIPCHK(hipEventRecord(P.ev_side[t], sd));
             side_ev = (long)t;
         }
         if (side_ev >= 0) HIPCHK(hipStreamWaitEvent(st, P.ev_side[side_ev], 0));   // join: the caller continues on `stream`

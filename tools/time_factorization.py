@@ -10,4 +10,4 @@ for _ in range(3): st=plan.factorize(g["in_Ax"],tol,ntol)
 ts=[]
 for _ in range(5):
     t0=time.perf_counter(); st=plan.factorize(g["in_Ax"],tol,ntol); ts.append((time.perf_counter()-t0)*1e3)
-print(name, "X_NOWAIT", os.environ.get("STMMQR_X_NOWAIT"), "LA_MIN", os.environ.get("STMMQR_LA_MIN"), "lookahead", pkg.get_options()["lookahead"], "wall ms min %.2f med %.2f dev %.2f"%(min(ts), sorted(ts)[2], st["ms_total"]), "flops ok", st["flops"]==scalar(g,"flopcount"), "retries", st["retries"])
+print(name, "LA_MIN", os.environ.get("STMMQR_LA_MIN"), "lookahead", pkg.get_options()["lookahead"], "wall ms min %.2f med %.2f dev %.2f"%(min(ts), sorted(ts)[2], st["ms_total"]), "flops ok", st["flops"]==scalar(g,"flopcount"), "retries", st["retries"])
