@@ -379,10 +379,13 @@ typedef struct stmmqr_options {
                                look-ahead step applies T + column block 0 in one fused launch when every workgroup of that launch
                                fits the compute units the side stream leaves alone (counted with the fronts' row BOUNDS) and the
                                panels are expected to reach at most STMMQR_LA_FUSED_ROWS rows (5120; 0 turns it off).      */
-    int pair_update;        /* 1 (default): fronts of >= 16384 rows apply the block reflectors of two consecutive panels in
-                               one sweep over the columns beyond the next two panels (1.5 instead of 3 passes over the
-                               trailing matrix per panel); a property of the front (plan time), it changes rounding only.
-                               0: every front panel by panel.  (A single-sweep form, 16 instead of 24 bytes per entry and pair, was
+    int pair_update;        /* fronts of >= 16384 rows apply the block reflectors of several consecutive panels in ONE sweep over
+                               the columns beyond the next panel (their update is bound by what a sweep moves per MFMA):
+                               4 (default): four panels per sweep (k_upd_wq / k_upd_yq / k_upd_cq: 0.75 passes over the trailing
+                               matrix per panel; round 4: configs[4] stand-in 4127 -> 3640 ms against pairs);
+                               1: two panels per sweep (k_upd_w2 / k_upd_y2 / k_upd_c2: 1.5 passes; the round-2/3 form);
+                               0: every front panel by panel (3 passes).  A property of the front (plan time); it changes
+                               rounding only.  (A single-sweep form of the pair, 16 instead of 24 bytes per entry and pair, was
                                built in round 3, measured slower at one wave per SIMD and removed in round 4:
                                profiles/EXPERIMENTS.md.)                                                                    */
 } stmmqr_options;

@@ -159,7 +159,7 @@ __global__ __launch_bounds__(CA_NT) void k_panel_ca(DevCtx c, const int *__restr
         for (int it = 0; it < 4000; it++) __builtin_amdgcn_s_sleep(100);
     }
     FrontNum *num = &c.fnum[f];
-    PanelDesc *pd = &num->pd[p & 1];
+    PanelDesc *pd = &num->pd[STM_PDI(p)];
     double *F = c.Farena + s.foff;
     int *St = c.Stair + s.rp;
     double *Tau = c.Tau + s.rp;
@@ -500,7 +500,7 @@ __global__ __launch_bounds__(CA_NT) void k_panel_ca(DevCtx c, const int *__restr
     // front (no trailing columns) gets it from k_cpack's extra workgroup (t_deferred = 2); no live reflector: T = 0 here
     const int tdef = !live ? 0 : ((defer_ok && k2 < n) ? 1 : 2);
     if (!live) {
-        double *Tout = c.Tws + (long long)(2 * slot + (p & 1)) * STM_NB * STM_NB;
+        double *Tout = c.Tws + (long long)STM_TSLOT(slot, p) * STM_NB * STM_NB;
         double *Tkeep = c.Tall ? c.Tall + (long long)(s.tpan + p) * STM_NB * STM_NB : nullptr;
         for (int e = tid; e < STM_NB * STM_NB; e += CA_NT) { Tout[e] = 0.0; if (Tkeep) Tkeep[e] = 0.0; }
     }

@@ -31,6 +31,9 @@ struct FrontSym {
 };
 
 // one pending block reflector (written by the panel kernel, read by the update kernel)
+#define STM_PD_RING 4                                           // panel descriptions and T factors kept per front
+#define STM_PDI(p) ((p) & (STM_PD_RING - 1))
+#define STM_TSLOT(slot, p) ((long long)STM_PD_RING * (slot) + STM_PDI(p))
 struct PanelDesc {
     int pg1, pt;             // rows [pg1, pt)
     int pk1, pnb;            // built from columns [pk1, pk1+pnb)
@@ -164,7 +167,7 @@ struct FrontNum {
     long long rsize;         // entries of the packed R+H block     (qr_rhpack's return value; 2.2e9 at the largest size)
     double flops;            // reference flop count of this front  (FLOP_COUNT, :1571)
     double flops_upd;        // the part of `flops` that the trailing update does: sum (t-g) * 4 * (fn - k2), k2 = panel end
-    // pending block reflectors, double buffered by panel parity so that the look-ahead schedule can factorize
-    // panel p+1 while the tail of update p is still reading the description of panel p
-    PanelDesc pd[2];
+    // pending block reflectors, a ring by panel number: the look-ahead schedule factorizes panel p+1 while the tail of update p
+    // is still reading the description of panel p, and the sweeps of the large fronts (pair / quad update) read the last 2 / 4
+    PanelDesc pd[STM_PD_RING];
 };

@@ -36,7 +36,7 @@
 namespace {
 
 thread_local std::string g_err;
-stmmqr_options g_opt = {STM_NB, 64, 0, 0, 0, 1, STM_TALL_MIN, 1, 0, 1};      // (panel_algo 0: by panel height)
+stmmqr_options g_opt = {STM_NB, 64, 0, 0, 0, 1, STM_TALL_MIN, 1, 0, 4};      // (panel_algo 0: by panel height)
 size_t g_chunk[4] = {32, 5000, 4, 4};     // FCHUNK, SMALL, MINCHUNK, MINCHUNK_RATIO (SparseQR.h:16-19)
 
 // offsets inside the reference's sparse_common for the stock LP64 build; verified against the real header
@@ -117,10 +117,12 @@ struct Step {
     int lds_big = 0;       // dynamic LDS of the panel launch when every front may take the one-workgroup panel (recovery, tests)
     int lds_plan = 0;      // ... when only the fronts planned for it do (the pipeline groups need the update's LDS only)
     // the fronts in flight are listed in three classes: [0, n_norm) every panel's update on all trailing columns;
-    // then the pair-update fronts (is_pair) at an even panel (update of column blocks 0, 1 only) and at an odd panel
-    // (block 0, then the pair update of the two last panels on the columns beyond)
-    int n_norm = 0, n_pe = 0, n_po = 0;
-    int maxsl_pe = 0, maxsl_po = 0, maxcbp_po = 0;
+    // then the sweep fronts (is_pair; w = 2 or 4 panels per sweep, stmmqr_plan::sweep) by panel number mod w: class r updates the
+    // column blocks 0 .. w-1-r only (the columns of the next panels), the last class then applies the w last panels at once to
+    // everything beyond
+    int n_norm = 0, n_pk[4] = {0, 0, 0, 0};
+    int maxsl_pk[4] = {0, 0, 0, 0}, maxcbp_po = 0;
+    int n_sweep() const { return n_pk[0] + n_pk[1] + n_pk[2] + n_pk[3]; }
     int cpk_off = 0, cpk_parts_off = 0, n_cpk = 0, cpk_maxparts = 1;   // big fronts whose last panel runs here
     // slab recycling: the fronts whose packed R+H block is staged at the end of this step (the small fronts that started here and
     // the big fronts packed here, kept fronts excluded) + copy parts
@@ -153,7 +155,8 @@ struct stmmqr_plan {
     std::vector<std::vector<Level>> glevels;   // [group][level]
     std::vector<std::vector<Step>> gsteps;     // [group][step]
     std::vector<long long> wlists;             // host copy of d_wlists
-    std::vector<char> pair_front;              // per front: takes the pair update (plan time)
+    std::vector<char> pair_front;              // per front: takes the pair / quad update (plan time)
+    int sweep = 2;                             // panels per sweep of those fronts: 2 (k_upd_w2 / y2 / c2) or 4 (k_upd_wq / yq / cq)
     std::vector<int> group;                    // per front: phase on this device, -1 = elsewhere
     std::vector<int> h_tslot;                  // host copy of d_tslot
     std::vector<char> shared;                  // per front: STMMQR_GROUP_SHARED -- alone in its group, driven step by step
@@ -266,6 +269,7 @@ struct stmmqr_plan {
         c.Rdead = d_Rdead.p; c.Cmap = d_Cmap.p; c.Cursor = d_Cursor.p; c.Rhoff = d_Rhoff.p; c.Rboff = d_Rboff.p;
         c.tol = last_tol; c.ntol = (int)last_ntol;
         c.dbg = getenv("STMMQR_DBG") ? atoi(getenv("STMMQR_DBG")) : 0;
+        c.sweep = sweep;
         c.tune = tune;                                            // (env STMMQR_TUNE when the schedule was built)
         c.Ypend = d_Ypend.p; c.ypoff = d_ypoff.p;
         c.rh_top = recycle ? d_rhtop.p : nullptr; c.rh_cap = rh_cap;
@@ -541,6 +545,7 @@ void build_schedule(stmmqr_plan &P, std::vector<int> &tslot)
         if ((size_t)f < P.shared.size() && P.shared[f]) return false;   // (the pair update has no column-block stride)
         return g_opt.pair_update && is_big(f) && s.fm_est >= pair_min && s.npanels >= 4;
     };
+    P.sweep = (g_opt.pair_update == 4) ? 4 : 2;
     P.pair_front.assign(std::max(1L, nf), 0);
     for (long f = 0; f < nf; f++) P.pair_front[f] = (P.group[f] >= 0 && is_pair((int)f)) ? 1 : 0;
     P.ypoff.assign(std::max(1L, nf), -1);
@@ -548,7 +553,7 @@ void build_schedule(stmmqr_plan &P, std::vector<int> &tslot)
     for (long f = 0; f < nf; f++)
         if (P.pair_front[f]) {
             P.ypoff[f] = P.yp_doubles;
-            P.yp_doubles += (long long)((P.fs[f].fn + 31) / 32) * (2 * STM_NB * 32);
+            P.yp_doubles += (long long)((P.fs[f].fn + 31) / 32) * (P.sweep * STM_NB * 32);
         }
     tslot.assign(std::max(1L, nf), 0);
     P.glevels.assign(ngroups, std::vector<Level>());
@@ -745,7 +750,7 @@ void build_schedule(stmmqr_plan &P, std::vector<int> &tslot)
             for (const auto &fp : panel_at[t]) { active.push_back(fp.first); pan_now[fp.first] = fp.second; }
             // heaviest update first (the order inside a launch does not change any result); classes: see Step
             auto work_at = [&](int f) { return (long)stm_upd_ncb(P.fs[f], pan_now[f]) * stm_upd_nsl(P.fs[f]); };
-            auto cls = [&](int f) { return !is_pair(f) ? 0 : ((pan_now[f] & 1) ? 2 : 1); };
+            auto cls = [&](int f) { return !is_pair(f) ? 0 : 1 + pan_now[f] % P.sweep; };
             std::stable_sort(active.begin(), active.end(), [&](int a, int b) {
                 return cls(a) != cls(b) ? cls(a) < cls(b) : work_at(a) > work_at(b);
             });
@@ -765,8 +770,10 @@ void build_schedule(stmmqr_plan &P, std::vector<int> &tslot)
                 // (+1: Gram block.  Pair-update fronts: two blocks per partial, at most stm_pair_slots partials per column block in the
                 //  sweep of an odd panel -- a workgroup takes up to four slabs --, and the panel-by-panel updates of the next panels'
                 //  columns use the first 2 + 1 column blocks with the full slab count)
+                //  (quad update: four blocks per partial, three Gram blocks, 4 + 1 column blocks in the panel-by-panel updates)
                 if (is_pair(f))
-                    wp += std::max((long long)(ncb + 1) * stm_pair_slots(nsl, P.tune) * (2 * STM_NB * 32), 3LL * nsl * (STM_NB * 32));
+                    wp += std::max((long long)(ncb + P.sweep - 1) * stm_pair_slots(nsl, P.tune) * (P.sweep * STM_NB * 32),
+                                   (P.sweep + 1LL) * nsl * (STM_NB * 32));
                 else
                     wp += (long long)(ncb + 1) * nsl * (STM_NB * 32);
                 const int k = cls(f);
@@ -775,13 +782,10 @@ void build_schedule(stmmqr_plan &P, std::vector<int> &tslot)
                     ncbsum += ncb;
                     S.maxcb = std::max(S.maxcb, ncb);
                     S.maxsl = std::max(S.maxsl, nsl);
-                } else if (k == 1) {
-                    S.n_pe++;
-                    S.maxsl_pe = std::max(S.maxsl_pe, nsl);
                 } else {
-                    S.n_po++;
-                    S.maxsl_po = std::max(S.maxsl_po, nsl);
-                    S.maxcbp_po = std::max(S.maxcbp_po, ncb - 1);
+                    S.n_pk[k - 1]++;
+                    S.maxsl_pk[k - 1] = std::max(S.maxsl_pk[k - 1], nsl);
+                    if (k == P.sweep) S.maxcbp_po = std::max(S.maxcbp_po, ncb - 1);
                 }
                 S.nsub = std::max(S.nsub, stm_tall_launches(s, p, P.tall_min));
                 S.nca = std::max(S.nca, stm_ca_slabs(s));
@@ -800,7 +804,7 @@ void build_schedule(stmmqr_plan &P, std::vector<int> &tslot)
             // by k_upd_w).  Either form gives the same bits.
             S.split = (S.maxsl >= 3 || ncbsum >= 512) ? 1 : 0;
             P.wp_doubles = std::max(P.wp_doubles, wp);
-            if (S.n_pe + S.n_po == 0) P.wp2_doubles = std::max(P.wp2_doubles, wp);
+            if (S.n_sweep() == 0) P.wp2_doubles = std::max(P.wp2_doubles, wp);
             // fronts at their last panel: packed at the end of the step, slot released for the next
             S.cpk_off = (int)P.lists.size();
             S.n_cpk = (int)ending[t].size();
@@ -1090,7 +1094,7 @@ int build_plan(stmmqr_plan &P, const stmmqr_symbolic_view &v)
     LCHK(P.d_fs.upload(P.fs, st));
     LCHK(P.d_fnum.alloc(std::max(1L, nf)));
     HIPCHK(hipMemsetAsync(P.d_fnum.p, 0, std::max(1L, nf) * sizeof(FrontNum), st));
-    LCHK(P.d_T.alloc((size_t)2 * P.tslots * STM_NB * STM_NB));
+    LCHK(P.d_T.alloc((size_t)STM_PD_RING * P.tslots * STM_NB * STM_NB));
     LCHK(P.d_Gp.alloc((size_t)P.tslots * (P.gp_slabs + 1) * STM_NB * STM_NB));
     LCHK(P.d_Tall.alloc((size_t)std::max(1LL, P.tpanels) * STM_NB * STM_NB));
     LCHK(P.d_Wp.alloc((size_t)P.wp_doubles));
@@ -1294,7 +1298,7 @@ int run_schedule(stmmqr_plan &P, bool detail, int grp, const StepReq *req = null
     auto update = [&](const Step &S, int cb0, int ncb, bool gram, double *Wp, hipStream_t q) -> int {
         const bool split = S.split && g_opt.split_update;
         const bool whole = (cb0 == 0 && gram);                 // the step's whole update: the pair-update classes too
-        const bool pairs = whole && (S.n_pe + S.n_po) > 0;
+        const bool pairs = whole && S.n_sweep() > 0;
         if (S.n_norm <= 0 || (ncb <= 0 && !(gram && split))) {
             if (!pairs) return 0;
         }
@@ -1319,18 +1323,20 @@ int run_schedule(stmmqr_plan &P, bool detail, int grp, const StepReq *req = null
                 }
             }
             if (pairs) {
-                // even panel: column blocks 0, 1 (the columns of the next two panels), T by the Gram block
+                // panel r of a sweep of w: column blocks 0 .. w-1-r (the columns of the next panels), T by the Gram block; after the
+                // last one the w panels at once on everything beyond
                 int o = S.n_norm;
-                if (S.n_pe > 0) {
-                    LCHK(stm_launch_update_split(c, act + o, pl + o, S.n_pe, 0, 2, S.maxsl_pe, Wp, wl + o, wcnt, 1, q));
+                for (int r = 0; r < P.sweep; r++) {
+                    const int n = S.n_pk[r];
+                    if (n <= 0) continue;
+                    LCHK(stm_launch_update_split(c, act + o, pl + o, n, 0, P.sweep - r, S.maxsl_pk[r], Wp, wl + o, wcnt, 1, q));
                     nlaunch += 2;
-                }
-                // odd panel: block 0, then both panels at once on everything beyond
-                o += S.n_pe;
-                if (S.n_po > 0) {
-                    LCHK(stm_launch_update_split(c, act + o, pl + o, S.n_po, 0, 1, S.maxsl_po, Wp, wl + o, wcnt, 1, q));
-                    LCHK(stm_launch_update_pair(c, act + o, pl + o, S.n_po, S.maxcbp_po, S.maxsl_po, Wp, wl + o, wcnt, q));
-                    nlaunch += 5;
+                    if (r == P.sweep - 1) {
+                        if (P.sweep == 4) LCHK(stm_launch_update_quad(c, act + o, pl + o, n, S.maxcbp_po, S.maxsl_pk[r], Wp, wl + o, wcnt, q));
+                        else LCHK(stm_launch_update_pair(c, act + o, pl + o, n, S.maxcbp_po, S.maxsl_pk[r], Wp, wl + o, wcnt, q));
+                        nlaunch += 3;
+                    }
+                    o += n;
                 }
             }
             return 0;
@@ -1371,7 +1377,7 @@ int run_schedule(stmmqr_plan &P, bool detail, int grp, const StepReq *req = null
         if (req->what & STMMQR_STEP_PREP) e = prep(S, st);
         if (!e && (req->what & STMMQR_STEP_PANEL) && S.n_act > 0) e = panels(S);
         if (!e && (req->what & (STMMQR_STEP_UPDATE | STMMQR_STEP_GRAM)) && S.n_act > 0) {
-            if (S.n_pe + S.n_po > 0) return fail(STMMQR_ERR_INVALID, "pair-update fronts cannot be stepped (mark the front STMMQR_GROUP_SHARED)");
+            if (S.n_sweep() > 0) return fail(STMMQR_ERR_INVALID, "pair-update fronts cannot be stepped (mark the front STMMQR_GROUP_SHARED)");
             int nmine = 0;
             if ((req->what & STMMQR_STEP_UPDATE) && req->cb_first >= 0 && req->cb_first < S.maxcb)
                 nmine = (S.maxcb - req->cb_first + c.cbskip) / (1 + c.cbskip);
@@ -1399,7 +1405,7 @@ int run_schedule(stmmqr_plan &P, bool detail, int grp, const StepReq *req = null
     // deficient front can have more rows than its estimate), not with the estimate the 5120-row rule uses.
     const long la_slots = 2 * (getenv("STMMQR_SIDE_RESERVE") ? std::max(0L, atol(getenv("STMMQR_SIDE_RESERVE"))) : 32L);
     auto b0_fused = [&](const Step &S) -> bool {
-        if (la_fused_rows <= 0 || !S.split || !g_opt.split_update || S.maxsl > 256 || S.n_pe + S.n_po > 0 || c.cbskip != 0) return false;
+        if (la_fused_rows <= 0 || !S.split || !g_opt.split_update || S.maxsl > 256 || S.n_sweep() > 0 || c.cbskip != 0) return false;
         long wgs = 0;
         for (int i = 0; i < S.n_norm; i++) wgs += 2L * stm_upd_nsl(P.fs[P.lists[S.act_off + i]]);
         if (wgs > la_slots) return false;
@@ -1417,7 +1423,7 @@ int run_schedule(stmmqr_plan &P, bool detail, int grp, const StepReq *req = null
             if (ncb > 1) tiles += (long)(ncb - 1) * ((stm_panel_rows_est(fsym, p) + STM_UPD_SLAB - 1) / STM_UPD_SLAB);   // (expected rows, not the bound)
             pwg += stm_use_ca(fsym, p, P.plan_algo, P.ca_min) ? stm_ca_slabs(fsym) : stm_tall_launches(fsym, p, P.tall_min);
         }
-        return tiles >= (b0_fused(S) ? std::min(la_min, la_min_fused) : la_min) && pwg <= la_maxpwg && S.n_pe + S.n_po == 0;      // (pair-update steps stay on one stream)
+        return tiles >= (b0_fused(S) ? std::min(la_min, la_min_fused) : la_min) && pwg <= la_maxpwg && S.n_sweep() == 0;      // (pair-update steps stay on one stream)
     };
     // Look-ahead needs the device's side stream (a CU-masked stream, created once per process and released by an atexit
     // handler): it is only created when some step of this group really goes there -- small matrices never touch it.
@@ -1992,7 +1998,7 @@ int stmmqr_plan_set_groups(stmmqr_plan *plan, const int *group)
     LCHK(upload_recycle(P));
     // workspaces only grow (a regrouping of the same tree usually needs what it needed before)
     auto grow = [](auto &buf, size_t n) -> int { return buf.n >= n && buf.p ? 0 : buf.alloc(n); };
-    LCHK(grow(P.d_T, (size_t)2 * P.tslots * STM_NB * STM_NB));
+    LCHK(grow(P.d_T, (size_t)STM_PD_RING * P.tslots * STM_NB * STM_NB));
     LCHK(grow(P.d_Gp, (size_t)P.tslots * (P.gp_slabs + 1) * STM_NB * STM_NB));
     LCHK(grow(P.d_Wp, (size_t)P.wp_doubles));
     LCHK(grow(P.d_Ypend, (size_t)std::max(1LL, P.yp_doubles)));
@@ -2162,7 +2168,7 @@ static int panel_copy(stmmqr_plan &P, stm_long f, stm_long p, double *buf, int o
     if (on_device) {
         // device buffer: ONE launch packs / unpacks the six ranges
         void *homes[6] = {P.d_F.p + s.foff + (long long)p * STM_NB * s.ld,
-                          P.d_T.p + (long long)(2 * P.h_tslot[(size_t)f] + (int)(p & 1)) * STM_NB * STM_NB, P.d_Tau.p + s.rp, P.d_Stair.p + s.rp,
+                          P.d_T.p + (long long)STM_TSLOT(P.h_tslot[(size_t)f], (int)p) * STM_NB * STM_NB, P.d_Tau.p + s.rp, P.d_Stair.p + s.rp,
                           P.d_Rdead.p + s.col1, P.d_fnum.p + f};
         const long long offs[6] = {m.f_off * 8, m.t_off * 8, m.tau_off * 8, m.stair_off * 8, m.dead_off * 8, m.num_off * 8};
         const long long bytes[6] = {(long long)s.ld * m.nb * 8, 8LL * STM_NB * STM_NB, 8LL * s.fn, 4LL * s.fn, (long long)s.fp, (long long)sizeof(FrontNum)};
@@ -2177,7 +2183,7 @@ static int panel_copy(stmmqr_plan &P, stm_long f, stm_long p, double *buf, int o
         return 0;
     };
     LCHK(cp(P.d_F.p + s.foff + (long long)p * STM_NB * s.ld, m.f_off, (size_t)s.ld * (size_t)m.nb * sizeof(double)));
-    LCHK(cp(P.d_T.p + (long long)(2 * P.h_tslot[(size_t)f] + (int)(p & 1)) * STM_NB * STM_NB, m.t_off, sizeof(double) * STM_NB * STM_NB));
+    LCHK(cp(P.d_T.p + (long long)STM_TSLOT(P.h_tslot[(size_t)f], (int)p) * STM_NB * STM_NB, m.t_off, sizeof(double) * STM_NB * STM_NB));
     LCHK(cp(P.d_Tau.p + s.rp, m.tau_off, (size_t)s.fn * sizeof(double)));
     LCHK(cp(P.d_Stair.p + s.rp, m.stair_off, (size_t)s.fn * sizeof(int)));
     LCHK(cp(P.d_Rdead.p + s.col1, m.dead_off, (size_t)s.fp));

@@ -46,6 +46,7 @@ struct DevCtx {
     long long *rh_top;         // slab recycling: {bump pointer of the R+H arena (doubles), overflow word}; nullptr = the packed blocks are
                                //  placed by k_rh_scan at the end (Post order), every front keeps its slab until then
     long long rh_cap;          // ... capacity of that arena (doubles)
+    int sweep;                 // panels per sweep of the pair / quad update fronts (2 or 4): their panel-by-panel updates bring that many column blocks
     int tune;                  // env STMMQR_TUNE, measurement sweeps only (0 = the shipped rules): bits 0-3 force 2^(x-1) slabs per
                                //  workgroup of the pair update's kernels
     int dbg;                   // env STMMQR_DBG, ablations / cross-checks only: 1 no in-panel apply (LDS panel path),
@@ -72,6 +73,8 @@ int stm_launch_update(const DevCtx &c, const int *flist, const int *plist, int n
 int stm_launch_update_fused(const DevCtx &c, const int *flist, const int *plist, int nfr, int cb0, int ncb, int maxsl, double *Wp,
                             const long long *wpoff, int *wcnt, int *wflag, int epoch, int with_gram, hipStream_t st);
 int stm_launch_update_pair(const DevCtx &c, const int *flist, const int *plist, int nfr, int ncbp, int maxsl, double *Wp,
+                           const long long *wpoff, int *wcnt, hipStream_t st);
+int stm_launch_update_quad(const DevCtx &c, const int *flist, const int *plist, int nfr, int ncbp, int maxsl, double *Wp,
                            const long long *wpoff, int *wcnt, hipStream_t st);
 int stm_launch_update_split(const DevCtx &c, const int *flist, const int *plist, int nfr, int cb0, int ncb, int maxsl, double *Wp,
                             const long long *wpoff, int *wcnt, int with_gram, hipStream_t st);

@@ -191,7 +191,7 @@ __global__ __launch_bounds__(NT) void k_setup(DevCtx c, const int *__restrict__ 
     if (tid == 0) {
         FrontNum *nm = &c.fnum[f];
         nm->fm = fm; nm->g = 0; nm->rank = min(fm, s.fp); nm->done = 0; nm->hdr = 0; nm->prog = 0; nm->perr = 0; nm->gcnt = 0;
-        nm->pd[0].pnb = 0; nm->pd[1].pnb = 0; nm->cm = 0; nm->rsize = 0; nm->flops = 0; nm->flops_upd = 0;
+        for (int q = 0; q < STM_PD_RING; q++) nm->pd[q].pnb = 0; nm->cm = 0; nm->rsize = 0; nm->flops = 0; nm->flops_upd = 0;
     }
 }
 
@@ -839,7 +839,7 @@ __device__ __forceinline__ void dev_panel(PanelShared &ps, const FrontSym &s, Fr
     int g = num->g, rank = num->rank;
     __syncthreads();                                   // everyone has read FrontNum before anyone writes it
     if (was_done) {
-        if (tid == 0) num->pd[p & 1].pnb = 0;
+        if (tid == 0) num->pd[STM_PDI(p)].pnb = 0;
         return;
     }
     const int ntol = min(ntol_global - s.col1, npiv);
@@ -1110,7 +1110,7 @@ __device__ __forceinline__ void dev_panel(PanelShared &ps, const FrontSym &s, Fr
 #endif
 #undef STAMP
 #undef CSTAMP
-    PanelDesc *pd = &num->pd[p & 1];
+    PanelDesc *pd = &num->pd[STM_PDI(p)];
     if (tid < STM_NB) pd->pdiag[tid] = (tid < nbp) ? s_diag[tid] : STM_BIGROW;
     if (tid == 0) {
         num->g = g; num->rank = rank; num->done = done;
@@ -1656,7 +1656,7 @@ __global__ __launch_bounds__(NT) void k_front_wg(DevCtx c, const int *__restrict
                                  dyn_lds, lds_doubles, c.dbg, nullptr, Tkeep(p), c.sig);
         const int k2 = min(s.fn, (p + 1) * STM_NB);
         const int ncb = (s.fn - k2 + BN - 1) / BN;
-        const PanelDesc *pd = &num->pd[p & 1];
+        const PanelDesc *pd = &num->pd[STM_PDI(p)];
         for (int cb = 0; cb < ncb; cb++)
             dev_update_block(F, s.ld, pd->pg1, pd->pt - pd->pg1, pd->pk1, pd->pnb, pd->pdiag, s_Tw, k2 + cb * BN,
                              min(BN, s.fn - (k2 + cb * BN)), dyn_lds);
@@ -1912,10 +1912,10 @@ __global__ __launch_bounds__(NTP) void k_panel(DevCtx c, const int *__restrict__
     if (p >= s.npanels || stm_use_ca(s, p, c.panel_algo, c.ca_min_rows)) return;      // (the Gram-based panel kernel takes those)
     FrontNum *num = &c.fnum[f];
     double *F = c.Farena + s.foff;
-    double *T = c.Tws + (long long)(2 * c.tslot[f] + (p & 1)) * STM_NB * STM_NB;
+    double *T = c.Tws + (long long)STM_TSLOT(c.tslot[f], p) * STM_NB * STM_NB;
     int *St = c.Stair + s.rp;
     double *Tkeep = c.Tall ? c.Tall + (long long)(s.tpan + p) * STM_NB * STM_NB : nullptr;
-    PanelDesc *pd = &num->pd[p & 1];
+    PanelDesc *pd = &num->pd[STM_PDI(p)];
     const int b = blockIdx.y;
     if ((c.dbg & 2048) && b == ((c.dbg >> 20) & 7)) {          // tests: column group (dbg >> 20) & 7 starts ~1 ms late
         for (int it = 0; it < 4000; it++) __builtin_amdgcn_s_sleep(100);
@@ -2009,11 +2009,11 @@ __global__ __launch_bounds__(NT) void k_update(DevCtx c, const int *__restrict__
     const int p = plist[blockIdx.y];
     const FrontSym s = c.fs[f];
     if (p >= s.npanels) return;
-    const PanelDesc *pd = &c.fnum[f].pd[p & 1];
+    const PanelDesc *pd = &c.fnum[f].pd[STM_PDI(p)];
     const int cbg = cb0 + (int)blockIdx.x * (1 + c.cbskip);
     const int c0 = pd->pc0 + cbg * BN;
     if (c0 >= s.fn) return;
-    double *Tw = c.Tws + (long long)(2 * c.tslot[f] + (p & 1)) * STM_NB * STM_NB;
+    double *Tw = c.Tws + (long long)STM_TSLOT(c.tslot[f], p) * STM_NB * STM_NB;
     if (pd->t_deferred) {
         // T was left to the update: every column-block workgroup builds it from its own Gram matrix; the first one
         // stores it (T slot of the plan, kept T of the Q-apply)
@@ -2037,7 +2037,7 @@ __global__ __launch_bounds__(NT) void k_update_n(DevCtx c, int f)
     const int c0 = pd->pc0 + (int)blockIdx.x * BN;
     if (c0 >= s.fn) return;
     dev_update_block<true>(c.Farena + s.foff, s.ld, pd->pg1, pd->pt - pd->pg1, pd->pk1, pd->pnb, pd->pdiag,
-                           c.Tws + (long long)(2 * c.tslot[f]) * STM_NB * STM_NB, c0, min(BN, s.fn - c0), dyn_lds);
+                           c.Tws + STM_TSLOT(c.tslot[f], 0) * STM_NB * STM_NB, c0, min(BN, s.fn - c0), dyn_lds);
 }
 
 // standalone T factor of the pending block reflector described by FrontNum (qr_larftb seam)
@@ -2058,7 +2058,7 @@ __global__ __launch_bounds__(NT) void k_larft(DevCtx c, int f)
     }
     __syncthreads();
     dev_gram_T<NT>(c.Farena + s.foff + (long long)num->pk1 * s.ld, s.ld, num->pg1, num->pt, num->pnb, s_diag, s_tau, s_G,
-               s_T, c.Tws + (long long)(2 * c.tslot[f]) * STM_NB * STM_NB, dyn_lds);
+               s_T, c.Tws + STM_TSLOT(c.tslot[f], 0) * STM_NB * STM_NB, dyn_lds);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -2079,7 +2079,7 @@ __global__ __launch_bounds__(NT) void k_upd_w(DevCtx c, const int *__restrict__ 
     const int fi = blockIdx.z, f = flist[fi], p = plist[fi];
     const FrontSym s = c.fs[f];
     if (p >= s.npanels) return;
-    const PanelDesc *pd = &c.fnum[f].pd[p & 1];
+    const PanelDesc *pd = &c.fnum[f].pd[STM_PDI(p)];
     const int g1 = pd->pg1, mp = pd->pt - pd->pg1, nbp = pd->pnb;
     const int cb = blockIdx.x, sl = blockIdx.y;
     // the front's slice of the workspace: (ncbf + 1) column-block slots of nslf slabs (both symbolic: the host sized it so)
@@ -2123,10 +2123,10 @@ __global__ __launch_bounds__(NT) void k_upd_w(DevCtx c, const int *__restrict__ 
         }
         __syncthreads();
     }
-    // (the Gram block's slot comes after the front's last column block; a pair-update front only ever brings column blocks 0 and 1
+    // (the Gram block's slot comes after the front's last column block; a pair / quad update front only ever brings column blocks 0 .. sweep-1
     //  here -- everything beyond goes through k_upd_w2, whose slots are packed more tightly: stm_pair_slots -- so its Gram block
     //  sits right behind those two)
-    const int gslot = (c.ypoff && c.ypoff[f] >= 0) ? min(ncbf, 2) : ncbf;
+    const int gslot = (c.ypoff && c.ypoff[f] >= 0) ? min(ncbf, c.sweep) : ncbf;
     double *W = Wp + wpoff[fi] + ((long long)(gram ? gslot : cb) * nslf + sl) * (STM_NB * BN);
     __shared__ int s_ticket;
     const int nsl = (mp + SLAB - 1) / SLAB;
@@ -2192,7 +2192,7 @@ __global__ __launch_bounds__(NT) void k_upd_w(DevCtx c, const int *__restrict__ 
         s_G[(e / BN) * WS + (e % BN)] = gsum;                  // G(row, col) = v_row' v_col
     }
     __syncthreads();
-    double *Tout = c.Tws + (long long)(2 * c.tslot[f] + (p & 1)) * STM_NB * STM_NB;
+    double *Tout = c.Tws + (long long)STM_TSLOT(c.tslot[f], p) * STM_NB * STM_NB;
     double *Tkeep = c.Tall ? c.Tall + (long long)(s.tpan + p) * STM_NB * STM_NB : nullptr;
     double (*s_Tb)[STM_NB + 1] = reinterpret_cast<double (*)[STM_NB + 1]>(Cs);            // (the C chunk image is free as well)
     dev_T_from_gram(reinterpret_cast<double (*)[STM_NB + 1]>(s_G), s_Tb, s_tau, nbp, threadIdx.x);
@@ -2212,7 +2212,7 @@ __global__ __launch_bounds__(NT) void k_upd_c(DevCtx c, const int *__restrict__ 
     const int fi = blockIdx.z, f = flist[fi], p = plist[fi];
     const FrontSym s = c.fs[f];
     if (p >= s.npanels) return;
-    const PanelDesc *pd = &c.fnum[f].pd[p & 1];
+    const PanelDesc *pd = &c.fnum[f].pd[STM_PDI(p)];
     const int g1 = pd->pg1, mp = pd->pt - pd->pg1, nbp = pd->pnb;
     const int cb = blockIdx.x, sl = blockIdx.y;
     const int nslf = stm_upd_nsl(s);
@@ -2242,7 +2242,7 @@ __global__ __launch_bounds__(NT) void k_upd_c(DevCtx c, const int *__restrict__ 
     // panel); W1 = the slabs' partials added in slab order by k_upd_w
     {
         const double *W0 = Wp + wpoff[fi] + ((long long)cb * nslf) * (STM_NB * BN);
-        const double *T = c.Tws + (long long)(2 * c.tslot[f] + (p & 1)) * STM_NB * STM_NB;
+        const double *T = c.Tws + (long long)STM_TSLOT(c.tslot[f], p) * STM_NB * STM_NB;
         for (int e = tid; e < STM_NB * BN; e += NT) {
             const double v = W0[e];                                 // (the slabs' partials were added by k_upd_w)
             s_W1[(e / BN) * WS + (e % BN)] = v;
@@ -2330,7 +2330,7 @@ __global__ __launch_bounds__(NT, 2) void k_upd_f(DevCtx c, const int *__restrict
     const FrontSym s = c.fs[f];
     if (p >= s.npanels) return;
     FrontNum *num = &c.fnum[f];
-    const PanelDesc *pd = &num->pd[p & 1];
+    const PanelDesc *pd = &num->pd[STM_PDI(p)];
     const int g1 = pd->pg1, mp = pd->pt - pd->pg1, nbp = pd->pnb;
     const int sl = blockIdx.x;
     const bool gram = with_gram && blockIdx.y == 0;
@@ -2373,14 +2373,14 @@ __global__ __launch_bounds__(NT, 2) void k_upd_f(DevCtx c, const int *__restrict
         }
     }
     const int nsl = (mp + SLAB - 1) / SLAB;
-    const int gslot = (c.ypoff && c.ypoff[f] >= 0) ? min(ncbf, 2) : ncbf;                         // (as in k_upd_w)
+    const int gslot = (c.ypoff && c.ypoff[f] >= 0) ? min(ncbf, c.sweep) : ncbf;                         // (as in k_upd_w)
     double *Wslot = Wp + wpoff[fi] + ((long long)(gram ? gslot : cb) * nslf) * (STM_NB * BN);     // slot 0 of the column block
     double *W = Wslot + (long long)sl * (STM_NB * BN);
 #pragma unroll
     for (int r = 0; r < 4; r++) st_agent(&W[(16 * mi + l4 + 4 * r) * BN + 16 * ni + l15], acc[r]);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    double *Tslot = c.Tws + (long long)(2 * c.tslot[f] + (p & 1)) * STM_NB * STM_NB;
+    double *Tslot = c.Tws + (long long)STM_TSLOT(c.tslot[f], p) * STM_NB * STM_NB;
     if (gram) {
         // ---- Gram block: the last slab to arrive builds T and raises tready (k_upd_w) ----
         if (tid == 0) {
@@ -2560,7 +2560,7 @@ __device__ __forceinline__ int stm_pair_spw(int nsl, int tune)
 struct PairGeom { int g1, mp, mp1, mp2, nb1, nb2, k1a, k1b, pc0; };
 __device__ __forceinline__ bool pair_geom(const FrontNum *num, int p, PairGeom &G)
 {
-    const PanelDesc *pa = &num->pd[(p - 1) & 1], *pb = &num->pd[p & 1];
+    const PanelDesc *pa = &num->pd[STM_PDI(p - 1)], *pb = &num->pd[STM_PDI(p)];
     G.nb1 = pa->pnb;
     if (G.nb1 <= 0) return false;                               // (panel a did nothing: then b did nothing either)
     G.nb2 = pb->pnb > 0 ? pb->pnb : 0;
@@ -2604,7 +2604,7 @@ __global__ __launch_bounds__(NT) void k_upd_w2(DevCtx c, const int *__restrict__
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, l15 = lane & 15, l4 = lane >> 4;
     // (the chunk images are read 16 bytes at a time: they start on a 16-byte boundary of the LDS, one spare double is allocated)
     double *Vs1 = dyn_lds + ((((unsigned)(uintptr_t)dyn_lds) >> 3) & 1), *Vs2 = Vs1 + STM_NB * VS2, *Cs = Vs2 + STM_NB * VS2;
-    const PanelDesc *pa = &num->pd[(p - 1) & 1], *pb = &num->pd[p & 1];
+    const PanelDesc *pa = &num->pd[STM_PDI(p - 1)], *pb = &num->pd[STM_PDI(p)];
     if (tid < STM_NB) {
         s_pd1[tid] = (tid < G.nb1) ? pa->pdiag[tid] : STM_BIGROW;
         s_pd2[tid] = (tid < G.nb2) ? pb->pdiag[tid] : STM_BIGROW;
@@ -2699,8 +2699,8 @@ __global__ __launch_bounds__(NT) void k_upd_y2(DevCtx c, const int *__restrict__
     const int nslp = stm_pair_slots(nslf, c.tune);
     double *W0 = Wp + wpoff[fi] + ((long long)cb * nslp) * (2 * STM_NB * BN);
     const double *Gr = Wp + wpoff[fi] + ((long long)ncbp * nslp) * (2 * STM_NB * BN) + STM_NB * BN;     // W2 part of the Gram block
-    const double *T1 = c.Tws + (long long)(2 * c.tslot[f] + ((p - 1) & 1)) * STM_NB * STM_NB;
-    const double *T2 = c.Tws + (long long)(2 * c.tslot[f] + (p & 1)) * STM_NB * STM_NB;
+    const double *T1 = c.Tws + (long long)STM_TSLOT(c.tslot[f], p - 1) * STM_NB * STM_NB;
+    const double *T2 = c.Tws + (long long)STM_TSLOT(c.tslot[f], p) * STM_NB * STM_NB;
     const bool has2 = G.nb2 > 0;
     for (int e = tid; e < STM_NB * BN; e += NT) {
         s_W1[(e / BN) * WS + (e % BN)] = W0[e];
@@ -2766,7 +2766,7 @@ __global__ __launch_bounds__(NT) void k_upd_c2(DevCtx c, const int *__restrict__
     const int nc = min(BN, s.fn - c0);
     const long long ld = s.ld;
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, l15 = lane & 15, l4 = lane >> 4;
-    const PanelDesc *pa = &num->pd[(p - 1) & 1], *pb = &num->pd[p & 1];
+    const PanelDesc *pa = &num->pd[STM_PDI(p - 1)], *pb = &num->pd[STM_PDI(p)];
     const double *Fb = c.Farena + s.foff + G.g1;
     const double *__restrict__ V1g = Fb + (long long)G.k1a * ld, *__restrict__ V2g = Fb + (long long)G.k1b * ld;
     double *__restrict__ Cg = c.Farena + s.foff + G.g1 + (long long)c0 * ld;
@@ -2792,11 +2792,13 @@ __global__ __launch_bounds__(NT) void k_upd_c2(DevCtx c, const int *__restrict__
         yn0[kk] = Yn[(4 * kk + l4) * BN + l15];
         yn1[kk] = Yn[(4 * kk + l4) * BN + 16 + l15];
     }
-    int dmax = -1;                                      // last row (relative to g1) that holds a unit diagonal; BIGROW: a dead reflector
-#pragma unroll 8
-    for (int q = 0; q < STM_NB; q++) {
-        dmax = max(dmax, (q < G.nb1) ? pa->pdiag[q] - G.g1 : STM_BIGROW);
-        dmax = max(dmax, (q < G.nb2) ? pb->pdiag[q] - G.g1 : STM_BIGROW);
+    // last row (relative to g1) that holds a unit diagonal; BIGROW: a dead reflector.  One load per lane and a wave reduction (round 4:
+    // it was a loop of 64 dependent loads in front of every workgroup's tiles)
+    int dmax;
+    {
+        const int q = lane & 31;
+        const int d = (lane < 32) ? ((q < G.nb1) ? pa->pdiag[q] - G.g1 : STM_BIGROW) : ((q < G.nb2) ? pb->pdiag[q] - G.g1 : STM_BIGROW);
+        dmax = wave_max_int(d);
     }
     const int rbeg = sl * SLAB, rend = min(G.mp, (sl + spw) * SLAB);
     const int ntile = (rend - rbeg + 15) >> 4;
@@ -2922,6 +2924,376 @@ __global__ __launch_bounds__(NT) void k_upd_c2(DevCtx c, const int *__restrict__
     for (; tix < ntile; tix += NW) general_tile(tix);
 }
 
+// ------------------------------------------------------------------------------------------------
+// Quad update (round 4, options.pair_update = 4): the block reflectors of FOUR consecutive panels q0 = p-3 .. q3 = p
+// (p = 3 mod 4) in ONE sweep over the columns beyond panel p+1.  The sweeps of a 27 000-row front are bound by what they
+// move per MFMA: a 16-row tile of k_upd_c2 brings 4 KB of C in, 4 KB out and 8 KB of V for 32 MFMAs; with four panels it is
+// the same C for 64 MFMAs (0.75 instead of 1.5 passes over the trailing columns per panel).
+//   k_upd_wq : partial W_i = V_i(slab)' C(slab), i = 1..4 (the same C: before any application); three more column blocks with
+//              C := V_1, V_2, V_3 give the Gram blocks G_ij = V_i'V_j (i > j)
+//   k_upd_yq : Y_i = T_i' (W_i - sum_{j<i} G_ij Y_j)   -- V_i' of C after the applications before it --, negated, to Ypend
+//   k_upd_cq : C(slab) -= sum_i V_i Y_i
+// Exactly H_3' H_2' H_1' H_0' C in exact arithmetic.  The columns of the next FOUR panels are updated panel by panel (column
+// blocks 0 .. 3-r after panel r of a quad).  Which fronts take it is symbolic (stmmqr_plan::pair_front), as for the pair.
+// ------------------------------------------------------------------------------------------------
+#define QP 4                       // panels per sweep
+#define QRB 32                     // rows per chunk of k_upd_wq (five chunk images: 46 KB of LDS, three workgroups per CU)
+#define VSQ (QRB + 4)              // column stride of the chunk images: 16-byte operand reads conflict free (as VS2)
+#define YSQ 48                     // row stride of -Y in k_upd_cq's LDS: the two 32-lane halves of an 8-byte read on disjoint banks
+struct QuadGeom { int g1, mp, pc0; int mpi[QP], nb[QP], k1[QP]; };
+// (entry i of a per-panel array for a run-time i: selects over constant indices, so that the arrays stay in registers)
+__device__ __forceinline__ int qsel(const int (&a)[QP], int i)
+{
+    int r = a[0];
+#pragma unroll
+    for (int q = 1; q < QP; q++) r = (i == q) ? a[q] : r;
+    return r;
+}
+__device__ __forceinline__ bool quad_geom(const FrontNum *num, int p, QuadGeom &G)
+{
+    const PanelDesc *p0 = &num->pd[STM_PDI(p - (QP - 1))];
+    if (p0->pnb <= 0) return false;                             // (the first panel did nothing: then none of them did)
+    G.g1 = p0->pg1;
+    G.pc0 = p0->pc0 + QP * STM_NB;                              // first column beyond panel p+1
+    G.mp = 0;
+#pragma unroll
+    for (int i = 0; i < QP; i++) {
+        const PanelDesc *pi = &num->pd[STM_PDI(p - (QP - 1) + i)];
+        const int nb = pi->pnb > 0 ? pi->pnb : 0;
+        G.nb[i] = nb;
+        G.mpi[i] = nb > 0 ? pi->pt - G.g1 : 0;
+        G.k1[i] = nb > 0 ? pi->pk1 : p0->pk1;
+        G.mp = max(G.mp, G.mpi[i]);
+    }
+    return G.mp > 0;
+}
+
+__global__ __launch_bounds__(NT) void k_upd_wq(DevCtx c, const int *__restrict__ flist, const int *__restrict__ plist, double *Wp,
+                                               const long long *__restrict__ wpoff, int *wcnt)
+{
+    extern __shared__ double dyn_lds[];
+    __shared__ int s_pd[QP][STM_NB];
+    __shared__ int s_ticket;
+    const int fi = blockIdx.z, f = flist[fi], p = plist[fi];
+    const FrontSym s = c.fs[f];
+    if (p >= s.npanels || (p & (QP - 1)) != QP - 1) return;
+    FrontNum *num = &c.fnum[f];
+    QuadGeom G;
+    if (!quad_geom(num, p, G)) return;
+    const int ncbp = stm_upd_ncb(s, p) - 1, nslf = stm_upd_nsl(s);   // sweep column blocks: beyond block 0 of panel p
+    if (ncbp <= 0) return;
+    const int cbx = blockIdx.x, sl = blockIdx.y;
+    const int gj = cbx - ncbp;                                       // >= 0: Gram block, C := V_gj
+    if (gj >= QP - 1) return;
+    const bool gram = gj >= 0;
+    if (gram && qsel(G.nb, gj + 1) <= 0) return;                     // (no panel behind it: nobody reads its products)
+    const int c0 = gram ? qsel(G.k1, gj) : G.pc0 + cbx * BN;
+    if (c0 >= s.fn || sl * SLAB >= G.mp) return;
+    const int nsl = (G.mp + SLAB - 1) / SLAB;
+    const int spw = stm_pair_spw(nsl, c.tune);
+    if (sl % spw) return;
+    const int nc = gram ? qsel(G.nb, gj) : min(BN, s.fn - c0);
+    const long long ld = s.ld;
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, l15 = lane & 15, l4 = lane >> 4;
+    // five chunk images (the V of the four panels and C) of 32 rows: 46 KB, three workgroups per CU.  (Measured against it: chunks of 64
+    // rows in two phases -- panels 0, 1 then 2, 3 against one C image, three images as k_upd_w2, 168 registers -- c5mid 607 -> 621 ms.)
+    double *Vs = dyn_lds + ((((unsigned)(uintptr_t)dyn_lds) >> 3) & 1), *Cs = Vs + QP * STM_NB * VSQ;
+    if (tid < STM_NB) {
+#pragma unroll
+        for (int i = 0; i < QP; i++) s_pd[i][tid] = (tid < G.nb[i]) ? num->pd[STM_PDI(p - (QP - 1) + i)].pdiag[tid] : STM_BIGROW;
+    }
+    __syncthreads();
+    const double *Fb = c.Farena + s.foff + G.g1;
+    const double *Cg = Fb + (long long)c0 * ld;
+    const int mi = wid >> 1, ni = wid & 1;
+    d4 acc[QP];
+#pragma unroll
+    for (int i = 0; i < QP; i++) acc[i] = (d4){0, 0, 0, 0};
+    const int rend = min(G.mp, (sl + spw) * SLAB);
+    const int lrow = tid & (QRB - 1), lcg = tid / QRB;              // staging: thread = (row of the chunk, group of 4 columns)
+    double cv[QP][4], cc[4];
+    auto chunk_load = [&](int i) {
+        const int ic = min(i, G.mp - 1);
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const int col = lcg * 4 + q;
+#pragma unroll
+            for (int pi = 0; pi < QP; pi++) cv[pi][q] = Fb[ic + (long long)(G.k1[pi] + min(col, max(G.nb[pi], 1) - 1)) * ld];
+            cc[q] = Cg[ic + (long long)min(col, nc - 1) * ld];
+        }
+    };
+    auto chunk_to_lds = [&](int i) {
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const int col = lcg * 4 + q;
+            double vg = 0.0;
+#pragma unroll
+            for (int pi = 0; pi < QP; pi++) {
+                const int d = s_pd[pi][col] - G.g1;                  // (BIGROW beyond nb: everything masked)
+                const double v = (i < G.mpi[pi] && col < G.nb[pi] && i >= d) ? ((i == d) ? 1.0 : cv[pi][q]) : 0.0;
+                Vs[(pi * STM_NB + col) * VSQ + lrow] = v;
+                vg = (pi == gj) ? v : vg;
+            }
+            Cs[col * VSQ + lrow] = gram ? vg : ((i < G.mp && col < nc) ? cc[q] : 0.0);
+        }
+    };
+    chunk_load(sl * SLAB + lrow);
+    const d2v *Ap = reinterpret_cast<const d2v *>(Vs + (16 * mi + l15) * VSQ + 2 * l4);
+    const d2v *Bp = reinterpret_cast<const d2v *>(Cs + (16 * ni + l15) * VSQ + 2 * l4);
+    for (int r0 = sl * SLAB; r0 < rend; r0 += QRB) {
+        chunk_to_lds(r0 + lrow);
+        __syncthreads();
+        if (r0 + QRB < rend) chunk_load(r0 + QRB + lrow);
+#pragma unroll
+        for (int kk = 0; kk < QRB / 8; kk++) {
+            const d2v b = Bp[4 * kk];
+#pragma unroll
+            for (int pi = 0; pi < QP; pi++) {
+                const d2v a = Ap[pi * (STM_NB * VSQ / 2) + 4 * kk];
+                acc[pi] = __builtin_amdgcn_mfma_f64_16x16x4f64(a.x, b.x, acc[pi], 0, 0, 0);
+                acc[pi] = __builtin_amdgcn_mfma_f64_16x16x4f64(a.y, b.y, acc[pi], 0, 0, 0);
+            }
+        }
+        __syncthreads();
+    }
+    // slot of (column block, slab group): QP blocks W_1 .. W_4; the Gram blocks are column blocks ncbp .. ncbp + 2
+    const int ngrp = (nsl + spw - 1) / spw;
+    double *W0 = Wp + wpoff[fi] + ((long long)cbx * stm_pair_slots(nslf, c.tune)) * (QP * STM_NB * BN);
+    double *W = W0 + (long long)(sl / spw) * (QP * STM_NB * BN);
+    if (ngrp == 1) {
+#pragma unroll
+        for (int pi = 0; pi < QP; pi++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) W[pi * STM_NB * BN + (16 * mi + l4 + 4 * r) * BN + 16 * ni + l15] = acc[pi][r];
+        return;
+    }
+#pragma unroll
+    for (int pi = 0; pi < QP; pi++)
+#pragma unroll
+        for (int r = 0; r < 4; r++) st_agent(&W[pi * STM_NB * BN + (16 * mi + l4 + 4 * r) * BN + 16 * ni + l15], acc[pi][r]);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    int *cnt = wcnt + wpoff[fi] / (STM_NB * BN) + cbx;
+    if (tid == 0) {
+        s_ticket = __hip_atomic_fetch_add(cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (s_ticket == ngrp - 1) {
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __hip_atomic_store(cnt, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+    __syncthreads();
+    if (s_ticket != ngrp - 1) return;
+    double v[QP * STM_NB * BN / NT];
+#pragma unroll
+    for (int q = 0; q < QP * STM_NB * BN / NT; q++) v[q] = stm_ordered_sum<true>(W0 + tid + q * NT, QP * STM_NB * BN, ngrp);   // fixed order
+#pragma unroll
+    for (int q = 0; q < QP * STM_NB * BN / NT; q++) W0[tid + q * NT] = v[q];
+}
+
+// -Y of a quad, once per column block (between k_upd_wq and k_upd_cq)
+__global__ __launch_bounds__(NT) void k_upd_yq(DevCtx c, const int *__restrict__ flist, const int *__restrict__ plist, double *Wp,
+                                               const long long *__restrict__ wpoff)
+{
+    extern __shared__ double dyn_lds[];
+    const int fi = blockIdx.y, f = flist[fi], p = plist[fi];
+    const FrontSym s = c.fs[f];
+    if (p >= s.npanels || (p & (QP - 1)) != QP - 1) return;
+    FrontNum *num = &c.fnum[f];
+    QuadGeom G;
+    if (!quad_geom(num, p, G)) return;
+    const int ncbp = stm_upd_ncb(s, p) - 1, nslf = stm_upd_nsl(s);
+    const int cb = blockIdx.x, tid = threadIdx.x;
+    if (cb >= ncbp || G.pc0 + cb * BN >= s.fn) return;
+    double *s_Y = dyn_lds, *s_Z = s_Y + QP * STM_NB * WS, *s_T = s_Z + STM_NB * WS, *s_G = s_T + STM_NB * WS;
+    const long long nslp = stm_pair_slots(nslf, c.tune);
+    const double *W0 = Wp + wpoff[fi] + ((long long)cb * nslp) * (QP * STM_NB * BN);
+    double *Yo = c.Ypend + c.ypoff[f] + (long long)((G.pc0 + cb * BN) >> 5) * (QP * STM_NB * BN);         // by absolute column block
+    const int l = tid & 31, cg = tid >> 5;
+#pragma unroll 1
+    for (int i = 0; i < QP; i++) {
+        double y[4] = {0, 0, 0, 0};
+        if (qsel(G.nb, i) > 0) {                                // (uniform)
+            double z[4];
+#pragma unroll
+            for (int x = 0; x < 4; x++) z[x] = W0[i * STM_NB * BN + l * BN + cg * 4 + x];
+#pragma unroll 1
+            for (int j = 0; j < i; j++) {                       // Z = W_i - sum_j G_ij Y_j  ( = V_i' of C after the applications 0 .. i-1 )
+                const double *Gr = Wp + wpoff[fi] + ((long long)(ncbp + j) * nslp) * (QP * STM_NB * BN) + i * STM_NB * BN;   // G_ij(a, b) = v_ia' v_jb
+                __syncthreads();
+                for (int e = tid; e < STM_NB * BN; e += NT) s_G[(e / BN) * WS + (e % BN)] = Gr[e];
+                __syncthreads();
+                const double *Yj = s_Y + j * STM_NB * WS;
+                for (int b = 0; b < STM_NB; b++) {
+                    const double gq = s_G[l * WS + b];
+#pragma unroll
+                    for (int x = 0; x < 4; x++) z[x] -= gq * Yj[b * WS + cg * 4 + x];
+                }
+            }
+            const double *T = c.Tws + STM_TSLOT(c.tslot[f], p - (QP - 1) + i) * STM_NB * STM_NB;
+            __syncthreads();
+#pragma unroll
+            for (int x = 0; x < 4; x++) s_Z[l * WS + cg * 4 + x] = z[x];
+            for (int e = tid; e < STM_NB * STM_NB; e += NT) s_T[(e / STM_NB) * WS + (e % STM_NB)] = T[e];     // s_T[col][row] = T(row, col)
+            __syncthreads();
+            for (int q = 0; q <= l; q++) {                      // Y_i = T_i' Z
+                const double tq = s_T[l * WS + q];
+#pragma unroll
+                for (int x = 0; x < 4; x++) y[x] += tq * s_Z[q * WS + cg * 4 + x];
+            }
+        }
+#pragma unroll
+        for (int x = 0; x < 4; x++) {
+            s_Y[i * STM_NB * WS + l * WS + cg * 4 + x] = y[x];
+            Yo[(i * STM_NB + l) * BN + cg * 4 + x] = -y[x];
+        }
+    }
+}
+
+__global__ __launch_bounds__(NT, 2) void k_upd_cq(DevCtx c, const int *__restrict__ flist, const int *__restrict__ plist)
+{
+    __shared__ double s_Y[QP * STM_NB * YSQ];
+    const int fi = blockIdx.z, f = flist[fi], p = plist[fi];
+    const FrontSym s = c.fs[f];
+    if (p >= s.npanels || (p & (QP - 1)) != QP - 1) return;
+    const FrontNum *num = &c.fnum[f];
+    QuadGeom G;
+    if (!quad_geom(num, p, G)) return;
+    const int ncbp = stm_upd_ncb(s, p) - 1;
+    const int cb = blockIdx.x, sl = blockIdx.y;
+    if (cb >= ncbp) return;
+    const int c0 = G.pc0 + cb * BN;
+    if (c0 >= s.fn || sl * SLAB >= G.mp) return;
+    const int nsl_all = (G.mp + SLAB - 1) / SLAB;
+    const int spw = stm_pair_spw(nsl_all, c.tune);
+    if (sl % spw) return;
+    const int nc = min(BN, s.fn - c0);
+    const long long ld = s.ld;
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, l15 = lane & 15, l4 = lane >> 4;
+    const double *__restrict__ Fb = c.Farena + s.foff + G.g1;
+    double *__restrict__ Cg = c.Farena + s.foff + G.g1 + (long long)c0 * ld;
+    const double *__restrict__ Yn = c.Ypend + c.ypoff[f] + (long long)(c0 >> 5) * (QP * STM_NB * BN);    // -Y, [128][32] (k_upd_yq)
+    // As k_upd_c2: no chunk images and no barriers in the loop -- D(col, row) = C(row, col) - sum_k Y(k, col) V(row, k), C the
+    // accumulator operand, V the B operand, both straight from global memory in whole 128-byte segments.  -Y is the A operand: 128 x 32
+    // here, kept in LDS (in registers it would leave one wave per SIMD; measured, timing only: 1.52 x the time of k_upd_c2 for twice its
+    // MFMAs in registers, 1.33 x from LDS at two waves).
+    for (int e = tid; e < QP * STM_NB * BN; e += NT) s_Y[(e >> 5) * YSQ + (e & 31)] = Yn[e];
+    int dmax = -1;                                      // last row (relative to g1) that holds a unit diagonal; BIGROW: a dead reflector
+    int rfull = G.mp;
+#pragma unroll
+    for (int i = 0; i < QP / 2; i++) {                  // (one load per lane and a wave reduction for two panels)
+        const int pi = 2 * i + (lane >> 5), q = lane & 31;
+        const int d = (q < qsel(G.nb, pi)) ? num->pd[STM_PDI(p - (QP - 1) + pi)].pdiag[q] - G.g1 : STM_BIGROW;
+        dmax = max(dmax, wave_max_int(d));
+    }
+#pragma unroll
+    for (int i = 0; i < QP; i++) rfull = min(rfull, G.mpi[i]);
+    __syncthreads();
+    const double *y0p = s_Y + l4 * YSQ + l15, *y1p = y0p + 16;
+    const int rbeg = sl * SLAB, rend = min(G.mp, (sl + spw) * SLAB);
+    const int ntile = (rend - rbeg + 15) >> 4;
+    rfull = min(rfull, rend);                           // rows below this are inside all four panels
+    // tiles [t_lo, t_hi) are interior (nothing if the column block is ragged, a panel is short of 32 columns or some reflector is dead)
+    int t_lo = (dmax >= STM_BIGROW || nc < BN) ? ntile : max(0, (dmax + 1 - rbeg + 15) >> 4);
+    int t_hi = (rfull - rbeg) >> 4;
+    if (t_lo > ntile) t_lo = ntile;
+    if (t_hi < t_lo) t_hi = t_lo;
+    // general form of one tile (masks, clamped loads, predicated stores)
+    auto general_tile = [&](int tix) {
+        const int i = rbeg + 16 * tix + l15;                                           // my row (relative to g1)
+        const int row = min(i, G.mp - 1);                                              // (clamped: masked afterwards)
+        d4 a0, a1;
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            a0[r] = Cg[row + (long long)min(l4 + 4 * r, nc - 1) * ld];
+            a1[r] = Cg[row + (long long)min(16 + l4 + 4 * r, nc - 1) * ld];
+        }
+#pragma unroll 1
+        for (int pi = 0; pi < QP; pi++) {
+            const PanelDesc *pp = &num->pd[STM_PDI(p - (QP - 1) + pi)];
+            const double *Vg = Fb + (long long)qsel(G.k1, pi) * ld;
+            const int nbi = qsel(G.nb, pi), mpi = qsel(G.mpi, pi);
+            double v[STM_NB / 4];
+#pragma unroll
+            for (int kk = 0; kk < STM_NB / 4; kk++) v[kk] = Vg[row + (long long)min(4 * kk + l4, max(nbi, 1) - 1) * ld];
+#pragma unroll
+            for (int kk = 0; kk < STM_NB / 4; kk++) {
+                const int col = 4 * kk + l4;
+                const int d = (col < nbi) ? pp->pdiag[col] - G.g1 : STM_BIGROW;
+                const double bv = (i < mpi && i >= d) ? ((i == d) ? 1.0 : v[kk]) : 0.0;
+                a0 = __builtin_amdgcn_mfma_f64_16x16x4f64(y0p[(pi * STM_NB + 4 * kk) * YSQ], bv, a0, 0, 0, 0);
+                a1 = __builtin_amdgcn_mfma_f64_16x16x4f64(y1p[(pi * STM_NB + 4 * kk) * YSQ], bv, a1, 0, 0, 0);
+            }
+        }
+        if (i < G.mp) {
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                if (l4 + 4 * r < nc) Cg[i + (long long)(l4 + 4 * r) * ld] = a0[r];
+                if (16 + l4 + 4 * r < nc) Cg[i + (long long)(16 + l4 + 4 * r) * ld] = a1[r];
+            }
+        }
+    };
+    int tix = wid;
+    for (; tix < t_lo; tix += NW) general_tile(tix);
+    if (tix < t_hi) {
+        // interior tiles (every panel of the quad has its 32 columns: they are the 128 consecutive columns from k1[0]), four per trip:
+        // C three tiles ahead, V one, counted waits, as k_upd_c2
+        const int nint = (t_hi - 1 - tix) / NW + 1, ntrip = nint >> 2;
+        if (ntrip > 0) {
+            const double *cp = Cg + (rbeg + 16 * tix + l15) + (long long)l4 * ld;
+            const double *vp = Fb + (long long)G.k1[0] * ld + (rbeg + 16 * tix + l15) + (long long)l4 * ld;
+            const long long ld4 = 4 * ld;
+            struct TC { double c0[4], c1[4]; };
+            struct TV { double v[QP * STM_NB / 4]; };
+            auto load_c = [&](TC &t, int off) {
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    t.c0[r] = cp[off + r * ld4];
+                    t.c1[r] = cp[off + (4 + r) * ld4];
+                }
+            };
+            auto load_v = [&](TV &t, int off) {
+#pragma unroll
+                for (int kk = 0; kk < QP * STM_NB / 4; kk++) t.v[kk] = vp[off + kk * ld4];
+            };
+            TC cb4[4];
+            TV vb2[2];
+            const int step = 16 * NW, offlast = step * (4 * ntrip - 1);
+            load_v(vb2[0], 0);
+            load_c(cb4[0], 0);
+            load_c(cb4[1], min(step, offlast));
+            load_c(cb4[2], min(2 * step, offlast));
+            for (int trip = 0; trip < ntrip; trip++) {
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    const int off = step * (4 * trip + q);
+                    load_v(vb2[(q + 1) & 1], min(off + step, offlast));
+                    load_c(cb4[(q + 3) & 3], min(off + 3 * step, offlast));
+                    __builtin_amdgcn_sched_barrier(0);
+                    const TC &tc = cb4[q];
+                    const TV &tv = vb2[q & 1];
+                    d4 a0 = {tc.c0[0], tc.c0[1], tc.c0[2], tc.c0[3]}, a1 = {tc.c1[0], tc.c1[1], tc.c1[2], tc.c1[3]};
+#pragma unroll
+                    for (int kk = 0; kk < QP * STM_NB / 4; kk++) {
+                        a0 = __builtin_amdgcn_mfma_f64_16x16x4f64(y0p[4 * YSQ * kk], tv.v[kk], a0, 0, 0, 0);
+                        a1 = __builtin_amdgcn_mfma_f64_16x16x4f64(y1p[4 * YSQ * kk], tv.v[kk], a1, 0, 0, 0);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                    double *sp = const_cast<double *>(cp) + off;
+#pragma unroll
+                    for (int r = 0; r < 4; r++) {
+                        sp[r * ld4] = a0[r];
+                        sp[(4 + r) * ld4] = a1[r];
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+            tix += 4 * ntrip * NW;
+        }
+    }
+    for (; tix < ntile; tix += NW) general_tile(tix);
+}
+
 // T of the LAST panel of a front whose panel kernel left it pending (PanelDesc::t_deferred == 2: the Gram-based panel never
 // builds T, and no trailing update follows the last panel).  Only the Q-apply on the resident factors reads it (DevCtx::Tall).
 __device__ void dev_tlast(const DevCtx &c, int f, const FrontSym &s, FrontNum *num, double *scratch)
@@ -2929,7 +3301,7 @@ __device__ void dev_tlast(const DevCtx &c, int f, const FrontSym &s, FrontNum *n
     __shared__ PanelShared ps;
     const int p = s.npanels - 1;
     if (p < 0) return;
-    const PanelDesc *pd = &num->pd[p & 1];
+    const PanelDesc *pd = &num->pd[STM_PDI(p)];
     if (pd->t_deferred != 2 || pd->pnb <= 0) return;
     const int tid = threadIdx.x;
     if (tid < STM_NB) {
@@ -2938,7 +3310,7 @@ __device__ void dev_tlast(const DevCtx &c, int f, const FrontSym &s, FrontNum *n
         ps.tau[tid] = (d != STM_BIGROW) ? c.Tau[s.rp + pd->pk1 + tid] : 0.0;
     }
     __syncthreads();
-    double *Tout = c.Tws + (long long)(2 * c.tslot[f] + (p & 1)) * STM_NB * STM_NB;
+    double *Tout = c.Tws + (long long)STM_TSLOT(c.tslot[f], p) * STM_NB * STM_NB;
     dev_gram_T<NT>(c.Farena + s.foff + (long long)pd->pk1 * s.ld, s.ld, pd->pg1, pd->pt, pd->pnb, ps.diag, ps.tau, ps.G, ps.T, Tout,
                    scratch);
     if (c.Tall) {
@@ -3969,6 +4341,16 @@ int stm_launch_update_pair(const DevCtx &c, const int *flist, const int *plist, 
     hipLaunchKernelGGL(k_upd_c2, dim3(ncbp, maxsl, nfr), dim3(NT), 0, st, c, flist, plist, (const double *)Wp, wpoff);
     return (int)hipGetLastError();
 }
+int stm_launch_update_quad(const DevCtx &c, const int *flist, const int *plist, int nfr, int ncbp, int maxsl, double *Wp,
+                           const long long *wpoff, int *wcnt, hipStream_t st)
+{
+    if (nfr <= 0 || ncbp <= 0 || maxsl <= 0) return 0;
+    hipLaunchKernelGGL(k_upd_wq, dim3(ncbp + QP - 1, maxsl, nfr), dim3(NT), (size_t)((QP + 1) * BN * VSQ + 2) * sizeof(double), st, c, flist,
+                       plist, Wp, wpoff, wcnt);
+    hipLaunchKernelGGL(k_upd_yq, dim3(ncbp, nfr), dim3(NT), (size_t)((QP + 3) * STM_NB * WS) * sizeof(double), st, c, flist, plist, Wp, wpoff);
+    hipLaunchKernelGGL(k_upd_cq, dim3(ncbp, maxsl, nfr), dim3(NT), 0, st, c, flist, plist);
+    return (int)hipGetLastError();
+}
 int stm_launch_update_notrans(const DevCtx &c, int f, int ncb, hipStream_t st)
 {
     if (ncb <= 0) return 0;
@@ -4112,6 +4494,7 @@ int stm_configure_kernels(void)
     CK(hipFuncSetAttribute((const void *)k_panel, hipFuncAttributeMaxDynamicSharedMemorySize, 131072));
     CK(hipFuncSetAttribute((const void *)k_update, hipFuncAttributeMaxDynamicSharedMemorySize, 65536));
     CK(hipFuncSetAttribute((const void *)k_update_n, hipFuncAttributeMaxDynamicSharedMemorySize, 65536));
+    CK(hipFuncSetAttribute((const void *)k_upd_yq, hipFuncAttributeMaxDynamicSharedMemorySize, 65536));
     CK(hipFuncSetAttribute((const void *)k_qapply, hipFuncAttributeMaxDynamicSharedMemorySize, 131072));
     CK(hipFuncSetAttribute((const void *)k_qapply_t, hipFuncAttributeMaxDynamicSharedMemorySize, 131072));
     CK(hipFuncSetAttribute((const void *)k_rsolve, hipFuncAttributeMaxDynamicSharedMemorySize, 131072));

@@ -76,7 +76,7 @@ struct OneFront {
         const long cn = n - s.fp, cm = std::min(m, cn);
         std::vector<int> zero1(1, 0);
         bool ok = d_F.up(Fd) && d_St.up(st32) && d_fs.up(&s, 1) && d_nm.up(&nm, 1) &&
-                  d_C.alloc((size_t)std::max(1L, cm * (cm + 1) / 2 + cm * (cn - cm))) && d_T.alloc(2 * STM_NB * STM_NB) && d_Gp.alloc((size_t)(stm_ca_slabs(s) + 1) * STM_NB * STM_NB) &&
+                  d_C.alloc((size_t)std::max(1L, cm * (cm + 1) / 2 + cm * (cn - cm))) && d_T.alloc((size_t)STM_PD_RING * STM_NB * STM_NB) && d_Gp.alloc((size_t)(stm_ca_slabs(s) + 1) * STM_NB * STM_NB) &&
                   d_Tau.alloc((size_t)std::max(1L, n)) && d_Rdead.alloc((size_t)std::max(1L, n)) && d_tslot.up(zero1) &&
                   d_flist.up(zero1) && d_Rhoff.alloc((size_t)std::max(1L, n)) && d_Rboff.alloc(1) &&
                   d_RH.alloc((size_t)std::max(1L, m * n));

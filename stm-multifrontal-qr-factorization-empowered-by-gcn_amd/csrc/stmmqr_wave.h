@@ -61,6 +61,14 @@ __device__ __forceinline__ double wave_sum_stride8(double v)
 __device__ __forceinline__ int red8_idx(int lane) { return ((lane >> 1) & 1) + 2 * (lane & 1) + 4 * ((lane >> 2) & 1); }
 __device__ __forceinline__ constexpr int red8_lane(int x) { return ((x >> 1) & 1) + 2 * (x & 1) + 4 * ((x >> 2) & 1); }
 
+// maximum of an int over the 64 lanes of the wave, in every lane
+__device__ __forceinline__ int wave_max_int(int v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = max(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
 __device__ __forceinline__ double wave_reduce8_partial(const double (&v)[8])
 {
     const int lane = threadIdx.x & 63;

@@ -165,18 +165,19 @@ def test_lookahead_events_without_system_fence_same_bits(pkg, monkeypatch, name)
 
 @pytest.mark.parametrize("name", NAMES)
 @pytest.mark.parametrize("bfc", [16, 64])
-def test_pair_update_everywhere(pkg, oracle, monkeypatch, name, bfc):
-    """options.pair_update: fronts of >= 16384 rows apply the block reflectors of two consecutive panels in one sweep
-    (k_upd_w2 / k_upd_y2 / k_upd_c2) on the columns beyond the next two panels.  STMMQR_PAIR_MIN=1 gives that path to every large
-    front with at least four panels (here: fn >= 16 / 64): integers, R rows and the factors against the golden vectors and
-    the oracle, exactly as for the one-panel-at-a-time update (different rounding, same tolerances)."""
+@pytest.mark.parametrize("mode", [1, 4])
+def test_pair_update_everywhere(pkg, oracle, monkeypatch, name, bfc, mode):
+    """options.pair_update: fronts of >= 16384 rows apply the block reflectors of two (mode 1: k_upd_w2 / k_upd_y2 / k_upd_c2) or four
+    (mode 4: k_upd_wq / k_upd_yq / k_upd_cq) consecutive panels in one sweep on the columns beyond the next panel.  STMMQR_PAIR_MIN=1
+    gives that path to every large front with at least four panels (here: fn >= 16 / 64): integers, R rows and the factors against the
+    golden vectors and the oracle, exactly as for the one-panel-at-a-time update (different rounding, same tolerances)."""
     g = load_golden(name)
     monkeypatch.setenv("STMMQR_PAIR_MIN", "1")
-    pkg.set_options(big_front_cols=bfc, pair_update=1)
+    pkg.set_options(big_front_cols=bfc, pair_update=mode)
     try:
         S, G = gpu_run(pkg, g)
     finally:
-        pkg.set_options(big_front_cols=64, pair_update=1)
+        pkg.set_options(big_front_cols=64, pair_update=4)
     N = numeric_from_gpu(S, G)
     compare_integers(S, N, g)
     assert G.stats["flops"] == scalar(g, "flopcount")

@@ -258,7 +258,7 @@ def test_shared_fronts_equal_unsharded(name, nranks, small, on_device):
         assert int((span > 1).sum()) >= 1
         out = _run_ranks(pkg, sh, sym, g, tol, ntol, nranks, owner, phase, span, on_device)
     finally:
-        pkg.set_options(pair_update=1, big_front_cols=64)
+        pkg.set_options(pair_update=4, big_front_cols=64)
     G = sh.merge_shards(sym, [o[1] for o in out], ntol)
     assert sum(o[0]["flops"] for o in out) == ref.stats["flops"]
     assert sum(o[0]["retries"] for o in out) == 0
@@ -289,7 +289,7 @@ def test_native_shared_front_loop_equals_unsharded(name, nranks, small):
         assert int((span > 1).sum()) >= 1
         out = _run_ranks(pkg, sh, sym, g, tol, ntol, nranks, owner, phase, span, True, native=True)
     finally:
-        pkg.set_options(pair_update=1, big_front_cols=64)
+        pkg.set_options(pair_update=4, big_front_cols=64)
     G = sh.merge_shards(sym, [o[1] for o in out], ntol)
     assert sum(o[0]["flops"] for o in out) == ref.stats["flops"]
     assert sum(o[0]["retries"] for o in out) == 0

@@ -237,6 +237,7 @@ def test_random_matrices_against_lapack():
 
 @pytest.mark.parametrize("name,opts,env", [
     ("pair update on every large front", dict(pair_update=1, big_front_cols=16), {"STMMQR_PAIR_MIN": "1"}),
+    ("quad update on every large front", dict(pair_update=4, big_front_cols=16), {"STMMQR_PAIR_MIN": "1"}),
     ("Gram-based panel everywhere", dict(panel_algo=2, big_front_cols=16), {}),
     ("look-ahead on every step", dict(), {"STMMQR_LA_MIN": "0", "STMMQR_LA_MIN_FUSED": "0"}),
 ])
