@@ -2549,6 +2549,7 @@ __device__ __forceinline__ void upd2_chunk_to_lds(const UpdChunk2 &ck, int i, in
 // the LDS rate with a 32-bank modulus: two-way conflicts on the 66-double stride (profiles/r03_a_*: 39 % of the LDS cycles)
 #define VS2 (RB + 4)
 typedef double d2v __attribute__((ext_vector_type(2)));
+typedef unsigned v4u __attribute__((ext_vector_type(4)));
 
 // slabs of 256 rows one workgroup of the pair kernels takes (the pair's rows in slabs -> 1, 2 or 4)
 __device__ __forceinline__ int stm_pair_spw(int nsl, int tune)
@@ -2940,6 +2941,13 @@ __global__ __launch_bounds__(NT) void k_upd_c2(DevCtx c, const int *__restrict__
 #define QRB 32                     // rows per chunk of k_upd_wq (five chunk images: 46 KB of LDS, three workgroups per CU)
 #define VSQ (QRB + 4)              // column stride of the chunk images: 16-byte operand reads conflict free (as VS2)
 #define YSQ 48                     // row stride of -Y in k_upd_cq's LDS: the two 32-lane halves of an 8-byte read on disjoint banks
+// slabs of 256 rows one workgroup of the quad kernels takes: as the pair's rule, and 8 from 64 slabs on (configs[4] stand-in, 203 slabs:
+// 3434 -> 3370 ms; c5mid, 106 slabs: +-0; 8 everywhere: c5mid 580 -> 596.  tune >> 8: another threshold, measurement sweeps)
+__device__ __forceinline__ int stm_quad_spw(int nsl, int tune)
+{
+    if (tune & 15) return 1 << ((tune & 15) - 1);
+    return (nsl >= ((tune >> 8) ? (tune >> 8) : 64)) ? 8 : stm_pair_spw(nsl, 0);
+}
 struct QuadGeom { int g1, mp, pc0; int mpi[QP], nb[QP], k1[QP]; };
 // (entry i of a per-panel array for a run-time i: selects over constant indices, so that the arrays stay in registers)
 __device__ __forceinline__ int qsel(const int (&a)[QP], int i)
@@ -2968,7 +2976,7 @@ __device__ __forceinline__ bool quad_geom(const FrontNum *num, int p, QuadGeom &
     return G.mp > 0;
 }
 
-__global__ __launch_bounds__(NT) void k_upd_wq(DevCtx c, const int *__restrict__ flist, const int *__restrict__ plist, double *Wp,
+__global__ __launch_bounds__(NT, 3) void k_upd_wq(DevCtx c, const int *__restrict__ flist, const int *__restrict__ plist, double *Wp,
                                                const long long *__restrict__ wpoff, int *wcnt)
 {
     extern __shared__ double dyn_lds[];
@@ -2990,7 +2998,7 @@ __global__ __launch_bounds__(NT) void k_upd_wq(DevCtx c, const int *__restrict__
     const int c0 = gram ? qsel(G.k1, gj) : G.pc0 + cbx * BN;
     if (c0 >= s.fn || sl * SLAB >= G.mp) return;
     const int nsl = (G.mp + SLAB - 1) / SLAB;
-    const int spw = stm_pair_spw(nsl, c.tune);
+    const int spw = stm_quad_spw(nsl, c.tune);
     if (sl % spw) return;
     const int nc = gram ? qsel(G.nb, gj) : min(BN, s.fn - c0);
     const long long ld = s.ld;
@@ -3165,7 +3173,7 @@ __global__ __launch_bounds__(NT, 2) void k_upd_cq(DevCtx c, const int *__restric
     const int c0 = G.pc0 + cb * BN;
     if (c0 >= s.fn || sl * SLAB >= G.mp) return;
     const int nsl_all = (G.mp + SLAB - 1) / SLAB;
-    const int spw = stm_pair_spw(nsl_all, c.tune);
+    const int spw = stm_quad_spw(nsl_all, c.tune);
     if (sl % spw) return;
     const int nc = min(BN, s.fn - c0);
     const long long ld = s.ld;
@@ -3198,6 +3206,8 @@ __global__ __launch_bounds__(NT, 2) void k_upd_cq(DevCtx c, const int *__restric
     int t_hi = (rfull - rbeg) >> 4;
     if (t_lo > ntile) t_lo = ntile;
     if (t_hi < t_lo) t_hi = t_lo;
+    t_lo = __builtin_amdgcn_readfirstlane(t_lo);        // (uniform in fact; dmax came through a wave reduction)
+    t_hi = __builtin_amdgcn_readfirstlane(t_hi);
     // general form of one tile (masks, clamped loads, predicated stores)
     auto general_tile = [&](int tix) {
         const int i = rbeg + 16 * tix + l15;                                           // my row (relative to g1)
@@ -3233,65 +3243,102 @@ __global__ __launch_bounds__(NT, 2) void k_upd_cq(DevCtx c, const int *__restric
             }
         }
     };
-    int tix = wid;
-    for (; tix < t_lo; tix += NW) general_tile(tix);
-    if (tix < t_hi) {
-        // interior tiles (every panel of the quad has its 32 columns: they are the 128 consecutive columns from k1[0]), four per trip:
-        // C three tiles ahead, V one, counted waits, as k_upd_c2
-        const int nint = (t_hi - 1 - tix) / NW + 1, ntrip = nint >> 2;
+    for (int tix = wid; tix < t_lo; tix += NW) general_tile(tix);
+    // Interior rows in SUPER tiles of 32 rows: lane l15 takes the rows 2 l15 and 2 l15 + 1, so that every load and store of the loop is a
+    // 16-byte access (half the vector-memory instructions for the same bytes: the texture-address path was 71 % busy in k_upd_c2) -- the
+    // even rows are one MFMA tile, the odd rows another, both fed from the same registers.  V comes in two halves (panels 0, 1 and
+    // panels 2, 3 of the quad: 64 registers each), each requested again as soon as its MFMAs are issued; C one super tile ahead; two super
+    // tiles per trip, counted waits.  Requests beyond the wave's last super tile are clamped to it (loaded again, never used).
+    const int ns = (t_hi - t_lo) >> 1;                  // interior super tiles of the workgroup
+    int sdone = 0;                                      // ... of this wave that the pipeline took
+    if (ns > wid) {
+        const int nmine = __builtin_amdgcn_readfirstlane((ns - 1 - wid) / NW + 1), ntrip = nmine >> 1;
         if (ntrip > 0) {
-            const double *cp = Cg + (rbeg + 16 * tix + l15) + (long long)l4 * ld;
-            const double *vp = Fb + (long long)G.k1[0] * ld + (rbeg + 16 * tix + l15) + (long long)l4 * ld;
-            const long long ld4 = 4 * ld;
-            struct TC { double c0[4], c1[4]; };
-            struct TV { double v[QP * STM_NB / 4]; };
+            // Buffer addressing: one resource descriptor per operand (base: this wave's first interior row of C's / V's first column),
+            // ONE 32-bit lane offset for every request, the column and tile offsets scalar -- with 64-bit lane addresses the 40 address
+            // pairs of a super tile do not fit beside the V halves and the C images (spills inside the loop; scratch reloads share the
+            // memory counter).  Everything that feeds a scalar offset is made uniform for the compiler (readfirstlane), see DESIGN.md.
+            const int widu = __builtin_amdgcn_readfirstlane(wid);
+            const long long r0u = rbeg + 16 * t_lo + 32 * widu;
+            const __amdgpu_buffer_rsrc_t rc = __builtin_amdgcn_make_buffer_rsrc((void *)(Cg + r0u), 0, 0x7fffffff, 0x00020000);
+            const __amdgpu_buffer_rsrc_t rv =
+                __builtin_amdgcn_make_buffer_rsrc((void *)const_cast<double *>(Fb + (long long)G.k1[0] * ld + r0u), 0, 0x7fffffff, 0x00020000);
+            const int voff = (int)((2 * l15 + (long long)l4 * ld) * 8);
+            const int ld4b = (int)(4 * ld * 8);                  // bytes between columns c and c + 4 (ld <= 2^26)
+            struct TC { d2v c0[4], c1[4]; };
+            struct TVh { d2v v[QP * STM_NB / 8]; };
             auto load_c = [&](TC &t, int off) {
 #pragma unroll
                 for (int r = 0; r < 4; r++) {
-                    t.c0[r] = cp[off + r * ld4];
-                    t.c1[r] = cp[off + (4 + r) * ld4];
+                    t.c0[r] = __builtin_bit_cast(d2v, __builtin_amdgcn_raw_buffer_load_b128(rc, voff, off * 8 + r * ld4b, 0));
+                    t.c1[r] = __builtin_bit_cast(d2v, __builtin_amdgcn_raw_buffer_load_b128(rc, voff, off * 8 + (4 + r) * ld4b, 0));
                 }
             };
-            auto load_v = [&](TV &t, int off) {
+            auto load_vh = [&](TVh &t, int off, int h) {
 #pragma unroll
-                for (int kk = 0; kk < QP * STM_NB / 4; kk++) t.v[kk] = vp[off + kk * ld4];
+                for (int kk = 0; kk < QP * STM_NB / 8; kk++)
+                    t.v[kk] = __builtin_bit_cast(d2v, __builtin_amdgcn_raw_buffer_load_b128(rv, voff, off * 8 + (h * (QP * STM_NB / 8) + kk) * ld4b, 0));
             };
-            TC cb4[4];
-            TV vb2[2];
-            const int step = 16 * NW, offlast = step * (4 * ntrip - 1);
-            load_v(vb2[0], 0);
-            load_c(cb4[0], 0);
-            load_c(cb4[1], min(step, offlast));
-            load_c(cb4[2], min(2 * step, offlast));
+            TC cb2[2];
+            TVh va, vb;
+            const int step = 32 * NW, offlast = step * (2 * ntrip - 1);
+            load_c(cb2[0], 0);                                   // (in the order of a step -- the scheduler would move C behind V --:
+            __builtin_amdgcn_sched_barrier(0);                   //  the counted waits of the loop's first pass are then those of
+            load_vh(va, 0, 0);                                   //  every other; the loop header takes the weaker of both)
+            __builtin_amdgcn_sched_barrier(0);
+            load_vh(vb, 0, 1);
+            __builtin_amdgcn_sched_barrier(0);
             for (int trip = 0; trip < ntrip; trip++) {
 #pragma unroll
-                for (int q = 0; q < 4; q++) {
-                    const int off = step * (4 * trip + q);
-                    load_v(vb2[(q + 1) & 1], min(off + step, offlast));
-                    load_c(cb4[(q + 3) & 3], min(off + 3 * step, offlast));
+                for (int q = 0; q < 2; q++) {
+                    const int off = step * (2 * trip + q), offn = min(off + step, offlast);
+                    load_c(cb2[q ^ 1], offn);
                     __builtin_amdgcn_sched_barrier(0);
-                    const TC &tc = cb4[q];
-                    const TV &tv = vb2[q & 1];
-                    d4 a0 = {tc.c0[0], tc.c0[1], tc.c0[2], tc.c0[3]}, a1 = {tc.c1[0], tc.c1[1], tc.c1[2], tc.c1[3]};
+                    const TC &tc = cb2[q];
+                    d4 a0e = {tc.c0[0].x, tc.c0[1].x, tc.c0[2].x, tc.c0[3].x}, a0o = {tc.c0[0].y, tc.c0[1].y, tc.c0[2].y, tc.c0[3].y};
+                    d4 a1e = {tc.c1[0].x, tc.c1[1].x, tc.c1[2].x, tc.c1[3].x}, a1o = {tc.c1[0].y, tc.c1[1].y, tc.c1[2].y, tc.c1[3].y};
 #pragma unroll
-                    for (int kk = 0; kk < QP * STM_NB / 4; kk++) {
-                        a0 = __builtin_amdgcn_mfma_f64_16x16x4f64(y0p[4 * YSQ * kk], tv.v[kk], a0, 0, 0, 0);
-                        a1 = __builtin_amdgcn_mfma_f64_16x16x4f64(y1p[4 * YSQ * kk], tv.v[kk], a1, 0, 0, 0);
+                    for (int kk = 0; kk < QP * STM_NB / 8; kk++) {
+                        const double y0 = y0p[4 * YSQ * kk], y1 = y1p[4 * YSQ * kk];
+                        a0e = __builtin_amdgcn_mfma_f64_16x16x4f64(y0, va.v[kk].x, a0e, 0, 0, 0);
+                        a1e = __builtin_amdgcn_mfma_f64_16x16x4f64(y1, va.v[kk].x, a1e, 0, 0, 0);
+                        a0o = __builtin_amdgcn_mfma_f64_16x16x4f64(y0, va.v[kk].y, a0o, 0, 0, 0);
+                        a1o = __builtin_amdgcn_mfma_f64_16x16x4f64(y1, va.v[kk].y, a1o, 0, 0, 0);
+                        if ((kk & 3) == 3) __builtin_amdgcn_sched_barrier(0);          // (keeps the -Y operands of at most four steps in registers)
                     }
                     __builtin_amdgcn_sched_barrier(0);
-                    double *sp = const_cast<double *>(cp) + off;
+                    load_vh(va, offn, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int kk = 0; kk < QP * STM_NB / 8; kk++) {
+                        const double y0 = y0p[4 * YSQ * (QP * STM_NB / 8 + kk)], y1 = y1p[4 * YSQ * (QP * STM_NB / 8 + kk)];
+                        a0e = __builtin_amdgcn_mfma_f64_16x16x4f64(y0, vb.v[kk].x, a0e, 0, 0, 0);
+                        a1e = __builtin_amdgcn_mfma_f64_16x16x4f64(y1, vb.v[kk].x, a1e, 0, 0, 0);
+                        a0o = __builtin_amdgcn_mfma_f64_16x16x4f64(y0, vb.v[kk].y, a0o, 0, 0, 0);
+                        a1o = __builtin_amdgcn_mfma_f64_16x16x4f64(y1, vb.v[kk].y, a1o, 0, 0, 0);
+                        if ((kk & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                    load_vh(vb, offn, 1);
 #pragma unroll
                     for (int r = 0; r < 4; r++) {
-                        sp[r * ld4] = a0[r];
-                        sp[(4 + r) * ld4] = a1[r];
+                        const double e0 = a0e[r], o0 = a0o[r], e1 = a1e[r], o1 = a1o[r];       // (scalars first: DESIGN.md, compiler findings)
+                        const d2v t0 = {e0, o0}, t1 = {e1, o1};
+                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u, t0), rc, voff, off * 8 + r * ld4b, 0);
+                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u, t1), rc, voff, off * 8 + (4 + r) * ld4b, 0);
                     }
                     __builtin_amdgcn_sched_barrier(0);
                 }
             }
-            tix += 4 * ntrip * NW;
+            sdone = 2 * ntrip;
+        }
+        // this wave's super tiles that the pipeline did not take (at most one): as two tiles of the general form
+        for (int q = sdone; q < nmine; q++) {
+            general_tile(t_lo + 2 * (wid + q * NW));
+            general_tile(t_lo + 2 * (wid + q * NW) + 1);
         }
     }
-    for (; tix < ntile; tix += NW) general_tile(tix);
+    for (int tix = t_lo + 2 * ns + wid; tix < ntile; tix += NW) general_tile(tix);
 }
 
 // T of the LAST panel of a front whose panel kernel left it pending (PanelDesc::t_deferred == 2: the Gram-based panel never
