@@ -579,9 +579,10 @@ def _run(args, torch, rank, world, local, guard):
         panel_flops = max(flops - det["flops_update"], 0.0)
         panel_tf = panel_flops / ms_panel * 1e-9
         upd_tf = det["flops_update"] / ms_upd * 1e-9
-        # (fronts with the pair update sweep the trailing columns once per TWO panels: 12 B per (row, col) and panel there --
-        #  the bytes of THIS implementation, not the 24 of a panel-by-panel update)
-        upd_bytes = ((det["flops_update"] - det["flops_update_pair"]) * 24.0 + det["flops_update_pair"] * 12.0) / (4.0 * 32.0)
+        # (fronts with the pair / quad update sweep the trailing columns once per TWO / FOUR panels: 12 / 6 B per (row, col) and panel
+        #  there -- the bytes of THIS implementation, not the 24 of a panel-by-panel update)
+        sweep_bytes = 6.0 if pkg.get_options()["pair_update"] == 4 else 12.0
+        upd_bytes = ((det["flops_update"] - det["flops_update_pair"]) * 24.0 + det["flops_update_pair"] * sweep_bytes) / (4.0 * 32.0)
         upd_gbs = upd_bytes / ms_upd * 1e-6
         pmc, pmc_file = {}, None
         for cand in sorted((ROOT / "profiles").glob(f"r*_{name}_pmc_fetch_write_per_kernel.json")) or \
@@ -609,11 +610,11 @@ def _run(args, torch, rank, world, local, guard):
                      "ms": ms_panel, "launch_groups": det["npanel_launch"], "avg_us_per_step": ms_panel / npl * 1e3,
                      "traffic": pmc_traffic(["k_panel", "k_panel_ca"]),
                      "note": "latency-bound: a serial chain of Householder columns (DESIGN.md 4-5)"}
-        upd_obj = {"bound": "hbm", "kernel": "k_upd_w + k_upd_c / k_update / k_upd_w2 + k_upd_c2 (dlarfb on v_mfma_f64_16x16x4_f64)", "achieved": upd_gbs,
+        upd_obj = {"bound": "hbm", "kernel": "k_upd_w + k_upd_c / k_update / k_upd_wq + k_upd_cq (dlarfb on v_mfma_f64_16x16x4_f64)", "achieved": upd_gbs,
                    "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": upd_gbs / PEAK_HBM_GBS, "ms": ms_upd,
                    "launch_groups": det["nupdate_launch"], "avg_us_per_step": ms_upd / nul * 1e3,
                    "mfma_tflops": upd_tf, "mfma_frac": upd_tf / PEAK_FP64_MFMA_TFLOPS,
-                   "traffic": pmc_traffic(["k_upd_w", "k_upd_c", "k_update", "k_upd_w2", "k_upd_c2"])}
+                   "traffic": pmc_traffic(["k_upd_w", "k_upd_c", "k_update", "k_upd_w2", "k_upd_c2", "k_upd_wq", "k_upd_cq"])}
         roof = dict(panel_obj if ms_panel >= ms_upd else upd_obj)
         roof["dominant_by"] = "HIP-event pairs around every launch of the family, no syncs in between (detail pass)"
         roof["panel_kernels"] = panel_obj

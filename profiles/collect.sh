@@ -35,4 +35,7 @@ if [ "$WHAT" = bench ] || [ "$WHAT" = all ]; then
   python3 $ROOT/bench.py --workload c5mid_standin --steps 3 --warmup 1 --no-cpu > $OUT/${TAG}_bench_c5mid_standin.json 2> $OUT/${TAG}_bench_c5mid_standin.err
   tail -c 400 $OUT/${TAG}_bench_c5mid_standin.json; echo
   python3 $ROOT/bench.py --workload micro --steps 3 --warmup 1 > $OUT/${TAG}_bench_micro.json 2> $OUT/${TAG}_bench_micro.err
+  # configs[4] at full size (52 022 columns): ~3 s per factorization
+  python3 $ROOT/bench.py --workload c5_standin --steps 2 --warmup 1 --no-cpu > $OUT/${TAG}_bench_c5_standin.json 2> $OUT/${TAG}_bench_c5_standin.err
+  tail -c 400 $OUT/${TAG}_bench_c5_standin.json; echo
 fi
