@@ -139,6 +139,13 @@ static inline __host__ __device__ int stm_pair_slots(int nslf, int tune)
     if (tune & 15) return nslf;
     return nslf < 16 ? nslf : (nslf + 3) / 4 > 16 ? (nslf + 3) / 4 : 16;
 }
+// quad update: a workgroup takes up to 8 slabs (stm_quad_spw: 8 from 64 slabs on, else the pair's rule), so at most this many partials
+static inline __host__ __device__ int stm_quad_slots(int nslf, int tune)
+{
+    if (tune & 15) return nslf;
+    if (tune >> 8) return stm_pair_slots(nslf, 0);               // (another 8-slab threshold, measurement sweeps: the pair's stride covers it)
+    return nslf < 16 ? nslf : (nslf + 7) / 8 > 16 ? (nslf + 7) / 8 : 16;
+}
 #define STM_PAIR_MIN_ROWS 16384  // fronts with at least this many (estimated) rows take the pair update (stmmqr_options::pair_update);
                                  // measured: 27 000 rows -12 %, 7818 rows +17 % (and no look-ahead for pair steps)
 

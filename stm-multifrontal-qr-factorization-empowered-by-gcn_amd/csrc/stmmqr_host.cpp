@@ -772,7 +772,8 @@ void build_schedule(stmmqr_plan &P, std::vector<int> &tslot)
                 //  columns use the first 2 + 1 column blocks with the full slab count)
                 //  (quad update: four blocks per partial, three Gram blocks, 4 + 1 column blocks in the panel-by-panel updates)
                 if (is_pair(f))
-                    wp += std::max((long long)(ncb + P.sweep - 1) * stm_pair_slots(nsl, P.tune) * (P.sweep * STM_NB * 32),
+                    wp += std::max((long long)(ncb + P.sweep - 1) * (P.sweep == 4 ? stm_quad_slots(nsl, P.tune) : stm_pair_slots(nsl, P.tune)) *
+                                       (P.sweep * STM_NB * 32),
                                    (P.sweep + 1LL) * nsl * (STM_NB * 32));
                 else
                     wp += (long long)(ncb + 1) * nsl * (STM_NB * 32);

@@ -3066,7 +3066,7 @@ __global__ __launch_bounds__(NT, 3) void k_upd_wq(DevCtx c, const int *__restric
     }
     // slot of (column block, slab group): QP blocks W_1 .. W_4; the Gram blocks are column blocks ncbp .. ncbp + 2
     const int ngrp = (nsl + spw - 1) / spw;
-    double *W0 = Wp + wpoff[fi] + ((long long)cbx * stm_pair_slots(nslf, c.tune)) * (QP * STM_NB * BN);
+    double *W0 = Wp + wpoff[fi] + ((long long)cbx * stm_quad_slots(nslf, c.tune)) * (QP * STM_NB * BN);
     double *W = W0 + (long long)(sl / spw) * (QP * STM_NB * BN);
     if (ngrp == 1) {
 #pragma unroll
@@ -3114,7 +3114,7 @@ __global__ __launch_bounds__(NT) void k_upd_yq(DevCtx c, const int *__restrict__
     const int cb = blockIdx.x, tid = threadIdx.x;
     if (cb >= ncbp || G.pc0 + cb * BN >= s.fn) return;
     double *s_Y = dyn_lds, *s_Z = s_Y + QP * STM_NB * WS, *s_T = s_Z + STM_NB * WS, *s_G = s_T + STM_NB * WS;
-    const long long nslp = stm_pair_slots(nslf, c.tune);
+    const long long nslp = stm_quad_slots(nslf, c.tune);
     const double *W0 = Wp + wpoff[fi] + ((long long)cb * nslp) * (QP * STM_NB * BN);
     double *Yo = c.Ypend + c.ypoff[f] + (long long)((G.pc0 + cb * BN) >> 5) * (QP * STM_NB * BN);         // by absolute column block
     const int l = tid & 31, cg = tid >> 5;
