@@ -3249,7 +3249,9 @@ __global__ __launch_bounds__(NT, 2) void k_upd_cq(DevCtx c, const int *__restric
     // even rows are one MFMA tile, the odd rows another, both fed from the same registers.  V comes in two halves (panels 0, 1 and
     // panels 2, 3 of the quad: 64 registers each), each requested again as soon as its MFMAs are issued; C one super tile ahead; two super
     // tiles per trip, counted waits.  Requests beyond the wave's last super tile are clamped to it (loaded again, never used).
-    const int ns = (t_hi - t_lo) >> 1;                  // interior super tiles of the workgroup
+    // (the buffer requests address 128 columns from one base with 32-bit offsets: fronts of more than 2^21 rows take the general tiles)
+    const bool buf_ok = ld * (long long)(QP * STM_NB * sizeof(double)) < (1LL << 31) - (1 << 20);
+    const int ns = buf_ok ? (t_hi - t_lo) >> 1 : 0;     // interior super tiles of the workgroup
     int sdone = 0;                                      // ... of this wave that the pipeline took
     if (ns > wid) {
         const int nmine = __builtin_amdgcn_readfirstlane((ns - 1 - wid) / NW + 1), ntrip = nmine >> 1;
