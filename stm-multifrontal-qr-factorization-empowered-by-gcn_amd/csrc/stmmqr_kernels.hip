@@ -3006,11 +3006,20 @@ __global__ __launch_bounds__(NT, 3) void k_upd_wq(DevCtx c, const int *__restric
     // five chunk images (the V of the four panels and C) of 32 rows: 46 KB, three workgroups per CU.  (Measured against it: chunks of 64
     // rows in two phases -- panels 0, 1 then 2, 3 against one C image, three images as k_upd_w2, 168 registers -- c5mid 607 -> 621 ms.)
     double *Vs = dyn_lds + ((((unsigned)(uintptr_t)dyn_lds) >> 3) & 1), *Cs = Vs + QP * STM_NB * VSQ;
-    if (tid < STM_NB) {
-#pragma unroll
-        for (int i = 0; i < QP; i++) s_pd[i][tid] = (tid < G.nb[i]) ? num->pd[STM_PDI(p - (QP - 1) + i)].pdiag[tid] : STM_BIGROW;
+    __shared__ int s_dm[2];
+    if (tid < 2 * 64) {                                              // (the four panels' diagonals; their maximum: BIGROW if any is missing)
+        const int i = tid >> 5, q = tid & 31;
+        const int d = (q < qsel(G.nb, i)) ? num->pd[STM_PDI(p - (QP - 1) + i)].pdiag[q] : STM_BIGROW;
+        s_pd[i][q] = d;
+        const int dm = wave_max_int(d);
+        if (lane == 0) s_dm[wid] = dm;
     }
     __syncthreads();
+    // chunks below every unit diagonal, inside all four panels' rows, with full column blocks need no masks (all but the first 128 rows and
+    // the last rows of a quad): their staging is a plain copy -- the masks are ~8 VALU instructions per element, 160 per thread and chunk
+    const int dmax = max(s_dm[0], s_dm[1]);
+    const int rfull = min(min(G.mpi[0], G.mpi[1]), min(G.mpi[2], G.mpi[3]));
+    const bool plain_ok = dmax < STM_BIGROW && nc == BN;
     const double *Fb = c.Farena + s.foff + G.g1;
     const double *Cg = Fb + (long long)c0 * ld;
     const int mi = wid >> 1, ni = wid & 1;
@@ -3031,6 +3040,17 @@ __global__ __launch_bounds__(NT, 3) void k_upd_wq(DevCtx c, const int *__restric
         }
     };
     auto chunk_to_lds = [&](int i) {
+        const int r0c = i - lrow;                                    // first row of the chunk (uniform)
+        if (plain_ok && r0c > dmax - G.g1 && r0c + QRB <= rfull) {
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const int col = lcg * 4 + q;
+#pragma unroll
+                for (int pi = 0; pi < QP; pi++) Vs[(pi * STM_NB + col) * VSQ + lrow] = cv[pi][q];
+                Cs[col * VSQ + lrow] = cc[q];                        // (a Gram block's C columns ARE V_gj's: loaded from the same place)
+            }
+            return;
+        }
 #pragma unroll
         for (int q = 0; q < 4; q++) {
             const int col = lcg * 4 + q;
