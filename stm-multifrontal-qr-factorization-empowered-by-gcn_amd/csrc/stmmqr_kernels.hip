@@ -267,8 +267,17 @@ __device__ __forceinline__ void upd_chunk_load(UpdChunk &ck, const double *Vg, c
     }
 }
 __device__ __forceinline__ void upd_chunk_to_lds(const UpdChunk &ck, int i, int mp, int nbp, int nc, const int *s_pd, int g1,
-                                                 int lrow, int lcg, double *Vs, double *Cs, bool c_is_v = false)
+                                                 int lrow, int lcg, double *Vs, double *Cs, bool c_is_v = false, bool plain = false)
 {
+    if (plain) {                                               // (uniform: a chunk below every unit diagonal, inside the panel's rows,
+#pragma unroll                                                 //  full blocks -- nothing to mask: the same values by a plain copy)
+        for (int q = 0; q < 8; q++) {
+            const int col = lcg * 8 + q;
+            Vs[col * VS + lrow] = ck.v[q];
+            Cs[col * VS + lrow] = c_is_v ? ck.v[q] : ck.c[q];
+        }
+        return;
+    }
 #pragma unroll
     for (int q = 0; q < 8; q++) {
         const int col = lcg * 8 + q;
@@ -280,14 +289,25 @@ __device__ __forceinline__ void upd_chunk_to_lds(const UpdChunk &ck, int i, int 
 }
 
 __device__ __forceinline__ void upd_chunk_v_to_lds(const UpdChunk &ck, int i, int mp, int nbp, const int *s_pd, int g1, int lrow,
-                                                   int lcg, double *Vs)
+                                                   int lcg, double *Vs, bool plain = false)
 {
+    if (plain) {
+#pragma unroll
+        for (int q = 0; q < 8; q++) Vs[(lcg * 8 + q) * VS + lrow] = ck.v[q];
+        return;
+    }
 #pragma unroll
     for (int q = 0; q < 8; q++) {
         const int col = lcg * 8 + q;
         const int d = s_pd[col] - g1;
         Vs[col * VS + lrow] = (i < mp && col < nbp && i >= d) ? ((i == d) ? 1.0 : ck.v[q]) : 0.0;
     }
+}
+// last row (relative to g1) below which a chunk of a full panel needs no masks; BIGROW: never (a dead reflector, a short panel)
+__device__ __forceinline__ int upd_plain_from(const int *s_pd, int g1, int lane)
+{
+    const int dm = wave_max_int(lane < STM_NB ? s_pd[lane] : -1);
+    return dm >= STM_BIGROW ? STM_BIGROW : dm - g1;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -2111,8 +2131,9 @@ __global__ __launch_bounds__(NT) void k_upd_w(DevCtx c, const int *__restrict__ 
     const int rend = min(mp, (sl + 1) * SLAB);
     UpdChunk ck;
     upd_chunk_load(ck, Vg, Cg, ld, sl * SLAB + (tid & 63), mp, nbp, nc, tid >> 6);
+    const int pfrom = (nc == BN) ? upd_plain_from(s_pd, g1, lane) : STM_BIGROW;
     for (int r0 = sl * SLAB; r0 < rend; r0 += RB) {
-        upd_chunk_to_lds(ck, r0 + (tid & 63), mp, nbp, nc, s_pd, g1, tid & 63, tid >> 6, Vs, Cs, gram);
+        upd_chunk_to_lds(ck, r0 + (tid & 63), mp, nbp, nc, s_pd, g1, tid & 63, tid >> 6, Vs, Cs, gram, r0 > pfrom && r0 + RB <= mp);
         __syncthreads();
         if (r0 + RB < rend) upd_chunk_load(ck, Vg, Cg, ld, r0 + RB + (tid & 63), mp, nbp, nc, tid >> 6);
 #pragma unroll
@@ -2266,6 +2287,7 @@ __global__ __launch_bounds__(NT) void k_upd_c(DevCtx c, const int *__restrict__ 
     }
     __syncthreads();
     const int rend = min(mp, (sl + spw) * SLAB);
+    const int pfrom = upd_plain_from(s_pd, g1, tid & 63);
     // C never goes through LDS here: a thread keeps the eight entries of its row that it loaded, V.W2 comes back from the
     // MFMA layout through the (otherwise unused) C image and the thread subtracts and stores from registers -- two
     // barriers per chunk instead of three (the next chunk's V image is written after the second one, its product
@@ -2275,7 +2297,7 @@ __global__ __launch_bounds__(NT) void k_upd_c(DevCtx c, const int *__restrict__ 
         double cc[8];
 #pragma unroll
         for (int q = 0; q < 8; q++) cc[q] = ck.c[q];
-        upd_chunk_v_to_lds(ck, i, mp, nbp, s_pd, g1, lrow, lcg, Vs);
+        upd_chunk_v_to_lds(ck, i, mp, nbp, s_pd, g1, lrow, lcg, Vs, r0 > pfrom && r0 + RB <= mp);
         __syncthreads();
         if (r0 + RB < rend) upd_chunk_load(ck, Vg, Cg, ld, i + RB, mp, nbp, nc, lcg);
         d4 u0 = {0, 0, 0, 0}, u1 = {0, 0, 0, 0};
