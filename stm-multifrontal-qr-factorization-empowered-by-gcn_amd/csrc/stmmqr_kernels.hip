@@ -3174,6 +3174,7 @@ __global__ __launch_bounds__(NT) void k_upd_yq(DevCtx c, const int *__restrict__
                 for (int e = tid; e < STM_NB * BN; e += NT) s_G[(e / BN) * WS + (e % BN)] = Gr[e];
                 __syncthreads();
                 const double *Yj = s_Y + j * STM_NB * WS;
+#pragma unroll
                 for (int b = 0; b < STM_NB; b++) {
                     const double gq = s_G[l * WS + b];
 #pragma unroll
@@ -3186,10 +3187,13 @@ __global__ __launch_bounds__(NT) void k_upd_yq(DevCtx c, const int *__restrict__
             for (int x = 0; x < 4; x++) s_Z[l * WS + cg * 4 + x] = z[x];
             for (int e = tid; e < STM_NB * STM_NB; e += NT) s_T[(e / STM_NB) * WS + (e % STM_NB)] = T[e];     // s_T[col][row] = T(row, col)
             __syncthreads();
-            for (int q = 0; q <= l; q++) {                      // Y_i = T_i' Z
-                const double tq = s_T[l * WS + q];
 #pragma unroll
-                for (int x = 0; x < 4; x++) y[x] += tq * s_Z[q * WS + cg * 4 + x];
+            for (int q = 0; q < STM_NB; q++) {                  // Y_i = T_i' Z  (the trip count as a predicate: the LDS reads up front)
+                const double tq = s_T[l * WS + q];
+                if (q <= l) {
+#pragma unroll
+                    for (int x = 0; x < 4; x++) y[x] += tq * s_Z[q * WS + cg * 4 + x];
+                }
             }
         }
 #pragma unroll
