@@ -58,7 +58,19 @@ template <bool AGENT>
 __device__ __forceinline__ double stm_ordered_sum(const double *p, long long stride, int n)
 {
     double v = 0;
-    for (int q = 0; q < n; q += 8) {
+    int q = 0;
+    // (tall fronts -- 100+ slabs: the bulk in batches of 32 loads, the same order of additions: a batch is a memory round trip)
+    for (; q + 32 <= n; q += 32) {
+        double t[32];
+#pragma unroll
+        for (int u = 0; u < 32; u++) {
+            const double *a = p + (long long)(q + u) * stride;
+            t[u] = AGENT ? ld_agent(a) : *a;
+        }
+#pragma unroll
+        for (int u = 0; u < 32; u++) v += t[u];
+    }
+    for (; q < n; q += 8) {
         double t[8];
 #pragma unroll
         for (int u = 0; u < 8; u++) {
