@@ -4253,29 +4253,43 @@ __global__ __launch_bounds__(RS_NT) void k_rbig_prep(DevCtx c, const QbDesc *__r
 __global__ __launch_bounds__(STM_QB_ROWS) void k_rbig_init(DevCtx c, const QbDesc *__restrict__ qd, const int *__restrict__ Rj,
                                                            const double *W, const double *X, double *Acc0, const int *Rm)
 {
+    // y - R12 x2 for the rows of the live pivot columns.  A workgroup takes 64 rows; its eight waves share the non-pivotal columns
+    // (chunks of 16, wave w the chunks w, w + 8, ...) and their partial sums are added in wave order (round 4: a thread per row ran
+    // through all the columns alone -- 250 dependent round trips on a front with 4000 of them, 276 us per launch).
+    __shared__ double s_p[STM_QB_ROWS / 64][64];
     const QbDesc d = qd[blockIdx.y];
     const FrontSym s = c.fs[d.f];
     const int rm = Rm[blockIdx.y];
-    const int i = blockIdx.x * STM_QB_ROWS + threadIdx.x;
-    if (i >= rm) return;
+    const int lrow = threadIdx.x & 63, cl = threadIdx.x >> 6;
+    const int i = blockIdx.x * 64 + lrow;
+    if (blockIdx.x * 64 >= rm) return;
+    const int ic = min(i, rm - 1);
     const int *rj = Rj + s.rp;
     const double *F = c.Farena + s.foff;
     const long long ld = s.ld;
-    // (coalesced over the rows; X[rj[k]] uniform; four partial sums and an unrolled body keep 16 loads in flight: the loop
-    //  is a chain of memory round trips otherwise)
-    double a0 = W[c.Hii[s.hip + i]], a1 = 0, a2 = 0, a3 = 0;
-    int k = s.fp;
-    for (; k + 16 <= s.fn; k += 16) {
+    // (coalesced over the rows; X[rj[k]] uniform; four partial sums and an unrolled body keep 16 loads in flight)
+    double a0 = 0, a1 = 0, a2 = 0, a3 = 0;
+    const int nfull = (s.fn - s.fp) / 16;
+    for (int ch = cl; ch < nfull; ch += STM_QB_ROWS / 64) {
+        const int k = s.fp + 16 * ch;
 #pragma unroll
         for (int u = 0; u < 16; u += 4) {
-            a0 -= F[i + (long long)(k + u) * ld] * X[rj[k + u]];
-            a1 -= F[i + (long long)(k + u + 1) * ld] * X[rj[k + u + 1]];
-            a2 -= F[i + (long long)(k + u + 2) * ld] * X[rj[k + u + 2]];
-            a3 -= F[i + (long long)(k + u + 3) * ld] * X[rj[k + u + 3]];
+            a0 -= F[ic + (long long)(k + u) * ld] * X[rj[k + u]];
+            a1 -= F[ic + (long long)(k + u + 1) * ld] * X[rj[k + u + 1]];
+            a2 -= F[ic + (long long)(k + u + 2) * ld] * X[rj[k + u + 2]];
+            a3 -= F[ic + (long long)(k + u + 3) * ld] * X[rj[k + u + 3]];
         }
     }
-    for (; k < s.fn; k++) a0 -= F[i + (long long)k * ld] * X[rj[k]];
-    Acc0[d.xoff + i] = (a0 + a1) + (a2 + a3);
+    if (cl == 0)
+        for (int k = s.fp + 16 * nfull; k < s.fn; k++) a0 -= F[ic + (long long)k * ld] * X[rj[k]];
+    s_p[cl][lrow] = (a0 + a1) + (a2 + a3);
+    __syncthreads();
+    if (cl == 0 && i < rm) {
+        double a = W[c.Hii[s.hip + i]];
+#pragma unroll
+        for (int w = 0; w < STM_QB_ROWS / 64; w++) a += s_p[w][lrow];
+        Acc0[d.xoff + i] = a;
+    }
 }
 __global__ __launch_bounds__(STM_QB_ROWS) void k_rbig_step(DevCtx c, const QbDesc *__restrict__ qd, int kstep, double *X, double *Acc0,
                                                            const int *Lc0, const int *Rm)
@@ -4539,7 +4553,8 @@ int stm_launch_rsolve_big(const DevCtx &c, const QbDesc *qd, int nq, int max_ste
 {
     if (nq <= 0) return 0;
     hipLaunchKernelGGL(k_rbig_prep, dim3(nq), dim3(RS_NT), 0, st, c, qd, X, Lc, Rm, err);
-    hipLaunchKernelGGL(k_rbig_init, dim3(max_nslab, nq), dim3(STM_QB_ROWS), 0, st, c, qd, Rj, W, (const double *)X, Acc, (const int *)Rm);
+    hipLaunchKernelGGL(k_rbig_init, dim3(max_nslab * (STM_QB_ROWS / 64), nq), dim3(STM_QB_ROWS), 0, st, c, qd, Rj, W, (const double *)X, Acc,
+                       (const int *)Rm);
     for (int k = 0; k < max_steps; k++)
         hipLaunchKernelGGL(k_rbig_step, dim3(max_nslab, nq), dim3(STM_QB_ROWS), 0, st, c, qd, k, X, Acc, (const int *)Lc, (const int *)Rm);
     return (int)hipGetLastError();
