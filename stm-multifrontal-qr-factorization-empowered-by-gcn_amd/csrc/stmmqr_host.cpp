@@ -233,6 +233,17 @@ struct stmmqr_plan {
     std::vector<int> level_lds_rt;                  // dynamic LDS of k_rtsolve per level
     DevBuf<int> d_Dq;
     DevBuf<QbDesc> d_qb;
+    // grouped split Q-apply (k_qbig_step4): T4 of every group of four panels of every split front, built at the first Q-apply after a
+    // factorization (t4_valid); t4_ok: the buffers exist (they are allocated at that first use; no room: the per-panel launches stay)
+    std::vector<Qt4ItemHost> t4items;
+    std::vector<int> t4fronts;
+    std::vector<long long> t4dqo, qbt4off;
+    long long t4_doubles = 0, dq4_ints = 0, wq4_doubles = 0;
+    DevBuf<Qt4ItemHost> d_t4items;
+    DevBuf<int> d_t4fronts, d_Dq4;
+    DevBuf<long long> d_t4dqo, d_qbt4off;
+    DevBuf<double> d_T4, d_Wq4;
+    bool t4_valid = false, t4_ok = false, t4_tried = false;
     struct QbLevel { int off = 0, n = 0, max_np = 0, max_nslab = 0, max_fm = 0, max_rsteps = 0; };
     DevBuf<int> d_Rm;                               // rows of R (live pivots) of the split fronts of a level (k_rbig_*)
     std::vector<QbLevel> level_qbig;               // descriptors (d_qb) of the fronts of each level that take the split Q-apply
@@ -1699,6 +1710,7 @@ int stmmqr_factorize_begin(stmmqr_plan *plan, const stm_long *Ap, const stm_long
     P.factored = false;
     P.rowmap_ready = false;
     P.scr_valid = false;
+    P.t4_valid = false;
     P.evused = 0;
     P.begun = true;
     P.first_group = true;
@@ -2587,6 +2599,8 @@ int ensure_rowmap(stmmqr_plan &P)
         P.level_lds_rs.assign(LV.size(), 0);
         P.level_lds_rt.assign(LV.size(), 0);
         P.level_qbig.assign(LV.size(), stmmqr_plan::QbLevel());
+        P.t4items.clear(); P.t4fronts.clear(); P.t4dqo.clear(); P.qbt4off.clear();
+        P.t4_doubles = 0; P.dq4_ints = 0; P.t4_ok = false; P.t4_tried = false; P.t4_valid = false;
         std::vector<QbDesc> qb;
         long xf = 1, dq = 1, wq = 1;
         for (size_t l = 0; l < LV.size(); l++) {
@@ -2602,6 +2616,19 @@ int ensure_rowmap(stmmqr_plan &P)
                     QbDesc d;
                     d.f = f; d.xoff = (int)xo; d.dqoff = (int)dqo; d.wqoff = (int)wo; d.nslab = (s.fm_ub + STM_QB_ROWS - 1) / STM_QB_ROWS; d.pad = 0;
                     qb.push_back(d);
+                    {
+                        const int ngr = (s.npanels + 3) / 4;
+                        P.qbt4off.push_back(P.t4_doubles);
+                        P.t4fronts.push_back(f);
+                        P.t4dqo.push_back(P.dq4_ints);
+                        for (int g = 0; g < ngr; g++) {
+                            Qt4ItemHost it;
+                            it.f = f; it.g = g; it.off = P.t4_doubles + (long long)g * stm_qt4_doubles(); it.dqo = P.dq4_ints;
+                            P.t4items.push_back(it);
+                        }
+                        P.t4_doubles += (long long)ngr * stm_qt4_doubles();
+                        P.dq4_ints += s.fn;
+                    }
                     xo += s.fm_ub; dqo += s.fn; wo += 2L * d.nslab * STM_NB;
                     auto &Q = P.level_qbig[l];
                     Q.n++; Q.max_np = std::max(Q.max_np, s.npanels); Q.max_nslab = std::max(Q.max_nslab, d.nslab);
@@ -2617,6 +2644,7 @@ int ensure_rowmap(stmmqr_plan &P)
         LCHK(P.d_Xf.alloc((size_t)xf));
         LCHK(P.d_Dq.alloc((size_t)dq));
         LCHK(P.d_Wq.alloc((size_t)wq));
+        P.wq4_doubles = 4 * wq;
         if (qb.empty()) qb.push_back(QbDesc());
         LCHK(P.d_qb.alloc(qb.size()));
         LCHK(P.d_Rm.alloc(qb.size()));
@@ -2660,6 +2688,7 @@ int ensure_scratch(stmmqr_plan &P)
             if (!P.kept[(size_t)f]) { P.fs_scr[(size_t)f].foff = o; o += (long long)P.fs[f].ld * P.fs[f].fn; }
     }
     P.scr_valid = false;
+    P.t4_valid = false;
     LCHK(P.d_scr.alloc((size_t)std::max(1LL, P.scr_all ? all : P.scr_doubles)));
     std::vector<FrontSym> t = P.fs_scr;
     for (long f = 0; f < P.nf; f++)
@@ -2697,12 +2726,45 @@ int run_qapply(stmmqr_plan &P, int method)
     // blocked form with the kept T factors; STMMQR_DBG bit 13 selects the reflector-by-reflector kernel (same result up
     // to rounding: used by the tests to cross-check the two)
     const bool blocked = c.Tall && !(c.dbg & 8192);
+    // grouped split Q-apply: its buffers at the first use (STMMQR_QT4=0: the per-panel launches)
+    const bool want_t4 = !(getenv("STMMQR_QT4") && atoi(getenv("STMMQR_QT4")) == 0);       // (read at every call: tests compare both)
+    if (blocked && want_t4 && !P.t4_tried && !P.t4items.empty()) {
+        P.t4_tried = true;
+        size_t freeb = 0, totalb = 0;
+        if (hipMemGetInfo(&freeb, &totalb) == hipSuccess &&
+            8.0 * ((double)P.t4_doubles + (double)P.wq4_doubles) + 4.0 * (double)P.dq4_ints < 0.25 * (double)freeb) {
+            LCHK(P.d_T4.alloc((size_t)P.t4_doubles));
+            LCHK(P.d_Wq4.alloc((size_t)std::max(1LL, P.wq4_doubles)));
+            LCHK(P.d_Dq4.alloc((size_t)std::max(1LL, P.dq4_ints)));
+            LCHK(P.d_t4items.upload(P.t4items, P.stream));
+            LCHK(P.d_t4fronts.upload(P.t4fronts, P.stream));
+            LCHK(P.d_t4dqo.upload(P.t4dqo, P.stream));
+            LCHK(P.d_qbt4off.upload(P.qbt4off, P.stream));
+            P.t4_ok = true;
+            P.t4_valid = false;
+        }
+    }
+    const bool use_t4 = blocked && want_t4 && P.t4_ok;
+    if (use_t4 && getenv("STMMQR_MEMDUMP") && !P.t4_valid)
+        fprintf(stderr, "[stmmqr_hip] grouped Q-apply: T4 of %zu groups of %zu split fronts, %.3f GB (+ %.3f GB of slab partials)\n", P.t4items.size(),
+                P.t4fronts.size(), 8e-9 * (double)P.t4_doubles, 8e-9 * (double)P.wq4_doubles);
     auto launch = [&](size_t l, int m) -> int {
         LCHK(level_to_front_form(P, l));
         if (blocked) {
             LCHK(stm_launch_qapply_t(c, L0 + LV[l].all_off, LV[l].n_all, m, P.d_W.p, P.level_lds_qa[l], P.stream));
-            // the large fronts of the level (independent of the others): rows split over workgroups, a launch per panel
+            // the large fronts of the level (independent of the others): rows split over workgroups, a launch per group of four panels
+            // (k_qbig_step4, T4 built at the first use after a factorization) or per panel
             const auto &Q = P.level_qbig[l];
+            if (Q.n > 0 && use_t4) {
+                if (!P.t4_valid) {
+                    LCHK(stm_launch_qt4_build(c, P.d_t4fronts.p, P.d_t4dqo.p, (int)P.t4fronts.size(), P.d_t4items.p, (int)P.t4items.size(), P.d_Dq4.p,
+                                              P.d_T4.p, P.stream));
+                    P.t4_valid = true;
+                }
+                LCHK(stm_launch_qapply_big4(c, P.d_qb.p + Q.off, P.d_qbt4off.p + Q.off, Q.n, Q.max_np, Q.max_nslab, Q.max_fm, m, P.d_W.p, P.d_Xf.p,
+                                            P.d_Dq.p, P.d_Wq4.p, P.d_T4.p, P.stream));
+                return 0;
+            }
             LCHK(stm_launch_qapply_big(c, P.d_qb.p + Q.off, Q.n, Q.max_np, Q.max_nslab, Q.max_fm, m, P.d_W.p, P.d_Xf.p, P.d_Dq.p,
                                        P.d_Wq.p, P.stream));
             return 0;

@@ -94,6 +94,12 @@ int stm_launch_rh_copy(const DevCtx &c, const int *flist, const int *nparts, int
 // Q-apply / triangular solve on the resident factors
 int stm_launch_qapply(const DevCtx &c, const int *flist, int nfr, int method, double *W, int lds_bytes, int *err, hipStream_t st);
 int stm_launch_qapply_t(const DevCtx &c, const int *flist, int nfr, int method, double *W, int lds_bytes, hipStream_t st);
+int stm_qt4_doubles(void);
+struct Qt4ItemHost { int f, g; long long off, dqo; };     // (= Qt4Item of stmmqr_kernels.hip)
+int stm_launch_qt4_build(const DevCtx &c, const int *fl, const long long *dqo, int nfronts, const void *items, int nitems, int *Dq4, double *T4all,
+                         hipStream_t st);
+int stm_launch_qapply_big4(const DevCtx &c, const QbDesc *qd, const long long *t4off, int nq, int max_npanels, int max_nslab, int max_fm,
+                           int method, double *W, double *Xf, int *Dq, double *Wq4, const double *T4all, hipStream_t st);
 int stm_launch_qapply_big(const DevCtx &c, const QbDesc *qd, int nq, int max_npanels, int max_nslab, int max_fm, int method, double *W,
                           double *Xf, int *Dq, double *Wq, hipStream_t st);
 int stm_launch_rsolve_big(const DevCtx &c, const QbDesc *qd, int nq, int max_steps, int max_nslab, const int *Rj, const double *W,

@@ -4024,6 +4024,293 @@ __global__ __launch_bounds__(QB_ROWS) void k_qbig_step(DevCtx c, const QbDesc *_
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Grouped split Q-apply (round 4): FOUR panels (128 reflectors) of a large front per launch instead of one.  The launches of
+// k_qbig_step are a chain (launch k needs the x of launch k-1) of ~10 us each whatever they do -- two dependent memory round trips --,
+// 1473 of them per Q'b on the default workload.  The product of the four block reflectors of a group is ONE block reflector,
+//     H_0 H_1 H_2 H_3 = I - V T4 V',    T4 = [T_0 X_01 X_02 X_03; 0 T_1 X_12 X_13; 0 0 T_2 X_23; 0 0 0 T_3]   (128 x 128),
+// with the blocks X_ij of the compact WY recurrence ( [X_0j; ..; X_{j-1,j}] = -T4(0:j, 0:j) [G_0j; ..; G_{j-1,j}] T_j, G_ij = V_i'V_j ).
+// T4 of every group of every split front is built ONCE per factorization, at the first Q-apply (k_qt4_number, k_qt4_build: the Gram
+// matrix of the group's 128 columns by MFMA, then sixteen 32 x 32 block products), and kept in both layouts (T4 for Q x, its transpose
+// for Q'x: the matrix-vector product of a launch reads it with the lanes along the output index).
+// ------------------------------------------------------------------------------------------------
+#define QG 4
+#define QGN (QG * STM_NB)
+#define QT4_DOUBLES (2 * QGN * QGN)                  // per group: T4 column-major, then T4 row-major
+struct Qt4Item { int f, g; long long off, dqo; };    // T4 of group g of front f at T4all + off; the front's reflector numbering at Dq4 + dqo
+
+__global__ __launch_bounds__(QA_NT) void k_qt4_number(DevCtx c, const int *__restrict__ fl, const long long *__restrict__ dqo, int *Dq4)
+{
+    __shared__ int s_scan[QA_NW];
+    const int f = fl[blockIdx.x];
+    const FrontSym s = c.fs[f];
+    const int fm = c.fnum[f].fm;
+    if (fm <= 0 || s.fn <= 0) return;
+    qa_number_reflectors(s, fm, c.Stair + s.rp, c.Tau + s.rp, Dq4 + dqo[blockIdx.x], s_scan);
+}
+
+#define QT4_VS 36
+__global__ __launch_bounds__(512) void k_qt4_build(DevCtx c, const Qt4Item *__restrict__ items, const int *__restrict__ Dq4, double *T4all)
+{
+    extern __shared__ double lds[];                   // Gram phase: the chunk image [QGN][QT4_VS]; block phase: five 32 x 33 blocks
+    __shared__ int s_d[QGN], s_t[QGN], s_rng[2][8];
+    const Qt4Item it = items[blockIdx.x];
+    const int f = it.f, g = it.g;
+    const FrontSym s = c.fs[f];
+    const int fm = c.fnum[f].fm;
+    double *T4c = T4all + it.off, *T4r = T4c + QGN * QGN;
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, l15 = lane & 15, l4 = lane >> 4;
+    const int k0 = g * QGN;
+    if (tid < QGN) {
+        const int k = k0 + tid;
+        int d = -1, t = 0;
+        if (fm > 0 && k < s.fn) { d = Dq4[it.dqo + k]; t = c.Stair[s.rp + k]; }
+        s_d[tid] = (d >= 0) ? d : STM_BIGROW;
+        s_t[tid] = (d >= 0) ? max(t, d + 1) : 0;
+        const int lo = wave_max_int(-s_d[tid]), hi = wave_max_int(s_t[tid]);
+        if (lane == 0) { s_rng[0][wid] = -lo; s_rng[1][wid] = hi; }
+    }
+    __syncthreads();
+    const int rmin = min(s_rng[0][0], s_rng[0][1]), rmax = min(fm, max(s_rng[1][0], s_rng[1][1]));
+    if (rmin >= STM_BIGROW || rmax <= rmin) {                       // no live reflector in the group: T4 = 0
+        for (int e = tid; e < QT4_DOUBLES; e += 512) st_agent(&T4c[e], 0.0);
+        return;
+    }
+    const double *F = c.Farena + s.foff;
+    const long long ld = s.ld;
+    // ---- G = V'V (128 x 128) over the rows [rmin, rmax): wave w the tile row w ----
+    d4 acc[8];
+#pragma unroll
+    for (int q = 0; q < 8; q++) acc[q] = (d4){0, 0, 0, 0};
+    double *Vs = lds;
+    const int srow = tid & 31, scg = tid >> 5;
+    for (int r0 = rmin; r0 < rmax; r0 += 32) {
+        const int i = r0 + srow, ic = min(i, fm - 1);
+#pragma unroll
+        for (int q = 0; q < 8; q++) {
+            const int col = scg * 8 + q, k = min(k0 + col, s.fn - 1);
+            const double val = F[ic + (long long)k * ld];
+            const int d = s_d[col], t = s_t[col];
+            Vs[col * QT4_VS + srow] = (i == d) ? 1.0 : ((i > d && i < t) ? val : 0.0);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int kk = 0; kk < 8; kk++) {
+            const double a = Vs[(16 * wid + l15) * QT4_VS + 4 * kk + l4];
+#pragma unroll
+            for (int tc = 0; tc < 8; tc++) {
+                const double b = Vs[(16 * tc + l15) * QT4_VS + 4 * kk + l4];
+                acc[tc] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[tc], 0, 0, 0);
+            }
+        }
+        __syncthreads();
+    }
+    // G to the T4c area (column-major; overwritten block column by block column below), write-through: read back by other waves
+#pragma unroll
+    for (int tc = 0; tc < 8; tc++)
+#pragma unroll
+        for (int r = 0; r < 4; r++) st_agent(&T4c[(16 * wid + l4 + 4 * r) + QGN * (16 * tc + l15)], acc[tc][r]);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    // ---- the blocks of T4 ----
+    double *Ab = lds, *Bb = Ab + 32 * 33, *Yb = Bb + 32 * 33;        // Yb: three blocks
+    const int oa = tid & 31, ob = tid >> 5;                          // my two outputs of a block product: (oa, ob), (oa, ob + 16)
+    const int np = s.npanels;
+    auto load_T = [&](int i, double *dst) {                          // T of panel 4 g + i (column-major), zero beyond the front's panels
+        const int p = QG * g + i;
+        const double *T = c.Tall + (long long)(s.tpan + min(p, np - 1)) * STM_NB * STM_NB;
+        for (int e = tid; e < 32 * 32; e += 512) dst[(e & 31) * 33 + (e >> 5)] = (p < np) ? T[e] : 0.0;       // dst[row][col]
+    };
+    auto load_blk = [&](int i, int j, double *dst) {                 // block (i, j) of the T4c area
+        for (int e = tid; e < 32 * 32; e += 512) dst[(e & 31) * 33 + (e >> 5)] = ld_agent(&T4c[(32 * i + (e & 31)) + QGN * (32 * j + (e >> 5))]);
+    };
+    auto mm = [&](const double *A, const double *B, double &o0, double &o1) {      // += A B at my two outputs
+#pragma unroll 8
+        for (int q = 0; q < 32; q++) {
+            const double a = A[oa * 33 + q];
+            o0 += a * B[q * 33 + ob];
+            o1 += a * B[q * 33 + ob + 16];
+        }
+    };
+    for (int j = 1; j < QG; j++) {
+        load_T(j, Bb);
+        for (int i = 0; i < j; i++) {                                // Y_i = G_ij T_j
+            __syncthreads();
+            load_blk(i, j, Ab);
+            __syncthreads();
+            double y0 = 0, y1 = 0;
+            mm(Ab, Bb, y0, y1);
+            Yb[i * 32 * 33 + oa * 33 + ob] = y0;
+            Yb[i * 32 * 33 + oa * 33 + ob + 16] = y1;
+        }
+        for (int i = 0; i < j; i++) {                                // X_ij = - sum_{l = i .. j-1} T4_il Y_l
+            double x0 = 0, x1 = 0;
+            for (int l = i; l < j; l++) {
+                __syncthreads();
+                if (l == i) load_T(i, Ab);
+                else load_blk(i, l, Ab);
+                __syncthreads();
+                mm(Ab, Yb + l * 32 * 33, x0, x1);
+            }
+            st_agent(&T4c[(32 * i + oa) + QGN * (32 * j + ob)], -x0);
+            st_agent(&T4c[(32 * i + oa) + QGN * (32 * j + ob + 16)], -x1);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    }
+    // diagonal blocks, zeros below them, and the row-major copy
+    for (int i = 0; i < QG; i++) {
+        __syncthreads();
+        load_T(i, Ab);
+        __syncthreads();
+        for (int e = tid; e < 32 * 32; e += 512) st_agent(&T4c[(32 * i + (e & 31)) + QGN * (32 * i + (e >> 5))], Ab[(e & 31) * 33 + (e >> 5)]);
+    }
+    for (int e = tid; e < QGN * QGN; e += 512) {
+        const int r = e & (QGN - 1), cc = e >> 7;
+        if ((r >> 5) > (cc >> 5)) st_agent(&T4c[e], 0.0);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    for (int e = tid; e < QGN * QGN; e += 512) {
+        const int cc = e & (QGN - 1), r = e >> 7;                    // T4r[c + 128 r] = T4(r, c)
+        T4r[e] = ld_agent(&T4c[r + QGN * cc]);
+    }
+}
+
+__global__ __launch_bounds__(QB_ROWS) void k_qbig_step4(DevCtx c, const QbDesc *__restrict__ qd, const long long *__restrict__ t4off, int k,
+                                                      int method, double *Xf0, const int *Dq0, double *Wq0, const double *T4all)
+{
+    __shared__ int s_d[2][QGN], s_t[2][QGN], s_rng[2][2][2];
+    __shared__ double s_part[QB_ROWS / 64][QGN], s_w[QGN], s_y[QGN], s_yp[QB_ROWS / QGN][QGN];
+    const QbDesc qdd = qd[blockIdx.y];
+    const int f = qdd.f, nslab = qdd.nslab;
+    if ((int)blockIdx.x >= nslab) return;
+    const FrontSym s = c.fs[f];
+    const int fm = c.fnum[f].fm;
+    if (fm <= 0 || s.fn <= 0) return;
+    const int ng = (s.npanels + QG - 1) / QG;
+    if (k > ng) return;
+    // launch k: apply the (k-1)-th group of the order, form the partials of the k-th (Q'x: ascending, Q x: descending)
+    const int gg[2] = {(k >= 1) ? (method ? ng - k : k - 1) : -1, (k < ng) ? (method ? ng - 1 - k : k) : -1};
+    double *Xf = Xf0 + qdd.xoff;
+    const int *Dq = Dq0 + qdd.dqoff;
+    double *Wq = Wq0 + (long long)qdd.wqoff * QG;
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int *St = c.Stair + s.rp;
+    const double *F = c.Farena + s.foff;
+    const long long ld = s.ld;
+    const int i = blockIdx.x * QB_ROWS + tid, ic = min(i, fm - 1);
+    if (tid < 2 * QGN) {
+        const int w = tid >> 7, j = tid & (QGN - 1), kc = gg[w] * QGN + j;
+        int d = -1, t = 0;
+        if (gg[w] >= 0 && kc < s.fn) { d = Dq[kc]; t = St[kc]; }
+        s_d[w][j] = (d >= 0) ? d : STM_BIGROW;
+        s_t[w][j] = (d >= 0) ? max(t, d + 1) : 0;
+        const int lo = wave_max_int(-s_d[w][j]), hi = wave_max_int(s_t[w][j]);
+        if (lane == 0) { s_rng[w][(tid >> 6) & 1][0] = -lo; s_rng[w][(tid >> 6) & 1][1] = hi; }
+    }
+    double x = (i < fm) ? Xf[i] : 0.0;
+    __syncthreads();
+    bool on[2];
+#pragma unroll
+    for (int w = 0; w < 2; w++) {
+        const int r0 = min(s_rng[w][0][0], s_rng[w][1][0]), r1 = max(s_rng[w][0][1], s_rng[w][1][1]);
+        on[w] = (gg[w] >= 0 && r0 < STM_BIGROW && (int)blockIdx.x * QB_ROWS < r1 && ((int)blockIdx.x + 1) * QB_ROWS > r0);      // (uniform)
+    }
+    // Both groups' columns go through ONE pipeline of 16 sub-blocks of 16 columns (8 of the group to apply, then 8 of the group whose
+    // partials are formed: their loads do not depend on x), four sub-blocks (64 loads per thread) in flight: a launch is a handful of
+    // memory round trips whatever it does, so what counts is how many loads each of them carries.
+    constexpr int SB = 16, NSB = QGN / SB, DEPTH = 4;
+    auto load_v = [&](int idx, double (&v)[SB]) {       // sub-block idx of the pipeline (uniform: nothing is loaded for an idle phase)
+        const int w = idx / NSB, sb = idx % NSB;
+        if (!on[w]) return;
+        const double *Vp = F + (long long)(gg[w] * QGN + sb * SB) * ld;
+        const int nbp = s.fn - (gg[w] * QGN + sb * SB);
+#pragma unroll
+        for (int j = 0; j < SB; j++) v[j] = (nbp > 0) ? Vp[ic + (long long)min(j, nbp - 1) * ld] : 0.0;     // unconditional, masked below
+    };
+    double buf[DEPTH][SB];
+#pragma unroll
+    for (int q = 0; q < DEPTH; q++)
+#pragma unroll
+        for (int j = 0; j < SB; j++) buf[q][j] = 0.0;
+    if (on[0]) {
+        // y = T4' w (Q'x) or T4 w (Q x): lanes along the output index, four parts of 32 terms each -- requested first
+        const double *M = T4all + t4off[blockIdx.y] + (long long)gg[0] * QT4_DOUBLES + (method ? 0 : QGN * QGN);
+        const int o = tid & (QGN - 1), part = tid >> 7;
+        double m[32];
+#pragma unroll
+        for (int q = 0; q < 32; q++) m[q] = M[o + QGN * (32 * part + q)];
+        if (tid < QGN) s_w[tid] = stm_ordered_sum<false>(Wq + (long long)(gg[0] & 1) * nslab * QGN + tid, QGN, nslab);      // fixed order
+#pragma unroll
+        for (int q = 0; q < DEPTH; q++) load_v(q, buf[q]);
+        __syncthreads();
+        {
+            double p0 = 0, p1 = 0, p2 = 0, p3 = 0;
+#pragma unroll
+            for (int q = 0; q < 32; q += 4) {
+                p0 += m[q] * s_w[32 * part + q];
+                p1 += m[q + 1] * s_w[32 * part + q + 1];
+                p2 += m[q + 2] * s_w[32 * part + q + 2];
+                p3 += m[q + 3] * s_w[32 * part + q + 3];
+            }
+            s_yp[part][o] = (p0 + p1) + (p2 + p3);
+        }
+        __syncthreads();
+        if (tid < QGN) s_y[tid] = (s_yp[0][tid] + s_yp[1][tid]) + (s_yp[2][tid] + s_yp[3][tid]);
+        __syncthreads();
+    } else {
+#pragma unroll
+        for (int q = 0; q < DEPTH; q++) load_v(q, buf[q]);
+    }
+    double a = x;
+#pragma unroll
+    for (int idx = 0; idx < 2 * NSB; idx++) {
+        double (&v)[SB] = buf[idx % DEPTH];
+        const int w = idx / NSB, sb = idx % NSB;
+        if (idx == NSB) {                               // between the phases: x after the group that was applied
+            if (on[0] && i < fm && a != x) Xf[i] = a;
+            x = (i < fm) ? a : 0.0;
+        }
+        if (w == 0) {
+            if (on[0]) {
+#pragma unroll
+                for (int j = 0; j < SB; j++) {
+                    const int d = s_d[0][sb * SB + j], t = s_t[0][sb * SB + j];
+                    const double vv = (i > d && i < t) ? v[j] : ((i == d) ? 1.0 : 0.0);
+                    a -= vv * s_y[sb * SB + j];
+                }
+            }
+        } else if (gg[1] >= 0) {
+            double accv[SB];
+#pragma unroll
+            for (int j = 0; j < SB; j++) {
+                const int d = s_d[1][sb * SB + j], t = s_t[1][sb * SB + j];
+                const double vv = (i < fm && i > d && i < t) ? v[j] : ((i == d) ? 1.0 : 0.0);
+                accv[j] = on[1] ? vv * x : 0.0;
+            }
+            double part[8];
+#pragma unroll
+            for (int q = 0; q < SB / 8; q++) {
+#pragma unroll
+                for (int xx = 0; xx < 8; xx++) part[xx] = accv[8 * q + xx];
+                const double rw = wave_reduce8(part);                             // lane l: total of value red8_idx(l)
+                if (lane < 8) s_part[wid][sb * SB + 8 * q + red8_idx(lane)] = rw;
+            }
+        }
+        if (idx + DEPTH < 2 * NSB) load_v(idx + DEPTH, v);
+    }
+    if (gg[1] >= 0) {
+        __syncthreads();
+        if (tid < QGN) {
+            double vsum = 0;
+#pragma unroll
+            for (int w = 0; w < QB_ROWS / 64; w++) vsum += s_part[w][tid];
+            Wq[((long long)(gg[1] & 1) * nslab + blockIdx.x) * QGN + tid] = vsum;
+        }
+    }
+}
+
 #define RS_NT 1024               // the back substitution streams R through one workgroup: more loads in flight
 __global__ __launch_bounds__(RS_NT) void k_rsolve(DevCtx c, const int *__restrict__ flist, const int *__restrict__ Rj,
                                                   const double *W, double *X, int *err)
@@ -4537,6 +4824,28 @@ int stm_launch_qapply_big(const DevCtx &c, const QbDesc *qd, int nq, int max_npa
     hipLaunchKernelGGL(k_qbig_prep, dim3(nq), dim3(QA_NT), 0, st, c, qd, (const double *)W, Xf, Dq);
     for (int k = 0; k <= max_npanels; k++)
         hipLaunchKernelGGL(k_qbig_step, dim3(max_nslab, nq), dim3(QB_ROWS), 0, st, c, qd, k, method, Xf, (const int *)Dq, Wq);
+    hipLaunchKernelGGL(k_qbig_finish, dim3((max_fm + 255) / 256, nq), dim3(256), 0, st, c, qd, W, (const double *)Xf);
+    return (int)hipGetLastError();
+}
+int stm_qt4_doubles(void) { return QT4_DOUBLES; }
+// T4 of every group of every split front (items) -- once per factorization
+int stm_launch_qt4_build(const DevCtx &c, const int *fl, const long long *dqo, int nfronts, const void *items, int nitems, int *Dq4, double *T4all,
+                         hipStream_t st)
+{
+    if (nfronts <= 0 || nitems <= 0) return 0;
+    hipLaunchKernelGGL(k_qt4_number, dim3(nfronts), dim3(QA_NT), 0, st, c, fl, dqo, Dq4);
+    const size_t lds = sizeof(double) * (size_t)((QGN * QT4_VS > 5 * 32 * 33) ? QGN * QT4_VS : 5 * 32 * 33);
+    hipLaunchKernelGGL(k_qt4_build, dim3(nitems), dim3(512), lds, st, c, (const Qt4Item *)items, (const int *)Dq4, T4all);
+    return (int)hipGetLastError();
+}
+int stm_launch_qapply_big4(const DevCtx &c, const QbDesc *qd, const long long *t4off, int nq, int max_npanels, int max_nslab, int max_fm,
+                           int method, double *W, double *Xf, int *Dq, double *Wq4, const double *T4all, hipStream_t st)
+{
+    if (nq <= 0 || max_npanels <= 0) return 0;
+    const int max_ng = (max_npanels + QG - 1) / QG;
+    hipLaunchKernelGGL(k_qbig_prep, dim3(nq), dim3(QA_NT), 0, st, c, qd, (const double *)W, Xf, Dq);
+    for (int k = 0; k <= max_ng; k++)
+        hipLaunchKernelGGL(k_qbig_step4, dim3(max_nslab, nq), dim3(QB_ROWS), 0, st, c, qd, t4off, k, method, Xf, (const int *)Dq, Wq4, T4all);
     hipLaunchKernelGGL(k_qbig_finish, dim3((max_fm + 255) / 256, nq), dim3(256), 0, st, c, qd, W, (const double *)Xf);
     return (int)hipGetLastError();
 }

@@ -149,12 +149,17 @@ def test_solve_full_size_standin(pkg, name):
         plan.close()
 
 
-@pytest.mark.parametrize("name", ["bcsstk14", "syn_rankdef_grid", "grid20_standin", "lns_3937"])
-def test_split_qapply_on_small_fronts(pkg, oracle, monkeypatch, name):
+@pytest.mark.parametrize("name", ["bcsstk14", "syn_rankdef_grid", "grid20_standin", "lns_3937", "syn_dupcol", "bayer10"])
+@pytest.mark.parametrize("qt4", ["1", "0"])
+def test_split_qapply_on_small_fronts(pkg, oracle, monkeypatch, name, qt4):
     """STMMQR_QBIG_MIN = 1 (read when the plan is made) sends EVERY front through the split Q-apply of the large fronts
-    (rows over workgroups, one launch per panel, slab partials of V'x summed in slab order): same Q'X / Q X as the oracle
-    applies from the downloaded factors, and as the one-workgroup kernel."""
+    (rows over workgroups, slab partials of V'x summed in slab order; STMMQR_QT4 = 1, the default: a launch per group of FOUR panels
+    with the group's 128 x 128 T4 built at the first use, k_qt4_build / k_qbig_step4; 0: a launch per panel): same Q'X / Q X as the
+    oracle applies from the downloaded factors, and as the one-workgroup kernel."""
+    if name not in NAMES:
+        pytest.skip("fixture not present")
     g = load_golden(name)
+    monkeypatch.setenv("STMMQR_QT4", qt4)
     monkeypatch.setenv("STMMQR_QBIG_MIN", "1")
     S, plan = factorized_plan(pkg, g)
     monkeypatch.delenv("STMMQR_QBIG_MIN")
