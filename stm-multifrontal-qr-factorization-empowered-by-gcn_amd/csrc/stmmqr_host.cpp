@@ -1022,8 +1022,10 @@ int build_plan(stmmqr_plan &P, const stmmqr_symbolic_view &v)
         tpan_total += s.npanels;
         {
             // Q-apply: fronts with this many entries or more are split over workgroups (k_qbig_*); STMMQR_QBIG_MIN
-            // overrides the threshold (tests send small fronts through that path)
-            const long qbig_min = getenv("STMMQR_QBIG_MIN") ? atol(getenv("STMMQR_QBIG_MIN")) : (2L << 20);
+            // overrides the threshold (tests send small fronts through that path).  2 M entries until round 4; with the grouped launches
+            // (k_qbig_step4) smaller fronts pay too, at 256 KB of T4 per four panels -- default workload, threshold: Q'b / solve ms,
+            // GB of T4: 2 M 13.1 / 20.6, 0.31; 1 M 12.5 / 20.0, 0.39; 256 K 11.9 / 19.5, 0.61; 128 K 11.6 / 19.2, 0.81.  1 M.
+            const long qbig_min = getenv("STMMQR_QBIG_MIN") ? atol(getenv("STMMQR_QBIG_MIN")) : (1L << 20);
             s.qbig = (fm * fn >= qbig_min && fn >= 1) ? 1 : 0;
         }
         s.parent = (int)parent[f];

@@ -4053,7 +4053,7 @@ __global__ __launch_bounds__(QA_NT) void k_qt4_number(DevCtx c, const int *__res
 __global__ __launch_bounds__(512) void k_qt4_build(DevCtx c, const Qt4Item *__restrict__ items, const int *__restrict__ Dq4, double *T4all)
 {
     extern __shared__ double lds[];                   // Gram phase: the chunk image [QGN][QT4_VS]; block phase: five 32 x 33 blocks
-    __shared__ int s_d[QGN], s_t[QGN], s_rng[2][8];
+    __shared__ int s_d[QGN], s_t[QGN], s_rng[2][8], s_live[QG];
     const Qt4Item it = items[blockIdx.x];
     const int f = it.f, g = it.g;
     const FrontSym s = c.fs[f];
@@ -4071,6 +4071,11 @@ __global__ __launch_bounds__(512) void k_qt4_build(DevCtx c, const Qt4Item *__re
         if (lane == 0) { s_rng[0][wid] = -lo; s_rng[1][wid] = hi; }
     }
     __syncthreads();
+    if (tid < QG) {
+        int lv = 0;
+        for (int j = 0; j < STM_NB; j++) lv |= (s_d[STM_NB * tid + j] < STM_BIGROW);
+        s_live[tid] = lv;
+    }
     const int rmin = min(s_rng[0][0], s_rng[0][1]), rmax = min(fm, max(s_rng[1][0], s_rng[1][1]));
     if (rmin >= STM_BIGROW || rmax <= rmin) {                       // no live reflector in the group: T4 = 0
         for (int e = tid; e < QT4_DOUBLES; e += 512) st_agent(&T4c[e], 0.0);
@@ -4116,10 +4121,13 @@ __global__ __launch_bounds__(512) void k_qt4_build(DevCtx c, const Qt4Item *__re
     double *Ab = lds, *Bb = Ab + 32 * 33, *Yb = Bb + 32 * 33;        // Yb: three blocks
     const int oa = tid & 31, ob = tid >> 5;                          // my two outputs of a block product: (oa, ob), (oa, ob + 16)
     const int np = s.npanels;
-    auto load_T = [&](int i, double *dst) {                          // T of panel 4 g + i (column-major), zero beyond the front's panels
+    // T of panel 4 g + i (column-major); zero beyond the front's panels and for a panel without a live reflector -- the factorization
+    // never wrote T of the panels behind the one where the rows ran out (the per-panel kernels never read it either)
+    auto load_T = [&](int i, double *dst) {
         const int p = QG * g + i;
+        const bool live = p < np && s_live[i];
         const double *T = c.Tall + (long long)(s.tpan + min(p, np - 1)) * STM_NB * STM_NB;
-        for (int e = tid; e < 32 * 32; e += 512) dst[(e & 31) * 33 + (e >> 5)] = (p < np) ? T[e] : 0.0;       // dst[row][col]
+        for (int e = tid; e < 32 * 32; e += 512) dst[(e & 31) * 33 + (e >> 5)] = live ? T[e] : 0.0;           // dst[row][col]
     };
     auto load_blk = [&](int i, int j, double *dst) {                 // block (i, j) of the T4c area
         for (int e = tid; e < 32 * 32; e += 512) dst[(e & 31) * 33 + (e >> 5)] = ld_agent(&T4c[(32 * i + (e & 31)) + QGN * (32 * j + (e >> 5))]);
