@@ -244,7 +244,9 @@ struct stmmqr_plan {
     DevBuf<long long> d_t4dqo, d_qbt4off;
     DevBuf<double> d_T4, d_Wq4;
     bool t4_valid = false, t4_ok = false, t4_tried = false;
-    struct QbLevel { int off = 0, n = 0, max_np = 0, max_nslab = 0, max_fm = 0, max_rsteps = 0; };
+    struct QbLevel { int off = 0, n = 0, max_np = 0, max_nslab = 0, max_fm = 0, max_rsteps = 0, t4i_off = 0, t4i_n = 0; };
+    std::vector<char> t4_level_valid;          // T4 of the level's split fronts is built (per level: with per-level scratch only the
+                                               //  level at hand is in front form)
     DevBuf<int> d_Rm;                               // rows of R (live pivots) of the split fronts of a level (k_rbig_*)
     std::vector<QbLevel> level_qbig;               // descriptors (d_qb) of the fronts of each level that take the split Q-apply
     hipGraphExec_t graph_exec = nullptr;           // options.use_graph: the captured schedule of group 0
@@ -2608,6 +2610,7 @@ int ensure_rowmap(stmmqr_plan &P)
         for (size_t l = 0; l < LV.size(); l++) {
             long xo = 0, dqo = 0, wo = 0;
             P.level_qbig[l].off = (int)qb.size();
+            P.level_qbig[l].t4i_off = (int)P.t4items.size();
             for (int q = 0; q < LV[l].n_all; q++) {
                 const int f = P.lists[LV[l].all_off + q];
                 const FrontSym &s = P.fs[f];
@@ -2641,6 +2644,7 @@ int ensure_rowmap(stmmqr_plan &P)
                     P.level_lds_rs[l] = std::max(P.level_lds_rs[l], (int)((((s.fp + 1) & ~1) + (s.fn - s.fp) + 2) * 8 + s.fp * 4 + 16));
                 }
             }
+            P.level_qbig[l].t4i_n = (int)P.t4items.size() - P.level_qbig[l].t4i_off;
             xf = std::max(xf, xo); dq = std::max(dq, dqo); wq = std::max(wq, wo);
         }
         LCHK(P.d_Xf.alloc((size_t)xf));
@@ -2758,10 +2762,11 @@ int run_qapply(stmmqr_plan &P, int method)
             // (k_qbig_step4, T4 built at the first use after a factorization) or per panel
             const auto &Q = P.level_qbig[l];
             if (Q.n > 0 && use_t4) {
-                if (!P.t4_valid) {
-                    LCHK(stm_launch_qt4_build(c, P.d_t4fronts.p, P.d_t4dqo.p, (int)P.t4fronts.size(), P.d_t4items.p, (int)P.t4items.size(), P.d_Dq4.p,
+                if (!P.t4_valid) { P.t4_level_valid.assign(LV.size(), 0); P.t4_valid = true; }
+                if (!P.t4_level_valid[l]) {                          // (the level's fronts are in front form now: level_to_front_form)
+                    LCHK(stm_launch_qt4_build(c, P.d_t4fronts.p + Q.off, P.d_t4dqo.p + Q.off, Q.n, P.d_t4items.p + Q.t4i_off, Q.t4i_n, P.d_Dq4.p,
                                               P.d_T4.p, P.stream));
-                    P.t4_valid = true;
+                    P.t4_level_valid[l] = 1;
                 }
                 LCHK(stm_launch_qapply_big4(c, P.d_qb.p + Q.off, P.d_qbt4off.p + Q.off, Q.n, Q.max_np, Q.max_nslab, Q.max_fm, m, P.d_W.p, P.d_Xf.p,
                                             P.d_Dq.p, P.d_Wq4.p, P.d_T4.p, P.stream));
