@@ -1,3 +1,5 @@
+"""Q'b and least-squares solve on the resident factors of one fixture, timed (STMMQR_QT4=0: per-panel split Q-apply; STMMQR_QBIG_MIN: split
+threshold; STMMQR_MEMDUMP=1: size of T4).  usage: python tools/time_resident.py [fixture]"""
 import sys, os, importlib, time, numpy as np
 sys.path.insert(0,'/root/repo'); sys.path.insert(0,'/root/repo/tests')
 from stmmqr_testlib import Symbolic, load_golden, scalar, csc_matvec
