@@ -36,7 +36,7 @@
 namespace {
 
 thread_local std::string g_err;
-stmmqr_options g_opt = {STM_NB, 64, 0, 0, 0, 1, STM_TALL_MIN, 1, 0, 4};      // (panel_algo 0: by panel height)
+stmmqr_options g_opt = {STM_NB, 64, 0, 0, 0, 1, STM_TALL_MIN, 2, 0, 4};      // (panel_algo 0: by panel height)
 size_t g_chunk[4] = {32, 5000, 4, 4};     // FCHUNK, SMALL, MINCHUNK, MINCHUNK_RATIO (SparseQR.h:16-19)
 
 // offsets inside the reference's sparse_common for the stock LP64 build; verified against the real header
@@ -1443,16 +1443,86 @@ int run_schedule(stmmqr_plan &P, bool detail, int grp, const StepReq *req = null
     };
     // Look-ahead needs the device's side stream (a CU-masked stream, created once per process and released by an atexit
     // handler): it is only created when some step of this group really goes there -- small matrices never touch it.
-    bool la = g_opt.lookahead && !detail && !P.serial_panels && SV.size() > 1;
+    // Passenger launches (options.lookahead = 2, the default): ONE stream, no events.  The chain stays  panel(t) -> T(t) + block 0 (one fused
+    // launch) -> panel(t+1); the two launches of the update beyond block 0 ride on the chain's launches as extra workgroups behind the
+    // chain's own (k_upd_w of step t behind T + block 0 of step t, k_upd_c of step t behind the panels of step t+1: stmmqr_kernels.hip,
+    // "Passenger launches").  Every workgroup does what it does in the serial order: same bits.  A step takes part when its update is the
+    // row-parallel form and every workgroup of its fused launch is resident at once (they wait for each other, bounded: two per CU);
+    // any other step runs in the serial order after the riders of the step before it.
+    const bool pass = g_opt.lookahead >= 2 && !detail && !P.serial_panels && c.cbskip == 0 && g_opt.split_update && !(c.dbg & 512) &&
+                      !(getenv("STMMQR_PASSENGERS") && atoi(getenv("STMMQR_PASSENGERS")) == 0);
+    bool la = g_opt.lookahead && !pass && !detail && !P.serial_panels && SV.size() > 1;
     if (la) {
         bool any = false;
         for (const Step &S : SV)
             if (S.n_act > 0 && S.maxcb > 1 && worth_it(S)) { any = true; break; }
         la = any;
     }
-    if (la && !P.side) P.side = side_stream_for(P.device);
-    la = la && P.side;
-    if (!la) {
+    if (pass) {
+        const long fw_max = getenv("STMMQR_PASS_MAXWG") ? atol(getenv("STMMQR_PASS_MAXWG")) : 384;
+        const int abl = getenv("STMMQR_PASS_ABL") ? atoi(getenv("STMMQR_PASS_ABL")) : 0;   // timing-only ablations (WRONG results): 1 no k_upd_w riders, 2 no k_upd_c riders
+        const Step *pend = nullptr;                            // the step whose k_upd_c beyond block 0 is still due
+        auto flush_alone = [&]() -> int {
+            if (!pend) return 0;
+            const Step &Q = *pend;
+            pend = nullptr;
+            LCHK(stm_launch_update_c(c, L0 + Q.act_off, L0 + Q.plist_off, Q.n_norm, 1, Q.maxcb - 1, Q.maxsl, P.d_Wp2.p,
+                                     P.d_wlists.p + Q.wp_off, st));
+            nlaunch++;
+            return 0;
+        };
+        for (const Step &S : SV) {
+            cur_step = (int)(&S - SV.data());
+            int e = prep(S, st);
+            if (e) return e;
+            if (S.n_act > 0) {
+                const int *act = L0 + S.act_off, *pl = L0 + S.plist_off;
+                if (S.nca_use) { LCHK(stm_launch_panel_ca(c, act, pl, S.n_act, S.nca, 1, st)); nlaunch++; }
+                if (S.npipe_use) {
+                    const int lds = (c.dbg & (64 | 256)) ? S.lds_big : S.lds_plan;
+                    if (pend && (abl & 2)) pend = nullptr;
+                    if (pend && (abl & 4)) {                     // (measurement: the riders as launches of their own, same order)
+                        LCHK(stm_launch_panel(c, act, pl, S.n_act, S.nsub, 1, lds, st));
+                        if (abl & 8) {
+                            const Step &Q = *pend;
+                            pend = nullptr;
+                            LCHK(stm_launch_panel_pc(c, act, pl, -1, S.nsub, 1, lds, L0 + Q.act_off, L0 + Q.plist_off, Q.n_norm, 1, Q.maxcb - 1,
+                                                     Q.maxsl, P.d_Wp2.p, P.d_wlists.p + Q.wp_off, st));
+                        }
+                        if ((e = flush_alone())) return e;
+                    } else if (pend) {
+                        const Step &Q = *pend;
+                        pend = nullptr;
+                        LCHK(stm_launch_panel_pc(c, act, pl, S.n_act, S.nsub, 1, lds, L0 + Q.act_off, L0 + Q.plist_off, Q.n_norm, 1, Q.maxcb - 1,
+                                                 Q.maxsl, P.d_Wp2.p, P.d_wlists.p + Q.wp_off, st));
+                    } else
+                        LCHK(stm_launch_panel(c, act, pl, S.n_act, S.nsub, 1, lds, st));
+                    nlaunch++;
+                } else if ((e = flush_alone()))
+                    return e;
+                long fwg = 0;
+                for (int i = 0; i < S.n_norm; i++) fwg += 2L * stm_upd_nsl(P.fs[P.lists[S.act_off + i]]);
+                const bool ride = S.split && S.n_sweep() == 0 && S.n_norm > 0 && S.maxcb > 1 && S.maxsl <= 256 && fwg <= fw_max &&
+                                  !g_opt.fused_update;
+                if (ride) {
+                    const int epoch = cur_step + 1 + grp * (1 << 20);
+                    if (abl & 4) {
+                        LCHK(stm_launch_update_fw(c, act, pl, S.n_norm, 1, S.maxsl, P.d_Wp.p, P.d_wlists.p + S.wp_off, P.d_wcnt.p, P.d_wflag.p,
+                                                  epoch, P.d_Wp2.p, P.d_wcnt2.p, st));
+                        LCHK(stm_launch_update_w(c, act, pl, S.n_norm, 1, S.maxcb - 1, S.maxsl, P.d_Wp2.p, P.d_wlists.p + S.wp_off, P.d_wcnt2.p, st));
+                    } else
+                    LCHK(stm_launch_update_fw(c, act, pl, S.n_norm, (abl & 1) ? 1 : S.maxcb, S.maxsl, P.d_Wp.p, P.d_wlists.p + S.wp_off, P.d_wcnt.p,
+                                              P.d_wflag.p, epoch, P.d_Wp2.p, P.d_wcnt2.p, st));
+                    nlaunch++;
+                    pend = &S;
+                } else if ((e = update(S, 0, S.maxcb, true, P.d_Wp.p, st)))
+                    return e;
+            }
+            if ((e = post(S, st))) return e;
+        }
+        int e = flush_alone();
+        if (e) return e;
+    } else if (!la) {
         for (const Step &S : SV) {
             cur_step = (int)(&S - SV.data());
             int e = prep(S, st);
@@ -1888,6 +1958,14 @@ int stmmqr_factorize_finish(stmmqr_plan *plan, stmmqr_stats *stats)
         bytes_pack += 16.0 * (csize + (double)nm.rsize);
     }
     bytes_asm += 8.0 * (double)P.anz + P.bytes_assemble_idx;
+    if (getenv("STMMQR_DBG") && (atoi(getenv("STMMQR_DBG")) & 32768)) {
+        unsigned long long hb[64];
+        HIPCHK(hipMemcpy(hb, P.d_dbg.p, sizeof hb, hipMemcpyDeviceToHost));
+        const double n = hb[56] ? 100.0 * (double)hb[56] : 1.0;
+        fprintf(stderr, "[block-0 launch, slab 0, us] descriptors+loads issued %.2f  phase 1 %.2f  partials+ticket %.2f  wait %.2f  sums %.2f  T %.2f  W2 %.2f  phase 2 %.2f  (%llu)\n",
+                hb[48] / n, hb[49] / n, hb[50] / n, hb[51] / n, hb[52] / n, hb[53] / n, hb[54] / n, hb[55] / n, hb[56]);
+        HIPCHK(hipMemset(P.d_dbg.p, 0, sizeof hb));
+    }
     if (getenv("STMMQR_DBG") && (atoi(getenv("STMMQR_DBG")) & 48)) {
         unsigned long long hb[64];
         HIPCHK(hipMemcpy(hb, P.d_dbg.p, sizeof hb, hipMemcpyDeviceToHost));
@@ -1898,6 +1976,8 @@ int stmmqr_factorize_finish(stmmqr_plan *plan, stmmqr_stats *stats)
                 hb[0], hb[1], hb[2], hb[3], hb[4]);
         fprintf(stderr, "[last group of the panel pipeline, cycles] load %llu  waits %llu  apply-loads %llu  applies %llu  factor %llu  gram %llu\n", hb[6],
                 hb[7], hb[12], hb[8] + hb[11], hb[9], hb[10]);
+        fprintf(stderr, "[panel workgroups] %llu  cycles %llu  100 MHz ticks %llu  => %.3f GHz, %.2f us per workgroup\n", hb[46], hb[44], hb[45],
+                hb[45] ? 0.1 * (double)hb[44] / (double)hb[45] : 0.0, hb[46] ? 0.01 * (double)hb[45] / (double)hb[46] : 0.0);
         fprintf(stderr, "[Gram-based panels] panels %llu  refresh rounds %llu  slab workgroups %llu\n", hb[13], hb[14], hb[15]);
         HIPCHK(hipMemset(P.d_dbg.p, 0, sizeof hb));
     }

@@ -72,6 +72,16 @@ int stm_launch_panel_ca(const DevCtx &c, const int *flist, const int *plist, int
 int stm_launch_update(const DevCtx &c, const int *flist, const int *plist, int nfr, int cb0, int ncb, hipStream_t st);
 int stm_launch_update_fused(const DevCtx &c, const int *flist, const int *plist, int nfr, int cb0, int ncb, int maxsl, double *Wp,
                             const long long *wpoff, int *wcnt, int *wflag, int epoch, int with_gram, hipStream_t st);
+// passenger launches (options.lookahead = 2): the update beyond block 0 rides on the chain's own launches
+int stm_launch_panel_pc(const DevCtx &c, const int *flist, const int *plist, int nfr, int nsub, int defer_ok, int lds_doubles,
+                        const int *uflist, const int *uplist, int unfr, int ucb0, int uncb, int umaxsl, const double *Wp,
+                        const long long *uwpoff, hipStream_t st);
+int stm_launch_update_fw(const DevCtx &c, const int *flist, const int *plist, int nfr, int ncb, int maxsl, double *Wp,
+                         const long long *wpoff, int *wcnt, int *wflag, int epoch, double *Wp2, int *wcnt2, hipStream_t st);
+int stm_launch_update_w(const DevCtx &c, const int *flist, const int *plist, int nfr, int cb0, int ncb, int maxsl, double *Wp,
+                        const long long *wpoff, int *wcnt, hipStream_t st);
+int stm_launch_update_c(const DevCtx &c, const int *flist, const int *plist, int nfr, int cb0, int ncb, int maxsl, const double *Wp,
+                        const long long *wpoff, hipStream_t st);
 int stm_launch_update_pair(const DevCtx &c, const int *flist, const int *plist, int nfr, int ncbp, int maxsl, double *Wp,
                            const long long *wpoff, int *wcnt, hipStream_t st);
 int stm_launch_update_quad(const DevCtx &c, const int *flist, const int *plist, int nfr, int ncbp, int maxsl, double *Wp,

@@ -18,6 +18,7 @@
 //  * the block reflector is applied with fp64 MFMA tiles (16x16x4): W = V'C over 64-row chunks, W = T'W,
 //    C -= V W; V is read in place from F with the unit-diagonal/zero mask applied on the fly.
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <stdint.h>
 #include <stdlib.h>
 #include "stmmqr_device.h"
@@ -1919,14 +1920,12 @@ __device__ __forceinline__ void dev_wave_panel(PanelShared &ps, WaveShared &wsh,
 // ------------------------------------------------------------------------------------------------
 // large fronts: panel and trailing update are separate launches (many workgroups per update)
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(NTP) void k_panel(DevCtx c, const int *__restrict__ flist, const int *__restrict__ plist, int nsub,
-                                               int defer_ok, int lds_doubles)
+// the body of k_panel: column group b of panel p of front f (fi: the front's place in the launch's lists)
+__device__ __forceinline__ void dev_k_panel(const DevCtx &c, const int *__restrict__ flist, const int *__restrict__ plist, int fi, int b,
+                                            int nsub, int defer_ok, int lds_doubles, PanelShared &ps, WaveShared &wsh, double *dyn_lds)
 {
-    extern __shared__ double dyn_lds[];
-    __shared__ PanelShared ps;
-    __shared__ WaveShared wsh;
-    const int f = flist[blockIdx.x];
-    const int p = plist[blockIdx.x];                           // every front of a step is at its own panel
+    const int f = flist[fi];
+    const int p = plist[fi];                                   // every front of a step is at its own panel
     __builtin_amdgcn_s_setprio(3);                             // (critical path: ahead of the side stream's update waves)
     const FrontSym s = c.fs[f];
     if (p >= s.npanels || stm_use_ca(s, p, c.panel_algo, c.ca_min_rows)) return;      // (the Gram-based panel kernel takes those)
@@ -1936,7 +1935,6 @@ __global__ __launch_bounds__(NTP) void k_panel(DevCtx c, const int *__restrict__
     int *St = c.Stair + s.rp;
     double *Tkeep = c.Tall ? c.Tall + (long long)(s.tpan + p) * STM_NB * STM_NB : nullptr;
     PanelDesc *pd = &num->pd[STM_PDI(p)];
-    const int b = blockIdx.y;
     if ((c.dbg & 2048) && b == ((c.dbg >> 20) & 7)) {          // tests: column group (dbg >> 20) & 7 starts ~1 ms late
         for (int it = 0; it < 4000; it++) __builtin_amdgcn_s_sleep(100);
     }
@@ -2022,6 +2020,19 @@ __global__ __launch_bounds__(NTP) void k_panel(DevCtx c, const int *__restrict__
     if (threadIdx.x == 0) { pd->mode = 0; pd->t_deferred = 0; }
 }
 
+__global__ __launch_bounds__(NTP) void k_panel(DevCtx c, const int *__restrict__ flist, const int *__restrict__ plist, int nsub,
+                                               int defer_ok, int lds_doubles)
+{
+    extern __shared__ double dyn_lds[];
+    __shared__ PanelShared ps;
+    __shared__ WaveShared wsh;
+    const unsigned long long t0c = clock64(), t0w = wall_clock64();
+    dev_k_panel(c, flist, plist, blockIdx.x, blockIdx.y, nsub, defer_ok, lds_doubles, ps, wsh, dyn_lds);
+    if ((c.dbg & 16) && c.dbgbuf && threadIdx.x == 0) {           // diagnosis: shader clock held during the panels (cycles / 100 MHz ticks)
+        atomicAdd(&c.dbgbuf[44], clock64() - t0c); atomicAdd(&c.dbgbuf[45], wall_clock64() - t0w); atomicAdd(&c.dbgbuf[46], 1ull);
+    }
+}
+
 __global__ __launch_bounds__(NT) void k_update(DevCtx c, const int *__restrict__ flist, const int *__restrict__ plist, int cb0)
 {
     extern __shared__ double dyn_lds[];
@@ -2091,23 +2102,25 @@ __global__ __launch_bounds__(NT) void k_larft(DevCtx c, int f)
 // ------------------------------------------------------------------------------------------------
 #define SLAB STM_UPD_SLAB
 
-__global__ __launch_bounds__(NT) void k_upd_w(DevCtx c, const int *__restrict__ flist, const int *__restrict__ plist, int cb0,
-                                              int with_gram, double *Wp, const long long *__restrict__ wpoff, int *wcnt)
+// the body of k_upd_w: workgroup (cb, sl) of front fi of the launch's lists; ncbx = column blocks of the launch (the last one is
+// the Gram block when with_gram)
+template <bool PRE = false>        // PRE: the slab's four chunks requested at once (riders: two workgroups per CU, little else hides a round trip)
+__device__ __forceinline__ void dev_k_upd_w(const DevCtx &c, const int *__restrict__ flist, const int *__restrict__ plist, int cb0,
+                                            int with_gram, double *Wp, const long long *__restrict__ wpoff, int *wcnt, int cb, int sl,
+                                            int fi, int ncbx, double *dyn_lds)
 {
-    extern __shared__ double dyn_lds[];
     __shared__ int s_pd[STM_NB];
-    const int fi = blockIdx.z, f = flist[fi], p = plist[fi];
+    const int f = flist[fi], p = plist[fi];
     const FrontSym s = c.fs[f];
     if (p >= s.npanels) return;
     const PanelDesc *pd = &c.fnum[f].pd[STM_PDI(p)];
     const int g1 = pd->pg1, mp = pd->pt - pd->pg1, nbp = pd->pnb;
-    const int cb = blockIdx.x, sl = blockIdx.y;
     // the front's slice of the workspace: (ncbf + 1) column-block slots of nslf slabs (both symbolic: the host sized it so)
     const int ncbf = stm_upd_ncb(s, p), nslf = stm_upd_nsl(s);
     // with_gram: the LAST column block of the launch is the Gram block (T may have been left to this kernel):
     // C = V, partial V'V per slab; the last slab workgroup of a front to arrive sums them in slab order and
     // builds T (dlarft recurrence) for k_upd_c
-    const bool gram = with_gram && (cb == (int)gridDim.x - 1);
+    const bool gram = with_gram && (cb == ncbx - 1);
     if ((c.dbg & 16) && c.dbgbuf && threadIdx.x == 0) {                  // diagnosis: launched / useful workgroups
         atomicAdd(&c.dbgbuf[40], 1ull);
         const int c0d = gram ? pd->pk1 : pd->pc0 + (cb0 + cb * (1 + c.cbskip)) * BN;
@@ -2129,6 +2142,27 @@ __global__ __launch_bounds__(NT) void k_upd_w(DevCtx c, const int *__restrict__ 
     const int mi = wid >> 1, ni = wid & 1;
     d4 acc = {0, 0, 0, 0};
     const int rend = min(mp, (sl + 1) * SLAB);
+    if constexpr (PRE) {
+        UpdChunk ckp[SLAB / RB];
+#pragma unroll
+        for (int q = 0; q < SLAB / RB; q++) upd_chunk_load(ckp[q], Vg, Cg, ld, sl * SLAB + q * RB + (tid & 63), mp, nbp, nc, tid >> 6);
+        const int pfrom = (nc == BN) ? upd_plain_from(s_pd, g1, lane) : STM_BIGROW;
+#pragma unroll
+        for (int q = 0; q < SLAB / RB; q++) {
+            const int r0 = sl * SLAB + q * RB;
+            if (r0 < rend) {
+                upd_chunk_to_lds(ckp[q], r0 + (tid & 63), mp, nbp, nc, s_pd, g1, tid & 63, tid >> 6, Vs, Cs, gram, r0 > pfrom && r0 + RB <= mp);
+                __syncthreads();
+#pragma unroll
+                for (int kk = 0; kk < RB / 4; kk++) {
+                    const double a = Vs[(16 * mi + l15) * VS + 4 * kk + l4];
+                    const double b = Cs[(16 * ni + l15) * VS + 4 * kk + l4];
+                    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
+                }
+                __syncthreads();
+            }
+        }
+    } else {
     UpdChunk ck;
     upd_chunk_load(ck, Vg, Cg, ld, sl * SLAB + (tid & 63), mp, nbp, nc, tid >> 6);
     const int pfrom = (nc == BN) ? upd_plain_from(s_pd, g1, lane) : STM_BIGROW;
@@ -2143,6 +2177,7 @@ __global__ __launch_bounds__(NT) void k_upd_w(DevCtx c, const int *__restrict__ 
             acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
         }
         __syncthreads();
+    }
     }
     // (the Gram block's slot comes after the front's last column block; a pair / quad update front only ever brings column blocks 0 .. sweep-1
     //  here -- everything beyond goes through k_upd_w2, whose slots are packed more tightly: stm_pair_slots -- so its Gram block
@@ -2223,6 +2258,13 @@ __global__ __launch_bounds__(NT) void k_upd_w(DevCtx c, const int *__restrict__ 
         Tout[e] = tv;
         if (Tkeep) Tkeep[e] = tv;
     }
+}
+
+__global__ __launch_bounds__(NT) void k_upd_w(DevCtx c, const int *__restrict__ flist, const int *__restrict__ plist, int cb0,
+                                              int with_gram, double *Wp, const long long *__restrict__ wpoff, int *wcnt)
+{
+    extern __shared__ double dyn_lds[];
+    dev_k_upd_w(c, flist, plist, cb0, with_gram, Wp, wpoff, wcnt, blockIdx.x, blockIdx.y, blockIdx.z, gridDim.x, dyn_lds);
 }
 
 __global__ __launch_bounds__(NT) void k_upd_c(DevCtx c, const int *__restrict__ flist, const int *__restrict__ plist, int cb0,
@@ -2341,22 +2383,21 @@ __global__ __launch_bounds__(NT) void k_upd_c(DevCtx c, const int *__restrict__ 
 // (the host falls back to the two-launch form beyond 256 slabs).  The waits are bounded; one that runs out sets perr.
 // Arithmetic = k_upd_w + k_upd_c exactly (same chunks, same MFMA sequence, same summation order): the same bits.
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(NT, 2) void k_upd_f(DevCtx c, const int *__restrict__ flist, const int *__restrict__ plist, int cb0,
-                                              int with_gram, double *Wp, const long long *__restrict__ wpoff, int *wcnt,
-                                              int *wflag, int epoch)
+// the body of k_upd_f: workgroup (slab sl, column block by [0 = the Gram block when with_gram]) of front fi of the launch's lists
+__device__ __forceinline__ void dev_k_upd_f(const DevCtx &c, const int *__restrict__ flist, const int *__restrict__ plist, int cb0,
+                                            int with_gram, double *Wp, const long long *__restrict__ wpoff, int *wcnt, int *wflag,
+                                            int epoch, int sl, int by, int fi, double *dyn_lds)
 {
-    extern __shared__ double dyn_lds[];
     __shared__ int s_pd[STM_NB];
     __shared__ int s_ticket, s_ok;
-    const int fi = blockIdx.z, f = flist[fi], p = plist[fi];
+    const int f = flist[fi], p = plist[fi];
     const FrontSym s = c.fs[f];
     if (p >= s.npanels) return;
     FrontNum *num = &c.fnum[f];
     const PanelDesc *pd = &num->pd[STM_PDI(p)];
     const int g1 = pd->pg1, mp = pd->pt - pd->pg1, nbp = pd->pnb;
-    const int sl = blockIdx.x;
-    const bool gram = with_gram && blockIdx.y == 0;
-    const int cb = (int)blockIdx.y - (with_gram ? 1 : 0);          // launch-relative column block
+    const bool gram = with_gram && by == 0;
+    const int cb = by - (with_gram ? 1 : 0);                       // launch-relative column block
     const int ncbf = stm_upd_ncb(s, p), nslf = stm_upd_nsl(s);
     if (gram && !pd->t_deferred) return;
     if (!gram && cb0 + cb * (1 + c.cbskip) >= ncbf) return;
@@ -2520,6 +2561,373 @@ __global__ __launch_bounds__(NT, 2) void k_upd_f(DevCtx c, const int *__restrict
             __syncthreads();
         }
     }
+}
+
+__global__ __launch_bounds__(NT, 2) void k_upd_f(DevCtx c, const int *__restrict__ flist, const int *__restrict__ plist, int cb0,
+                                              int with_gram, double *Wp, const long long *__restrict__ wpoff, int *wcnt,
+                                              int *wflag, int epoch)
+{
+    extern __shared__ double dyn_lds[];
+    dev_k_upd_f(c, flist, plist, cb0, with_gram, Wp, wpoff, wcnt, wflag, epoch, blockIdx.x, blockIdx.y, blockIdx.z, dyn_lds);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Passenger launches (options.lookahead = 2, the default).  The chain of a large front is panel(t) -> T(t) + update of column
+// block 0 -> panel(t+1); the rest of update t (column blocks 1..) does not feed panel t+1.  Instead of a second stream (two
+// cross-stream hand-offs of ~9 us per step) the two launches of that rest RIDE on the chain's own launches, as extra workgroups
+// behind the chain's in dispatch order:
+//   B(t)   = k_upd_fw : T(t) + block 0 (k_upd_f's workgroups)          + k_upd_w of blocks 1.. of step t
+//   A(t+1) = k_panel_pc: panel(t+1) (k_panel's workgroups, dispatched first) + k_upd_c of blocks 1.. of step t
+// Every workgroup does exactly what it does in the serial order (same bits); a launch lasts as long as its longest role.
+// Dependencies: k_upd_w(t) needs V(t) [A(t)] and C after k_upd_c(t-1) [A(t)]; k_upd_c(t) needs its partial sums [B(t)] and T(t)
+// [B(t)]; block 0 of step t+1 is block 1 of step t: complete after A(t+1), before B(t+1).
+// ------------------------------------------------------------------------------------------------
+// k_upd_c's tile by a 512-thread workgroup: the two 256-thread halves take alternate 64-row chunks of the slab; every row of C sees
+// exactly the operations of k_upd_c.  lds: STM_NB * WS (W2) + per half the V image and the product image (BN * VS each).
+#define STM_PC_LDS_DOUBLES (STM_NB * WS + 4 * BN * VS)
+__device__ __forceinline__ void dev_upd_c_h2(const DevCtx &c, const int *__restrict__ flist, const int *__restrict__ plist, int cb0,
+                                             const double *Wp, const long long *__restrict__ wpoff, int fi, int cb, int sl,
+                                             double *dyn_lds, int *s_pd)
+{
+    const int f = flist[fi], p = plist[fi];
+    const FrontSym s = c.fs[f];
+    if (p >= s.npanels) return;
+    const PanelDesc *pd = &c.fnum[f].pd[STM_PDI(p)];
+    const int g1 = pd->pg1, mp = pd->pt - pd->pg1, nbp = pd->pnb;
+    const int nslf = stm_upd_nsl(s);
+    const int c0 = pd->pc0 + (cb0 + cb * (1 + c.cbskip)) * BN;
+    if (nbp <= 0 || mp <= 0 || c0 >= s.fn || sl * SLAB >= mp) return;
+    const int nsl_all = (mp + SLAB - 1) / SLAB;
+    const int spw = (nsl_all >= 32) ? 4 : (nsl_all >= 16) ? 2 : 1;      // (as k_upd_c)
+    if (sl % spw) return;
+    const int nc = min(BN, s.fn - c0);
+    const long long ld = s.ld;
+    const int half = threadIdx.x >> 8, tid = threadIdx.x & 255, lane = tid & 63, wid = tid >> 6, l15 = lane & 15, l4 = lane >> 4;
+    double *Ws = dyn_lds, *Vs = Ws + STM_NB * WS + half * (2 * BN * VS), *Cs = Vs + BN * VS;
+    double *s_W1 = dyn_lds + STM_NB * WS, *s_T = s_W1 + BN * VS;       // (half 0's images: first written after the prologue)
+    if (threadIdx.x < STM_NB) s_pd[threadIdx.x] = ((int)threadIdx.x < nbp) ? pd->pdiag[threadIdx.x] : STM_BIGROW;
+    const double *Vg = c.Farena + s.foff + g1 + (long long)pd->pk1 * ld;
+    double *Cg = c.Farena + s.foff + g1 + (long long)c0 * ld;
+    const int lrow = tid & 63, lcg = tid >> 6;
+    const int rbeg = sl * SLAB, rend = min(mp, (sl + spw) * SLAB);
+    int r0 = rbeg + half * RB;
+    // (a rider has the CU to itself -- the launch carries the panel's registers and LDS -- so nothing else hides its round trips:
+    //  the first two chunks of the half are requested before the prologue, from then on two trips ahead)
+    UpdChunk ck0, ck1;
+    upd_chunk_load(ck0, Vg, Cg, ld, r0 + lrow, mp, nbp, nc, lcg);
+    upd_chunk_load(ck1, Vg, Cg, ld, r0 + 2 * RB + lrow, mp, nbp, nc, lcg);
+    {
+        const double *W0 = Wp + wpoff[fi] + ((long long)cb * nslf) * (STM_NB * BN);
+        const double *T = c.Tws + (long long)STM_TSLOT(c.tslot[f], p) * STM_NB * STM_NB;
+        for (int e = threadIdx.x; e < STM_NB * BN; e += 2 * NT) {
+            const double v = W0[e];
+            s_W1[(e / BN) * WS + (e % BN)] = v;
+            s_T[(e / STM_NB) * WS + (e % STM_NB)] = T[e];          // s_T[col][row] = T(row, col)
+        }
+        __syncthreads();
+        const int l = threadIdx.x & 31, cg = threadIdx.x >> 5;     // 16 groups of 2 columns: the sums of k_upd_c, entry by entry
+        double w2[2] = {0, 0};
+#pragma unroll
+        for (int q = 0; q < STM_NB; q++) {
+            const double tq = s_T[l * WS + q];                     // T(q, l)
+            if (q <= l) {
+#pragma unroll
+                for (int x = 0; x < 2; x++) w2[x] += tq * s_W1[q * WS + cg * 2 + x];
+            }
+        }
+        __syncthreads();                                           // (Ws does not alias the prologue images; the barrier orders
+                                                                   //  the reads of s_W1 / s_T before half 0's first V image)
+#pragma unroll
+        for (int x = 0; x < 2; x++) Ws[l * WS + cg * 2 + x] = w2[x];
+    }
+    const int pfrom = upd_plain_from(s_pd, g1, lane);
+    const int nch = (rend - rbeg + RB - 1) / RB, trips = (nch + 1) / 2;
+    auto trip = [&](UpdChunk &ck) {
+        const bool valid = r0 < rend;
+        const int i = r0 + lrow;
+        double cc[8];
+#pragma unroll
+        for (int q = 0; q < 8; q++) cc[q] = ck.c[q];
+        upd_chunk_v_to_lds(ck, i, mp, nbp, s_pd, g1, lrow, lcg, Vs, valid && r0 > pfrom && r0 + RB <= mp);
+        __syncthreads();                                           // (the first trip: Ws too)
+        if (r0 + 4 * RB < rend) upd_chunk_load(ck, Vg, Cg, ld, i + 4 * RB, mp, nbp, nc, lcg);      // (this buffer's next trip)
+        d4 u0 = {0, 0, 0, 0}, u1 = {0, 0, 0, 0};
+#pragma unroll
+        for (int kk = 0; kk < STM_NB / 4; kk++) {
+            const double a = Vs[(4 * kk + l4) * VS + 16 * wid + l15];
+            const double b0 = Ws[(4 * kk + l4) * WS + l15];
+            const double b1 = Ws[(4 * kk + l4) * WS + 16 + l15];
+            u0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b0, u0, 0, 0, 0);
+            u1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b1, u1, 0, 0, 0);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const int row = 16 * wid + l4 + 4 * r;
+            Cs[l15 * VS + row] = u0[r];
+            Cs[(16 + l15) * VS + row] = u1[r];
+        }
+        __syncthreads();
+        if (valid && i < mp) {
+#pragma unroll
+            for (int q = 0; q < 8; q++) {
+                const int col = lcg * 8 + q;
+                if (col < nc) Cg[i + col * ld] = cc[q] - Cs[col * VS + lrow];
+            }
+        }
+        r0 += 2 * RB;
+    };
+    for (int j = 0; j < trips; j += 2) {
+        trip(ck0);
+        if (j + 1 < trips) trip(ck1);
+    }
+}
+
+// A launch: the panel pipeline's workgroups (blockIdx.z = 0: front blockIdx.x, column group blockIdx.y) and, behind them in dispatch
+// order, k_upd_c's tiles of the previous step's update beyond block 0 (blockIdx.z - 1 = front of THAT step's lists, blockIdx.x =
+// column block, blockIdx.y = slab).
+__global__ __launch_bounds__(NTP) void k_panel_pc(DevCtx c, const int *__restrict__ flist, const int *__restrict__ plist, int npan,
+                                                  int nsub, int defer_ok, int lds_doubles, const int *__restrict__ uflist,
+                                                  const int *__restrict__ uplist, int ucb0, const double *Wp,
+                                                  const long long *__restrict__ uwpoff)
+{
+    extern __shared__ double dyn_lds[];
+    __shared__ PanelShared ps;
+    __shared__ WaveShared wsh;
+    if (blockIdx.z == 0) {
+        if ((int)blockIdx.x >= npan || (int)blockIdx.y >= nsub) return;
+        const unsigned long long t0c = clock64(), t0w = wall_clock64();
+        dev_k_panel(c, flist, plist, blockIdx.x, blockIdx.y, nsub, defer_ok, lds_doubles, ps, wsh, dyn_lds);
+        if ((c.dbg & 16) && c.dbgbuf && threadIdx.x == 0) {
+            atomicAdd(&c.dbgbuf[44], clock64() - t0c); atomicAdd(&c.dbgbuf[45], wall_clock64() - t0w); atomicAdd(&c.dbgbuf[46], 1ull);
+        }
+        return;
+    }
+    dev_upd_c_h2(c, uflist, uplist, ucb0, Wp, uwpoff, (int)blockIdx.z - 1, blockIdx.x, blockIdx.y, dyn_lds, ps.stair);
+}
+
+// ------------------------------------------------------------------------------------------------
+// T + column block 0 of a step in ONE launch with ONE meeting point (the chain's launch between two panels; k_upd_f with the
+// Gram block needs two: the Gram slabs meet and build T, the block's slabs meet, wait for T, one of them forms T'W and hands it
+// to the others -- ~25 us of dependent round trips for a 4000 x 32 block).  Here every slab workgroup of block 0 accumulates its
+// partial V'V beside its partial V'C (one more MFMA accumulator on the V image it has staged anyway), stores both, takes a
+// ticket; the last arriver raises the flag; then EVERY slab workgroup adds the partials in slab order, builds T (dev_T_from_gram)
+// and T'W for itself -- redundant arithmetic instead of a second hand-off -- and applies from the registers.
+// Arithmetic = k_upd_w (Gram block + block 0) + k_upd_c exactly: the same bits.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void dev_k_upd_b0(const DevCtx &c, const int *__restrict__ flist, const int *__restrict__ plist, double *Wp,
+                                             const long long *__restrict__ wpoff, int *wcnt, int *wflag, int epoch, int sl, int fi,
+                                             double *dyn_lds)
+{
+    __shared__ int s_pd[STM_NB];
+    __shared__ int s_ticket, s_ok;
+    __shared__ double s_tau[STM_NB];
+    const bool tl = (c.dbg & 32768) && c.dbgbuf && threadIdx.x == 0 && sl == 0;
+    unsigned long long tl0 = tl ? wall_clock64() : 0;
+#define B0TL(k) do { if (tl) { const unsigned long long t1 = wall_clock64(); atomicAdd(&c.dbgbuf[48 + (k)], t1 - tl0); tl0 = t1; } } while (0)
+    const int f = flist[fi], p = plist[fi];
+    const FrontSym s = c.fs[f];
+    if (p >= s.npanels) return;
+    FrontNum *num = &c.fnum[f];
+    const PanelDesc *pd = &num->pd[STM_PDI(p)];
+    const int g1 = pd->pg1, mp = pd->pt - pd->pg1, nbp = pd->pnb;
+    const int ncbf = stm_upd_ncb(s, p), nslf = stm_upd_nsl(s);
+    if (ncbf <= 0) return;
+    const int c0 = pd->pc0;
+    if (nbp <= 0 || mp <= 0 || c0 >= s.fn || sl * SLAB >= mp) return;
+    const bool deferred = pd->t_deferred != 0;                     // T was left to the update by the panel kernel
+    const int nc = min(BN, s.fn - c0);
+    const long long ld = s.ld;
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, l15 = lane & 15, l4 = lane >> 4;
+    const int lrow = tid & 63, lcg = tid >> 6;
+    double *Vs = dyn_lds, *Cs = Vs + STM_NB * VS, *Ws = Cs + BN * VS;
+    if (tid < STM_NB) {
+        s_pd[tid] = (tid < nbp) ? pd->pdiag[tid] : STM_BIGROW;
+        s_tau[tid] = (tid < nbp) ? c.Tau[s.rp + pd->pk1 + tid] : 0.0;
+    }
+    const double *Vg = c.Farena + s.foff + g1 + (long long)pd->pk1 * ld;
+    double *Cg = c.Farena + s.foff + g1 + (long long)c0 * ld;
+    const int r00 = sl * SLAB, rend = min(mp, (sl + 1) * SLAB);
+    UpdChunk ck[SLAB / RB];
+#pragma unroll
+    for (int q = 0; q < SLAB / RB; q++) upd_chunk_load(ck[q], Vg, Cg, ld, r00 + q * RB + lrow, mp, nbp, nc, lcg);
+    const int nsl = (mp + SLAB - 1) / SLAB;
+    const int gslot = (c.ypoff && c.ypoff[f] >= 0) ? min(ncbf, c.sweep) : ncbf;                         // (as in k_upd_w)
+    double *Wslot = Wp + wpoff[fi];                                                                     // column block 0
+    double *Gslot = Wp + wpoff[fi] + ((long long)gslot * nslf) * (STM_NB * BN);
+    double *Tslot = c.Tws + (long long)STM_TSLOT(c.tslot[f], p) * STM_NB * STM_NB;
+    __syncthreads();
+    B0TL(0);
+    // ---- phase 1: partial W1 = V(slab)' C(slab) and, for a deferred T, partial G = V(slab)' V(slab) ----
+    const int mi = wid >> 1, ni = wid & 1;
+    d4 acc = {0, 0, 0, 0}, accg = {0, 0, 0, 0};
+#pragma unroll
+    for (int q = 0; q < SLAB / RB; q++) {
+        const int r0 = r00 + q * RB;
+        if (r0 < rend) {
+            upd_chunk_to_lds(ck[q], r0 + lrow, mp, nbp, nc, s_pd, g1, lrow, lcg, Vs, Cs);
+            __syncthreads();
+#pragma unroll
+            for (int kk = 0; kk < RB / 4; kk++) {
+                const double a = Vs[(16 * mi + l15) * VS + 4 * kk + l4];
+                const double b = Cs[(16 * ni + l15) * VS + 4 * kk + l4];
+                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
+            }
+            if (deferred) {
+#pragma unroll
+                for (int kk = 0; kk < RB / 4; kk++) {
+                    const double a = Vs[(16 * mi + l15) * VS + 4 * kk + l4];
+                    const double b = Vs[(16 * ni + l15) * VS + 4 * kk + l4];      // (the Gram block of k_upd_w: C = V)
+                    accg = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, accg, 0, 0, 0);
+                }
+            }
+            __syncthreads();
+        }
+    }
+    double *s_G = Vs, *s_W1 = Vs + STM_NB * WS, *s_T = Cs;         // (the chunk images are free between the phases)
+    B0TL(1);
+    bool last = true;
+    if (nsl > 1) {
+        double *W = Wslot + (long long)sl * (STM_NB * BN), *G = Gslot + (long long)sl * (STM_NB * BN);
+#pragma unroll
+        for (int r = 0; r < 4; r++) st_agent(&W[(16 * mi + l4 + 4 * r) * BN + 16 * ni + l15], acc[r]);
+        if (deferred) {
+#pragma unroll
+            for (int r = 0; r < 4; r++) st_agent(&G[(16 * mi + l4 + 4 * r) * BN + 16 * ni + l15], accg[r]);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        int *cnt = wcnt + wpoff[fi] / (STM_NB * BN);
+        int *flag = wflag + wpoff[fi] / (STM_NB * BN);
+        if (tid == 0) {
+            s_ticket = __hip_atomic_fetch_add(cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (s_ticket == nsl - 1) {
+                __hip_atomic_store(cnt, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                st_agent(flag, epoch);                             // (every partial was acknowledged before its ticket)
+            }
+        }
+        __syncthreads();
+        last = (s_ticket == nsl - 1);
+        B0TL(2);
+        if (!stm_wait_ge(flag, epoch, c.abort, &s_ok)) { if (tid == 0) STM_SET_PERR(c, num); return; }
+        B0TL(3);
+        for (int e = tid; e < STM_NB * BN; e += NT) {
+            s_W1[(e / BN) * WS + (e % BN)] = stm_ordered_sum<true>(Wslot + e, STM_NB * BN, nsl);        // fixed order: deterministic
+            if (deferred) s_G[(e / BN) * WS + (e % BN)] = stm_ordered_sum<true>(Gslot + e, STM_NB * BN, nsl);
+        }
+    } else {
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            s_W1[(16 * mi + l4 + 4 * r) * WS + 16 * ni + l15] = acc[r];
+            if (deferred) s_G[(16 * mi + l4 + 4 * r) * WS + 16 * ni + l15] = accg[r];
+        }
+    }
+    __syncthreads();
+    B0TL(4);
+    double (*s_Tb)[STM_NB + 1] = reinterpret_cast<double (*)[STM_NB + 1]>(s_T);       // T(row, col) = s_Tb[row][col]
+    if (deferred) {
+        dev_T_from_gram(reinterpret_cast<double (*)[STM_NB + 1]>(s_G), s_Tb, s_tau, nbp, tid);
+        if (last) {
+            double *Tkeep = c.Tall ? c.Tall + (long long)(s.tpan + p) * STM_NB * STM_NB : nullptr;
+            for (int e = tid; e < STM_NB * STM_NB; e += NT) {
+                const int a = e % STM_NB, b = e / STM_NB;
+                const double tv = (a <= b && a < nbp && b < nbp) ? s_Tb[a][b] : 0.0;
+                Tslot[e] = tv;
+                if (Tkeep) Tkeep[e] = tv;
+            }
+        }
+    } else {
+        for (int e = tid; e < STM_NB * STM_NB; e += NT) s_Tb[e % STM_NB][e / STM_NB] = Tslot[e];
+        __syncthreads();
+    }
+    B0TL(5);
+    // W2 = T' W1 (k_upd_c's prologue)
+    {
+        const int l = tid & 31, cg = tid >> 5;
+        double w2[4] = {0, 0, 0, 0};
+#pragma unroll
+        for (int q = 0; q < STM_NB; q++) {
+            const double tq = (q < nbp && l < nbp) ? s_Tb[q][l] : 0.0;          // T(q, l)
+            if (q <= l) {
+#pragma unroll
+                for (int x = 0; x < 4; x++) w2[x] += tq * s_W1[q * WS + cg * 4 + x];
+            }
+        }
+#pragma unroll
+        for (int x = 0; x < 4; x++) Ws[l * WS + cg * 4 + x] = w2[x];
+    }
+    __syncthreads();
+    B0TL(6);
+    // ---- phase 2: C(slab) -= V(slab) W2 from the registers (k_upd_c) ----
+#pragma unroll
+    for (int q = 0; q < SLAB / RB; q++) {
+        const int r0 = r00 + q * RB;
+        if (r0 < rend) {
+            const int i = r0 + lrow;
+            upd_chunk_to_lds(ck[q], i, mp, nbp, nc, s_pd, g1, lrow, lcg, Vs, Cs);
+            __syncthreads();
+            d4 u0 = {0, 0, 0, 0}, u1 = {0, 0, 0, 0};
+#pragma unroll
+            for (int kk = 0; kk < STM_NB / 4; kk++) {
+                const double a = Vs[(4 * kk + l4) * VS + 16 * wid + l15];
+                const double b0 = Ws[(4 * kk + l4) * WS + l15];
+                const double b1 = Ws[(4 * kk + l4) * WS + 16 + l15];
+                u0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b0, u0, 0, 0, 0);
+                u1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b1, u1, 0, 0, 0);
+            }
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const int row = 16 * wid + l4 + 4 * r;
+                Cs[l15 * VS + row] -= u0[r];
+                Cs[(16 + l15) * VS + row] -= u1[r];
+            }
+            __syncthreads();
+            if (i < mp) {
+#pragma unroll
+                for (int qq = 0; qq < 8; qq++) {
+                    const int col = lcg * 8 + qq;
+                    if (col < nc) Cg[i + col * ld] = Cs[col * VS + lrow];
+                }
+            }
+            __syncthreads();
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    B0TL(7);
+    if (tl) atomicAdd(&c.dbgbuf[56], 1ull);
+#undef B0TL
+}
+
+// B launch, one meeting point: block 0 + T by dev_k_upd_b0 (blockIdx.z < nfr, slab blockIdx.x, blockIdx.y = 0) and, behind it, the
+// riders: k_upd_w's tiles of the column blocks beyond block 0 (as k_upd_fw).
+__global__ __launch_bounds__(NT, 2) void k_upd_b0w(DevCtx c, const int *__restrict__ flist, const int *__restrict__ plist, int nfr,
+                                                   int maxsl, int ncbrest, double *Wp, const long long *__restrict__ wpoff, int *wcnt,
+                                                   int *wflag, int epoch, double *Wp2, int *wcnt2)
+{
+    extern __shared__ double dyn_lds[];
+    if ((int)blockIdx.z < nfr) {
+        if ((int)blockIdx.x >= maxsl || blockIdx.y >= 1) return;
+        dev_k_upd_b0(c, flist, plist, Wp, wpoff, wcnt, wflag, epoch, blockIdx.x, blockIdx.z, dyn_lds);
+        return;
+    }
+    if ((int)blockIdx.x >= ncbrest || (int)blockIdx.y >= maxsl) return;
+    dev_k_upd_w<true>(c, flist, plist, 1, 0, Wp2, wpoff, wcnt2, blockIdx.x, blockIdx.y, (int)blockIdx.z - nfr, ncbrest, dyn_lds);
+}
+
+// B launch: T + column block 0 of the step (k_upd_f's workgroups: blockIdx.z < nfr, slab blockIdx.x, blockIdx.y = 0 the Gram block /
+// 1 block 0) and, behind them, k_upd_w's tiles of the column blocks beyond block 0 (blockIdx.z - nfr = front, blockIdx.x = column
+// block - 1, blockIdx.y = slab) into the passengers' workspace.
+__global__ __launch_bounds__(NT, 2) void k_upd_fw(DevCtx c, const int *__restrict__ flist, const int *__restrict__ plist, int nfr,
+                                                  int maxsl, int ncbrest, double *Wp, const long long *__restrict__ wpoff, int *wcnt,
+                                                  int *wflag, int epoch, double *Wp2, int *wcnt2)
+{
+    extern __shared__ double dyn_lds[];
+    if ((int)blockIdx.z < nfr) {
+        if ((int)blockIdx.x >= maxsl || blockIdx.y >= 2) return;
+        dev_k_upd_f(c, flist, plist, 0, 1, Wp, wpoff, wcnt, wflag, epoch, blockIdx.x, blockIdx.y, blockIdx.z, dyn_lds);
+        return;
+    }
+    if ((int)blockIdx.x >= ncbrest || (int)blockIdx.y >= maxsl) return;
+    dev_k_upd_w<true>(c, flist, plist, 1, 0, Wp2, wpoff, wcnt2, blockIdx.x, blockIdx.y, (int)blockIdx.z - nfr, ncbrest, dyn_lds);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -4735,6 +5143,81 @@ int stm_launch_update_fused(const DevCtx &c, const int *flist, const int *plist,
                        with_gram ? 1 : 0, Wp, wpoff, wcnt, wflag, epoch);
     return (int)hipGetLastError();
 }
+// Passenger launches (k_panel_pc / k_upd_fw above).  A: the panels of a step + k_upd_c of the column blocks ucb0 .. ucb0 + uncb - 1 of the
+// fronts (uflist, uplist, uwpoff: the PREVIOUS step's lists) out of the passengers' workspace.
+int stm_launch_panel_pc(const DevCtx &c, const int *flist, const int *plist, int nfr, int nsub, int defer_ok, int lds_doubles,
+                        const int *uflist, const int *uplist, int unfr, int ucb0, int uncb, int umaxsl, const double *Wp,
+                        const long long *uwpoff, hipStream_t st)
+{
+    if (unfr <= 0 || uncb <= 0 || umaxsl <= 0 || (c.dbg & 512)) {
+        if (unfr > 0 && uncb > 0 && umaxsl > 0)
+            hipLaunchKernelGGL(k_upd_c, dim3(uncb, umaxsl, unfr), dim3(NT), (size_t)stm_update_lds_bytes(), st, c, uflist, uplist, ucb0, Wp, uwpoff);
+        return stm_launch_panel(c, flist, plist, nfr, nsub, defer_ok, lds_doubles, st);
+    }
+    if (nfr <= 0 && !(nfr < 0)) {
+        hipLaunchKernelGGL(k_upd_c, dim3(uncb, umaxsl, unfr), dim3(NT), (size_t)stm_update_lds_bytes(), st, c, uflist, uplist, ucb0, Wp, uwpoff);
+        return (int)hipGetLastError();
+    }
+    if (nfr < 0) nfr = 0;                                         // (measurements: the riders alone, in their rider form)
+    size_t bytes = (size_t)lds_doubles * sizeof(double);
+    if (bytes < (size_t)stm_update_lds_bytes()) bytes = stm_update_lds_bytes();
+    const int lds_arg = (int)(bytes / sizeof(double));            // what k_panel would be told: its rules must not see the passengers
+    if (bytes < (size_t)STM_PC_LDS_DOUBLES * sizeof(double)) bytes = (size_t)STM_PC_LDS_DOUBLES * sizeof(double);
+    hipLaunchKernelGGL(k_panel_pc, dim3(nfr > uncb ? nfr : uncb, nsub > umaxsl ? nsub : umaxsl, 1 + unfr), dim3(NTP), bytes, st, c, flist,
+                       plist, nfr, nsub, defer_ok, lds_arg, uflist, uplist, ucb0, Wp, uwpoff);
+    return (int)hipGetLastError();
+}
+// B: T + column block 0 of the step's fronts in one fused launch (as stm_launch_update_fused(cb0 = 0, ncb = 1, with_gram)) + k_upd_w of
+// their column blocks 1 .. ncb - 1 into the passengers' workspace (Wp2 / wcnt2)
+int stm_launch_update_fw(const DevCtx &c, const int *flist, const int *plist, int nfr, int ncb, int maxsl, double *Wp,
+                         const long long *wpoff, int *wcnt, int *wflag, int epoch, double *Wp2, int *wcnt2, hipStream_t st)
+{
+    if (nfr <= 0 || maxsl <= 0) return 0;
+    const int rest = ncb - 1;
+    static int one = -1;
+    if (one < 0) one = getenv("STMMQR_B0_ONE") ? atoi(getenv("STMMQR_B0_ONE")) : 1;       // (0: k_upd_f with its two meeting points)
+    if (one) {
+        hipLaunchKernelGGL(k_upd_b0w, dim3(maxsl > rest ? maxsl : rest, rest > 0 ? maxsl : 1, rest > 0 ? 2 * nfr : nfr), dim3(NT),
+                           (size_t)stm_update_lds_bytes(), st, c, flist, plist, nfr, maxsl, rest > 0 ? rest : 0, Wp, wpoff, wcnt, wflag, epoch,
+                           Wp2, wcnt2);
+        return (int)hipGetLastError();
+    }
+    if (rest <= 0) return stm_launch_update_fused(c, flist, plist, nfr, 0, 1, maxsl, Wp, wpoff, wcnt, wflag, epoch, 1, st);
+    hipLaunchKernelGGL(k_upd_fw, dim3(maxsl > rest ? maxsl : rest, maxsl > 2 ? maxsl : 2, 2 * nfr), dim3(NT), (size_t)stm_update_lds_bytes(),
+                       st, c, flist, plist, nfr, maxsl, rest, Wp, wpoff, wcnt, wflag, epoch, Wp2, wcnt2);
+    return (int)hipGetLastError();
+}
+static int stm_anyorder(void)
+{
+    static int v = -1;
+    if (v < 0) v = getenv("STMMQR_ANYORDER") ? atoi(getenv("STMMQR_ANYORDER")) : 0;
+    return v;
+}
+// k_upd_w alone into the passengers' workspace (measurements: the riders as launches of their own)
+int stm_launch_update_w(const DevCtx &c, const int *flist, const int *plist, int nfr, int cb0, int ncb, int maxsl, double *Wp,
+                        const long long *wpoff, int *wcnt, hipStream_t st)
+{
+    if (nfr <= 0 || ncb <= 0 || maxsl <= 0) return 0;
+    if (stm_anyorder())
+        hipExtLaunchKernelGGL(k_upd_w, dim3(ncb, maxsl, nfr), dim3(NT), (size_t)(2 * BN * VS) * sizeof(double), st, nullptr, nullptr,
+                              hipExtAnyOrderLaunch, c, flist, plist, cb0, 0, Wp, wpoff, wcnt);
+    else
+    hipLaunchKernelGGL(k_upd_w, dim3(ncb, maxsl, nfr), dim3(NT), (size_t)(2 * BN * VS) * sizeof(double), st, c, flist, plist, cb0, 0, Wp,
+                       wpoff, wcnt);
+    return (int)hipGetLastError();
+}
+// k_upd_c alone (the passengers' last phase when no panel launch follows)
+int stm_launch_update_c(const DevCtx &c, const int *flist, const int *plist, int nfr, int cb0, int ncb, int maxsl, const double *Wp,
+                        const long long *wpoff, hipStream_t st)
+{
+    if (nfr <= 0 || ncb <= 0 || maxsl <= 0) return 0;
+    if (stm_anyorder())
+        hipExtLaunchKernelGGL(k_upd_c, dim3(ncb, maxsl, nfr), dim3(NT), (size_t)stm_update_lds_bytes(), st, nullptr, nullptr,
+                              hipExtAnyOrderLaunch, c, flist, plist, cb0, Wp, wpoff);
+    else
+    hipLaunchKernelGGL(k_upd_c, dim3(ncb, maxsl, nfr), dim3(NT), (size_t)stm_update_lds_bytes(), st, c, flist, plist, cb0, Wp, wpoff);
+    return (int)hipGetLastError();
+}
 int stm_launch_update_pair(const DevCtx &c, const int *flist, const int *plist, int nfr, int ncbp, int maxsl, double *Wp,
                            const long long *wpoff, int *wcnt, hipStream_t st)
 {
@@ -4919,6 +5402,7 @@ int stm_configure_kernels(void)
     // allow the panel kernels to ask for up to 144 KiB of dynamic LDS (160 KiB per CU on gfx950)
     CK(hipFuncSetAttribute((const void *)k_front_wg, hipFuncAttributeMaxDynamicSharedMemorySize, 122880));
     CK(hipFuncSetAttribute((const void *)k_panel, hipFuncAttributeMaxDynamicSharedMemorySize, 131072));
+    CK(hipFuncSetAttribute((const void *)k_panel_pc, hipFuncAttributeMaxDynamicSharedMemorySize, 131072));
     CK(hipFuncSetAttribute((const void *)k_update, hipFuncAttributeMaxDynamicSharedMemorySize, 65536));
     CK(hipFuncSetAttribute((const void *)k_update_n, hipFuncAttributeMaxDynamicSharedMemorySize, 65536));
     CK(hipFuncSetAttribute((const void *)k_upd_yq, hipFuncAttributeMaxDynamicSharedMemorySize, 65536));

@@ -111,8 +111,9 @@ def test_column_pipeline_everywhere(pkg, oracle, monkeypatch, name, late):
 @pytest.mark.parametrize("name", NAMES)
 @pytest.mark.parametrize("bfc,algo", [(64, 0), (16, 0), (16, 2), (8, 1)])
 def test_lookahead_schedule_same_bits(pkg, name, bfc, algo):
-    """options.lookahead (default 1): the update beyond the next panel's columns, the packing of finished fronts and the
-    assembly of the next ones run on a second stream beside the panel chain.  options.fused_update (default 0): the
+    """options.lookahead: 1 = the update beyond the next panel's columns, the packing of finished fronts and the assembly of
+    the next ones run on a second stream beside the panel chain; 2 (default) = one stream, the update beyond block 0 rides
+    on the chain's own launches (panel + k_upd_c riders, T + block 0 + k_upd_w riders).  options.fused_update (default 0): the
     row-parallel update is one launch whose workgroups meet through global memory between V'C and the application.
     Every kernel does the arithmetic it does in the serial two-launch order: the factors must be the same bits (the other
     tests, which run with the defaults, cover parity).  STMMQR_LA_MIN=0 sends every eligible step to the side stream."""
@@ -121,14 +122,14 @@ def test_lookahead_schedule_same_bits(pkg, name, bfc, algo):
     out = []
     os.environ["STMMQR_LA_MIN"] = "0"
     try:
-        for la, fused in ((0, 0), (1, 0), (0, 1), (1, 1)):
+        for la, fused in ((0, 0), (1, 0), (0, 1), (1, 1), (2, 0)):
             pkg.set_options(lookahead=la, fused_update=fused, big_front_cols=bfc, panel_algo=algo)
             S, G = gpu_run(pkg, g)
             assert G.stats["retries"] == 0            # (rank-deficient fixtures too: no bounded wait of the fused block-0 launch runs out)
             out.append((G.Stack[:G.rh_total].copy(), G.HTau.copy(), G.HStair.copy(), G.Rdead.copy(), G.rank))
     finally:
         del os.environ["STMMQR_LA_MIN"]
-        pkg.set_options(lookahead=1, fused_update=0, big_front_cols=64, panel_algo=0)
+        pkg.set_options(lookahead=2, fused_update=0, big_front_cols=64, panel_algo=0)
     a = out[0]
     for b in out[1:]:
         assert a[4] == b[4]
@@ -152,7 +153,7 @@ def test_lookahead_events_without_system_fence_same_bits(pkg, monkeypatch, name)
         try:
             S, G = gpu_run(pkg, g)
         finally:
-            pkg.set_options(lookahead=1)
+            pkg.set_options(lookahead=2)
             monkeypatch.delenv("STMMQR_LA_SYSFENCE", raising=False)
         assert G.stats["retries"] == 0
         out.append((G.Stack[:G.rh_total].copy(), G.HTau.copy(), G.HStair.copy(), G.rank))
