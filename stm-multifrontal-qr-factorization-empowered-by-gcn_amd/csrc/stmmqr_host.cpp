@@ -1460,6 +1460,7 @@ int run_schedule(stmmqr_plan &P, bool detail, int grp, const StepReq *req = null
     }
     if (pass) {
         const long fw_max = getenv("STMMQR_PASS_MAXWG") ? atol(getenv("STMMQR_PASS_MAXWG")) : 384;
+        const int pass_rows = getenv("STMMQR_PASS_ROWS") ? atoi(getenv("STMMQR_PASS_ROWS")) : 5120;
         const int abl = getenv("STMMQR_PASS_ABL") ? atoi(getenv("STMMQR_PASS_ABL")) : 0;   // timing-only ablations (WRONG results): 1 no k_upd_w riders, 2 no k_upd_c riders
         const Step *pend = nullptr;                            // the step whose k_upd_c beyond block 0 is still due
         auto flush_alone = [&]() -> int {
@@ -1501,9 +1502,15 @@ int run_schedule(stmmqr_plan &P, bool detail, int grp, const StepReq *req = null
                 } else if ((e = flush_alone()))
                     return e;
                 long fwg = 0;
-                for (int i = 0; i < S.n_norm; i++) fwg += 2L * stm_upd_nsl(P.fs[P.lists[S.act_off + i]]);
+                int rows_max = 0;                                  // (the rows the panels are expected to reach, not the bound)
+                for (int i = 0; i < S.n_norm; i++) {
+                    fwg += 2L * stm_upd_nsl(P.fs[P.lists[S.act_off + i]]);
+                    rows_max = std::max(rows_max, stm_panel_rows_est(P.fs[P.lists[S.act_off + i]], P.lists[S.plist_off + i]));
+                }
+                // (beyond ~5000 rows -- 20+ slabs -- the one-launch block 0 is the slower form: its slab workgroups idle while the
+                //  partials are added; measured on the 7818-row fronts of c5mini)
                 const bool ride = S.split && S.n_sweep() == 0 && S.n_norm > 0 && S.maxcb > 1 && S.maxsl <= 256 && fwg <= fw_max &&
-                                  !g_opt.fused_update;
+                                  rows_max <= pass_rows && !g_opt.fused_update;
                 if (ride) {
                     const int epoch = cur_step + 1 + grp * (1 << 20);
                     if (abl & 4) {

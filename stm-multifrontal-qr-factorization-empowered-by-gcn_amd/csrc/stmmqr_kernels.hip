@@ -2586,8 +2586,8 @@ __global__ __launch_bounds__(NT, 2) void k_upd_f(DevCtx c, const int *__restrict
 // exactly the operations of k_upd_c.  lds: STM_NB * WS (W2) + per half the V image and the product image (BN * VS each).
 #define STM_PC_LDS_DOUBLES (STM_NB * WS + 4 * BN * VS)
 __device__ __forceinline__ void dev_upd_c_h2(const DevCtx &c, const int *__restrict__ flist, const int *__restrict__ plist, int cb0,
-                                             const double *Wp, const long long *__restrict__ wpoff, int fi, int cb, int sl,
-                                             double *dyn_lds, int *s_pd)
+                                             const double *Wp, const long long *__restrict__ wpoff, int fi, int cb, int sl0,
+                                             int rspw, double *dyn_lds, int *s_pd)
 {
     const int f = flist[fi], p = plist[fi];
     const FrontSym s = c.fs[f];
@@ -2596,10 +2596,10 @@ __device__ __forceinline__ void dev_upd_c_h2(const DevCtx &c, const int *__restr
     const int g1 = pd->pg1, mp = pd->pt - pd->pg1, nbp = pd->pnb;
     const int nslf = stm_upd_nsl(s);
     const int c0 = pd->pc0 + (cb0 + cb * (1 + c.cbskip)) * BN;
+    // (a rider takes rspw consecutive slabs -- the launch's choice: the rows of C are independent, the arithmetic does not change --
+    //  so that one prologue, during which nothing else runs on this CU, serves more rows)
+    const int sl = sl0 * rspw, spw = rspw;
     if (nbp <= 0 || mp <= 0 || c0 >= s.fn || sl * SLAB >= mp) return;
-    const int nsl_all = (mp + SLAB - 1) / SLAB;
-    const int spw = (nsl_all >= 32) ? 4 : (nsl_all >= 16) ? 2 : 1;      // (as k_upd_c)
-    if (sl % spw) return;
     const int nc = min(BN, s.fn - c0);
     const long long ld = s.ld;
     const int half = threadIdx.x >> 8, tid = threadIdx.x & 255, lane = tid & 63, wid = tid >> 6, l15 = lane & 15, l4 = lane >> 4;
@@ -2688,7 +2688,7 @@ __device__ __forceinline__ void dev_upd_c_h2(const DevCtx &c, const int *__restr
 __global__ __launch_bounds__(NTP) void k_panel_pc(DevCtx c, const int *__restrict__ flist, const int *__restrict__ plist, int npan,
                                                   int nsub, int defer_ok, int lds_doubles, const int *__restrict__ uflist,
                                                   const int *__restrict__ uplist, int ucb0, const double *Wp,
-                                                  const long long *__restrict__ uwpoff)
+                                                  const long long *__restrict__ uwpoff, int rspw)
 {
     extern __shared__ double dyn_lds[];
     __shared__ PanelShared ps;
@@ -2702,7 +2702,7 @@ __global__ __launch_bounds__(NTP) void k_panel_pc(DevCtx c, const int *__restric
         }
         return;
     }
-    dev_upd_c_h2(c, uflist, uplist, ucb0, Wp, uwpoff, (int)blockIdx.z - 1, blockIdx.x, blockIdx.y, dyn_lds, ps.stair);
+    dev_upd_c_h2(c, uflist, uplist, ucb0, Wp, uwpoff, (int)blockIdx.z - 1, blockIdx.x, blockIdx.y, rspw, dyn_lds, ps.stair);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -2897,11 +2897,93 @@ __device__ __forceinline__ void dev_k_upd_b0(const DevCtx &c, const int *__restr
 #undef B0TL
 }
 
+// k_upd_w's tiles as riders of the B launch: a workgroup takes rspw consecutive slabs of its column block (one descriptor chain for
+// several tiles; the partial sum of every slab is formed and stored separately, exactly as by k_upd_w, so the ordered sums -- and
+// the bits -- do not change), the loads run one chunk ahead across the slab boundaries, one ticket for all its slabs.
+__device__ __forceinline__ void dev_upd_w_rider(const DevCtx &c, const int *__restrict__ flist, const int *__restrict__ plist, int cb0,
+                                                double *Wp, const long long *__restrict__ wpoff, int *wcnt, int cb, int y, int rspw,
+                                                int fi, double *dyn_lds)
+{
+    __shared__ int s_pd[STM_NB];
+    __shared__ int s_ticket;
+    const int f = flist[fi], p = plist[fi];
+    const FrontSym s = c.fs[f];
+    if (p >= s.npanels) return;
+    const PanelDesc *pd = &c.fnum[f].pd[STM_PDI(p)];
+    const int g1 = pd->pg1, mp = pd->pt - pd->pg1, nbp = pd->pnb;
+    const int ncbf = stm_upd_ncb(s, p), nslf = stm_upd_nsl(s);
+    if (cb0 + cb >= ncbf) return;
+    const int c0 = pd->pc0 + (cb0 + cb) * BN;
+    const int sl0 = y * rspw;
+    if (nbp <= 0 || mp <= 0 || c0 >= s.fn || sl0 * SLAB >= mp) return;
+    const int nc = min(BN, s.fn - c0);
+    const long long ld = s.ld;
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, l15 = lane & 15, l4 = lane >> 4;
+    double *Vs = dyn_lds, *Cs = Vs + STM_NB * VS;
+    if (tid < STM_NB) s_pd[tid] = (tid < nbp) ? pd->pdiag[tid] : STM_BIGROW;
+    __syncthreads();
+    const double *Vg = c.Farena + s.foff + g1 + (long long)pd->pk1 * ld;
+    const double *Cg = c.Farena + s.foff + g1 + (long long)c0 * ld;
+    const int mi = wid >> 1, ni = wid & 1;
+    const int nsl = (mp + SLAB - 1) / SLAB;
+    const int rend = min(mp, (sl0 + rspw) * SLAB);
+    double *W = Wp + wpoff[fi] + ((long long)cb * nslf + sl0) * (STM_NB * BN);
+    d4 acc = {0, 0, 0, 0};
+    UpdChunk ck;
+    upd_chunk_load(ck, Vg, Cg, ld, sl0 * SLAB + (tid & 63), mp, nbp, nc, tid >> 6);
+    const int pfrom = (nc == BN) ? upd_plain_from(s_pd, g1, lane) : STM_BIGROW;
+    int done = 0;
+    for (int r0 = sl0 * SLAB; r0 < rend; r0 += RB) {
+        upd_chunk_to_lds(ck, r0 + (tid & 63), mp, nbp, nc, s_pd, g1, tid & 63, tid >> 6, Vs, Cs, false, r0 > pfrom && r0 + RB <= mp);
+        __syncthreads();
+        if (r0 + RB < rend) upd_chunk_load(ck, Vg, Cg, ld, r0 + RB + (tid & 63), mp, nbp, nc, tid >> 6);
+#pragma unroll
+        for (int kk = 0; kk < RB / 4; kk++) {
+            const double a = Vs[(16 * mi + l15) * VS + 4 * kk + l4];
+            const double b = Cs[(16 * ni + l15) * VS + 4 * kk + l4];
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
+        }
+        __syncthreads();
+        if (((r0 + RB) % SLAB) == 0 || r0 + RB >= rend) {          // the slab's partial sum is complete
+            if (nsl == 1) {
+#pragma unroll
+                for (int r = 0; r < 4; r++) W[(16 * mi + l4 + 4 * r) * BN + 16 * ni + l15] = acc[r];
+            } else {
+#pragma unroll
+                for (int r = 0; r < 4; r++) st_agent(&W[(16 * mi + l4 + 4 * r) * BN + 16 * ni + l15], acc[r]);
+            }
+            W += STM_NB * BN;
+            acc = d4{0, 0, 0, 0};
+            done++;
+        }
+    }
+    if (nsl == 1) return;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    int *cnt = wcnt + wpoff[fi] / (STM_NB * BN) + cb;
+    if (tid == 0) {
+        s_ticket = __hip_atomic_fetch_add(cnt, done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (s_ticket + done == nsl) {
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __hip_atomic_store(cnt, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+    __syncthreads();
+    if (s_ticket + done != nsl) return;
+    double *W0 = Wp + wpoff[fi] + ((long long)cb * nslf) * (STM_NB * BN);
+    double v[STM_NB * BN / NT];
+#pragma unroll
+    for (int q = 0; q < STM_NB * BN / NT; q++) v[q] = stm_ordered_sum<true>(W0 + tid + q * NT, STM_NB * BN, nsl);   // fixed order
+#pragma unroll
+    for (int q = 0; q < STM_NB * BN / NT; q++) W0[tid + q * NT] = v[q];
+}
+
 // B launch, one meeting point: block 0 + T by dev_k_upd_b0 (blockIdx.z < nfr, slab blockIdx.x, blockIdx.y = 0) and, behind it, the
 // riders: k_upd_w's tiles of the column blocks beyond block 0 (as k_upd_fw).
 __global__ __launch_bounds__(NT, 2) void k_upd_b0w(DevCtx c, const int *__restrict__ flist, const int *__restrict__ plist, int nfr,
                                                    int maxsl, int ncbrest, double *Wp, const long long *__restrict__ wpoff, int *wcnt,
-                                                   int *wflag, int epoch, double *Wp2, int *wcnt2)
+                                                   int *wflag, int epoch, double *Wp2, int *wcnt2, int rspw)
 {
     extern __shared__ double dyn_lds[];
     if ((int)blockIdx.z < nfr) {
@@ -2909,8 +2991,8 @@ __global__ __launch_bounds__(NT, 2) void k_upd_b0w(DevCtx c, const int *__restri
         dev_k_upd_b0(c, flist, plist, Wp, wpoff, wcnt, wflag, epoch, blockIdx.x, blockIdx.z, dyn_lds);
         return;
     }
-    if ((int)blockIdx.x >= ncbrest || (int)blockIdx.y >= maxsl) return;
-    dev_k_upd_w<true>(c, flist, plist, 1, 0, Wp2, wpoff, wcnt2, blockIdx.x, blockIdx.y, (int)blockIdx.z - nfr, ncbrest, dyn_lds);
+    if ((int)blockIdx.x >= ncbrest || (int)blockIdx.y * rspw >= maxsl) return;
+    dev_upd_w_rider(c, flist, plist, 1, Wp2, wpoff, wcnt2, blockIdx.x, blockIdx.y, rspw, (int)blockIdx.z - nfr, dyn_lds);
 }
 
 // B launch: T + column block 0 of the step (k_upd_f's workgroups: blockIdx.z < nfr, slab blockIdx.x, blockIdx.y = 0 the Gram block /
@@ -5163,8 +5245,23 @@ int stm_launch_panel_pc(const DevCtx &c, const int *flist, const int *plist, int
     if (bytes < (size_t)stm_update_lds_bytes()) bytes = stm_update_lds_bytes();
     const int lds_arg = (int)(bytes / sizeof(double));            // what k_panel would be told: its rules must not see the passengers
     if (bytes < (size_t)STM_PC_LDS_DOUBLES * sizeof(double)) bytes = (size_t)STM_PC_LDS_DOUBLES * sizeof(double);
-    hipLaunchKernelGGL(k_panel_pc, dim3(nfr > uncb ? nfr : uncb, nsub > umaxsl ? nsub : umaxsl, 1 + unfr), dim3(NTP), bytes, st, c, flist,
-                       plist, nfr, nsub, defer_ok, lds_arg, uflist, uplist, ucb0, Wp, uwpoff);
+    // slabs per rider workgroup: a rider has its CU to itself (the launch carries the panel's registers and LDS), so its descriptor
+    // chain and prologue (~5 us) overlap with nothing; per slab ~2.4 us.  Rounds of ~240 workgroups (urows: the launch's tiles, a bound)
+    int rspw = 1;
+    {
+        static int force = -1;
+        if (force < 0) force = getenv("STMMQR_RSPW") ? atoi(getenv("STMMQR_RSPW")) : 0;
+        double best = 1e30;
+        for (int k = 1; k <= 16; k *= 2) {
+            const long wgs = (long)unfr * uncb * ((umaxsl + k - 1) / k);
+            const double t = (double)((wgs + 239) / 240) * (5.0 + 1.0 * k);
+            if (t < best) { best = t; rspw = k; }
+        }
+        if (force > 0) rspw = force;
+    }
+    const int uy = (umaxsl + rspw - 1) / rspw;
+    hipLaunchKernelGGL(k_panel_pc, dim3(nfr > uncb ? nfr : uncb, nsub > uy ? nsub : uy, 1 + unfr), dim3(NTP), bytes, st, c, flist,
+                       plist, nfr, nsub, defer_ok, lds_arg, uflist, uplist, ucb0, Wp, uwpoff, rspw);
     return (int)hipGetLastError();
 }
 // B: T + column block 0 of the step's fronts in one fused launch (as stm_launch_update_fused(cb0 = 0, ncb = 1, with_gram)) + k_upd_w of
@@ -5177,9 +5274,14 @@ int stm_launch_update_fw(const DevCtx &c, const int *flist, const int *plist, in
     static int one = -1;
     if (one < 0) one = getenv("STMMQR_B0_ONE") ? atoi(getenv("STMMQR_B0_ONE")) : 1;       // (0: k_upd_f with its two meeting points)
     if (one) {
-        hipLaunchKernelGGL(k_upd_b0w, dim3(maxsl > rest ? maxsl : rest, rest > 0 ? maxsl : 1, rest > 0 ? 2 * nfr : nfr), dim3(NT),
+        // slabs per rider workgroup: two (measured on the default workload: 1 slab 110.8 ms, 2 109.7, 4 110.1, 8 113.0 -- these riders
+        // share their CU with a second workgroup, so less of a descriptor chain is exposed than in the panel launch)
+        static int rspw = -1;
+        if (rspw < 0) rspw = getenv("STMMQR_RSPW_W") && atoi(getenv("STMMQR_RSPW_W")) > 0 ? atoi(getenv("STMMQR_RSPW_W")) : 2;
+        const int uy = (maxsl + rspw - 1) / rspw;
+        hipLaunchKernelGGL(k_upd_b0w, dim3(maxsl > rest ? maxsl : rest, rest > 0 ? uy : 1, rest > 0 ? 2 * nfr : nfr), dim3(NT),
                            (size_t)stm_update_lds_bytes(), st, c, flist, plist, nfr, maxsl, rest > 0 ? rest : 0, Wp, wpoff, wcnt, wflag, epoch,
-                           Wp2, wcnt2);
+                           Wp2, wcnt2, rspw);
         return (int)hipGetLastError();
     }
     if (rest <= 0) return stm_launch_update_fused(c, flist, plist, nfr, 0, 1, maxsl, Wp, wpoff, wcnt, wflag, epoch, 1, st);
