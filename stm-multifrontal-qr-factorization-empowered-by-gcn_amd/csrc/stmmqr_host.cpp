@@ -1461,6 +1461,7 @@ int run_schedule(stmmqr_plan &P, bool detail, int grp, const StepReq *req = null
     if (pass) {
         const long fw_max = getenv("STMMQR_PASS_MAXWG") ? atol(getenv("STMMQR_PASS_MAXWG")) : 384;
         const int pass_rows = getenv("STMMQR_PASS_ROWS") ? atoi(getenv("STMMQR_PASS_ROWS")) : 5120;
+        const long pass_tiles = getenv("STMMQR_PASS_TILES") ? atol(getenv("STMMQR_PASS_TILES")) : (1L << 40);   // (measured: riding always wins -- 2000: 123 ms, 3000: 117, never: 109.9 on the default workload)
         const int abl = getenv("STMMQR_PASS_ABL") ? atoi(getenv("STMMQR_PASS_ABL")) : 0;   // timing-only ablations (WRONG results): 1 no k_upd_w riders, 2 no k_upd_c riders
         const Step *pend = nullptr;                            // the step whose k_upd_c beyond block 0 is still due
         auto flush_alone = [&]() -> int {
@@ -1482,6 +1483,18 @@ int run_schedule(stmmqr_plan &P, bool detail, int grp, const StepReq *req = null
                 if (S.npipe_use) {
                     const int lds = (c.dbg & (64 | 256)) ? S.lds_big : S.lds_plan;
                     if (pend && (abl & 2)) pend = nullptr;
+                    if (pend) {
+                        // a rider has its CU to itself (the panel launch's registers and LDS): 2-3 x the time of k_upd_c's own launch
+                        // per tile.  Beyond pass_tiles tiles (a wide step of the lower tree levels) the riders would outlast any panel.
+                        long tiles = 0;
+                        for (int i = 0; i < pend->n_norm; i++) {
+                            const FrontSym &fsym = P.fs[P.lists[pend->act_off + i]];
+                            const int pp = P.lists[pend->plist_off + i];
+                            const int ncb = stm_upd_ncb(fsym, pp);
+                            if (ncb > 1) tiles += (long)(ncb - 1) * ((stm_panel_rows_est(fsym, pp) + STM_UPD_SLAB - 1) / STM_UPD_SLAB);
+                        }
+                        if (tiles > pass_tiles && (e = flush_alone())) return e;
+                    }
                     if (pend && (abl & 4)) {                     // (measurement: the riders as launches of their own, same order)
                         LCHK(stm_launch_panel(c, act, pl, S.n_act, S.nsub, 1, lds, st));
                         if (abl & 8) {

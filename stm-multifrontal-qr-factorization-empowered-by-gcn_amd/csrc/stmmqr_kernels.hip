@@ -321,6 +321,28 @@ __device__ __forceinline__ int upd_plain_from(const int *s_pd, int g1, int lane)
 // ------------------------------------------------------------------------------------------------
 __device__ __forceinline__ void dev_T_from_gram(double (*G)[STM_NB + 1], double (*T)[STM_NB + 1], const double *tau, int nc, int tid);
 
+// W2 = T' W1 (T upper triangular, NB x NB; W1 NB x BN) on the matrix cores: wave `wid` (0..3) gets the 16 x 16 tile (wid >> 1, wid & 1)
+// of W2 in the MFMA result layout, W2[16 (wid >> 1) + (lane >> 4) + 4 r][16 (wid & 1) + (lane & 15)] = result[r].  T(q, l) is read at
+// Tm[q * sq + l * sl] (any memory; it must hold zeros below the diagonal and beyond the panel's reflectors), W1[q][x] at W1[q * WS + x]
+// (LDS).  Rows l < 16 only see q < 16 (the skipped products are exact zeros).  EVERY form of the trailing update forms W2 here, so
+// that a front gets the same bits whichever form its step uses (the scalar loops this replaces were 2.7 us of every update
+// workgroup's prologue: 160 LDS reads per thread).
+__device__ __forceinline__ d4 dev_w2_tile(const double *Tm, int sq, int sl, const double *W1, int wid, int lane)
+{
+    const int mi = wid >> 1, ni = wid & 1, l15 = lane & 15, l4 = lane >> 4;
+    d4 acc = {0, 0, 0, 0};
+    const int nk = mi ? STM_NB / 4 : STM_NB / 8;
+#pragma unroll
+    for (int kk = 0; kk < STM_NB / 4; kk++) {
+        if (kk < nk) {
+            const double a = Tm[(4 * kk + l4) * sq + (16 * mi + l15) * sl];       // A[i = l][k = q] = T(q, l)
+            const double b = W1[(4 * kk + l4) * WS + 16 * ni + l15];               // B[k = q][j = x]
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
+        }
+    }
+    return acc;
+}
+
 // tau != nullptr: T was left to the update by the panel kernel (PanelDesc::t_deferred) -- G = V'V is accumulated beside
 // W1 (per 256-row slab, slabs added in order: bit-identical to the Gram block of k_upd_w) and T is built here by every
 // workgroup for itself (dev_T_from_gram); Tout / Tkeep (may be null) receive it from the caller's first column block.
@@ -410,15 +432,18 @@ __device__ void dev_update_block(double *F, long long ld, int g1, int mp, int k1
 #pragma unroll
                 for (int x = 0; x < 4; x++) w2[x] += tq * Ws[q * WS + cg * 4 + x];
             }
-        } else
-        for (int q = 0; q <= l; q++) {
-            const double tq = build_t ? s_Tm[q * WS + l] : T[q + l * STM_NB];
+            __syncthreads();
 #pragma unroll
-            for (int x = 0; x < 4; x++) w2[x] += tq * Ws[q * WS + cg * 4 + x];
+            for (int x = 0; x < 4; x++) Ws[l * WS + cg * 4 + x] = w2[x];
+        } else {
+            d4 t2 = {0, 0, 0, 0};
+            if (wid < 4) t2 = build_t ? dev_w2_tile(s_Tm, WS, 1, Ws, wid, lane) : dev_w2_tile(T, 1, STM_NB, Ws, wid, lane);
+            __syncthreads();
+            if (wid < 4) {
+#pragma unroll
+                for (int r = 0; r < 4; r++) Ws[(16 * mi + l4 + 4 * r) * WS + 16 * ni + l15] = t2[r];
+            }
         }
-        __syncthreads();
-#pragma unroll
-        for (int x = 0; x < 4; x++) Ws[l * WS + cg * 4 + x] = w2[x];
     }
     __syncthreads();
 
@@ -475,52 +500,53 @@ __device__ void dev_update_block(double *F, long long ld, int g1, int mp, int k1
 // ------------------------------------------------------------------------------------------------
 // tid: index of the thread among the (at least) 256 that work on THIS G / T (threadIdx.x, or threadIdx.x & 255 when the two halves
 // of a 512-thread workgroup each build their own); the barriers are the whole workgroup's either way.
+// Round 5: the recurrence is blocked all the way down -- T of 2h columns from the T of its two halves,
+//   T = [T11, -T11 (G12 T22); 0, T22]      (dlarft's own merge rule; G12 = V1'V2),
+// for h = 1, 2, 4, 8, 16: ten short steps of independent dot products (at most 16 terms, 256 outputs) instead of two 16-step chains of
+// dependent LDS round trips + the 16/16 merge (3.7 us -> 1 us: T sits on the chain of every step, between the panel and block 0).
+// A reflector with tau = 0 (dead / identity column) gives a zero row and column, as the column-by-column form does.
+// X = G12 T22 is kept in G's lower triangle (the block below the diagonal block pair: never read as G).
+template <int h>
+__device__ __forceinline__ void dev_T_merge(double (*G)[STM_NB + 1], double (*T)[STM_NB + 1], int tid)
+{
+    const int pr = tid / (h * h), ij = tid % (h * h), i = ij / h, j = ij % h;
+    const int A0 = 2 * h * pr, B0 = A0 + h;
+    const bool mine = tid < (STM_NB / 2) * h;
+    // (T11, T22 hold explicit zeros below their diagonals, so the sums run over all k with no predicates: the extra products
+    //  are exact zeros)
+    if (mine) {                                                      // X(i, j) = sum_k G12(i, k) T22(k, j)
+        double p0 = 0, p1 = 0;
+#pragma unroll
+        for (int k = 0; k < h; k += 2) {
+            p0 += G[A0 + i][B0 + k] * T[B0 + k][B0 + j];
+            if (k + 1 < h) p1 += G[A0 + i][B0 + k + 1] * T[B0 + k + 1][B0 + j];
+        }
+        G[B0 + i][A0 + j] = p0 + p1;
+    }
+    lds_barrier();                                                   // (LDS only: stores to global memory stay in flight)
+    if (mine) {                                                      // T12(i, j) = -sum_k T11(i, k) X(k, j)
+        double p0 = 0, p1 = 0;
+#pragma unroll
+        for (int k = 0; k < h; k += 2) {
+            p0 += T[A0 + i][A0 + k] * G[B0 + k][A0 + j];
+            if (k + 1 < h) p1 += T[A0 + i][A0 + k + 1] * G[B0 + k + 1][A0 + j];
+        }
+        T[A0 + i][B0 + j] = -(p0 + p1);
+    }
+    lds_barrier();
+}
 __device__ __forceinline__ void dev_T_from_gram(double (*G)[STM_NB + 1], double (*T)[STM_NB + 1], const double *tau, int nc, int tid)
 {
-    const int lane = tid & 63, wid = tid >> 6;
-    if (wid < 2 && lane < 16) {
-        const int o = 16 * wid, a = lane;
-        double trow[16];
-#pragma unroll
-        for (int b = 0; b < 16; b++) {
-            double v = 0;
-            if (o + b < nc) {
-                const double tb = tau[o + b];
-                double g[16];
-#pragma unroll
-                for (int l = 0; l < b; l++) g[l] = G[o + l][o + b];      // (broadcast reads, all in flight together)
-                double p0 = 0, p1 = 0, p2 = 0, p3 = 0;
-#pragma unroll
-                for (int l = 0; l < b; l += 4) {
-                    p0 += trow[l] * g[l];
-                    if (l + 1 < b) p1 += trow[l + 1] * g[l + 1];
-                    if (l + 2 < b) p2 += trow[l + 2] * g[l + 2];
-                    if (l + 3 < b) p3 += trow[l + 3] * g[l + 3];
-                }
-                v = (p0 + p1) + (p2 + p3);                           // (T(a,l) = 0 for l < a: no per-lane bounds)
-                v = (a < b && tb != 0.0) ? -tb * v : ((a == b) ? tb : 0.0);
-            }
-            trow[b] = v;
-            T[o + a][o + b] = v;
-        }
+    for (int e = tid; e < STM_NB * STM_NB; e += 256) {
+        const int a = e >> 5, b = e & 31;
+        T[a][b] = (a == b && a < nc) ? tau[a] : 0.0;
     }
-    __syncthreads();
-    const int bi = (tid >> 4) & 15, bj = tid & 15;
-    if (tid < 256) {
-        double acc = 0;                                              // X = G12 T22 (T22 is zero below its diagonal)
-#pragma unroll
-        for (int k = 0; k < 16; k++) acc += G[bi][16 + k] * T[16 + k][16 + bj];
-        G[16 + bi][bj] = acc;
-        T[16 + bi][bj] = 0.0;
-    }
-    __syncthreads();
-    if (tid < 256) {
-        double acc = 0;                                              // T12 = -T11 X
-#pragma unroll
-        for (int k = 0; k < 16; k++) acc += T[bi][k] * G[16 + k][bj];
-        T[bi][16 + bj] = -acc;
-    }
-    __syncthreads();
+    lds_barrier();
+    dev_T_merge<1>(G, T, tid);
+    dev_T_merge<2>(G, T, tid);
+    dev_T_merge<4>(G, T, tid);
+    dev_T_merge<8>(G, T, tid);
+    dev_T_merge<16>(G, T, tid);
 }
 
 template <int NTH>
@@ -2312,20 +2338,9 @@ __global__ __launch_bounds__(NT) void k_upd_c(DevCtx c, const int *__restrict__ 
             s_T[(e / STM_NB) * WS + (e % STM_NB)] = T[e];          // s_T[col][row] = T(row, col)
         }
         __syncthreads();
-        const int l = tid & 31, cg = tid >> 5;
-        double w2[4] = {0, 0, 0, 0};
-        // (round 4: unrolled with the trip count as a predicate -- the same sums in the same order, but the 32 x 5 LDS reads are all
-        //  issued up front instead of one dependent round trip per q: the prologue was 40 % of a workgroup's time)
+        const d4 w2 = dev_w2_tile(s_T, 1, WS, s_W1, wid, lane);      // (round 5: on the matrix cores, dev_w2_tile)
 #pragma unroll
-        for (int q = 0; q < STM_NB; q++) {
-            const double tq = s_T[l * WS + q];                     // T(q, l)
-            if (q <= l) {
-#pragma unroll
-                for (int x = 0; x < 4; x++) w2[x] += tq * s_W1[q * WS + cg * 4 + x];
-            }
-        }
-#pragma unroll
-        for (int x = 0; x < 4; x++) Ws[l * WS + cg * 4 + x] = w2[x];
+        for (int r = 0; r < 4; r++) Ws[(16 * (wid >> 1) + l4 + 4 * r) * WS + 16 * (wid & 1) + l15] = w2[r];
     }
     __syncthreads();
     const int rend = min(mp, (sl + spw) * SLAB);
@@ -2505,18 +2520,12 @@ __device__ __forceinline__ void dev_k_upd_f(const DevCtx &c, const int *__restri
         }
         __syncthreads();
         // W2 = T' W1 (k_upd_c's prologue, done once per column block here)
-        const int l = tid & 31, cg = tid >> 5;
-        double w2[4] = {0, 0, 0, 0};
-        for (int q = 0; q <= l; q++) {
-            const double tq = s_T[l * WS + q];                     // T(q, l)
+        const d4 w2 = dev_w2_tile(s_T, 1, WS, s_W1, wid, lane);
 #pragma unroll
-            for (int x = 0; x < 4; x++) w2[x] += tq * s_W1[q * WS + cg * 4 + x];
-        }
-#pragma unroll
-        for (int x = 0; x < 4; x++) Ws[l * WS + cg * 4 + x] = w2[x];
+        for (int r = 0; r < 4; r++) Ws[(16 * (wid >> 1) + l4 + 4 * r) * WS + 16 * (wid & 1) + l15] = w2[r];
         if (nsl > 1) {
 #pragma unroll
-            for (int x = 0; x < 4; x++) st_agent(&Wslot[l * BN + cg * 4 + x], w2[x]);
+            for (int r = 0; r < 4; r++) st_agent(&Wslot[(16 * (wid >> 1) + l4 + 4 * r) * BN + 16 * (wid & 1) + l15], w2[r]);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
             if (tid == 0) st_agent(flag, epoch);
@@ -2625,20 +2634,14 @@ __device__ __forceinline__ void dev_upd_c_h2(const DevCtx &c, const int *__restr
             s_T[(e / STM_NB) * WS + (e % STM_NB)] = T[e];          // s_T[col][row] = T(row, col)
         }
         __syncthreads();
-        const int l = threadIdx.x & 31, cg = threadIdx.x >> 5;     // 16 groups of 2 columns: the sums of k_upd_c, entry by entry
-        double w2[2] = {0, 0};
-#pragma unroll
-        for (int q = 0; q < STM_NB; q++) {
-            const double tq = s_T[l * WS + q];                     // T(q, l)
-            if (q <= l) {
-#pragma unroll
-                for (int x = 0; x < 2; x++) w2[x] += tq * s_W1[q * WS + cg * 2 + x];
-            }
-        }
+        d4 w2 = {0, 0, 0, 0};
+        if (half == 0) w2 = dev_w2_tile(s_T, 1, WS, s_W1, wid, lane);
         __syncthreads();                                           // (Ws does not alias the prologue images; the barrier orders
                                                                    //  the reads of s_W1 / s_T before half 0's first V image)
+        if (half == 0) {
 #pragma unroll
-        for (int x = 0; x < 2; x++) Ws[l * WS + cg * 2 + x] = w2[x];
+            for (int r = 0; r < 4; r++) Ws[(16 * (wid >> 1) + l4 + 4 * r) * WS + 16 * (wid & 1) + l15] = w2[r];
+        }
     }
     const int pfrom = upd_plain_from(s_pd, g1, lane);
     const int nch = (rend - rbeg + RB - 1) / RB, trips = (nch + 1) / 2;
@@ -2842,18 +2845,9 @@ __device__ __forceinline__ void dev_k_upd_b0(const DevCtx &c, const int *__restr
     B0TL(5);
     // W2 = T' W1 (k_upd_c's prologue)
     {
-        const int l = tid & 31, cg = tid >> 5;
-        double w2[4] = {0, 0, 0, 0};
+        const d4 w2 = dev_w2_tile(s_T, WS, 1, s_W1, wid, lane);      // (T(q, l) = s_Tb[q][l]: zero below the diagonal and beyond nbp)
 #pragma unroll
-        for (int q = 0; q < STM_NB; q++) {
-            const double tq = (q < nbp && l < nbp) ? s_Tb[q][l] : 0.0;          // T(q, l)
-            if (q <= l) {
-#pragma unroll
-                for (int x = 0; x < 4; x++) w2[x] += tq * s_W1[q * WS + cg * 4 + x];
-            }
-        }
-#pragma unroll
-        for (int x = 0; x < 4; x++) Ws[l * WS + cg * 4 + x] = w2[x];
+        for (int r = 0; r < 4; r++) Ws[(16 * (wid >> 1) + l4 + 4 * r) * WS + 16 * (wid & 1) + l15] = w2[r];
     }
     __syncthreads();
     B0TL(6);
