@@ -61,6 +61,24 @@ def host_cores():
     return n
 
 
+def host_shape():
+    """(sockets, NUMA nodes, CPUs) as the reference's get_plat.sh reads them from lscpu (STMMQR/get_plat.sh:3-5): what its TPSM pool is
+    compiled for (include/tpsm/Numainfo.h).  None when lscpu does not say."""
+    try:
+        out = subprocess.run(["lscpu"], capture_output=True, text=True, timeout=20).stdout
+        v = {}
+        for line in out.splitlines():
+            if line.startswith("Socket(s):"):
+                v["s"] = int(line.split()[1])
+            elif line.startswith("NUMA node(s):"):
+                v["n"] = int(line.split()[2])
+            elif line.startswith("CPU(s):"):
+                v["c"] = int(line.split()[1])
+        return (v["s"], v["n"], v["c"])
+    except Exception:
+        return None
+
+
 def _refdump_run(refdump, mtx, ordering, reps, threads, timeout, grain=1, pool=None):
     """one refdump process: `reps` SparseQR runs of the compiled reference, best qr_factorize time.
     grain = 1: serial qr_kernel(0) with `threads` MKL threads (the reference's BLAS-internal threading, STMMQR/README.md:94).
@@ -144,16 +162,35 @@ def cpu_baseline(name, g, budget_s=30.0, mtx_path=None, flops=None):
                                      mode="TPSM tree parallelism: pool 4 x nproc, SPQR_grain 2 x nproc, MKL sequential"))
                 for leg in plan:
                     tpsm = leg["grain"] > 1
-                    first_to = 300.0 if tpsm else max(120.0, 12 * max(ref_s, 1.0))
-                    r = _refdump_run(refdump, mtx, osel, 1, leg["threads"], first_to, leg["grain"], leg["pool"])
+                    # (the pool deadlocks when more tasks wait than it has threads, SURVEY.md 3.3: a TPSM leg that needs more than six times
+                    #  the serial leg's time on this host is not going to be the fastest leg -- it is cut there, not after five minutes)
+                    t_serial = min([l["seconds"] for l in legs if "seconds" in l], default=max(ref_s, 1.0))
+                    first_to = min(300.0, max(30.0, 6.0 * t_serial)) if tpsm else max(120.0, 12 * max(ref_s, 1.0))
                     rec = {"cores": leg["threads"], "mode": leg["mode"]}
+                    exe = refdump
+                    if tpsm:
+                        # The pool is configured at compile time for ONE host shape (Numainfo.h); oracle/Makefile builds it for the shapes
+                        # in TPSM_VARIANTS.  A pool built for another shape dies in TPSM_init (round 4: signal 11), so it is not started.
+                        shape = host_shape()
+                        exe = refdump.parent / ("refdump_tpsm_%d_%d_%d" % shape) if shape else None
+                        if exe is None or not exe.exists():
+                            have = sorted(q.name.replace("refdump_tpsm_", "") for q in refdump.parent.glob("refdump_tpsm_*"))
+                            rec["skipped"] = (f"no TPSM build for this host shape (sockets_nodes_cpus = {shape}); built: {have} "
+                                              f"(oracle/Makefile, TPSM_VARIANTS)")
+                            legs.append(rec)
+                            continue
+                        # (the pool size must be a multiple of the NUMA nodes and at most the CPUs: tpsm_main.c:389-393, tpsm_main.h:35)
+                        pool = min(max(4 * nproc, shape[1]), shape[2])
+                        leg = dict(leg, pool=pool - pool % shape[1])
+                        rec["mode"] = (f"TPSM tree parallelism ({exe.name}): pool {leg['pool']}, SPQR_grain {leg['grain']}, MKL sequential")
+                    r = _refdump_run(exe, mtx, osel, 1, leg["threads"], first_to, leg["grain"], leg["pool"])
                     if "error" in r:
                         rec["error"] = r["error"]
                         legs.append(rec)
                         continue
                     best, reps = r, 1
                     if r["seconds"] < 20.0:
-                        r2 = _refdump_run(refdump, mtx, osel, 2, leg["threads"], max(120.0, 8 * r["seconds"] + 60.0), leg["grain"], leg["pool"])
+                        r2 = _refdump_run(exe, mtx, osel, 2, leg["threads"], max(120.0, 8 * r["seconds"] + 60.0), leg["grain"], leg["pool"])
                         if "error" not in r2:
                             reps = 3
                             if r2["seconds"] < best["seconds"]:
@@ -170,6 +207,7 @@ def cpu_baseline(name, g, budget_s=30.0, mtx_path=None, flops=None):
                             "sample": f"{name}: qr_factorize of the compiled reference on this host ({nproc} cores); "
                                       f"legs: " + "; ".join(
                                           (f"{l['cores']} core(s) [{l['mode']}] {l['seconds'] * 1e3:.1f} ms best of {l['best_of']}" if "value" in l
+                                           else f"{l['cores']} core(s) [{l['mode']}] SKIPPED: {l['skipped']}" if "skipped" in l
                                            else f"{l['cores']} core(s) [{l['mode']}] FAILED: {l['error']}") for l in legs),
                             "seconds": best["seconds"], "legs": legs, "host_cores": nproc}
         except Exception as e:  # fall through to the port

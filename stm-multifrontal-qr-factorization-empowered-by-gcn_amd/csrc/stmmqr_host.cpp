@@ -1461,6 +1461,7 @@ int run_schedule(stmmqr_plan &P, bool detail, int grp, const StepReq *req = null
     if (pass) {
         const long fw_max = getenv("STMMQR_PASS_MAXWG") ? atol(getenv("STMMQR_PASS_MAXWG")) : 384;
         const int pass_rows = getenv("STMMQR_PASS_ROWS") ? atoi(getenv("STMMQR_PASS_ROWS")) : 5120;
+        const double pass_k = getenv("STMMQR_PASS_K") ? atof(getenv("STMMQR_PASS_K")) : 1e30;
         const long pass_tiles = getenv("STMMQR_PASS_TILES") ? atol(getenv("STMMQR_PASS_TILES")) : (1L << 40);   // (measured: riding always wins -- 2000: 123 ms, 3000: 117, never: 109.9 on the default workload)
         const int abl = getenv("STMMQR_PASS_ABL") ? atoi(getenv("STMMQR_PASS_ABL")) : 0;   // timing-only ablations (WRONG results): 1 no k_upd_w riders, 2 no k_upd_c riders
         const Step *pend = nullptr;                            // the step whose k_upd_c beyond block 0 is still due
@@ -1493,7 +1494,11 @@ int run_schedule(stmmqr_plan &P, bool detail, int grp, const StepReq *req = null
                             const int ncb = stm_upd_ncb(fsym, pp);
                             if (ncb > 1) tiles += (long)(ncb - 1) * ((stm_panel_rows_est(fsym, pp) + STM_UPD_SLAB - 1) / STM_UPD_SLAB);
                         }
-                        if (tiles > pass_tiles && (e = flush_alone())) return e;
+                        // (the panel launch they would ride on: ~25 us up to 512 rows, ~48 us up to 4096, ~72 us beyond)
+                        int prow = 0;
+                        for (int i = 0; i < S.n_act; i++) prow = std::max(prow, stm_panel_rows_est(P.fs[P.lists[S.act_off + i]], P.lists[S.plist_off + i]));
+                        const double panel_us = prow <= 512 ? 25.0 : prow <= 4096 ? 48.0 : 72.0;
+                        if ((tiles > pass_tiles || (double)tiles > pass_k * panel_us) && (e = flush_alone())) return e;
                     }
                     if (pend && (abl & 4)) {                     // (measurement: the riders as launches of their own, same order)
                         LCHK(stm_launch_panel(c, act, pl, S.n_act, S.nsub, 1, lds, st));

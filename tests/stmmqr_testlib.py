@@ -51,14 +51,48 @@ REFERENCE_TEST_MATRICES = ("dwt_992", "lns_3937", "bcsstk14", "epb1", "reorienta
 # ... two of them are too heavy for the scalar CPU oracle inside every parametrized test (2e10 / 1.9e11 flops: 7 s / 100 s per oracle
 # run): they have their own tests (tests/test_oracle_golden.py once each on the CPU, tests/test_gpu_factorize.py::test_reference_inputs)
 HEAVY_REAL = ("reorientation_8", "cvxqp3")
-# R rows of these are only determined relative to ||A|| (pivots near tol, condition numbers of 1e10 and more: the reference's own
-# driver prints res = 1e0 ... 1e3 for them); the tolerance applies to |difference| / max row norm
-ILL_CONDITIONED = {"bcsstk14": 1e-6, "lns_3937": 1e-6, "bayer10": 1e-9, "ex18": 1e-6, "reorientation_8": 1e-9, "cvxqp3": 1e-8}
+# ---- tolerances of floating-point comparisons on ill-conditioned inputs: DERIVED from the factor, one constant for every input ----
+# Two correct QR factorizations of A differ in R by about eps * cond(A) * ||R|| (rows whose pivot sits near tol are only determined
+# relative to ||A||: the reference's own driver prints res = 1e0 ... 1e3 for five of its nine test matrices), and a triangular solve
+# amplifies the rounding differences of two correct Q'b by cond(R).  cond(R) is estimated from the packed factor under test by a
+# few random probes (cond_probe: a LOWER estimate, typically within sqrt(n) of cond_2), and every comparison below is allowed
+# TOL_C * eps * cond_probe -- the same constant for bcsstk14 (cond 1e7) and ex18 (cond 1e12); no per-matrix table.
+# (Rounds 1-4 kept two hand-set tables here, "measured differences x 100": a tolerance chosen from the observed difference cannot fail.)
+EPS = float(np.finfo(np.float64).eps)
+TOL_C = 64.0     # (largest observed difference / (eps * cond_probe) over the fixtures: 5.1 -- bcsstk14, whose probes underestimate its condition most)
 
 
-# ... and a triangular solve amplifies the rounding differences of two correct Q'b by cond(R): the tolerance of solution-against-
-# solution comparisons on those inputs (measured differences x 100; the residual checks stay tight)
-SOLVE_TOL = {"bcsstk14": 1e-6, "lns_3937": 1e-6, "bayer10": 1e-5, "ex18": 1e-2, "reorientation_8": 1e-5, "cvxqp3": 1e-5}
+def cond_probe(orc, S, N, nprobe=3, seed=7):
+    """Lower estimate of cond_2(R) of the packed factor N (oracle-style Numeric): (max ||R z|| / ||z||) * (max ||R^-1 y|| / ||y||) over
+    a few random vectors on the live columns / rows; each factor is a lower bound of the norm it probes."""
+    rng = np.random.default_rng(seed)
+    n, rank = S.n, int(N.c.rank)
+    if rank == 0:
+        return 1.0
+    dead = np.asarray(N.Rdead[:n]) != 0
+    nr = ni = 0.0
+    for _ in range(nprobe):
+        z = rng.standard_normal(n)
+        z[dead] = 0.0
+        nr = max(nr, float(np.linalg.norm(orc.rmult(S, N, z)) / max(np.linalg.norm(z), 1e-300)))
+        y = np.zeros(S.m)
+        y[:rank] = rng.standard_normal(rank)
+        ni = max(ni, float(np.linalg.norm(orc.rsolve(S, N, y)) / np.linalg.norm(y)))
+    return max(nr * ni, 1.0)
+
+
+def solve_tol(kappa, floor=1e-9):
+    """allowed ||x - x_ref|| / ||x_ref|| between two correct solutions through factors of condition `kappa`"""
+    return max(floor, TOL_C * EPS * kappa)
+
+
+def rrow_excess(got, ref, kappa, rel=1e-10):
+    """R-row signatures (|diag|, ||row||, |<row, w>|) of two factorizations: the largest |difference| in units of what is allowed --
+    `rel` of the row's own norm, or TOL_C * eps * kappa of the LARGEST row norm, whichever is larger.  <= 1 passes."""
+    if ref.size == 0:
+        return 0.0
+    allowed = np.maximum(rel * np.maximum(ref[:, 1:2], 1e-300), TOL_C * EPS * kappa * np.max(ref[:, 1], initial=1e-300))
+    return float(np.max(np.abs(got - ref) / allowed, initial=0.0))
 
 
 def golden_names(include_big: bool = False):

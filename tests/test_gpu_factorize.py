@@ -4,7 +4,8 @@ import importlib
 import numpy as np
 import pytest
 
-from parity import ELEMENTWISE, ILL_CONDITIONED, compare_integers, compare_numeric, rrow_sig_all
+from parity import ELEMENTWISE, compare_integers, compare_numeric, rrow_sig_all
+from stmmqr_testlib import cond_probe, rrow_excess
 from stmmqr_testlib import Symbolic, golden_names, load_golden, numeric_from_gpu, scalar
 
 pytestmark = pytest.mark.gpu
@@ -45,9 +46,8 @@ def test_against_golden_and_oracle(pkg, oracle, name, bigcols):
     assert G.stats["flops"] == scalar(g, "flopcount")
     # 2. R rows against the reference (sign-invariant signatures)
     got, ref = rrow_sig_all(S, N), g["num_rrow_sig"]
-    ftol = ILL_CONDITIONED.get(name, 1e-10)
-    scale = np.max(ref[:, 1], initial=1e-300) if name in ILL_CONDITIONED else np.maximum(ref[:, 1:2], 1e-300)
-    assert np.max(np.abs(got - ref) / scale, initial=0.0) <= ftol
+    ex = rrow_excess(got, ref, cond_probe(oracle, S, N))          # (derived bound: TOL_C * eps * cond(R), stmmqr_testlib)
+    assert ex <= 1.0, (name, ex)
     # 3. everything else against the CPU oracle on the same input
     ch = oracle.chunk(int(scalar(g, "FCHUNK")), int(scalar(g, "SMALL")), int(scalar(g, "MINCHUNK")),
                       int(scalar(g, "MINCHUNK_RATIO")))
@@ -79,9 +79,8 @@ def test_gram_panel_everywhere(pkg, oracle, monkeypatch, name, late):
     compare_integers(S, N, g)
     assert G.stats["flops"] == scalar(g, "flopcount")
     got, ref = rrow_sig_all(S, N), g["num_rrow_sig"]
-    ftol = ILL_CONDITIONED.get(name, 1e-10)
-    scale = np.max(ref[:, 1], initial=1e-300) if name in ILL_CONDITIONED else np.maximum(ref[:, 1:2], 1e-300)
-    assert np.max(np.abs(got - ref) / scale, initial=0.0) <= ftol
+    ex = rrow_excess(got, ref, cond_probe(oracle, S, N))          # (derived bound: TOL_C * eps * cond(R), stmmqr_testlib)
+    assert ex <= 1.0, (name, ex)
     No = oracle.factorize(S, g["in_Ap"], g["in_Ai"], g["in_Ax"], scalar(g, "in_tol"), int(scalar(g, "in_ntol")))
     compare_numeric(oracle, S, G, No, g, ftol=1e-10, name=name)
 
@@ -183,9 +182,8 @@ def test_pair_update_everywhere(pkg, oracle, monkeypatch, name, bfc, mode):
     compare_integers(S, N, g)
     assert G.stats["flops"] == scalar(g, "flopcount")
     got, ref = rrow_sig_all(S, N), g["num_rrow_sig"]
-    ftol = ILL_CONDITIONED.get(name, 1e-10)
-    scale = np.max(ref[:, 1], initial=1e-300) if name in ILL_CONDITIONED else np.maximum(ref[:, 1:2], 1e-300)
-    assert np.max(np.abs(got - ref) / scale, initial=0.0) <= ftol
+    ex = rrow_excess(got, ref, cond_probe(oracle, S, N))          # (derived bound: TOL_C * eps * cond(R), stmmqr_testlib)
+    assert ex <= 1.0, (name, ex)
     No = oracle.factorize(S, g["in_Ap"], g["in_Ai"], g["in_Ax"], scalar(g, "in_tol"), int(scalar(g, "in_ntol")))
     compare_numeric(oracle, S, G, No, g, ftol=1e-10, name=name)
 
@@ -419,7 +417,7 @@ def test_reference_inputs(pkg, oracle, name, bigcols):
     dwt_992: rank 496 of 992), staircases, row maps, block offsets, the flop count -- bit for bit; R rows by signatures;
     backward error on the live columns and Q Q' x = x through the packed factors.  No scalar oracle factorization here (the two
     heavy ones take 7 s / 100 s there): the oracle only applies Q from the DEVICE's factors."""
-    from stmmqr_testlib import GOLDEN, ILL_CONDITIONED as ILL, REFERENCE_TEST_MATRICES, aqr_probe_error
+    from stmmqr_testlib import GOLDEN, REFERENCE_TEST_MATRICES, aqr_probe_error
     assert name in REFERENCE_TEST_MATRICES
     if not (GOLDEN / f"{name}.npz").exists():
         pytest.skip("fixture not generated (tests/golden/make_golden.py)")
@@ -434,10 +432,10 @@ def test_reference_inputs(pkg, oracle, name, bigcols):
     compare_integers(S, N, g)
     assert G.stats["flops"] == scalar(g, "flopcount")
     got, ref = rrow_sig_all(S, N), g["num_rrow_sig"]
-    if name in ILL:
-        assert np.max(np.abs(got - ref), initial=0.0) <= ILL[name] * np.max(ref[:, 1], initial=1e-300)
-    else:
-        assert np.max(np.abs(got - ref) / np.maximum(ref[:, 1:2], 1e-300), initial=0.0) <= 1e-10
+    kappa = cond_probe(oracle, S, N)
+    ex = rrow_excess(got, ref, kappa)
+    print(f"[rrow] {name} cond_probe {kappa:.2e} excess {ex:.3f}")
+    assert ex <= 1.0, (name, ex, kappa)
     err = aqr_probe_error(oracle, S, N, g["in_Ap"], g["in_Ai"], g["in_Ax"], nprobe=2, live_only=(N.c.rank != S.n))
     assert err < 1e-13, err
     x = np.random.default_rng(3).standard_normal(S.m)
