@@ -446,6 +446,7 @@ void stmmqr_sparseqr_free(stmmqr_qr *qr);
  * interval: Fac_time), flops (the reference's count), flop bound, device ms of the factorization, ordering used,
  * QR_CHUNK_FLAG, retries */
 int stmmqr_sparseqr_info(const stmmqr_qr *qr, double *info);
+double stmmqr_sparseqr_tol(const stmmqr_qr *qr);                                   /* the tolerance really used: qr_tol(A) for QR_DEFAULT_TOL, -1 (EMPTY) for other negative ones (SparseQR.c:126-139) */
 const stm_long *stmmqr_sparseqr_q1fill(const stmmqr_qr *qr);                      /* [n] column permutation (singletons first) */
 const stm_qr_symbolic *stmmqr_sparseqr_symbolic_view(const stmmqr_qr *qr);       /* qr_symbolic of A or Y */
 stmmqr_plan *stmmqr_sparseqr_plan(stmmqr_qr *qr);                                 /* the device plan holding the factors */

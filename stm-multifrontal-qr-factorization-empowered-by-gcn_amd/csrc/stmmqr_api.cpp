@@ -105,14 +105,14 @@ SparseQR_factorization *SparseQR(int ordering, double tol, stm_sparse_csc *A, st
     double info[12] = {0};
     (void)stmmqr_sparseqr_info(impl, info);
     SparseQR_factorization &Q = a->pub;
-    Q.tol = tol;
+    Q.tol = stmmqr_sparseqr_tol(impl);              // the EFFECTIVE tolerance, as the reference stores it (SparseQR.c:126-139)
     Q.QRsym = const_cast<stm_qr_symbolic *>(stmmqr_sparseqr_symbolic_view(impl));
     Q.QRnum = nullptr;
     Q.Q1fill = const_cast<stm_long *>(stmmqr_sparseqr_q1fill(impl));
     Q.rank = (stm_long)info[0]; Q.n1rows = (stm_long)info[1]; Q.n1cols = (stm_long)info[2];
     Q.narows = m; Q.nacols = n;
     Q.Ana_time = info[4]; Q.Fac_time = info[5];
-    Q.allow_tol = tol >= 0 || tol <= -2;
+    Q.allow_tol = Q.tol >= 0;
     return &a->pub;
 }
 

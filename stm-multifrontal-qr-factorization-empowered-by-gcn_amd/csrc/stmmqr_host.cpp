@@ -1222,6 +1222,10 @@ int reset_group(stmmqr_plan &P, int grp)
     HIPCHK(hipMemsetAsync(P.d_wflag.p, 0, P.wcnt_n * sizeof(int), st));
     HIPCHK(hipMemsetAsync(P.d_wflag2.p, 0, P.wcnt_n * sizeof(int), st));
     HIPCHK(hipMemsetAsync(P.d_abort.p, 0, 2 * sizeof(int), st));
+    // slab recycling: a recycling plan holds the whole tree in this one group, and the aborted attempt has staged packed blocks behind
+    // the arena's bump pointer; the rerun stages every block again, so the pointer (and the overflow word) go back to zero -- otherwise
+    // the second set lands behind the first and overflows an arena that holds the estimate + 12.5 %
+    if (P.recycle) HIPCHK(hipMemsetAsync(P.d_rhtop.p, 0, 2 * sizeof(long long), st));
     HIPCHK(hipStreamSynchronize(st));                       // (`zero` lives on this stack frame)
     return 0;
 }
@@ -1803,6 +1807,18 @@ int stmmqr_factorize_begin(stmmqr_plan *plan, const stm_long *Ap, const stm_long
         if (e) return e;
     }
     if (!P.pattern_set) return fail(STMMQR_ERR_INVALID, "pattern of A was never given");
+    if (P.arena_overflow && P.recycle && !P.whole_call) {
+        // phased use (begin / group / finish by the caller): the previous factorization of this plan did not fit the R+H arena
+        // (finish returned OUT_OF_MEMORY and run_pack noted rh_grow / overflowed).  Those only take effect when the schedule is
+        // rebuilt, which stmmqr_factorize_device does in its own retry loop; here the rebuild happens at the next begin, so a
+        // caller that simply tries again gets the arena at its hard bound (then no recycling) instead of the same failure.
+        P.arena_overflow = false;
+        P.begun = false;
+        std::vector<int> grp(P.group.begin(), P.group.end());
+        for (size_t f = 0; f < grp.size(); f++) if (f < P.shared.size() && P.shared[f]) grp[f] |= STMMQR_GROUP_SHARED;
+        int e = stmmqr_plan_set_groups(plan, grp.data());
+        if (e) return e;
+    }
     const double host_ms_plan = P.stats.ms_host;
     P.stats = stmmqr_stats();
     P.stats.ms_host = host_ms_plan;
@@ -2821,8 +2837,10 @@ int level_to_front_form(stmmqr_plan &P, size_t l)
     const DevCtx c = P.ctx();
     if (P.scr_all) {
         if (P.scr_valid) return 0;
-        P.scr_valid = true;                                       // every front at once, kept until the next factorization
-        return stm_launch_rh_unpack(c, P.d_fs_scr.p, P.d_lists.p + P.own_off, P.n_own, 64, P.d_kept.p, P.d_RH.p, P.d_scr.p, P.stream);
+        // every front at once, kept until the next factorization (marked valid only once the launch was accepted)
+        const int e = stm_launch_rh_unpack(c, P.d_fs_scr.p, P.d_lists.p + P.own_off, P.n_own, 64, P.d_kept.p, P.d_RH.p, P.d_scr.p, P.stream);
+        P.scr_valid = (e == 0);
+        return e;
     }
     if (LV[l].n_all <= 0) return 0;
     return stm_launch_rh_unpack(c, P.d_fs_scr.p, P.d_lists.p + LV[l].all_off, LV[l].n_all, 64, P.d_kept.p, P.d_RH.p, P.d_scr.p, P.stream);
@@ -3290,14 +3308,16 @@ unsigned long long symbolic_key(const stm_qr_symbolic *S)
 {
     unsigned long long h = 0xcbf29ce484222325ULL;
     const stm_long sc[] = {S->m, S->n, S->anz, S->nf, S->maxfn, S->rjsize, S->hisize, S->do_rank_detection, S->keepH,
-                           (stm_long)(S->Qfill != nullptr), (stm_long)(S->Fm != nullptr)};
+                           (stm_long)(S->Qfill != nullptr), (stm_long)(S->Fm != nullptr), S->maxstack};   // (maxstack sizes the R+H arena)
     h = hash_bytes(sc, sizeof sc, h);
     auto add = [&](const stm_long *a, stm_long cnt) { if (a && cnt > 0) h = hash_bytes(a, (size_t)cnt * sizeof(stm_long), h); };
     add(S->Sp, S->m + 1); add(S->Sj, S->anz); add(S->Qfill, S->n); add(S->PLinv, S->m); add(S->Sleft, S->n + 2);
     add(S->Child, S->nf + 1); add(S->Childp, S->nf + 2); add(S->Super, S->nf + 1); add(S->Rp, S->nf + 1); add(S->Rj, S->rjsize);
     add(S->Post, S->nf); add(S->Hip, S->nf + 1); add(S->Fm, S->nf);
     h = hash_bytes(&g_opt, sizeof g_opt, h);
-    for (const char *k : {"STMMQR_CA_MIN", "STMMQR_PAIR_MIN", "STMMQR_SCHED", "STMMQR_RIDE", "STMMQR_QBIG_MIN"}) {
+    // (every knob of the environment that is read when the plan / its schedule / its arenas are built)
+    for (const char *k : {"STMMQR_CA_MIN", "STMMQR_PAIR_MIN", "STMMQR_SCHED", "STMMQR_RIDE", "STMMQR_QBIG_MIN", "STMMQR_RECYCLE", "STMMQR_TUNE",
+                          "STMMQR_RH_EST_SCALE"}) {
         const char *v = getenv(k);
         if (v) h = hash_bytes(v, strlen(v), h ^ 0x51ed);
     }
@@ -3393,6 +3413,14 @@ stm_qr_numeric *qr_factorize(stm_sparse_csc **Ahandle, stm_long freeA, double to
     auto set_status = [&](int st) { if (cc) cc_int(cc, g_layout.status) = st; };
     stm_sparse_csc *A = Ahandle ? *Ahandle : nullptr;
     if (!A) { set_status(STMMQR_ERR_INVALID); return nullptr; }
+    // A must be the matrix QRsym was made for BEFORE anything walks its arrays with QRsym's sizes (the cache key below hashes
+    // A->p over n + 1 and A->i over anz entries: a mismatched pair would be read past its end instead of being refused)
+    if ((stm_long)A->nrow != S->m || (stm_long)A->ncol != S->n || !A->p || (S->anz > 0 && (!A->i || !A->x)) ||
+        ((const stm_long *)A->p)[S->n] != S->anz || (stm_long)A->nzmax < S->anz) {
+        if (freeA) cc_free_sparse(Ahandle, cc);
+        set_status(STMMQR_ERR_INVALID);
+        return nullptr;
+    }
 
     stmmqr_symbolic_view v;
     v.m = S->m; v.n = S->n; v.anz = S->anz; v.nf = S->nf; v.maxfn = S->maxfn; v.rjsize = S->rjsize;
@@ -3436,15 +3464,34 @@ stm_qr_numeric *qr_factorize(stm_sparse_csc **Ahandle, stm_long freeA, double to
         const bool force = getenv("STMMQR_SEAM_EARLY_ALLOC") && atoi(getenv("STMMQR_SEAM_EARLY_ALLOC")) == 2;
         early_doubles = (cached && P->rh_total > 0) ? (size_t)((double)P->rh_total * 1.02) + 1024
                                                     : (force ? (size_t)std::max<stm_long>(S->maxstack, 1) : 0);
-        if (early_doubles * sizeof(double) >= (64u << 20))
-            early = std::thread([&early_stack, early_doubles]() {
-                early_stack = (double *)malloc(early_doubles * sizeof(double));
-                prefault(early_stack, early_doubles * sizeof(double));
-            });
-        else early_doubles = 0;
+        if (early_doubles * sizeof(double) >= (64u << 20)) {
+            try {                                                  // (nothing may be thrown across the C ABI: no helper, plain allocation later)
+                early = std::thread([&early_stack, early_doubles]() {
+                    early_stack = (double *)malloc(early_doubles * sizeof(double));
+                    prefault(early_stack, early_doubles * sizeof(double));
+                });
+            } catch (...) {
+                early_doubles = 0;
+            }
+        } else early_doubles = 0;
     }
     if (!st) st = stmmqr_factorize_device(P, same_pattern ? nullptr : (const stm_long *)A->p, same_pattern ? nullptr : (const stm_long *)A->i,
                                           (const double *)A->x, 0, tol, ntol, &stats);
+    if (st == STMMQR_ERR_OUT_OF_MEMORY && use_cache && !cached) {
+        // The cache keeps the device memory of the plans it holds (3 GB on the xenon1 stand-in, 25 GB on the configs[4] stand-in) after
+        // qr_factorize returns; the reference frees everything.  A new matrix that does not fit BESIDE a cached plan must not fail
+        // where the reference would succeed: the cache is emptied and the call tried once more.
+        bool any;
+        { std::lock_guard<std::mutex> lock(g_cache_mu); any = !g_cache.empty(); }
+        if (any) {
+            if (g_opt.verbose) fprintf(stderr, "[stmmqr_hip] out of device memory beside cached plans: cache emptied, trying again\n");
+            if (P) { stmmqr_plan_destroy(P); P = nullptr; }
+            stmmqr_plan_cache_clear();
+            st = 0;
+            P = stmmqr_plan_create(&v, -1, &st);
+            if (!st) st = stmmqr_factorize_device(P, (const stm_long *)A->p, (const stm_long *)A->i, (const double *)A->x, 0, tol, ntol, &stats);
+        }
+    }
     const double t_fact = now_ms();
     if (freeA) cc_free_sparse(Ahandle, cc);                    // :324-327
     if (early.joinable()) early.join();

@@ -389,6 +389,9 @@ int stmmqr_sparseqr_info(const stmmqr_qr *qr, double *info)
     return 0;
 }
 
+/* the tolerance the factorization really used: qr_tol(A) for tol <= -2 (QR_DEFAULT_TOL), EMPTY (-1) for any other negative one
+ * (SparseQR.c:126-139: what the reference stores in SparseQR_factorization::tol) */
+double stmmqr_sparseqr_tol(const stmmqr_qr *qr) { return qr ? qr->tol : -1.0; }
 const stm_long *stmmqr_sparseqr_q1fill(const stmmqr_qr *qr) { return qr ? qr->Q1fill.data() : nullptr; }
 const stm_qr_symbolic *stmmqr_sparseqr_symbolic_view(const stmmqr_qr *qr) { return qr && qr->sym ? stmmqr_analysis_symbolic(qr->sym) : nullptr; }
 stmmqr_plan *stmmqr_sparseqr_plan(stmmqr_qr *qr) { return qr ? qr->plan : nullptr; }

@@ -556,6 +556,66 @@ def test_slab_recycling_same_bits_and_less_memory(pkg, monkeypatch, name, cache)
 
 
 @pytest.mark.parametrize("name", ["bcsstk14", "grid20_standin", "lns_3937"])
+def test_recycling_plan_through_the_phased_interface(pkg, monkeypatch, name):
+    """A fresh one-group plan recycles its slabs from 256 MB on (STMMQR_RECYCLE=2: always) also when the CALLER drives it through
+    begin / group / finish.  Two recoveries that stmmqr_factorize_device does for itself must work there too: (a) a panel wait that
+    runs out -- the group is run again, and the bump pointer of the R+H arena goes back to zero with it (the rerun stages every block
+    again); (b) an arena overflow -- finish fails, and the NEXT begin rebuilds the schedule with the arena at its hard bound instead
+    of failing the same way for ever.  Same bits as a plan that never met either."""
+    g = load_golden(name)
+    S = Symbolic(g)
+    sym = sym_dict(S)
+    tol, ntol = scalar(g, "in_tol"), int(scalar(g, "in_ntol"))
+    monkeypatch.setenv("STMMQR_RECYCLE", "2")
+    pkg.set_options(tall_min_rows=0, big_front_cols=16)
+    try:
+        ref_plan = pkg.HipQR(sym)
+        ref_plan.factorize(g["in_Ax"], tol, ntol, g["in_Ap"], g["in_Ai"])
+        ref = ref_plan.download()
+        ref_plan.close()
+
+        def same(G):
+            assert G.rank == ref.rank and G.rh_total == ref.rh_total
+            for k in ("HStair", "HPinv", "Rdead", "Rblock_off"):
+                assert np.array_equal(getattr(G, k), getattr(ref, k)), k
+
+        # (a) forced panel-wait timeout inside the group
+        plan = pkg.HipQR(sym)
+        try:
+            monkeypatch.setenv("STMMQR_DBG", "4096")
+            plan.begin(g["in_Ax"], tol, ntol, g["in_Ap"], g["in_Ai"])
+            plan.run_group(0)
+            st = plan.finish()
+            monkeypatch.delenv("STMMQR_DBG")
+            assert st["flops"] == scalar(g, "flopcount")
+            same(plan.download())
+        finally:
+            monkeypatch.delenv("STMMQR_DBG", raising=False)
+            plan.close()
+        # (b) arena overflow on the phased path
+        monkeypatch.setenv("STMMQR_RH_EST_SCALE", "0.3")
+        plan = pkg.HipQR(sym)
+        monkeypatch.delenv("STMMQR_RH_EST_SCALE")
+        try:
+            plan.begin(g["in_Ax"], tol, ntol, g["in_Ap"], g["in_Ai"])
+            plan.run_group(0)
+            with pytest.raises(Exception):
+                plan.finish()                                           # the packed factors exceed the arena: reported, nothing written past it
+            plan.begin(g["in_Ax"], tol, ntol)                           # ... and the next attempt gets the arena at its hard bound
+            plan.run_group(0)
+            st = plan.finish()
+            assert st["flops"] == scalar(g, "flopcount")
+            G = plan.download()
+            same(G)
+            assert np.array_equal(G.Stack[:G.rh_total], ref.Stack[:ref.rh_total], equal_nan=True)
+            assert np.array_equal(G.HTau, ref.HTau, equal_nan=True)
+        finally:
+            plan.close()
+    finally:
+        pkg.set_options(tall_min_rows=0, big_front_cols=64)
+
+
+@pytest.mark.parametrize("name", ["bcsstk14", "grid20_standin", "lns_3937"])
 def test_rh_arena_overflow_is_recovered(pkg, monkeypatch, name):
     """The R+H arena of the slab recycling is sized from the full-rank pattern (+ 12.5 %); factors that do not fit (dead columns can
     make later fronts taller) are detected on the device (nothing is written past the arena), the arena is regrown to the
