@@ -432,6 +432,8 @@ def main():
     ap.add_argument("--big-front-cols", type=int, default=None)
     ap.add_argument("--panel-algo", type=int, default=None)
     ap.add_argument("--lookahead", type=int, default=None)
+    ap.add_argument("--no-large-front", dest="large_front", action="store_false",
+                    help="skip the un-headlined large-front block (c5mid / c5 stand-ins, ~15 s) of the default N = 1 line")
     ap.add_argument("--tall-min", type=int, default=None)
     ap.add_argument("--fused-update", type=int, default=None)
     ap.add_argument("--use-graph", type=int, default=None)
@@ -601,11 +603,26 @@ def _run(args, torch, rank, world, local, guard):
     # One extra, un-timed factorization with an event pair around every launch of a category (panel / update / assembly /
     # pack), recorded on the plan's stream with NO synchronisation in between: the schedule runs exactly as in the timed
     # region, and the pairs give each kernel family's own time (kernel-only: what rocprofv3 --kernel-trace --stats sums).
-    det = None
+    det, step_rows = None, []
     if rank == 0:                      # (the detail pass feeds rank 0's roofline object only)
         if sharded:
             plan.set_groups(np.zeros(S.nf, np.int32))
-        det = plan.factorize(None, tol, ntol, device_ptr=Ax.data_ptr(), detail=True)
+        # (STMMQR_DUMPSTEPS: the library writes one line per timeline step of a detail pass -- the tallest panel of the step and the
+        #  time of its panel / update launches -- which is what the latency roofline of the panel kernels below is made of)
+        with tempfile.TemporaryDirectory() as td:
+            dump = os.path.join(td, "steps.txt")
+            os.environ["STMMQR_DUMPSTEPS"] = dump
+            try:
+                det = plan.factorize(None, tol, ntol, device_ptr=Ax.data_ptr(), detail=True)
+            finally:
+                os.environ.pop("STMMQR_DUMPSTEPS", None)
+            try:
+                for line in open(dump):
+                    t = line.split()
+                    kv = dict(zip(t[1::2], t[2::2]))
+                    step_rows.append((int(kv["n_act"]), int(kv["maxrows"]), int(kv["nca_use"]), float(kv["panel_us"]), float(kv["upd_us"])))
+            except Exception:
+                step_rows = []
     if rank == 0:
         value = total_flops * args.steps / wall * 1e-9
         # Algorithmic work: the reference's flop count (FLOP_COUNT, :1571) splits into the dlarfb flops handed to the
@@ -643,16 +660,52 @@ def _run(args, torch, rank, world, local, guard):
             return (tot / calls) if calls and pmc_ok else None
 
         npl, nul = max(det["npanel_launch"], 1), max(det["nupdate_launch"], 1)
-        panel_obj = {"bound": "mfma", "kernel": "k_panel / k_panel_ca (+ k_front_wg): Householder panels; fp64 vector = matrix peak on gfx950",
+        panel_obj = {"bound": "mfma", "kernel": "k_panel (k_panel_pc in the timed schedule: the same workgroups + k_upd_c riders) / k_panel_ca (+ k_front_wg): Householder panels; fp64 vector = matrix peak on gfx950",
                      "achieved": panel_tf, "peak": PEAK_FP64_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": panel_tf / PEAK_FP64_MFMA_TFLOPS,
                      "ms": ms_panel, "launch_groups": det["npanel_launch"], "avg_us_per_step": ms_panel / npl * 1e3,
-                     "traffic": pmc_traffic(["k_panel", "k_panel_ca"]),
+                     "traffic": pmc_traffic(["k_panel", "k_panel_pc", "k_panel_ca"]),
                      "note": "latency-bound: a serial chain of Householder columns (DESIGN.md 4-5)"}
-        upd_obj = {"bound": "hbm", "kernel": "k_upd_w + k_upd_c / k_update / k_upd_wq + k_upd_cq (dlarfb on v_mfma_f64_16x16x4_f64)", "achieved": upd_gbs,
+        upd_obj = {"bound": "hbm", "kernel": "k_upd_w + k_upd_c (in the timed schedule: k_upd_b0w = T + block 0 + k_upd_w riders, k_upd_c riders of k_panel_pc) / k_update / k_upd_wq + k_upd_cq (dlarfb on v_mfma_f64_16x16x4_f64)", "achieved": upd_gbs,
                    "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": upd_gbs / PEAK_HBM_GBS, "ms": ms_upd,
                    "launch_groups": det["nupdate_launch"], "avg_us_per_step": ms_upd / nul * 1e3,
                    "mfma_tflops": upd_tf, "mfma_frac": upd_tf / PEAK_FP64_MFMA_TFLOPS,
-                   "traffic": pmc_traffic(["k_upd_w", "k_upd_c", "k_update", "k_upd_w2", "k_upd_c2", "k_upd_wq", "k_upd_cq"])}
+                   "traffic": pmc_traffic(["k_upd_w", "k_upd_c", "k_upd_b0w", "k_update", "k_upd_w2", "k_upd_c2", "k_upd_wq", "k_upd_cq"])}
+        # Latency roofline of the panel kernels ("small-front panel QR -> LDS / latency-bound").  A panel is a chain of 32
+        # dependent Householder column steps; what bounds a column step is not flops or bytes but its chain of dependent
+        # instructions.  Floors per column, from the guide's cycle constants and the 12 cycles per dependent fp64 VALU instruction
+        # measured on this chain (DESIGN.md 4b has the count instruction by instruction), at 2.4 GHz:
+        #   column pipeline (dev_tall_group: 13 + 3 exchange-adds, one LDS round trip + s_barrier, dlarfg's rsq / rcp Newton chains,
+        #   the dot-product and rank-1 FMAs of 4-8 rows x 4-8 columns per thread)                          0.45 us
+        #   wave panel (dev_wave_panel: the same without LDS, barrier and second reduction stage)           0.33 us
+        #   Gram-based panel (k_panel_ca: the chain runs on the 32 x 32 Gram matrix in one wave, + the panel's Gram reduction and
+        #   B := B M application, ~14 us, spread over its 32 columns)                                        0.60 us
+        # A step's class is its tallest panel's kernel (estimated rows: > 4096 Gram-based, <= 512 wave, else the pipeline); its panel
+        # time is the event pair around the step's panel launches in the detail pass (no riders there); 32 columns per step.
+        LAT_FLOOR = {"column_pipeline": 0.45, "wave_panel": 0.33, "gram_panel": 0.60}
+        lat = {}
+        for n_act, rows, nca, pus, uus in step_rows:
+            if n_act <= 0 or pus <= 0:
+                continue
+            cls = "gram_panel" if (nca > 0 and rows > 4096) else "wave_panel" if rows <= 512 else "column_pipeline"
+            e = lat.setdefault(cls, {"steps": 0, "us": 0.0})
+            e["steps"] += 1
+            e["us"] += pus
+        for cls, e in lat.items():
+            e["columns_on_the_chain"] = 32 * e["steps"]
+            e["achieved_us_per_column"] = e["us"] / e["columns_on_the_chain"]
+            e["latency_floor_us_per_column"] = LAT_FLOOR[cls]
+            e["frac_of_latency_floor"] = LAT_FLOOR[cls] / e["achieved_us_per_column"]
+        if lat:
+            top = max(lat, key=lambda k: lat[k]["us"])
+            panel_obj["latency"] = lat
+            panel_obj["latency_bound"] = {"kernel_class": top, **{k: lat[top][k] for k in ("latency_floor_us_per_column", "achieved_us_per_column",
+                                                                                         "frac_of_latency_floor")},
+                                          "note": "floor = dependent-instruction chain of one Householder column step (bench.py, DESIGN.md 4b); "
+                                                  "achieved = panel launch time of the steps this class bounds / 32 columns, hand-offs between "
+                                                  "column groups included"}
+            panel_obj["latency_floor_us_per_column"] = lat[top]["latency_floor_us_per_column"]
+            panel_obj["achieved_us_per_column"] = lat[top]["achieved_us_per_column"]
+            panel_obj["frac_of_latency_floor"] = lat[top]["frac_of_latency_floor"]
         roof = dict(panel_obj if ms_panel >= ms_upd else upd_obj)
         roof["dominant_by"] = "HIP-event pairs around every launch of the family, no syncs in between (detail pass)"
         roof["panel_kernels"] = panel_obj
@@ -755,6 +808,43 @@ def _run(args, torch, rank, world, local, guard):
                 out["own_symbolic_ms"] = (time.perf_counter() - t0) * 1e3
         except Exception as e:
             out["dropin_seam_error"] = str(e)
+        # The large-front class (BASELINE configs[4]'s structure: one dense root front carries the flops, the quad update on the matrix
+        # cores), un-headlined and outside `value`: the same library, the full-size stand-in and its n = 27 000 sibling, three / two
+        # timed factorizations each after one warm-up, plus one detail pass for the update kernels' own share of the MFMA peak.
+        if world == 1 and args.large_front and name == DEFAULT_WORKLOAD.get(1) and mtx_path is None:
+            lf = {}
+            for wl_name, nsteps in (("c5mid_standin", 3), ("c5_standin", 2)):
+                try:
+                    if plan is not None:
+                        plan.close(); plan = None
+                    g2 = load_golden(wl_name)
+                    S2 = Symbolic(g2)
+                    sym2 = {**S2.sc, **{k: v for k, v in S2.arr.items() if v is not None}}
+                    tol2, ntol2 = scalar(g2, "in_tol"), int(scalar(g2, "in_ntol"))
+                    p2 = pkg.HipQR(sym2, device=local)
+                    p2.set_pattern(g2["in_Ap"], g2["in_Ai"])
+                    Ax2 = torch.from_numpy(np.ascontiguousarray(g2["in_Ax"])).to(dev)
+                    p2.factorize(None, tol2, ntol2, device_ptr=Ax2.data_ptr())
+                    torch.cuda.synchronize()
+                    t0 = time.perf_counter()
+                    rt = 0
+                    for _ in range(nsteps):
+                        s2 = p2.factorize(None, tol2, ntol2, device_ptr=Ax2.data_ptr())
+                        rt += int(s2.get("retries", 0))
+                    torch.cuda.synchronize()
+                    ms2 = (time.perf_counter() - t0) / nsteps * 1e3
+                    d2 = p2.factorize(None, tol2, ntol2, device_ptr=Ax2.data_ptr(), detail=True)
+                    fl2 = float(scalar(g2, "flopcount"))
+                    assert int(round(s2["flops"])) == int(round(fl2)), (s2["flops"], fl2)
+                    lf[wl_name] = {"ms_per_step": ms2, "steps": nsteps, "tflops": fl2 / ms2 * 1e-9, "frac_of_fp64_mfma_peak": fl2 / ms2 * 1e-9 / PEAK_FP64_MFMA_TFLOPS,
+                                   "update_kernels_mfma_frac": d2["flops_update"] / max(d2["ms_update"], 1e-9) * 1e-9 / PEAK_FP64_MFMA_TFLOPS,
+                                   "update_kernels_ms": d2["ms_update"], "panel_kernels_ms": d2["ms_panel"] + d2["ms_small"], "retries": rt,
+                                   "flops_per_step": fl2, "n": int(S2.n), "device_bytes": d2.get("device_bytes", 0.0)}
+                    p2.close()
+                    del Ax2
+                except Exception as e:      # noqa: BLE001 (the headline line must come out whatever happens here)
+                    lf[wl_name] = {"error": str(e)[:300]}
+            out["large_front"] = lf
         if not args.no_cpu and world == 1:             # (the CPU baseline is reported at N = 1 only)
             cb = cpu_baseline(name, g, mtx_path=mtx_path, flops=flops)
             if mtx_path is not None and cb.get("kind") == "reference":
