@@ -1143,10 +1143,10 @@ int build_plan(stmmqr_plan &P, const stmmqr_symbolic_view &v)
     LCHK(P.d_Rhoff.alloc((size_t)v.rjsize));
     LCHK(P.d_Rboff.alloc((size_t)std::max(1L, nf)));
     LCHK(P.d_total.alloc(1));
-    LCHK(P.d_dbg.alloc(64));
+    LCHK(P.d_dbg.alloc(2048));                                // ([64] counters + the timeline of a STAMPS build: 16 + 64 b + idx)
     LCHK(P.d_amax.alloc(1));
     LCHK(P.d_sig.alloc(2));
-    HIPCHK(hipMemsetAsync(P.d_dbg.p, 0, 64 * sizeof(unsigned long long), st));
+    HIPCHK(hipMemsetAsync(P.d_dbg.p, 0, 2048 * sizeof(unsigned long long), st));
     LCHK(P.d_Rdead.alloc((size_t)std::max(1L, n)));
     LCHK(P.d_lists.upload(P.lists, st));
     LCHK(P.d_wlists.upload(P.wlists, st));
@@ -1999,6 +1999,24 @@ int stmmqr_factorize_finish(stmmqr_plan *plan, stmmqr_stats *stats)
         bytes_pack += 16.0 * (csize + (double)nm.rsize);
     }
     bytes_asm += 8.0 * (double)P.anz + P.bytes_assemble_idx;
+    if (getenv("STMMQR_DBG") && (atoi(getenv("STMMQR_DBG")) & 32) && getenv("STMMQR_TIMELINE")) {
+        // -DSTMMQR_STAMPS builds: wall-clock (100 MHz) timeline of panel 1 of the LAST front that ran one (the root), per column group
+        std::vector<unsigned long long> hb(2048);
+        HIPCHK(hipMemcpy(hb.data(), P.d_dbg.p, hb.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+        unsigned long long t0 = ~0ull;
+        for (int b = 0; b < 16; b++) if (hb[16 + 64 * b]) t0 = std::min(t0, hb[16 + 64 * b]);
+        for (int b = 0; b < 16; b++) {
+            const unsigned long long *q = &hb[16 + 64 * b];
+            if (!q[0]) continue;
+            fprintf(stderr, "[panel timeline] group %2d:", b);
+            auto us = [&](int i) { return q[i] ? 0.01 * (double)(q[i] - t0) : -1.0; };
+            fprintf(stderr, " start %.2f loaded %.2f |", us(0), us(1));
+            for (int h = 0; h < 6 && q[2 + 3 * h]; h++) fprintf(stderr, " wait %.2f vload %.2f applied %.2f |", us(2 + 3 * h), us(3 + 3 * h), us(4 + 3 * h));
+            fprintf(stderr, " cols");
+            for (int j = 0; j < 8; j++) if (q[20 + j]) fprintf(stderr, " %.2f", us(20 + j));
+            fprintf(stderr, " | published %.2f final %.2f\n", us(30), us(31));
+        }
+    }
     if (getenv("STMMQR_DBG") && (atoi(getenv("STMMQR_DBG")) & 32768)) {
         unsigned long long hb[64];
         HIPCHK(hipMemcpy(hb, P.d_dbg.p, sizeof hb, hipMemcpyDeviceToHost));

@@ -1262,9 +1262,9 @@ __device__ __forceinline__ void dev_tall_group(PanelShared &ps, const FrontSym &
     const bool stamp_me = (dbg & 16) && dbgbuf && (b == ns - 1);
 #define TSTAMP(idx) do { if (stamp_me) { __syncthreads(); ts1 = clock64(); if (tid == 0) atomicAdd(&dbgbuf[idx], ts1 - ts0); ts0 = ts1; } } while (0)
     // timeline of panel 1 (dbg & 32): wall clock (100 MHz) of thread 0 at the events of every group, dbgbuf[16 + 64 b + idx]
-    const bool tl_on = (dbg & 32) && dbgbuf && p == 1 && tid == 0;
-#define TL(idx) do { if (tl_on) dbgbuf[16 + 64 * b + (idx)] = wall_clock64(); } while (0)
-#define TLW(idx) do { if ((dbg & 32) && p == 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); TL(idx); } while (0)
+    const bool tl_on = (dbg & 32) && dbgbuf && p == (((dbg >> 24) & 127) ? ((dbg >> 24) & 127) : 1) && tid == 0 && s.parent < 0;      // (the root front only; panel = dbg bits 24-30)
+#define TL(idx) do { if (tl_on && ((idx) < 8 || (idx) >= 20) && !((idx) >= 26 && (idx) < 30)) dbgbuf[16 + 64 * b + (idx)] = wall_clock64(); } while (0)
+#define TLW(idx) do { if ((dbg & 32) && s.parent < 0 && p == (((dbg >> 24) & 127) ? ((dbg >> 24) & 127) : 1)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); TL(idx); } while (0)
 #define TCY(idx) do { if (tl_on && j == 4) dbgbuf[16 + 64 * b + 48 + (idx)] = clock64(); } while (0)
 #else
 #define TCY(idx) do { } while (0)
@@ -1309,6 +1309,9 @@ __device__ __forceinline__ void dev_tall_group(PanelShared &ps, const FrontSym &
             return;
         }
         TSTAMP(7);
+#ifdef STMMQR_STAMPS
+        tl_h = (sp == b - 1) ? half : 8;                       // (only the last two half applications: the ones on the chain)
+#endif
         TL(2 + 3 * tl_h);
         const int pc0 = SWT * sp + half * (SWT / 2);
         // (group sp ran out of rows?  Not num->done: a group that starts late would see the flag of a LATER group and
@@ -1436,9 +1439,6 @@ __device__ __forceinline__ void dev_tall_group(PanelShared &ps, const FrontSym &
         }
         TSTAMP(11);
         TL(4 + 3 * tl_h);
-#ifdef STMMQR_STAMPS
-        tl_h++;
-#endif
     }
     TSTAMP(8);
     // a group before mine ran out of rows (g reached fm): its reflectors were still due on my columns (applied above);
