@@ -7,6 +7,7 @@ g=load_golden(name); S=Symbolic(g); sym={**S.sc, **{k:v for k,v in S.arr.items()
 tol,ntol=scalar(g,"in_tol"),int(scalar(g,"in_ntol"))
 if os.environ.get("PAIR"): pkg.set_options(pair_update=int(os.environ["PAIR"]))
 if os.environ.get("LA"): pkg.set_options(lookahead=int(os.environ["LA"]))
+if os.environ.get("BFC"): pkg.set_options(big_front_cols=int(os.environ["BFC"]))
 plan=pkg.HipQR(sym); plan.set_pattern(g["in_Ap"],g["in_Ai"])
 for _ in range(3): st=plan.factorize(g["in_Ax"],tol,ntol)
 ts=[]
