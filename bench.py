@@ -659,17 +659,33 @@ def _run(args, torch, rank, world, local, guard):
                     calls += e["FETCH_SIZE"]["calls"]
             return (tot / calls) if calls and pmc_ok else None
 
+        def pmc_per_factorization(kernels):
+            """HBM bytes of these kernels per factorization in the committed PMC passes (k_amax runs once per factorization)"""
+            nfac = pmc.get("k_amax", {}).get("FETCH_SIZE", {}).get("calls", 0)
+            tot = 0.0
+            for k in kernels:
+                e = pmc.get(k, {})
+                if "FETCH_SIZE" in e and "WRITE_SIZE" in e:
+                    tot += (e["FETCH_SIZE"]["sum_kb"] * FETCH_CORRECTION + e["WRITE_SIZE"]["sum_kb"]) * 1024.0
+            return (tot / nfac) if nfac and pmc_ok else None
+
         npl, nul = max(det["npanel_launch"], 1), max(det["nupdate_launch"], 1)
         panel_obj = {"bound": "mfma", "kernel": "k_panel (k_panel_pc in the timed schedule: the same workgroups + k_upd_c riders) / k_panel_ca (+ k_front_wg): Householder panels; fp64 vector = matrix peak on gfx950",
                      "achieved": panel_tf, "peak": PEAK_FP64_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": panel_tf / PEAK_FP64_MFMA_TFLOPS,
                      "ms": ms_panel, "launch_groups": det["npanel_launch"], "avg_us_per_step": ms_panel / npl * 1e3,
-                     "traffic": pmc_traffic(["k_panel", "k_panel_pc", "k_panel_ca"]),
+                     "traffic": pmc_traffic(["k_panel", "k_panel_ca"]),
+                     "traffic_note": "per launch of k_panel / k_panel_ca alone; k_panel_pc's bytes are its riders' (update_kernels)",
                      "note": "latency-bound: a serial chain of Householder columns (DESIGN.md 4-5)"}
         upd_obj = {"bound": "hbm", "kernel": "k_upd_w + k_upd_c (in the timed schedule: k_upd_b0w = T + block 0 + k_upd_w riders, k_upd_c riders of k_panel_pc) / k_update / k_upd_wq + k_upd_cq (dlarfb on v_mfma_f64_16x16x4_f64)", "achieved": upd_gbs,
                    "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": upd_gbs / PEAK_HBM_GBS, "ms": ms_upd,
                    "launch_groups": det["nupdate_launch"], "avg_us_per_step": ms_upd / nul * 1e3,
                    "mfma_tflops": upd_tf, "mfma_frac": upd_tf / PEAK_FP64_MFMA_TFLOPS,
-                   "traffic": pmc_traffic(["k_upd_w", "k_upd_c", "k_upd_b0w", "k_update", "k_upd_w2", "k_upd_c2", "k_upd_wq", "k_upd_cq"])}
+                   "traffic": pmc_traffic(["k_upd_w", "k_upd_c", "k_upd_b0w", "k_update", "k_upd_w2", "k_upd_c2", "k_upd_wq", "k_upd_cq"]),
+                   # (the launches that carry update work in the timed schedule, k_panel_pc's riders included: its own panel bytes are
+                   #  ~1 % of it)
+                   "traffic_per_factorization": pmc_per_factorization(["k_upd_w", "k_upd_c", "k_upd_b0w", "k_panel_pc", "k_update", "k_upd_w2",
+                                                                       "k_upd_y2", "k_upd_c2", "k_upd_wq", "k_upd_yq", "k_upd_cq"]),
+                   "algorithmic_bytes_per_factorization": upd_bytes}
         # Latency roofline of the panel kernels (SURVEY 8d: "small-front panel QR -> LDS / latency-bound").  A panel is a chain of 32
         # dependent Householder column steps; what bounds a column step is not flops or bytes but its chain of dependent
         # instructions.  Floors per column, from the guide's cycle constants and the 12 cycles per dependent fp64 VALU instruction

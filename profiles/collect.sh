@@ -15,12 +15,12 @@ mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 DEF=xenon1_colamd_standin
 if [ "$WHAT" = pmc ] || [ "$WHAT" = all ]; then
-  rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_prof -o p -- python3 $ROOT/bench.py --steps 3 --warmup 1 --no-cpu > $OUT/${TAG}_prof.log 2>&1
+  rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_prof -o p -- python3 $ROOT/bench.py --steps 3 --warmup 1 --no-cpu --no-large-front > $OUT/${TAG}_prof.log 2>&1
   cp $OUT/${TAG}_prof/p_kernel_stats.csv $OUT/${TAG}_${DEF}_kernel_stats.csv
   rm -rf $OUT/${TAG}_prof
   for W in $DEF c5mid_standin; do
-    rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/${TAG}_pmc_fetch -o p -- python3 $ROOT/bench.py --workload $W --steps 1 --warmup 0 --no-cpu > $OUT/${TAG}_pmc_fetch.log 2>&1
-    rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/${TAG}_pmc_write -o p -- python3 $ROOT/bench.py --workload $W --steps 1 --warmup 0 --no-cpu > $OUT/${TAG}_pmc_write.log 2>&1
+    rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/${TAG}_pmc_fetch -o p -- python3 $ROOT/bench.py --workload $W --steps 1 --warmup 0 --no-cpu --no-large-front > $OUT/${TAG}_pmc_fetch.log 2>&1
+    rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/${TAG}_pmc_write -o p -- python3 $ROOT/bench.py --workload $W --steps 1 --warmup 0 --no-cpu --no-large-front > $OUT/${TAG}_pmc_write.log 2>&1
     python3 $ROOT/profiles/summarize_pmc.py $OUT/${TAG}_${W}_pmc_fetch_write_per_kernel.json $OUT/${TAG}_pmc_fetch $OUT/${TAG}_pmc_write > $OUT/${TAG}_${W}_pmc_summary.txt
     rm -rf $OUT/${TAG}_pmc_fetch $OUT/${TAG}_pmc_write
   done
