@@ -248,6 +248,9 @@ struct stmmqr_plan {
     std::vector<char> t4_level_valid;          // T4 of the level's split fronts is built (per level: with per-level scratch only the
                                                //  level at hand is in front form)
     DevBuf<int> d_Rm;                               // rows of R (live pivots) of the split fronts of a level (k_rbig_*)
+    // several right-hand sides per launch (RhsBatch, stmmqr_kernels.h): the per-vector buffers hold rhs_cap vectors at these strides
+    int rhs_cap = 1;
+    long long xf_doubles = 1, wq_doubles = 1;
     std::vector<QbLevel> level_qbig;               // descriptors (d_qb) of the fronts of each level that take the split Q-apply
     hipGraphExec_t graph_exec = nullptr;           // options.use_graph: the captured schedule of group 0
     double graph_tol = 0; int graph_ntol = 0, graph_dbg = 0; long long graph_opt = 0; long graph_nlaunch = 0;
@@ -2790,6 +2793,8 @@ int ensure_rowmap(stmmqr_plan &P)
         LCHK(P.d_Dq.alloc((size_t)dq));
         LCHK(P.d_Wq.alloc((size_t)wq));
         P.wq4_doubles = 4 * wq;
+        P.xf_doubles = xf; P.wq_doubles = wq; P.rhs_cap = 1;
+        P.d_U.release(); P.d_Xr.release();
         if (qb.empty()) qb.push_back(QbDesc());
         LCHK(P.d_qb.alloc(qb.size()));
         LCHK(P.d_Rm.alloc(qb.size()));
@@ -2864,9 +2869,38 @@ int level_to_front_form(stmmqr_plan &P, size_t l)
     return stm_launch_rh_unpack(c, P.d_fs_scr.p, P.d_lists.p + LV[l].all_off, LV[l].n_all, 64, P.d_kept.p, P.d_RH.p, P.d_scr.p, P.stream);
 }
 
-// W (device, S-row order) <- Q' W or Q W
-int run_qapply(stmmqr_plan &P, int method)
+// the per-vector buffers of the resident-factor operations for a batch of nb right-hand sides (grown on demand, never shrunk)
+int ensure_rhs_batch(stmmqr_plan &P, int nb)
 {
+    if (nb <= P.rhs_cap) return 0;
+    const size_t k = (size_t)nb;
+    LCHK(P.d_W.alloc(k * (size_t)std::max(1L, P.m)));
+    LCHK(P.d_Xs.alloc(k * (size_t)std::max(1L, P.n)));
+    LCHK(P.d_Xf.alloc(k * (size_t)P.xf_doubles));
+    LCHK(P.d_Wq.alloc(k * (size_t)P.wq_doubles));
+    if (P.d_Wq4.p) LCHK(P.d_Wq4.alloc(k * (size_t)std::max(1LL, P.wq4_doubles)));
+    if (P.d_U.p) { LCHK(P.d_U.alloc(k * (size_t)std::max(1L, P.rjsize))); LCHK(P.d_Xr.alloc(k * (size_t)std::max(1L, P.m))); }
+    P.rhs_cap = nb;
+    return 0;
+}
+RhsBatch rhs_strides(const stmmqr_plan &P)
+{
+    RhsBatch B;
+    B.w = P.m; B.x = P.n; B.xf = P.xf_doubles; B.wq = P.wq_doubles; B.wq4 = std::max(1LL, P.wq4_doubles); B.u = std::max(1L, P.rjsize);
+    return B;
+}
+// the largest batch the operations take in one pass (STMMQR_RHS_BATCH, default 32; 1: one vector after the other, as until round 4)
+int rhs_batch_max()
+{
+    static int v = -1;
+    if (v < 0) v = getenv("STMMQR_RHS_BATCH") ? std::max(1, atoi(getenv("STMMQR_RHS_BATCH"))) : 32;
+    return v;
+}
+
+// W (device, S-row order; nb vectors at stride m) <- Q' W or Q W
+int run_qapply(stmmqr_plan &P, int method, int nb = 1)
+{
+    const RhsBatch B = rhs_strides(P);
     DevCtx c = res_ctx(P);
     const int *L0 = P.d_lists.p;
     const auto &LV = P.glevels[0];
@@ -2881,7 +2915,7 @@ int run_qapply(stmmqr_plan &P, int method)
         if (hipMemGetInfo(&freeb, &totalb) == hipSuccess &&
             8.0 * ((double)P.t4_doubles + (double)P.wq4_doubles) + 4.0 * (double)P.dq4_ints < 0.25 * (double)freeb) {
             LCHK(P.d_T4.alloc((size_t)P.t4_doubles));
-            LCHK(P.d_Wq4.alloc((size_t)std::max(1LL, P.wq4_doubles)));
+            LCHK(P.d_Wq4.alloc((size_t)P.rhs_cap * (size_t)std::max(1LL, P.wq4_doubles)));
             LCHK(P.d_Dq4.alloc((size_t)std::max(1LL, P.dq4_ints)));
             LCHK(P.d_t4items.upload(P.t4items, P.stream));
             LCHK(P.d_t4fronts.upload(P.t4fronts, P.stream));
@@ -2898,7 +2932,7 @@ int run_qapply(stmmqr_plan &P, int method)
     auto launch = [&](size_t l, int m) -> int {
         LCHK(level_to_front_form(P, l));
         if (blocked) {
-            LCHK(stm_launch_qapply_t(c, L0 + LV[l].all_off, LV[l].n_all, m, P.d_W.p, P.level_lds_qa[l], P.stream));
+            LCHK(stm_launch_qapply_t(c, L0 + LV[l].all_off, LV[l].n_all, m, P.d_W.p, P.level_lds_qa[l], P.stream, nb, B));
             // the large fronts of the level (independent of the others): rows split over workgroups, a launch per group of four panels
             // (k_qbig_step4, T4 built at the first use after a factorization) or per panel
             const auto &Q = P.level_qbig[l];
@@ -2910,15 +2944,17 @@ int run_qapply(stmmqr_plan &P, int method)
                     P.t4_level_valid[l] = 1;
                 }
                 LCHK(stm_launch_qapply_big4(c, P.d_qb.p + Q.off, P.d_qbt4off.p + Q.off, Q.n, Q.max_np, Q.max_nslab, Q.max_fm, m, P.d_W.p, P.d_Xf.p,
-                                            P.d_Dq.p, P.d_Wq4.p, P.d_T4.p, P.stream));
+                                            P.d_Dq.p, P.d_Wq4.p, P.d_T4.p, P.stream, nb, B));
                 return 0;
             }
             LCHK(stm_launch_qapply_big(c, P.d_qb.p + Q.off, Q.n, Q.max_np, Q.max_nslab, Q.max_fm, m, P.d_W.p, P.d_Xf.p, P.d_Dq.p,
-                                       P.d_Wq.p, P.stream));
+                                       P.d_Wq.p, P.stream, nb, B));
             return 0;
         }
         if (P.level_lds_qa_all[l] > 131072) return fail(STMMQR_ERR_TOO_LARGE, "a front has more rows than the unblocked Q-apply kernel holds in LDS");
-        return stm_launch_qapply(c, L0 + LV[l].all_off, LV[l].n_all, m, P.d_W.p, P.level_lds_qa_all[l], P.d_err.p, P.stream);
+        for (int j = 0; j < nb; j++)                                  // (the reflector-by-reflector cross-check kernel: one vector per launch)
+            LCHK(stm_launch_qapply(c, L0 + LV[l].all_off, LV[l].n_all, m, P.d_W.p + (size_t)j * (size_t)P.m, P.level_lds_qa_all[l], P.d_err.p, P.stream));
+        return 0;
     };
     if (method == 0) {
         for (size_t l = 0; l < LV.size(); l++) LCHK(launch(l, 0));
@@ -2947,35 +2983,37 @@ int download_cols(stmmqr_plan &P, const DevBuf<double> &d, double *H, long ld, l
     HIPCHK(hipStreamSynchronize(P.stream));
     return 0;
 }
-// one vector through Q' (method 0) or Q (method 1): in / out are device vectors of length m in the reference's row order
-int qapply_vector(stmmqr_plan &P, int method, const double *in, double *out)
+// nb vectors (stride m in `in` / `out`, device, the reference's row order) through Q' (method 0) or Q (method 1) in ONE pass over the tree
+int qapply_vectors(stmmqr_plan &P, int method, const double *in, double *out, int nb)
 {
     hipStream_t st = P.stream;
     const int m = (int)P.m;
+    LCHK(ensure_rhs_batch(P, nb));
     if (method == 0) {
-        LCHK(stm_launch_perm(in, P.d_PLinv.p, P.d_W.p, m, 1, st));                     // W[PLinv[i]] = x[i]
-        LCHK(run_qapply(P, 0));
-        LCHK(stm_launch_perm(P.d_W.p, P.d_Wmap.p, out, m, 1, st));                     // out[Wmap[r]] = W[r]
+        LCHK(stm_launch_perm(in, P.d_PLinv.p, P.d_W.p, m, 1, st, nb, m, m));            // W[PLinv[i]] = x[i]
+        LCHK(run_qapply(P, 0, nb));
+        LCHK(stm_launch_perm(P.d_W.p, P.d_Wmap.p, out, m, 1, st, nb, m, m));            // out[Wmap[r]] = W[r]
     } else {
-        LCHK(stm_launch_perm(in, P.d_Wmap.p, P.d_W.p, m, 0, st));                      // W[r] = x[Wmap[r]]
-        LCHK(run_qapply(P, 1));
-        LCHK(stm_launch_perm(P.d_W.p, P.d_PLinv.p, out, m, 0, st));                    // out[i] = W[PLinv[i]]
+        LCHK(stm_launch_perm(in, P.d_Wmap.p, P.d_W.p, m, 0, st, nb, m, m));             // W[r] = x[Wmap[r]]
+        LCHK(run_qapply(P, 1, nb));
+        LCHK(stm_launch_perm(P.d_W.p, P.d_PLinv.p, out, m, 0, st, nb, m, m));           // out[i] = W[PLinv[i]]
     }
     return 0;
 }
-// back substitution R x = y on the device work vector W (internal row order) -> d_Xs (R's column order)
-int rsolve_vector(stmmqr_plan &P)
+// back substitution R x = y on the device work vectors W (internal row order; nb of them at stride m) -> d_Xs (R's column order, stride n)
+int rsolve_vector(stmmqr_plan &P, int nb = 1)
 {
+    const RhsBatch B = rhs_strides(P);
     DevCtx c = res_ctx(P);
     const int *L0 = P.d_lists.p;
     const auto &LV = P.glevels[0];
     hipStream_t st = P.stream;
     for (size_t l = LV.size(); l-- > 0;) {
         LCHK(level_to_front_form(P, l));
-        LCHK(stm_launch_rsolve(c, L0 + LV[l].all_off, LV[l].n_all, P.d_Rj.p, P.d_W.p, P.d_Xs.p, P.level_lds_rs[l], P.d_err.p, st));
+        LCHK(stm_launch_rsolve(c, L0 + LV[l].all_off, LV[l].n_all, P.d_Rj.p, P.d_W.p, P.d_Xs.p, P.level_lds_rs[l], P.d_err.p, st, nb, B));
         const auto &Q = P.level_qbig[l];         // the large fronts of the level: rows split over workgroups
         LCHK(stm_launch_rsolve_big(c, P.d_qb.p + Q.off, Q.n, Q.max_rsteps, Q.max_nslab, P.d_Rj.p, P.d_W.p, P.d_Xs.p, P.d_Xf.p,
-                                   P.d_Dq.p, P.d_Rm.p + Q.off, P.d_err.p, st));
+                                   P.d_Dq.p, P.d_Rm.p + Q.off, P.d_err.p, st, nb, B));
     }
     return 0;
 }
@@ -2998,7 +3036,11 @@ int stmmqr_plan_qmult(stmmqr_plan *plan, int method, double *X, stm_long ldx, st
     if (k == 0 || m == 0) return 0;
     if (method <= 1) {
         LCHK(upload_cols(P, P.d_Xall, X, ldx, m, k));
-        for (stm_long j = 0; j < k; j++) LCHK(qapply_vector(P, method, P.d_Xall.p + j * m, P.d_Xall.p + j * m));
+        // (batches of right-hand sides: every launch of the pass over the tree carries all of them, RhsBatch)
+        for (stm_long j = 0; j < k; j += rhs_batch_max()) {
+            const int nb = (int)std::min<stm_long>(rhs_batch_max(), k - j);
+            LCHK(qapply_vectors(P, method, P.d_Xall.p + j * m, P.d_Xall.p + j * m, nb));
+        }
         return download_cols(P, P.d_Xall, X, ldx, m, k);
     }
     // X Q' = (Q X')' and X Q = (Q' X')': the rows of X are the vectors (SparseQR.c:2040-2075: the same permutation pattern)
@@ -3007,7 +3049,10 @@ int stmmqr_plan_qmult(stmmqr_plan *plan, int method, double *X, stm_long ldx, st
         for (long i = 0; i < m; i++) T[(size_t)r * m + i] = X[r + (size_t)i * ldx];
     LCHK(upload_cols(P, P.d_Xall, T.data(), m, m, k));
     const int vm = (method == 2) ? 1 : 0;
-    for (stm_long r = 0; r < k; r++) LCHK(qapply_vector(P, vm, P.d_Xall.p + r * m, P.d_Xall.p + r * m));
+    for (stm_long r = 0; r < k; r += rhs_batch_max()) {
+        const int nb = (int)std::min<stm_long>(rhs_batch_max(), k - r);
+        LCHK(qapply_vectors(P, vm, P.d_Xall.p + r * m, P.d_Xall.p + r * m, nb));
+    }
     LCHK(download_cols(P, P.d_Xall, T.data(), m, m, k));
     for (stm_long r = 0; r < k; r++)
         for (long i = 0; i < m; i++) X[r + (size_t)i * ldx] = T[(size_t)r * m + i];
@@ -3035,29 +3080,38 @@ int stmmqr_plan_rsolve(stmmqr_plan *plan, int system, const double *B, stm_long 
     HIPCHK(hipMemsetAsync(P.d_err.p, 0, sizeof(int), st));
     LCHK(upload_cols(P, P.d_Xall, B, ldb, brows, nrhs));
     if ((size_t)(xrows * nrhs) > P.d_Yall.n) LCHK(P.d_Yall.alloc((size_t)std::max(1L, xrows * nrhs)));
+    const int nbmax = rhs_batch_max();
+    const RhsBatch RB = rhs_strides(P);
     if (system <= 1) {
-        for (stm_long j = 0; j < nrhs; j++) {
-            LCHK(stm_launch_perm(P.d_Xall.p + j * m, P.d_Wmap.p, P.d_W.p, (int)m, 0, st));          // W[r] = b[Wmap[r]]
-            LCHK(rsolve_vector(P));
-            LCHK(stm_launch_perm(P.d_Xs.p, (system == 1 && P.has_qfill) ? P.d_Qfill.p : nullptr, P.d_Yall.p + j * n, (int)n, 1, st));
+        for (stm_long j = 0; j < nrhs; j += nbmax) {
+            const int nb = (int)std::min<stm_long>(nbmax, nrhs - j);
+            LCHK(ensure_rhs_batch(P, nb));
+            LCHK(stm_launch_perm(P.d_Xall.p + j * m, P.d_Wmap.p, P.d_W.p, (int)m, 0, st, nb, m, m));          // W[r] = b[Wmap[r]]
+            LCHK(rsolve_vector(P, nb));
+            LCHK(stm_launch_perm(P.d_Xs.p, (system == 1 && P.has_qfill) ? P.d_Qfill.p : nullptr, P.d_Yall.p + j * n, (int)n, 1, st, nb, n, n));
         }
     } else {
         DevCtx c = res_ctx(P);
         const int *L0 = P.d_lists.p;
         const auto &LV = P.glevels[0];
-        if (!P.d_U.p) { LCHK(P.d_U.alloc((size_t)std::max(1L, P.rjsize))); LCHK(P.d_Xr.alloc((size_t)std::max(1L, m))); }
+        if (!P.d_U.p) {
+            LCHK(P.d_U.alloc((size_t)P.rhs_cap * (size_t)std::max(1L, P.rjsize)));
+            LCHK(P.d_Xr.alloc((size_t)P.rhs_cap * (size_t)std::max(1L, m)));
+        }
         for (int need : P.level_lds_rt)
             if (need > 131072) return fail(STMMQR_ERR_TOO_LARGE, "a front is too wide for the one-workgroup R' solve");
-        for (stm_long j = 0; j < nrhs; j++) {
+        for (stm_long j = 0; j < nrhs; j += nbmax) {
+            const int nb = (int)std::min<stm_long>(nbmax, nrhs - j);
+            LCHK(ensure_rhs_batch(P, nb));
             // b in R's column order: E'B gathers through Qfill
-            LCHK(stm_launch_perm(P.d_Xall.p + j * n, (system == 3 && P.has_qfill) ? P.d_Qfill.p : nullptr, P.d_Xs.p, (int)n, 0, st));
-            HIPCHK(hipMemsetAsync(P.d_Xr.p, 0, (size_t)std::max(1L, m) * sizeof(double), st));
+            LCHK(stm_launch_perm(P.d_Xall.p + j * n, (system == 3 && P.has_qfill) ? P.d_Qfill.p : nullptr, P.d_Xs.p, (int)n, 0, st, nb, n, n));
+            HIPCHK(hipMemsetAsync(P.d_Xr.p, 0, (size_t)nb * (size_t)std::max(1L, m) * sizeof(double), st));
             for (size_t l = 0; l < LV.size(); l++) {
                 LCHK(level_to_front_form(P, l));
                 LCHK(stm_launch_rtsolve(c, L0 + LV[l].all_off, LV[l].n_all, P.d_Xs.p, P.d_U.p, P.d_Xr.p, P.d_rowbase.p,
-                                        P.level_lds_rt[l], st));
+                                        P.level_lds_rt[l], st, nb, RB));
             }
-            HIPCHK(hipMemcpyAsync(P.d_Yall.p + j * m, P.d_Xr.p, (size_t)m * sizeof(double), hipMemcpyDeviceToDevice, st));
+            HIPCHK(hipMemcpyAsync(P.d_Yall.p + j * m, P.d_Xr.p, (size_t)nb * (size_t)m * sizeof(double), hipMemcpyDeviceToDevice, st));
         }
     }
     LCHK(download_cols(P, P.d_Yall, X, ldx, xrows, nrhs));
@@ -3080,11 +3134,13 @@ int stmmqr_plan_solve(stmmqr_plan *plan, const double *B, stm_long ldb, double *
     HIPCHK(hipMemsetAsync(P.d_err.p, 0, sizeof(int), st));
     LCHK(upload_cols(P, P.d_Xall, B, ldb, m, nrhs));
     if ((size_t)(n * nrhs) > P.d_Yall.n) LCHK(P.d_Yall.alloc((size_t)std::max(1L, n * nrhs)));
-    for (stm_long j = 0; j < nrhs; j++) {
-        LCHK(stm_launch_perm(P.d_Xall.p + j * m, P.d_PLinv.p, P.d_W.p, (int)m, 1, st));
-        LCHK(run_qapply(P, 0));
-        LCHK(rsolve_vector(P));
-        LCHK(stm_launch_perm(P.d_Xs.p, P.has_qfill ? P.d_Qfill.p : nullptr, P.d_Yall.p + j * n, (int)n, 1, st));   // X[Qfill[j]] = x[j]
+    for (stm_long j = 0; j < nrhs; j += rhs_batch_max()) {
+        const int nb = (int)std::min<stm_long>(rhs_batch_max(), nrhs - j);
+        LCHK(ensure_rhs_batch(P, nb));
+        LCHK(stm_launch_perm(P.d_Xall.p + j * m, P.d_PLinv.p, P.d_W.p, (int)m, 1, st, nb, m, m));
+        LCHK(run_qapply(P, 0, nb));
+        LCHK(rsolve_vector(P, nb));
+        LCHK(stm_launch_perm(P.d_Xs.p, P.has_qfill ? P.d_Qfill.p : nullptr, P.d_Yall.p + j * n, (int)n, 1, st, nb, n, n));   // X[Qfill[j]] = x[j]
     }
     LCHK(download_cols(P, P.d_Yall, X, ldx, n, nrhs));
     return check_device_err(P, "internal: live pivot count of a front differs from its rank");

@@ -102,21 +102,30 @@ int stm_launch_rh_window(const DevCtx &c, const int *flist, int nfr, int maxpart
 int stm_launch_rh_copy(const DevCtx &c, const int *flist, const int *nparts, int nfr, int maxparts, double *RH,
                        hipStream_t st);
 // Q-apply / triangular solve on the resident factors
+// Several right-hand sides per launch (QR_qmult / QR_solve take blocks of them: qr_panel, SparseQR.c:1591-1706): every kernel of
+// these operations takes right-hand side blockIdx.y (or .z) of a BATCH -- the same workgroups, one set per vector, in the same
+// launch -- with the per-vector buffers laid out at these strides (doubles).  The launches of one vector are a chain of ~10-25 us
+// kernels that leave the GPU nearly empty, so a batch costs little more than one vector.  nb = 1 with zero strides: one vector.
+struct RhsBatch { long long w, x, xf, wq, wq4, u; };
+
 int stm_launch_qapply(const DevCtx &c, const int *flist, int nfr, int method, double *W, int lds_bytes, int *err, hipStream_t st);
-int stm_launch_qapply_t(const DevCtx &c, const int *flist, int nfr, int method, double *W, int lds_bytes, hipStream_t st);
+int stm_launch_qapply_t(const DevCtx &c, const int *flist, int nfr, int method, double *W, int lds_bytes, hipStream_t st, int nb,
+                        const RhsBatch &B);
 int stm_qt4_doubles(void);
 struct Qt4ItemHost { int f, g; long long off, dqo; };     // (= Qt4Item of stmmqr_kernels.hip)
 int stm_launch_qt4_build(const DevCtx &c, const int *fl, const long long *dqo, int nfronts, const void *items, int nitems, int *Dq4, double *T4all,
                          hipStream_t st);
 int stm_launch_qapply_big4(const DevCtx &c, const QbDesc *qd, const long long *t4off, int nq, int max_npanels, int max_nslab, int max_fm,
-                           int method, double *W, double *Xf, int *Dq, double *Wq4, const double *T4all, hipStream_t st);
+                           int method, double *W, double *Xf, int *Dq, double *Wq4, const double *T4all, hipStream_t st, int nb,
+                           const RhsBatch &B);
 int stm_launch_qapply_big(const DevCtx &c, const QbDesc *qd, int nq, int max_npanels, int max_nslab, int max_fm, int method, double *W,
-                          double *Xf, int *Dq, double *Wq, hipStream_t st);
+                          double *Xf, int *Dq, double *Wq, hipStream_t st, int nb, const RhsBatch &B);
 int stm_launch_rsolve_big(const DevCtx &c, const QbDesc *qd, int nq, int max_steps, int max_nslab, const int *Rj, const double *W,
-                          double *X, double *Acc, int *Lc, int *Rm, int *err, hipStream_t st);
+                          double *X, double *Acc, int *Lc, int *Rm, int *err, hipStream_t st, int nb, const RhsBatch &B);
 int stm_launch_rsolve(const DevCtx &c, const int *flist, int nfr, const int *Rj, const double *W, double *X, int lds_bytes,
-                      int *err, hipStream_t st);
+                      int *err, hipStream_t st, int nb, const RhsBatch &B);
 int stm_launch_rtsolve(const DevCtx &c, const int *flist, int nfr, const double *Bp, double *U, double *Xr, const int *rowbase,
-                       int lds_bytes, hipStream_t st);
+                       int lds_bytes, hipStream_t st, int nb, const RhsBatch &B);
 int stm_launch_panel_msg(void *const homes[6], const long long offs[6], const long long bytes[6], void *buf, int out, hipStream_t st);
-int stm_launch_perm(const double *in, const int *perm, double *out, int n, int scatter, hipStream_t st);
+int stm_launch_perm(const double *in, const int *perm, double *out, int n, int scatter, hipStream_t st, int nb = 1, long long sin = 0,
+                    long long sout = 0);

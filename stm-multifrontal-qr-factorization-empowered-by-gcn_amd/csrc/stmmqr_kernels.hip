@@ -4258,8 +4258,9 @@ __global__ __launch_bounds__(QA_NT) void k_qapply(DevCtx c, const int *__restric
 //     y = T'w  (Q'x)  or  T w  (Q x),      x -= V y  (second sweep).
 // V is read in place with the unit-diagonal / staircase mask (reflector j of the panel: diagonal row dq[k], entries up
 // to HStair[k]); identity and dead columns have zero rows/columns in T and are masked out of V.
-__global__ __launch_bounds__(QA_NT) void k_qapply_t(DevCtx c, const int *__restrict__ flist, int method, double *W)
+__global__ __launch_bounds__(QA_NT) void k_qapply_t(DevCtx c, const int *__restrict__ flist, int method, double *W, RhsBatch B)
 {
+    W += (long long)blockIdx.y * B.w;                      // (right-hand side blockIdx.y of the batch)
     extern __shared__ double dyn_lds[];
     __shared__ int s_scan[QA_NW];
     __shared__ int s_d[STM_NB], s_t[STM_NB];
@@ -4374,8 +4375,9 @@ __global__ __launch_bounds__(QA_NT) void k_qapply_t(DevCtx c, const int *__restr
 #define QB_ROWS STM_QB_ROWS   // rows (= threads) of a step workgroup (128-row workgroups were measured: slower)
 // All split fronts of a tree level advance together: blockIdx.y = index into the level's descriptor list
 // (QbDesc: front, offsets of its slices of Xf / Dq / Wq, number of row slabs), launch k handles the k-th panel of each.
-__global__ __launch_bounds__(QA_NT) void k_qbig_prep(DevCtx c, const QbDesc *__restrict__ qd, const double *W, double *Xf0, int *Dq0)
+__global__ __launch_bounds__(QA_NT) void k_qbig_prep(DevCtx c, const QbDesc *__restrict__ qd, const double *W, double *Xf0, int *Dq0, RhsBatch B)
 {
+    W += (long long)blockIdx.y * B.w; Xf0 += (long long)blockIdx.y * B.xf;      // (the reflector numbering Dq0 is the same for every right-hand side)
     __shared__ int s_scan[QA_NW];
     const QbDesc d = qd[blockIdx.x];
     const FrontSym s = c.fs[d.f];
@@ -4386,8 +4388,9 @@ __global__ __launch_bounds__(QA_NT) void k_qbig_prep(DevCtx c, const QbDesc *__r
     for (int i = threadIdx.x; i < fm; i += QA_NT) Xf[i] = W[Hi[i]];
     qa_number_reflectors(s, fm, c.Stair + s.rp, c.Tau + s.rp, Dq0 + d.dqoff, s_scan);
 }
-__global__ __launch_bounds__(256) void k_qbig_finish(DevCtx c, const QbDesc *__restrict__ qd, double *W, const double *Xf0)
+__global__ __launch_bounds__(256) void k_qbig_finish(DevCtx c, const QbDesc *__restrict__ qd, double *W, const double *Xf0, RhsBatch B)
 {
+    W += (long long)blockIdx.z * B.w; Xf0 += (long long)blockIdx.z * B.xf;
     const QbDesc d = qd[blockIdx.y];
     const FrontSym s = c.fs[d.f];
     const int fm = c.fnum[d.f].fm;
@@ -4396,8 +4399,9 @@ __global__ __launch_bounds__(256) void k_qbig_finish(DevCtx c, const QbDesc *__r
     if (i < fm) W[Hi[i]] = Xf0[d.xoff + i];
 }
 __global__ __launch_bounds__(QB_ROWS) void k_qbig_step(DevCtx c, const QbDesc *__restrict__ qd, int k, int method, double *Xf0,
-                                                     const int *Dq0, double *Wq0)
+                                                     const int *Dq0, double *Wq0, RhsBatch B)
 {
+    Xf0 += (long long)blockIdx.z * B.xf; Wq0 += (long long)blockIdx.z * B.wq;
     __shared__ int s_d[2][STM_NB], s_t[2][STM_NB];
     __shared__ double s_part[QB_ROWS / 64][STM_NB], s_w[STM_NB], s_y[STM_NB], s_T[STM_NB][STM_NB + 1];
     const QbDesc qdd = qd[blockIdx.y];
@@ -4670,8 +4674,9 @@ __global__ __launch_bounds__(512) void k_qt4_build(DevCtx c, const Qt4Item *__re
 }
 
 __global__ __launch_bounds__(QB_ROWS) void k_qbig_step4(DevCtx c, const QbDesc *__restrict__ qd, const long long *__restrict__ t4off, int k,
-                                                      int method, double *Xf0, const int *Dq0, double *Wq0, const double *T4all)
+                                                      int method, double *Xf0, const int *Dq0, double *Wq0, const double *T4all, RhsBatch B)
 {
+    Xf0 += (long long)blockIdx.z * B.xf; Wq0 += (long long)blockIdx.z * B.wq4;
     __shared__ int s_d[2][QGN], s_t[2][QGN], s_rng[2][2][2];
     __shared__ double s_part[QB_ROWS / 64][QGN], s_w[QGN], s_y[QGN], s_yp[QB_ROWS / QGN][QGN];
     const QbDesc qdd = qd[blockIdx.y];
@@ -4805,8 +4810,9 @@ __global__ __launch_bounds__(QB_ROWS) void k_qbig_step4(DevCtx c, const QbDesc *
 
 #define RS_NT 1024               // the back substitution streams R through one workgroup: more loads in flight
 __global__ __launch_bounds__(RS_NT) void k_rsolve(DevCtx c, const int *__restrict__ flist, const int *__restrict__ Rj,
-                                                  const double *W, double *X, int *err)
+                                                  const double *W, double *X, int *err, RhsBatch B)
 {
+    W += (long long)blockIdx.y * B.w; X += (long long)blockIdx.y * B.x;
     extern __shared__ double dyn_lds[];
     __shared__ int s_scan[RS_NT / 64];
     const int f = flist[blockIdx.x];
@@ -4906,8 +4912,9 @@ __global__ __launch_bounds__(RS_NT) void k_rsolve(DevCtx c, const int *__restric
 //   (rowbase[f] = rows of R above front f's).  Dead pivot columns have no equation (the squeezed R of the reference).
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(RS_NT) void k_rtsolve(DevCtx c, const int *__restrict__ flist, const double *__restrict__ Bp,
-                                                   double *U, double *Xr, const int *__restrict__ rowbase)
+                                                   double *U, double *Xr, const int *__restrict__ rowbase, RhsBatch B)
 {
+    Bp += (long long)blockIdx.y * B.x; U += (long long)blockIdx.y * B.u; Xr += (long long)blockIdx.y * B.w;
     extern __shared__ double dyn_lds[];
     __shared__ int s_scan[RS_NT / 64];
     const int f = flist[blockIdx.x];
@@ -5002,8 +5009,9 @@ __global__ __launch_bounds__(RS_NT) void k_rtsolve(DevCtx c, const int *__restri
 // its rows above the block; workgroup 0 stores x.  All split fronts of a level advance together (blockIdx.y).
 // acc = the front's slice of Xf, Lc = its slice of Dq (the Q-apply has finished with both).
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(RS_NT) void k_rbig_prep(DevCtx c, const QbDesc *__restrict__ qd, double *X, int *Lc0, int *Rm, int *err)
+__global__ __launch_bounds__(RS_NT) void k_rbig_prep(DevCtx c, const QbDesc *__restrict__ qd, double *X, int *Lc0, int *Rm, int *err, RhsBatch B)
 {
+    X += (long long)blockIdx.y * B.x;                      // (the live-column lists Lc0 / Rm are the same for every right-hand side)
     __shared__ int s_scan[RS_NT / 64];
     const QbDesc d = qd[blockIdx.x];
     const FrontSym s = c.fs[d.f];
@@ -5030,8 +5038,9 @@ __global__ __launch_bounds__(RS_NT) void k_rbig_prep(DevCtx c, const QbDesc *__r
     }
 }
 __global__ __launch_bounds__(STM_QB_ROWS) void k_rbig_init(DevCtx c, const QbDesc *__restrict__ qd, const int *__restrict__ Rj,
-                                                           const double *W, const double *X, double *Acc0, const int *Rm)
+                                                           const double *W, const double *X, double *Acc0, const int *Rm, RhsBatch B)
 {
+    W += (long long)blockIdx.z * B.w; X += (long long)blockIdx.z * B.x; Acc0 += (long long)blockIdx.z * B.xf;
     // y - R12 x2 for the rows of the live pivot columns.  A workgroup takes 64 rows; its eight waves share the non-pivotal columns
     // (chunks of 16, wave w the chunks w, w + 8, ...) and their partial sums are added in wave order (round 4: a thread per row ran
     // through all the columns alone -- 250 dependent round trips on a front with 4000 of them, 276 us per launch).
@@ -5071,8 +5080,9 @@ __global__ __launch_bounds__(STM_QB_ROWS) void k_rbig_init(DevCtx c, const QbDes
     }
 }
 __global__ __launch_bounds__(STM_QB_ROWS) void k_rbig_step(DevCtx c, const QbDesc *__restrict__ qd, int kstep, double *X, double *Acc0,
-                                                           const int *Lc0, const int *Rm)
+                                                           const int *Lc0, const int *Rm, RhsBatch B)
 {
+    X += (long long)blockIdx.z * B.x; Acc0 += (long long)blockIdx.z * B.xf;
     constexpr int QS_NB = 32;
     __shared__ double s_tri[QS_NB][QS_NB + 1];
     __shared__ double s_x[QS_NB];
@@ -5119,8 +5129,9 @@ __global__ __launch_bounds__(STM_QB_ROWS) void k_rbig_step(DevCtx c, const QbDes
 }
 
 __global__ __launch_bounds__(256) void k_perm(const double *__restrict__ in, const int *__restrict__ perm, double *out, int n,
-                                               int scatter)
+                                               int scatter, long long sin, long long sout)
 {
+    in += (long long)blockIdx.y * sin; out += (long long)blockIdx.y * sout;      // (vector blockIdx.y of a batch)
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
     const int j = perm ? perm[i] : i;
@@ -5397,21 +5408,22 @@ int stm_launch_qapply(const DevCtx &c, const int *flist, int nfr, int method, do
     hipLaunchKernelGGL(k_qapply, dim3(nfr), dim3(QA_NT), (size_t)lds_bytes, st, c, flist, method, W, err);
     return (int)hipGetLastError();
 }
-int stm_launch_qapply_t(const DevCtx &c, const int *flist, int nfr, int method, double *W, int lds_bytes, hipStream_t st)
+int stm_launch_qapply_t(const DevCtx &c, const int *flist, int nfr, int method, double *W, int lds_bytes, hipStream_t st, int nb,
+                        const RhsBatch &B)
 {
     if (nfr <= 0) return 0;
-    hipLaunchKernelGGL(k_qapply_t, dim3(nfr), dim3(QA_NT), (size_t)lds_bytes, st, c, flist, method, W);
+    hipLaunchKernelGGL(k_qapply_t, dim3(nfr, nb), dim3(QA_NT), (size_t)lds_bytes, st, c, flist, method, W, B);
     return (int)hipGetLastError();
 }
 // the split fronts of one level: prep, max(npanels) + 1 steps, finish
 int stm_launch_qapply_big(const DevCtx &c, const QbDesc *qd, int nq, int max_npanels, int max_nslab, int max_fm, int method, double *W,
-                          double *Xf, int *Dq, double *Wq, hipStream_t st)
+                          double *Xf, int *Dq, double *Wq, hipStream_t st, int nb, const RhsBatch &B)
 {
     if (nq <= 0 || max_npanels <= 0) return 0;
-    hipLaunchKernelGGL(k_qbig_prep, dim3(nq), dim3(QA_NT), 0, st, c, qd, (const double *)W, Xf, Dq);
+    hipLaunchKernelGGL(k_qbig_prep, dim3(nq, nb), dim3(QA_NT), 0, st, c, qd, (const double *)W, Xf, Dq, B);
     for (int k = 0; k <= max_npanels; k++)
-        hipLaunchKernelGGL(k_qbig_step, dim3(max_nslab, nq), dim3(QB_ROWS), 0, st, c, qd, k, method, Xf, (const int *)Dq, Wq);
-    hipLaunchKernelGGL(k_qbig_finish, dim3((max_fm + 255) / 256, nq), dim3(256), 0, st, c, qd, W, (const double *)Xf);
+        hipLaunchKernelGGL(k_qbig_step, dim3(max_nslab, nq, nb), dim3(QB_ROWS), 0, st, c, qd, k, method, Xf, (const int *)Dq, Wq, B);
+    hipLaunchKernelGGL(k_qbig_finish, dim3((max_fm + 255) / 256, nq, nb), dim3(256), 0, st, c, qd, W, (const double *)Xf, B);
     return (int)hipGetLastError();
 }
 int stm_qt4_doubles(void) { return QT4_DOUBLES; }
@@ -5426,40 +5438,41 @@ int stm_launch_qt4_build(const DevCtx &c, const int *fl, const long long *dqo, i
     return (int)hipGetLastError();
 }
 int stm_launch_qapply_big4(const DevCtx &c, const QbDesc *qd, const long long *t4off, int nq, int max_npanels, int max_nslab, int max_fm,
-                           int method, double *W, double *Xf, int *Dq, double *Wq4, const double *T4all, hipStream_t st)
+                           int method, double *W, double *Xf, int *Dq, double *Wq4, const double *T4all, hipStream_t st, int nb,
+                           const RhsBatch &B)
 {
     if (nq <= 0 || max_npanels <= 0) return 0;
     const int max_ng = (max_npanels + QG - 1) / QG;
-    hipLaunchKernelGGL(k_qbig_prep, dim3(nq), dim3(QA_NT), 0, st, c, qd, (const double *)W, Xf, Dq);
+    hipLaunchKernelGGL(k_qbig_prep, dim3(nq, nb), dim3(QA_NT), 0, st, c, qd, (const double *)W, Xf, Dq, B);
     for (int k = 0; k <= max_ng; k++)
-        hipLaunchKernelGGL(k_qbig_step4, dim3(max_nslab, nq), dim3(QB_ROWS), 0, st, c, qd, t4off, k, method, Xf, (const int *)Dq, Wq4, T4all);
-    hipLaunchKernelGGL(k_qbig_finish, dim3((max_fm + 255) / 256, nq), dim3(256), 0, st, c, qd, W, (const double *)Xf);
+        hipLaunchKernelGGL(k_qbig_step4, dim3(max_nslab, nq, nb), dim3(QB_ROWS), 0, st, c, qd, t4off, k, method, Xf, (const int *)Dq, Wq4, T4all, B);
+    hipLaunchKernelGGL(k_qbig_finish, dim3((max_fm + 255) / 256, nq, nb), dim3(256), 0, st, c, qd, W, (const double *)Xf, B);
     return (int)hipGetLastError();
 }
 int stm_launch_rsolve(const DevCtx &c, const int *flist, int nfr, const int *Rj, const double *W, double *X, int lds_bytes,
-                      int *err, hipStream_t st)
+                      int *err, hipStream_t st, int nb, const RhsBatch &B)
 {
     if (nfr <= 0) return 0;
-    hipLaunchKernelGGL(k_rsolve, dim3(nfr), dim3(RS_NT), (size_t)lds_bytes, st, c, flist, Rj, W, X, err);
+    hipLaunchKernelGGL(k_rsolve, dim3(nfr, nb), dim3(RS_NT), (size_t)lds_bytes, st, c, flist, Rj, W, X, err, B);
     return (int)hipGetLastError();
 }
 // back substitution of the split fronts of one level: prep, init, max ceil(fp / 32) steps
 int stm_launch_rsolve_big(const DevCtx &c, const QbDesc *qd, int nq, int max_steps, int max_nslab, const int *Rj, const double *W,
-                          double *X, double *Acc, int *Lc, int *Rm, int *err, hipStream_t st)
+                          double *X, double *Acc, int *Lc, int *Rm, int *err, hipStream_t st, int nb, const RhsBatch &B)
 {
     if (nq <= 0) return 0;
-    hipLaunchKernelGGL(k_rbig_prep, dim3(nq), dim3(RS_NT), 0, st, c, qd, X, Lc, Rm, err);
-    hipLaunchKernelGGL(k_rbig_init, dim3(max_nslab * (STM_QB_ROWS / 64), nq), dim3(STM_QB_ROWS), 0, st, c, qd, Rj, W, (const double *)X, Acc,
-                       (const int *)Rm);
+    hipLaunchKernelGGL(k_rbig_prep, dim3(nq, nb), dim3(RS_NT), 0, st, c, qd, X, Lc, Rm, err, B);
+    hipLaunchKernelGGL(k_rbig_init, dim3(max_nslab * (STM_QB_ROWS / 64), nq, nb), dim3(STM_QB_ROWS), 0, st, c, qd, Rj, W, (const double *)X, Acc,
+                       (const int *)Rm, B);
     for (int k = 0; k < max_steps; k++)
-        hipLaunchKernelGGL(k_rbig_step, dim3(max_nslab, nq), dim3(STM_QB_ROWS), 0, st, c, qd, k, X, Acc, (const int *)Lc, (const int *)Rm);
+        hipLaunchKernelGGL(k_rbig_step, dim3(max_nslab, nq, nb), dim3(STM_QB_ROWS), 0, st, c, qd, k, X, Acc, (const int *)Lc, (const int *)Rm, B);
     return (int)hipGetLastError();
 }
 int stm_launch_rtsolve(const DevCtx &c, const int *flist, int nfr, const double *Bp, double *U, double *Xr, const int *rowbase,
-                       int lds_bytes, hipStream_t st)
+                       int lds_bytes, hipStream_t st, int nb, const RhsBatch &B)
 {
     if (nfr <= 0) return 0;
-    hipLaunchKernelGGL(k_rtsolve, dim3(nfr), dim3(RS_NT), (size_t)lds_bytes, st, c, flist, Bp, U, Xr, rowbase);
+    hipLaunchKernelGGL(k_rtsolve, dim3(nfr, nb), dim3(RS_NT), (size_t)lds_bytes, st, c, flist, Bp, U, Xr, rowbase, B);
     return (int)hipGetLastError();
 }
 // One panel message of a shared front (stmmqr_host.cpp: panel_msg) packed / unpacked on the device in ONE launch: six byte ranges
@@ -5486,10 +5499,10 @@ int stm_launch_panel_msg(void *const homes[6], const long long offs[6], const lo
     hipLaunchKernelGGL(k_panel_msg, dim3(gx, 6), dim3(256), 0, st, g, (char *)buf, out);
     return (int)hipGetLastError();
 }
-int stm_launch_perm(const double *in, const int *perm, double *out, int n, int scatter, hipStream_t st)
+int stm_launch_perm(const double *in, const int *perm, double *out, int n, int scatter, hipStream_t st, int nb, long long sin, long long sout)
 {
-    if (n <= 0) return 0;
-    hipLaunchKernelGGL(k_perm, dim3((n + 255) / 256), dim3(256), 0, st, in, perm, out, n, scatter);
+    if (n <= 0 || nb <= 0) return 0;
+    hipLaunchKernelGGL(k_perm, dim3((n + 255) / 256, nb), dim3(256), 0, st, in, perm, out, n, scatter, sin, sout);
     return (int)hipGetLastError();
 }
 
