@@ -9,7 +9,7 @@
 //   stmmqr_plan_download    the wrap-up half of qr_factorize (:554-742) incl. qr_hpinv (:991-1060)
 //   qr_factorize            the drop-in seam                                include/SparseQR.h:127-135
 //
-// There is NO CPU fallback in this file: every numeric operation is a kernel in stmmqr_kernels.hip.  If no
+// There is NO CPU fallback in this file: every numeric operation is a kernel of the stmmqr_*.hip translation units.  If no
 // gfx950 device is usable the entry points fail with STMMQR_ERR_DEVICE.
 #include <hip/hip_runtime.h>
 
@@ -1452,7 +1452,7 @@ int run_schedule(stmmqr_plan &P, bool detail, int grp, const StepReq *req = null
     // handler): it is only created when some step of this group really goes there -- small matrices never touch it.
     // Passenger launches (options.lookahead = 2, the default): ONE stream, no events.  The chain stays  panel(t) -> T(t) + block 0 (one fused
     // launch) -> panel(t+1); the two launches of the update beyond block 0 ride on the chain's launches as extra workgroups behind the
-    // chain's own (k_upd_w of step t behind T + block 0 of step t, k_upd_c of step t behind the panels of step t+1: stmmqr_kernels.hip,
+    // chain's own (k_upd_w of step t behind T + block 0 of step t, k_upd_c of step t behind the panels of step t+1: stmmqr_*.hip,
     // "Passenger launches").  Every workgroup does what it does in the serial order: same bits.  A step takes part when its update is the
     // row-parallel form and every workgroup of its fused launch is resident at once (they wait for each other, bounded: two per CU);
     // any other step runs in the serial order after the riders of the step before it.

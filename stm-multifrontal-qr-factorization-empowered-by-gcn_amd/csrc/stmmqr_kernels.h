@@ -1,4 +1,4 @@
-// stmmqr_kernels.h -- kernel argument block and launcher prototypes (host <-> stmmqr_kernels.hip)
+// stmmqr_kernels.h -- kernel argument block and launcher prototypes (host <-> the kernel translation units: stmmqr_kdev.h lists them)
 #pragma once
 #include <hip/hip_runtime_api.h>
 #include "stmmqr_device.h"
@@ -59,7 +59,7 @@ struct DevCtx {
                                //  16384 no wave-pipelined panels (short panels through the multi-workgroup pipeline too)
 };
 
-int stm_configure_kernels(void);
+int stm_configure_kernels(void);       // (stmmqr_panel.hip; calls the other translation units' stm_configure_*)
 int stm_update_lds_bytes(void);
 int stm_launch_sigma(const double *Ax, int anz, unsigned long long *amaxbits, double *sig, hipStream_t st);
 int stm_launch_gather_sx(const double *Ax, const int *smap, double *Sx, int anz, hipStream_t st);
@@ -112,7 +112,7 @@ int stm_launch_qapply(const DevCtx &c, const int *flist, int nfr, int method, do
 int stm_launch_qapply_t(const DevCtx &c, const int *flist, int nfr, int method, double *W, int lds_bytes, hipStream_t st, int nb,
                         const RhsBatch &B);
 int stm_qt4_doubles(void);
-struct Qt4ItemHost { int f, g; long long off, dqo; };     // (= Qt4Item of stmmqr_kernels.hip)
+struct Qt4ItemHost { int f, g; long long off, dqo; };     // (= Qt4Item of stmmqr_resident.hip)
 int stm_launch_qt4_build(const DevCtx &c, const int *fl, const long long *dqo, int nfronts, const void *items, int nitems, int *Dq4, double *T4all,
                          hipStream_t st);
 int stm_launch_qapply_big4(const DevCtx &c, const QbDesc *qd, const long long *t4off, int nq, int max_npanels, int max_nslab, int max_fm,

@@ -1,7 +1,7 @@
 // stmmqr_seams.cpp -- the reference's INNER seams (STMMQR/include/SparseQR.h:145-268) on host buffers.
 //
 // Each call copies its operands to the device, runs the SAME kernels the full factorization uses
-// (stmmqr_kernels.hip) on a one-front context and copies the results back: they exist so that every kernel
+// (stmmqr_panel.hip, stmmqr_update.hip, ...) on a one-front context and copies the results back: they exist so that every kernel
 // can be parity-tested against the reference function it replaces (tests/test_gpu_seams.py).  Integer-only
 // helpers of the reference (qr_fsize, qr_csize, qr_fcsize, qr_hpinv) are host code here exactly as they are
 // host code there; their device counterparts live inside k_setup / dev_cpack / the download step.
