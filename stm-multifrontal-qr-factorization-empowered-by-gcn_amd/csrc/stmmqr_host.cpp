@@ -11,36 +11,12 @@
 //
 // There is NO CPU fallback in this file: every numeric operation is a kernel of the stmmqr_*.hip translation units.  If no
 // gfx950 device is usable the entry points fail with STMMQR_ERR_DEVICE.
-#include <hip/hip_runtime.h>
-
-#include <algorithm>
-#include <chrono>
-#include <cmath>
-#include <cstdio>
-#include <cstdlib>
-#include <cstring>
-#include <string>
-#include <mutex>
-#include <thread>
-#include <vector>
-#ifdef __linux__
-#include <sys/mman.h>
-#endif
-#include <dlfcn.h>
-
-#include "../../include/stmmqr_hip.h"
-#include "stmmqr_device.h"
-#include "stmmqr_kernels.h"
-#include "stmmqr_internal.h"
-
-namespace {
+#include "stmmqr_plan.h"
 
 thread_local std::string g_err;
-stmmqr_options g_opt = {STM_NB, 64, 0, 0, 0, 1, STM_TALL_MIN, 2, 0, 4};      // (panel_algo 0: by panel height)
+stmmqr_options g_opt = {STM_NB, 64, 0, 0, 0, 1, STM_TALL_MIN, 2, 0, 4};      // (panel_algo 0: by panel height; lookahead 2: passenger launches)
 size_t g_chunk[4] = {32, 5000, 4, 4};     // FCHUNK, SMALL, MINCHUNK, MINCHUNK_RATIO (SparseQR.h:16-19)
 
-// offsets inside the reference's sparse_common for the stock LP64 build; verified against the real header
-// by tests/test_abi_layout.py where /root/reference is present.
 stm_common_layout g_layout = {
     /* status */ 1004, /* malloc_count */ 1032, /* memory_usage */ 1040, /* memory_inuse */ 1048,
     /* blas_ok */ 1100, /* SPQR_grain */ 1104, /* SPQR_small */ 1112, /* SPQR_shrink */ 1120,
@@ -52,262 +28,6 @@ int fail(int code, const std::string &msg)
     if (g_opt.verbose) fprintf(stderr, "[stmmqr_hip] error %d: %s\n", code, msg.c_str());
     return code;
 }
-
-#define HIPCHK(expr)                                                                                      \
-    do {                                                                                                  \
-        hipError_t e_ = (expr);                                                                           \
-        if (e_ != hipSuccess)                                                                             \
-            return fail(e_ == hipErrorOutOfMemory ? STMMQR_ERR_OUT_OF_MEMORY : STMMQR_ERR_DEVICE,        \
-                        std::string(#expr) + ": " + hipGetErrorString(e_));                              \
-    } while (0)
-#define LCHK(expr)                                                                                        \
-    do {                                                                                                  \
-        int e_ = (expr);                                                                                  \
-        if (e_ != 0) return fail(STMMQR_ERR_DEVICE, std::string(#expr) + ": " + hipGetErrorString((hipError_t)e_)); \
-    } while (0)
-
-double now_ms()
-{
-    using namespace std::chrono;
-    return duration<double, std::milli>(steady_clock::now().time_since_epoch()).count();
-}
-
-template <class T> struct DevBuf {
-    T *p = nullptr;
-    size_t n = 0;
-    int alloc(size_t count)
-    {
-        release();
-        n = count;
-        if (count == 0) count = 1;
-        hipError_t e = hipMalloc((void **)&p, count * sizeof(T));
-        if (e != hipSuccess) { p = nullptr; n = 0; return (int)e; }
-        return 0;
-    }
-    int upload(const std::vector<T> &h, hipStream_t st)
-    {
-        int e = alloc(h.size());
-        if (e) return e;
-        if (!h.empty()) return (int)hipMemcpyAsync(p, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice, st);
-        return 0;
-    }
-    void release()
-    {
-        if (p) (void)hipFree(p);
-        p = nullptr; n = 0;
-    }
-    ~DevBuf() { release(); }
-};
-
-struct Level {                           // tree level of a group: what the solve / Q-apply kernels walk (f1)
-    int all_off = 0, n_all = 0;          // every front of the level (small first, then big by npanels desc)
-    int n_small = 0, n_big = 0;
-};
-
-// One step of the factorization timeline.  Every front starts at the step after the last of its children has finished
-// (a small front takes one step, a big one a step per panel), so a front deep in a short branch does not wait for the
-// tallest front of its tree level: at every step the launches cover all the big fronts that are in flight, each at its
-// own panel.  Everything here is symbolic (lists built once per plan).
-struct Step {
-    int start_off = 0, n_start = 0, n_small = 0;      // fronts starting here (small first, then big): set up + assembled
-    int asm_parts_off = 0, asm_maxparts = 1, lds_small = 0;
-    int act_off = 0, plist_off = 0, n_act = 0;        // big fronts in flight + the panel each is at
-    int wp_off = 0;                                   // (index into d_wlists) their slices of the update workspace
-    int nsub = 1, nca = 1, nca_use = 0, npipe_use = 0, maxcb = 0, maxsl = 0, split = 0;
-    int lds_big = 0;       // dynamic LDS of the panel launch when every front may take the one-workgroup panel (recovery, tests)
-    int lds_plan = 0;      // ... when only the fronts planned for it do (the pipeline groups need the update's LDS only)
-    // the fronts in flight are listed in three classes: [0, n_norm) every panel's update on all trailing columns;
-    // then the sweep fronts (is_pair; w = 2 or 4 panels per sweep, stmmqr_plan::sweep) by panel number mod w: class r updates the
-    // column blocks 0 .. w-1-r only (the columns of the next panels), the last class then applies the w last panels at once to
-    // everything beyond
-    int n_norm = 0, n_pk[4] = {0, 0, 0, 0};
-    int maxsl_pk[4] = {0, 0, 0, 0}, maxcbp_po = 0;
-    int n_sweep() const { return n_pk[0] + n_pk[1] + n_pk[2] + n_pk[3]; }
-    int cpk_off = 0, cpk_parts_off = 0, n_cpk = 0, cpk_maxparts = 1;   // big fronts whose last panel runs here
-    // slab recycling: the fronts whose packed R+H block is staged at the end of this step (the small fronts that started here and
-    // the big fronts packed here, kept fronts excluded) + copy parts
-    int rhp_off = 0, rhp_parts_off = 0, n_rhp = 0, rhp_maxparts = 1;
-};
-
-}  // namespace
-
-struct stmmqr_plan {
-    int device = 0;
-    hipStream_t stream = nullptr;
-    // look-ahead: the panel chain runs on `stream` (high priority), everything that does not feed the next panel on `side`
-    hipStream_t side = nullptr;                               // (the device's shared side stream: side_stream_for)
-    std::vector<hipEvent_t> ev_main, ev_prep, ev_side;        // one of each per timeline step (no timing)
-    hipEvent_t ev[8] = {};
-    // detail timing: one event pair per launch category and level step, recorded on the plan's stream WITHOUT any
-    // synchronisation (the schedule runs exactly as in the timed region); the pairs are read after the final sync
-    struct EvPair { hipEvent_t a, b; int cat, step; };
-    std::vector<EvPair> evpairs;
-    size_t evused = 0;
-    long m = 0, n = 0, anz = 0, nf = 0, maxfn = 0, rjsize = 0, hisize = 0;
-    int do_rank = 1;
-    int ca_min = STM_CA_MIN_ROWS;                      // (env STMMQR_CA_MIN at plan time: experiments)
-    int plan_algo = 0;                                 // g_opt.panel_algo when the schedule was built
-    int tall_min = STM_TALL_MIN;                       // g_opt.tall_min_rows when the schedule was built
-    int tune = 0;                                      // env STMMQR_TUNE when the schedule was built (measurement sweeps)
-    std::vector<long> Sp, Sj, Qfill, PLinv, Sleft, Child, Childp, Super, Rp, Rj, Post, Hip, Fm;
-    bool has_qfill = false;
-    std::vector<FrontSym> fs;
-    std::vector<std::vector<Level>> glevels;   // [group][level]
-    std::vector<std::vector<Step>> gsteps;     // [group][step]
-    std::vector<long long> wlists;             // host copy of d_wlists
-    std::vector<char> pair_front;              // per front: takes the pair / quad update (plan time)
-    int sweep = 2;                             // panels per sweep of those fronts: 2 (k_upd_w2 / y2 / c2) or 4 (k_upd_wq / yq / cq)
-    std::vector<int> group;                    // per front: phase on this device, -1 = elsewhere
-    std::vector<int> h_tslot;                  // host copy of d_tslot
-    std::vector<char> shared;                  // per front: STMMQR_GROUP_SHARED -- alone in its group, driven step by step
-                                               //  (stmmqr_factorize_step), its trailing column blocks shared with other plans
-    std::vector<char> has_c;                   // per front: its packed contribution block has a slot in the C arena of this plan
-                                               //  (the front is factorized here, or it is a child of one that is: assign_arenas)
-    std::vector<long long> c_slot;             // ... and the size of that slot in doubles (the symbolic bound of csize)
-    int own_off = 0, n_own = 0;
-    // ---- slab recycling (the reference's stack discipline, SparseQR_factorize.c:405-422,925-933, re-cast for a timeline of steps):
-    // a front's slab lives from the step it starts to the step its contribution block is packed and its R+H block staged into the
-    // R+H arena; a contribution block from there to the step its parent starts.  Offsets are assigned by an address-ordered
-    // first-fit over that timeline (assign_arenas_timeline), all symbolic.  Fronts in `kept` keep their slab (never staged: their
-    // packed block is produced on the fly when the factors are downloaded) -- chosen where that makes the peak smaller (a root
-    // front that IS most of the factors).  Only plans that hold the whole tree in one group recycle (sharded plans: as before).
-    bool recycle = false;
-    long maxstack = 0;                   // QRsym->maxstack (0: unknown)
-    std::vector<char> kept;              // per front
-    std::vector<int> f_t0, f_t1, c_t1;   // slab: [f_t0, f_t1]; contribution block: [f_t1, c_t1]  (steps of group 0)
-    long long rh_cap = 0;                // capacity of the R+H arena (doubles)
-    long long rh_est_total = 0;          // all packed R+H blocks if no pivot column dies (symbolic; exact for full-rank input)
-    int rh_grow = 0;                     // 0: the arena is sized from that estimate; 1: from the hard bounds (it overflowed once)
-    long long scr_doubles = 0;           // scratch of the resident-factor operations: the widest tree level in front form
-    std::vector<FrontSym> fs_scr;        // FrontSym with foff into that scratch (kept fronts: their own slab, relative to it)
-    bool scr_all = false, scr_valid = false;   // the scratch holds every front (rebuilt once per factorization) / is up to date
-    bool overflowed = false;             // a factorization did not fit the R+H arena at its hard bound: this plan does not recycle
-    bool arena_overflow = false;         // the last factorization did not fit the arena (it is repeated with a larger one / without)
-    std::vector<int> lists;              // host copy of d_lists
-    int post_off = 0, rh_parts_off = 0, rh_maxparts = 1;
-    long long farena = 0, carena = 0;
-    int tslots = 1;
-    int gp_slabs = 1;                    // Gram-based panel: max slab workgroups of a front
-    long long tpanels = 0;               // panels of all fronts: one kept T each (Q-apply on the resident factors)
-    long long wp_doubles = 0;            // workspace of the row-parallel update (partial W blocks)
-    long long wp2_doubles = 0;           // ... of the side stream's copy: steps with pair-update fronts never go there
-    bool pattern_set = false;
-    double bytes_assemble_idx = 0;       // index bytes of the assembly (symbolic part of SURVEY 8d formula)
-
-    DevBuf<FrontSym> d_fs;
-    DevBuf<FrontNum> d_fnum;
-    DevBuf<double> d_F, d_C, d_T, d_Gp, d_Tall, d_Sx, d_Ax, d_Tau, d_RH, d_Wp, d_Wp2;
-    DevBuf<int> d_tslot, d_Sp, d_Sjrel, d_Sj0, d_Sleft, d_Child, d_Rjrel, d_Stair, d_Hii, d_Cmap, d_Cursor,
-        d_lists, d_smap;
-    DevBuf<long long> d_Rhoff;
-    DevBuf<long long> d_wlists;
-    DevBuf<double> d_Ypend;                    // -Y of the pair-update fronts, by absolute column block (DevCtx::Ypend)
-    DevBuf<long long> d_ypoff;                 // [nf] offsets into it (-1: not a pair-update front)
-    std::vector<long long> ypoff;
-    long long yp_doubles = 0;
-    DevBuf<int> d_wcnt, d_wcnt2;         // per column block of the update workspaces: slab tickets (zero between launches)
-    DevBuf<int> d_wflag, d_wflag2;       // ... fused update: step + 1 once W2 of the column block is in its slot
-    DevBuf<int> d_abort;
-    size_t wcnt_n = 1;
-    DevBuf<long long> d_Rboff, d_total;
-    DevBuf<long long> d_rhtop, d_fin;    // slab recycling: {bump pointer, overflow word}; Post-order offsets of the packed blocks
-    DevBuf<char> d_kept;
-    DevBuf<double> d_scr, d_bounce;      // resident-factor scratch (one tree level in front form); download window
-    DevBuf<FrontSym> d_fs_scr;
-    DevBuf<unsigned long long> d_dbg, d_amax;
-    DevBuf<double> d_sig;                           // {sg, 1/sg}: magnitude guard of the panel kernels
-    DevBuf<char> d_Rdead;
-
-    // results of the last factorization
-    bool factored = false, begun = false, first_group = true;
-    bool whole_call = false;             // inside stmmqr_factorize_device (which recovers the WHOLE factorization itself)
-    bool panel_wait_failed = false;      // a bounded inter-workgroup wait of a panel kernel ran out in the last factorization
-    bool serial_panels = false;          // recovery: every panel by ONE workgroup (no inter-workgroup waits at all)
-    long long rh_total = 0;
-    long rank = 0;
-    std::vector<FrontNum> h_fnum;
-    // Q-apply / solve on the resident factors
-    DevBuf<int> d_Rj, d_PLinv, d_Qfill, d_Wmap, d_err;
-    DevBuf<double> d_W, d_Xs, d_Io, d_Xf, d_Wq, d_Xall, d_Yall, d_U, d_Xr;
-    DevBuf<int> d_rowbase;                          // rows of R above each front (R rows are numbered front by front)
-    std::vector<int> level_lds_rt;                  // dynamic LDS of k_rtsolve per level
-    DevBuf<int> d_Dq;
-    DevBuf<QbDesc> d_qb;
-    // grouped split Q-apply (k_qbig_step4): T4 of every group of four panels of every split front, built at the first Q-apply after a
-    // factorization (t4_valid); t4_ok: the buffers exist (they are allocated at that first use; no room: the per-panel launches stay)
-    std::vector<Qt4ItemHost> t4items;
-    std::vector<int> t4fronts;
-    std::vector<long long> t4dqo, qbt4off;
-    long long t4_doubles = 0, dq4_ints = 0, wq4_doubles = 0;
-    DevBuf<Qt4ItemHost> d_t4items;
-    DevBuf<int> d_t4fronts, d_Dq4;
-    DevBuf<long long> d_t4dqo, d_qbt4off;
-    DevBuf<double> d_T4, d_Wq4;
-    bool t4_valid = false, t4_ok = false, t4_tried = false;
-    struct QbLevel { int off = 0, n = 0, max_np = 0, max_nslab = 0, max_fm = 0, max_rsteps = 0, t4i_off = 0, t4i_n = 0; };
-    std::vector<char> t4_level_valid;          // T4 of the level's split fronts is built (per level: with per-level scratch only the
-                                               //  level at hand is in front form)
-    DevBuf<int> d_Rm;                               // rows of R (live pivots) of the split fronts of a level (k_rbig_*)
-    // several right-hand sides per launch (RhsBatch, stmmqr_kernels.h): the per-vector buffers hold rhs_cap vectors at these strides
-    int rhs_cap = 1;
-    long long xf_doubles = 1, wq_doubles = 1;
-    std::vector<QbLevel> level_qbig;               // descriptors (d_qb) of the fronts of each level that take the split Q-apply
-    hipGraphExec_t graph_exec = nullptr;           // options.use_graph: the captured schedule of group 0
-    double graph_tol = 0; int graph_ntol = 0, graph_dbg = 0; long long graph_opt = 0; long graph_nlaunch = 0;
-    long sched_gen = 0, graph_gen = -1;            // schedule generation (bumped by every build_schedule) / the captured one
-    bool rowmap_ready = false;         // d_Wmap belongs to the factorization currently held
-    std::vector<int> level_lds_qa, level_lds_qa_all, level_lds_rs;   // dynamic LDS of k_qapply(_t) / k_rsolve per level of group 0
-                                                                     // (_all: the unblocked kernel takes the split fronts too)
-    double last_tol = 0;
-    long last_ntol = 0;
-    stmmqr_stats stats = {};
-
-    // device memory held right now (every DevBuf of the plan)
-    double device_bytes() const
-    {
-        double b = 0;
-        auto add = [&](const auto &buf) { b += (double)buf.n * sizeof(*buf.p); };
-        add(d_fs); add(d_fnum); add(d_F); add(d_C); add(d_T); add(d_Gp); add(d_Tall); add(d_Sx); add(d_Ax); add(d_Tau); add(d_RH);
-        add(d_Wp); add(d_Wp2); add(d_tslot); add(d_Sp); add(d_Sjrel); add(d_Sj0); add(d_Sleft); add(d_Child); add(d_Rjrel);
-        add(d_Stair); add(d_Hii); add(d_Cmap); add(d_Cursor); add(d_lists); add(d_smap); add(d_Rhoff); add(d_wlists);
-        add(d_wcnt); add(d_wcnt2); add(d_wflag); add(d_wflag2); add(d_Rboff); add(d_Rdead); add(d_Ypend); add(d_ypoff);
-        add(d_rhtop); add(d_fin); add(d_kept); add(d_scr); add(d_bounce); add(d_fs_scr);
-        return b;
-    }
-    DevCtx ctx() const
-    {
-        DevCtx c;
-        c.fs = d_fs.p; c.fnum = d_fnum.p; c.Farena = d_F.p; c.Carena = d_C.p; c.Tws = d_T.p; c.tslot = d_tslot.p;
-        c.Tall = d_Tall.p;
-        c.Gp = d_Gp.p; c.gp_slabs = gp_slabs; c.sig = d_sig.p; c.panel_algo = serial_panels ? 1 : plan_algo; c.ca_min_rows = ca_min;
-        c.Sx = d_Sx.p; c.Sp = d_Sp.p; c.Sjrel = d_Sjrel.p; c.Sj0 = d_Sj0.p; c.Sleft = d_Sleft.p;
-        c.Child = d_Child.p; c.Rjrel = d_Rjrel.p; c.Stair = d_Stair.p; c.Tau = d_Tau.p; c.Hii = d_Hii.p;
-        c.Rdead = d_Rdead.p; c.Cmap = d_Cmap.p; c.Cursor = d_Cursor.p; c.Rhoff = d_Rhoff.p; c.Rboff = d_Rboff.p;
-        c.tol = last_tol; c.ntol = (int)last_ntol;
-        c.dbg = getenv("STMMQR_DBG") ? atoi(getenv("STMMQR_DBG")) : 0;
-        c.sweep = sweep;
-        c.tune = tune;                                            // (env STMMQR_TUNE when the schedule was built)
-        c.Ypend = d_Ypend.p; c.ypoff = d_ypoff.p;
-        c.rh_top = recycle ? d_rhtop.p : nullptr; c.rh_cap = rh_cap;
-        if (serial_panels) c.dbg = (c.dbg & ~(2048 | 4096)) | 256;   // the one-workgroup LDS / in-place panel for every panel
-        c.tall_min = tall_min;
-        c.cbskip = 0;
-        c.dbgbuf = d_dbg.p;
-        c.abort = d_abort.p;
-        return c;
-    }
-    ~stmmqr_plan()
-    {
-        for (auto &e : ev)
-            if (e) (void)hipEventDestroy(e);
-        for (auto &q : evpairs) { if (q.a) (void)hipEventDestroy(q.a); if (q.b) (void)hipEventDestroy(q.b); }
-        if (graph_exec) (void)hipGraphExecDestroy(graph_exec);
-        for (auto *v : {&ev_main, &ev_prep, &ev_side})
-            for (auto &e : *v)
-                if (e) (void)hipEventDestroy(e);
-        if (stream) (void)hipStreamDestroy(stream);
-    }
-};
 
 namespace {
 
@@ -1235,7 +955,7 @@ int reset_group(stmmqr_plan &P, int grp)
 
 // One piece of one timeline step (stmmqr_factorize_step): what = STMMQR_STEP_* bits; the update takes the column blocks
 // cb_first, cb_first + cb_stride, ... (at most cb_count of them when cb_count >= 0) of the step's fronts.
-struct StepReq { int step, what, cb_first, cb_stride, cb_count; };
+// (StepReq: stmmqr_plan.h)
 
 // Events of the look-ahead schedule order two streams of ONE device: no timing, and no system-scope fence when they are recorded
 // (the host never inspects them; the kernels' own agent-scope release / acquire at their boundaries is what the other stream needs).
@@ -1677,6 +1397,10 @@ int run_pack(stmmqr_plan &P)
 }
 
 }  // namespace
+
+// (what the other host translation units need of the planner / scheduler: stmmqr_plan.h)
+int stm_run_schedule(stmmqr_plan &P, bool detail, int grp, const StepReq *req) { return run_schedule(P, detail, grp, req); }
+int stm_ensure_device(int device) { return ensure_device(device); }
 
 // =================================================================================================
 // C ABI
@@ -2181,7 +1905,7 @@ int stmmqr_plan_set_groups(stmmqr_plan *plan, const int *group)
 // Does front f have a contribution-block slot on this plan, allocated, that holds `csize` doubles?  A front that is neither
 // factorized here nor a child of a front that is has NO slot (its coff is 0: the first resident block's), and the arenas exist
 // only between the first stmmqr_factorize_begin after a (re)grouping and the next regrouping.
-static int check_c_slot(const stmmqr_plan &P, stm_long f, long long csize, const char *what)
+int stm_check_c_slot(const stmmqr_plan &P, stm_long f, long long csize, const char *what)
 {
     if (f < 0 || f >= P.nf) return fail(STMMQR_ERR_INVALID, std::string(what) + ": no such front");
     if (P.recycle)
@@ -2196,954 +1920,6 @@ static int check_c_slot(const stmmqr_plan &P, stm_long f, long long csize, const
     if (csize < 0 || csize > P.c_slot[(size_t)f])
         return fail(STMMQR_ERR_INVALID, std::string(what) + ": the block exceeds the front's slot");
     return 0;
-}
-
-/* info[0..5] = fm, rank, cm, csize, fn, fp of front f after it has been factorized (or imported) here */
-int stmmqr_plan_front_info(stmmqr_plan *plan, stm_long f, stm_long *info)
-{
-    if (!plan || f < 0 || f >= plan->nf || !info) return fail(STMMQR_ERR_INVALID, "bad front");
-    stmmqr_plan &P = *plan;
-    HIPCHK(hipSetDevice(P.device));
-    HIPCHK(hipStreamSynchronize(P.stream));
-    FrontNum nm;
-    HIPCHK(hipMemcpy(&nm, P.d_fnum.p + f, sizeof nm, hipMemcpyDeviceToHost));
-    const long cn = P.fs[f].fn - P.fs[f].fp, cm = nm.cm;
-    info[0] = nm.fm; info[1] = nm.rank; info[2] = cm; info[3] = cm * (cm + 1) / 2 + cm * (cn - cm);
-    info[4] = P.fs[f].fn; info[5] = P.fs[f].fp;
-    return 0;
-}
-
-/* copy out the packed contribution block (csize doubles) and the cm row ids of front f */
-int stmmqr_plan_export_front(stmmqr_plan *plan, stm_long f, double *C, stm_long *rows, int c_on_device)
-{
-    stm_long info[6];
-    int e = stmmqr_plan_front_info(plan, f, info);
-    if (e) return e;
-    stmmqr_plan &P = *plan;
-    if ((e = check_c_slot(P, f, info[3], "stmmqr_plan_export_front"))) return e;
-    if (info[3] > 0 && C)
-        HIPCHK(hipMemcpy(C, P.d_C.p + P.fs[f].coff, (size_t)info[3] * sizeof(double),
-                         c_on_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost));
-    if (info[2] > 0 && rows) {
-        std::vector<int> r32((size_t)info[2]);
-        HIPCHK(hipMemcpy(r32.data(), P.d_Hii.p + P.fs[f].hip + info[1], (size_t)info[2] * sizeof(int), hipMemcpyDeviceToHost));
-        for (long i = 0; i < info[2]; i++) rows[i] = r32[i];
-    }
-    return 0;
-}
-
-/* install the contribution block of a front that was factorized on another device */
-int stmmqr_plan_import_front(stmmqr_plan *plan, stm_long f, stm_long fm, stm_long rank, stm_long cm, const double *C,
-                             const stm_long *rows, int c_on_device)
-{
-    if (!plan || f < 0 || f >= plan->nf) return fail(STMMQR_ERR_INVALID, "bad front");
-    stmmqr_plan &P = *plan;
-    HIPCHK(hipSetDevice(P.device));
-    const long cn = P.fs[f].fn - P.fs[f].fp;
-    if (cm < 0 || cm > cn || rank < 0 || rank + cm > P.fs[f].fm_ub)
-        return fail(STMMQR_ERR_INVALID, "imported front does not fit the symbolic bounds");
-    const long csize = cm * (cm + 1) / 2 + cm * (cn - cm);
-    if (!P.begun) return fail(STMMQR_ERR_INVALID, "stmmqr_plan_import_front outside factorize_begin / factorize_finish (begin resets every front's state)");
-    if (int e = check_c_slot(P, f, csize, "stmmqr_plan_import_front")) return e;
-    if ((cm > 0 && !rows) || (csize > 0 && !C)) return fail(STMMQR_ERR_INVALID, "stmmqr_plan_import_front: null block / row ids");
-    HIPCHK(hipStreamSynchronize(P.stream));
-    FrontNum nm;
-    memset(&nm, 0, sizeof nm);
-    nm.fm = (int)fm; nm.rank = (int)rank; nm.cm = (int)cm; nm.done = 1; nm.g = (int)rank;
-    HIPCHK(hipMemcpy(P.d_fnum.p + f, &nm, sizeof nm, hipMemcpyHostToDevice));
-    if (csize > 0)
-        HIPCHK(hipMemcpy(P.d_C.p + P.fs[f].coff, C, (size_t)csize * sizeof(double),
-                         c_on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice));
-    if (cm > 0) {
-        std::vector<int> r32((size_t)cm);
-        for (long i = 0; i < cm; i++) r32[i] = (int)rows[i];
-        HIPCHK(hipMemcpy(P.d_Hii.p + P.fs[f].hip + rank, r32.data(), (size_t)cm * sizeof(int), hipMemcpyHostToDevice));
-    }
-    return 0;
-}
-
-// ---- a front shared between plans (one per device): every plan holds the whole front, panel q is factorized by the plan
-// with q % nparts == part and travels to the others, every plan updates the 32-column blocks of the panels it owns.
-// The arithmetic of a column block does not depend on who runs it: the bits are those of the unshared front (without the
-// pair update).  Unit of exchange in the reference: the contribution block, SparseQR_factorize.c:1228; here, inside one
-// front, the factorized panel. ----
-int stmmqr_plan_group_steps(stmmqr_plan *plan, int group)
-{
-    if (!plan || group < 0 || group >= (int)plan->gsteps.size()) { fail(STMMQR_ERR_INVALID, "no such front group"); return -1; }
-    return (int)plan->gsteps[(size_t)group].size();
-}
-
-int stmmqr_factorize_step(stmmqr_plan *plan, int group, int step, int what, int cb_first, int cb_stride, int cb_count)
-{
-    if (!plan || !plan->begun) return fail(STMMQR_ERR_INVALID, "stmmqr_factorize_begin was not called");
-    stmmqr_plan &P = *plan;
-    HIPCHK(hipSetDevice(P.device));
-    if (cb_stride < 1) return fail(STMMQR_ERR_INVALID, "column-block stride < 1");
-    StepReq rq = {step, what, cb_first, cb_stride, cb_count};
-    P.first_group = false;
-    return run_schedule(P, false, group, &rq);
-}
-
-namespace {
-struct PanelMsg { long long f_off, t_off, tau_off, stair_off, dead_off, num_off, total; long nb; };
-// layout of one panel message (doubles): the panel's columns of F (whole leading dimension), T of the panel's slot, then
-// the front's Tau / Stair / Rdead ranges and its FrontNum -- small next to the columns, and sending the whole ranges keeps
-// every plan's copy of them identical without tracking which entries a panel touched
-PanelMsg panel_msg(const FrontSym &s, long p)
-{
-    PanelMsg m;
-    const long k1 = p * STM_NB;
-    m.nb = std::max(0L, std::min((long)STM_NB, (long)s.fn - k1));
-    m.f_off = 0;
-    m.t_off = m.f_off + (long long)s.ld * STM_NB;
-    m.tau_off = m.t_off + STM_NB * STM_NB;
-    m.stair_off = m.tau_off + s.fn;
-    m.dead_off = m.stair_off + (s.fn + 1) / 2;
-    m.num_off = m.dead_off + (s.fp + 7) / 8;
-    m.total = m.num_off + (long long)((sizeof(FrontNum) + 7) / 8);
-    return m;
-}
-}  // namespace
-
-int stmmqr_plan_panel_doubles(stmmqr_plan *plan, stm_long f, stm_long *ndoubles)
-{
-    if (!plan || f < 0 || f >= plan->nf || !ndoubles) return fail(STMMQR_ERR_INVALID, "bad front");
-    *ndoubles = (stm_long)panel_msg(plan->fs[f], 0).total;
-    return 0;
-}
-
-static int panel_copy(stmmqr_plan &P, stm_long f, stm_long p, double *buf, int on_device, bool out, bool nosync = false)
-{
-    if (f < 0 || f >= P.nf || !buf) return fail(STMMQR_ERR_INVALID, "bad front / buffer");
-    const FrontSym &s = P.fs[f];
-    if (p < 0 || p >= s.npanels) return fail(STMMQR_ERR_INVALID, "no such panel");
-    if (P.group[f] < 0) return fail(STMMQR_ERR_INVALID, "the front is not factorized by this plan");
-    if (!P.begun || !P.d_F.p || P.d_F.n != (size_t)P.farena)
-        return fail(STMMQR_ERR_INVALID, "panel messages move between factorize_begin and factorize_finish (the front arena of the current grouping must exist)");
-    HIPCHK(hipSetDevice(P.device));
-    const PanelMsg m = panel_msg(s, p);
-    const hipMemcpyKind kind = on_device ? hipMemcpyDeviceToDevice : (out ? hipMemcpyDeviceToHost : hipMemcpyHostToDevice);
-    hipStream_t st = P.stream;
-    if (on_device) {
-        // device buffer: ONE launch packs / unpacks the six ranges
-        void *homes[6] = {P.d_F.p + s.foff + (long long)p * STM_NB * s.ld,
-                          P.d_T.p + (long long)STM_TSLOT(P.h_tslot[(size_t)f], (int)p) * STM_NB * STM_NB, P.d_Tau.p + s.rp, P.d_Stair.p + s.rp,
-                          P.d_Rdead.p + s.col1, P.d_fnum.p + f};
-        const long long offs[6] = {m.f_off * 8, m.t_off * 8, m.tau_off * 8, m.stair_off * 8, m.dead_off * 8, m.num_off * 8};
-        const long long bytes[6] = {(long long)s.ld * m.nb * 8, 8LL * STM_NB * STM_NB, 8LL * s.fn, 4LL * s.fn, (long long)s.fp, (long long)sizeof(FrontNum)};
-        LCHK(stm_launch_panel_msg(homes, offs, bytes, buf, out ? 1 : 0, st));
-        if (out && !nosync) HIPCHK(hipStreamSynchronize(st));
-        return 0;
-    }
-    auto cp = [&](void *dev, long long off, size_t bytes) -> int {
-        if (!bytes) return 0;
-        if (out) HIPCHK(hipMemcpyAsync(buf + off, dev, bytes, kind, st));
-        else HIPCHK(hipMemcpyAsync(dev, buf + off, bytes, kind, st));
-        return 0;
-    };
-    LCHK(cp(P.d_F.p + s.foff + (long long)p * STM_NB * s.ld, m.f_off, (size_t)s.ld * (size_t)m.nb * sizeof(double)));
-    LCHK(cp(P.d_T.p + (long long)STM_TSLOT(P.h_tslot[(size_t)f], (int)p) * STM_NB * STM_NB, m.t_off, sizeof(double) * STM_NB * STM_NB));
-    LCHK(cp(P.d_Tau.p + s.rp, m.tau_off, (size_t)s.fn * sizeof(double)));
-    LCHK(cp(P.d_Stair.p + s.rp, m.stair_off, (size_t)s.fn * sizeof(int)));
-    LCHK(cp(P.d_Rdead.p + s.col1, m.dead_off, (size_t)s.fp));
-    LCHK(cp(P.d_fnum.p + f, m.num_off, sizeof(FrontNum)));
-    if ((out || !on_device) && !nosync) HIPCHK(hipStreamSynchronize(st));   // the caller sends the buffer / reuses its host memory
-    return 0;
-}
-
-int stmmqr_plan_export_panel(stmmqr_plan *plan, stm_long f, stm_long p, double *buf, int on_device)
-{
-    if (!plan) return fail(STMMQR_ERR_INVALID, "null plan");
-    return panel_copy(*plan, f, p, buf, on_device, true);
-}
-
-int stmmqr_plan_import_panel(stmmqr_plan *plan, stm_long f, stm_long p, const double *buf, int on_device)
-{
-    if (!plan) return fail(STMMQR_ERR_INVALID, "null plan");
-    return panel_copy(*plan, f, p, const_cast<double *>(buf), on_device, false);
-}
-
-// The packed contribution block of a shared front is complete only in the columns of the panels a plan owns: the runs of
-// owned columns are contiguous in the packed block (column j of C = column fp + j of the front, SparseQR_factorize.c:1228).
-static int front_cols_copy(stmmqr_plan &P, stm_long f, int part, int nparts, double *buf, int on_device, stm_long *ndoubles, bool out)
-{
-    if (f < 0 || f >= P.nf || nparts < 1 || part < 0 || part >= nparts) return fail(STMMQR_ERR_INVALID, "bad front / part");
-    HIPCHK(hipSetDevice(P.device));
-    if (int e = check_c_slot(P, f, 0, out ? "stmmqr_plan_export_front_cols" : "stmmqr_plan_import_front_cols")) return e;
-    HIPCHK(hipStreamSynchronize(P.stream));
-    FrontNum nm;
-    HIPCHK(hipMemcpy(&nm, P.d_fnum.p + f, sizeof nm, hipMemcpyDeviceToHost));
-    const FrontSym &s = P.fs[f];
-    const long cn = s.fn - s.fp, cm = nm.cm;
-    if (cm < 0 || cm > cn || (long long)cm * (cm + 1) / 2 + (long long)cm * (cn - cm) > P.c_slot[(size_t)f])
-        return fail(STMMQR_ERR_INVALID, "front_cols: the front's contribution block does not fit its slot");
-    auto coff = [&](long j) -> long long { return j < cm ? (long long)j * (j + 1) / 2 : (long long)cm * (cm + 1) / 2 + (long long)(j - cm) * cm; };
-    const hipMemcpyKind kind = on_device ? hipMemcpyDeviceToDevice : (out ? hipMemcpyDeviceToHost : hipMemcpyHostToDevice);
-    long long pos = 0;
-    for (long q = s.fp / STM_NB; q * STM_NB < s.fn; q++) {
-        if (q % nparts != part) continue;
-        const long j0 = std::max(0L, q * STM_NB - (long)s.fp), j1 = std::min(cn, (q + 1) * STM_NB - (long)s.fp);
-        if (j1 <= j0 || cm <= 0) continue;
-        const long long a = coff(j0), b = coff(j1);
-        if (buf && b > a) {
-            if (out) HIPCHK(hipMemcpyAsync(buf + pos, P.d_C.p + s.coff + a, (size_t)(b - a) * sizeof(double), kind, P.stream));
-            else HIPCHK(hipMemcpyAsync(P.d_C.p + s.coff + a, buf + pos, (size_t)(b - a) * sizeof(double), kind, P.stream));
-        }
-        pos += b - a;
-    }
-    HIPCHK(hipStreamSynchronize(P.stream));
-    if (ndoubles) *ndoubles = (stm_long)pos;
-    return 0;
-}
-
-int stmmqr_plan_export_front_cols(stmmqr_plan *plan, stm_long f, int part, int nparts, double *buf, int on_device, stm_long *ndoubles)
-{
-    if (!plan) return fail(STMMQR_ERR_INVALID, "null plan");
-    return front_cols_copy(*plan, f, part, nparts, buf, on_device, ndoubles, true);
-}
-
-int stmmqr_plan_import_front_cols(stmmqr_plan *plan, stm_long f, int part, int nparts, const double *buf, int on_device)
-{
-    if (!plan || !buf) return fail(STMMQR_ERR_INVALID, "null plan / buffer");
-    return front_cols_copy(*plan, f, part, nparts, const_cast<double *>(buf), on_device, nullptr, false);
-}
-
-// ---- the panel loop of a SHARED front, native (round 4; sharded.run_shared_front is its Python twin and stays the CPU-testable
-// form).  One call per rank and shared front: the rank's place i in the group of R ranks [first_rank, first_rank + R), panel q
-// belongs to place q mod R.  Everything is enqueued -- compute on the plan's stream, messages on a comm stream of the plan, the
-// two ordered by events -- and the host returns without waiting: no per-step stream synchronisation, no interpreter between two
-// steps (the Python loop cost 55-74 us of host time per step).  The owner's send of panel t runs beside the rest of
-// its update of step t - 1; a receiver posts the receive of panel t before it starts its update of step t - 1.
-// The transport is a table of callbacks (stmmqr_transport): RCCL point-to-point (stmmqr_rccl_transport_create) on a node with
-// several GPUs; tests play the ranks on one GPU with a transport of their own. ----
-namespace {
-struct SharedRing {
-    stm_long f = -1;
-    int R = 0;
-    long long nd = 0;
-    std::vector<double *> buf;                 // R device buffers of one panel message each
-    std::vector<hipEvent_t> ev_free;           // slot q mod R: its last import / send has finished
-    hipEvent_t ev_exp = nullptr, ev_rcv = nullptr;
-};
-std::mutex g_ring_mu;
-std::vector<std::pair<stmmqr_plan *, SharedRing *>> g_rings;
-hipStream_t g_comm_stream[64] = {};
-
-SharedRing *ring_for(stmmqr_plan &P, stm_long f, int R)
-{
-    std::lock_guard<std::mutex> lock(g_ring_mu);
-    for (auto &pr : g_rings)
-        if (pr.first == &P && pr.second->f == f && pr.second->R == R) return pr.second;
-    SharedRing *r = new SharedRing();
-    r->f = f; r->R = R;
-    r->nd = panel_msg(P.fs[f], 0).total;
-    r->buf.assign((size_t)R, nullptr);
-    r->ev_free.assign((size_t)R, nullptr);
-    bool ok = true;
-    for (int q = 0; q < R && ok; q++) {
-        ok = hipMalloc((void **)&r->buf[(size_t)q], (size_t)r->nd * sizeof(double)) == hipSuccess &&
-             hipEventCreateWithFlags(&r->ev_free[(size_t)q], hipEventDisableTiming) == hipSuccess;
-    }
-    ok = ok && hipEventCreateWithFlags(&r->ev_exp, hipEventDisableTiming) == hipSuccess &&
-         hipEventCreateWithFlags(&r->ev_rcv, hipEventDisableTiming) == hipSuccess;
-    if (!ok) { delete r; return nullptr; }              // (buffers of a failed attempt are few and are left to process exit)
-    g_rings.push_back({&P, r});
-    return r;
-}
-}  // namespace
-
-void stmmqr_plan_release_rings(stmmqr_plan *plan)
-{
-    std::lock_guard<std::mutex> lock(g_ring_mu);
-    for (size_t i = 0; i < g_rings.size();) {
-        if (g_rings[i].first == plan) {
-            SharedRing *r = g_rings[i].second;
-            for (double *b : r->buf) if (b) (void)hipFree(b);
-            for (hipEvent_t e : r->ev_free) if (e) (void)hipEventDestroy(e);
-            if (r->ev_exp) (void)hipEventDestroy(r->ev_exp);
-            if (r->ev_rcv) (void)hipEventDestroy(r->ev_rcv);
-            delete r;
-            g_rings.erase(g_rings.begin() + (long)i);
-        } else i++;
-    }
-}
-
-int stmmqr_factorize_shared_front(stmmqr_plan *plan, int group, stm_long f, int first_rank, int nranks, const stmmqr_transport *tr)
-{
-    if (!plan || !plan->begun) return fail(STMMQR_ERR_INVALID, "stmmqr_factorize_begin was not called");
-    if (!tr || !tr->send || !tr->recv) return fail(STMMQR_ERR_INVALID, "null transport");
-    stmmqr_plan &P = *plan;
-    if (f < 0 || f >= P.nf || (size_t)f >= P.shared.size() || !P.shared[(size_t)f] || P.group[f] != group)
-        return fail(STMMQR_ERR_INVALID, "not a shared front of this group (stmmqr_plan_set_groups: STMMQR_GROUP_SHARED)");
-    const int R = nranks, i = tr->rank - first_rank;
-    if (R < 1 || i < 0 || i >= R) return fail(STMMQR_ERR_INVALID, "this rank is not in the front's group");
-    HIPCHK(hipSetDevice(P.device));
-    if (P.device < 0 || P.device >= 64) return fail(STMMQR_ERR_INVALID, "device index out of range");
-    if (!g_comm_stream[P.device]) HIPCHK(hipStreamCreateWithFlags(&g_comm_stream[P.device], hipStreamNonBlocking));
-    hipStream_t cs = g_comm_stream[P.device], st = P.stream;
-    const int nsteps = (int)P.gsteps[(size_t)group].size();
-    SharedRing *ring = ring_for(P, f, R);
-    if (!ring) return fail(STMMQR_ERR_OUT_OF_MEMORY, "panel message buffers");
-    const size_t bytes = (size_t)ring->nd * sizeof(double);
-    auto step = [&](int t, int what, int cb_first, int cb_stride, int cb_count) -> int {
-        StepReq rq = {t, what, cb_first, cb_stride, cb_count};
-        P.first_group = false;
-        return run_schedule(P, false, group, &rq);
-    };
-    auto mod = [&](int a) { return ((a % R) + R) % R; };
-    int e = step(0, STMMQR_STEP_PREP, 0, 1, -1);
-    for (int t = 0; t < nsteps && !e; t++) {
-        const int o = t % R, first = mod(i - t);               // my first column block of step t - 1
-        double *buf = ring->buf[(size_t)o];
-        if (i == o) {
-            if (t > 0) e = step(t - 1, STMMQR_STEP_UPDATE | STMMQR_STEP_GRAM, first, R, 1);      // block 0: the columns of my panel
-            if (!e) e = step(t, STMMQR_STEP_PANEL, 0, 1, -1);
-            if (e) break;
-            HIPCHK(hipStreamWaitEvent(st, ring->ev_free[(size_t)o], 0));                       // (the sends of panel t - R are out)
-            if ((e = panel_copy(P, f, t, buf, 1, true, true))) break;
-            HIPCHK(hipEventRecord(ring->ev_exp, st));
-            HIPCHK(hipStreamWaitEvent(cs, ring->ev_exp, 0));
-            if (tr->group_begin && tr->group_begin(tr->ctx)) { e = fail(STMMQR_ERR_DEVICE, "transport: group begin"); break; }
-            for (int j = 0; j < R && !e; j++)
-                if (j != i && tr->send(tr->ctx, buf, bytes, first_rank + j, (void *)cs)) e = fail(STMMQR_ERR_DEVICE, "transport: send of a panel failed");
-            if (tr->group_end && tr->group_end(tr->ctx) && !e) e = fail(STMMQR_ERR_DEVICE, "transport: group end");
-            if (e) break;
-            HIPCHK(hipEventRecord(ring->ev_free[(size_t)o], cs));
-            if (t > 0) e = step(t - 1, STMMQR_STEP_UPDATE, first + R, R, -1);                   // the rest, beside the sends
-        } else {
-            // the receive is posted first (its slot is free once the import of panel t - R has run), then the update of step t - 1
-            HIPCHK(hipStreamWaitEvent(cs, ring->ev_free[(size_t)o], 0));
-            if (tr->group_begin && tr->group_begin(tr->ctx)) { e = fail(STMMQR_ERR_DEVICE, "transport: group begin"); break; }
-            if (tr->recv(tr->ctx, buf, bytes, first_rank + o, (void *)cs)) e = fail(STMMQR_ERR_DEVICE, "transport: receive of a panel failed");
-            if (tr->group_end && tr->group_end(tr->ctx) && !e) e = fail(STMMQR_ERR_DEVICE, "transport: group end");
-            if (e) break;
-            HIPCHK(hipEventRecord(ring->ev_rcv, cs));
-            if (t > 0) e = step(t - 1, STMMQR_STEP_UPDATE | STMMQR_STEP_GRAM, first, R, -1);
-            if (e) break;
-            HIPCHK(hipStreamWaitEvent(st, ring->ev_rcv, 0));
-            if ((e = panel_copy(P, f, t, buf, 1, false, true))) break;
-            HIPCHK(hipEventRecord(ring->ev_free[(size_t)o], st));
-        }
-    }
-    if (!e) e = step(nsteps - 1, STMMQR_STEP_UPDATE | STMMQR_STEP_GRAM, mod(i - nsteps), R, -1);
-    if (!e) e = step(nsteps - 1, STMMQR_STEP_POST, 0, 1, -1);
-    // the caller gathers the contribution block (stmmqr_plan_export_front_cols) and goes on with the next phase: it needs the
-    // device to have finished this one -- ONE synchronisation per shared front, not one per step
-    HIPCHK(hipStreamSynchronize(cs));
-    HIPCHK(hipStreamSynchronize(st));
-    return e;
-}
-
-// ---- RCCL point-to-point transport (ncclSend / ncclRecv on the comm stream).  librccl is loaded at run time -- the library
-// has no link-time dependency on it: a one-GPU process never needs it, and under PyTorch the copy that torch.distributed has
-// already loaded is the one that is found. ----
-namespace {
-struct NcclId { char internal[128]; };
-typedef void *ncclComm_p;
-struct RcclApi {
-    void *h = nullptr;
-    int (*GetUniqueId)(NcclId *) = nullptr;
-    int (*CommInitRank)(ncclComm_p *, int, NcclId, int) = nullptr;
-    int (*CommDestroy)(ncclComm_p) = nullptr;
-    int (*Send)(const void *, size_t, int, int, ncclComm_p, hipStream_t) = nullptr;
-    int (*Recv)(void *, size_t, int, int, ncclComm_p, hipStream_t) = nullptr;
-    int (*GroupStart)(void) = nullptr;
-    int (*GroupEnd)(void) = nullptr;
-    const char *(*GetErrorString)(int) = nullptr;
-} g_rccl;
-int load_rccl()
-{
-    if (g_rccl.h) return 0;
-    const char *names[] = {getenv("STMMQR_RCCL_LIB"), "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
-    void *h = nullptr;
-    for (const char *n : names)
-        if (n && (h = dlopen(n, RTLD_NOW | RTLD_GLOBAL))) break;
-    if (!h) return fail(STMMQR_ERR_DEVICE, std::string("librccl not found: ") + (dlerror() ? dlerror() : ""));
-    RcclApi a;
-    a.h = h;
-    a.GetUniqueId = (int (*)(NcclId *))dlsym(h, "ncclGetUniqueId");
-    a.CommInitRank = (int (*)(ncclComm_p *, int, NcclId, int))dlsym(h, "ncclCommInitRank");
-    a.CommDestroy = (int (*)(ncclComm_p))dlsym(h, "ncclCommDestroy");
-    a.Send = (int (*)(const void *, size_t, int, int, ncclComm_p, hipStream_t))dlsym(h, "ncclSend");
-    a.Recv = (int (*)(void *, size_t, int, int, ncclComm_p, hipStream_t))dlsym(h, "ncclRecv");
-    a.GroupStart = (int (*)(void))dlsym(h, "ncclGroupStart");
-    a.GroupEnd = (int (*)(void))dlsym(h, "ncclGroupEnd");
-    a.GetErrorString = (const char *(*)(int))dlsym(h, "ncclGetErrorString");
-    if (!a.GetUniqueId || !a.CommInitRank || !a.CommDestroy || !a.Send || !a.Recv || !a.GroupStart || !a.GroupEnd)
-        return fail(STMMQR_ERR_DEVICE, "librccl lacks a point-to-point entry point");
-    g_rccl = a;
-    return 0;
-}
-struct RcclTransport { stmmqr_transport pub; ncclComm_p comm = nullptr; };
-int rccl_send(void *ctx, const void *buf, size_t bytes, int peer, void *stream)
-{
-    return g_rccl.Send(buf, bytes, 0 /* ncclInt8 */, peer, ((RcclTransport *)ctx)->comm, (hipStream_t)stream);
-}
-int rccl_recv(void *ctx, void *buf, size_t bytes, int peer, void *stream)
-{
-    return g_rccl.Recv(buf, bytes, 0 /* ncclInt8 */, peer, ((RcclTransport *)ctx)->comm, (hipStream_t)stream);
-}
-int rccl_gbegin(void *) { return g_rccl.GroupStart(); }
-int rccl_gend(void *) { return g_rccl.GroupEnd(); }
-}  // namespace
-
-int stmmqr_rccl_unique_id(char id[128])
-{
-    if (!id) return fail(STMMQR_ERR_INVALID, "null id");
-    if (int e = load_rccl()) return e;
-    NcclId u;
-    memset(&u, 0, sizeof u);
-    const int rc = g_rccl.GetUniqueId(&u);
-    if (rc) return fail(STMMQR_ERR_DEVICE, std::string("ncclGetUniqueId: ") + (g_rccl.GetErrorString ? g_rccl.GetErrorString(rc) : "error"));
-    memcpy(id, u.internal, 128);
-    return 0;
-}
-
-int stmmqr_rccl_transport_create(int world, int rank, const char id[128], stmmqr_transport **out)
-{
-    if (!out || !id || world < 1 || rank < 0 || rank >= world) return fail(STMMQR_ERR_INVALID, "bad transport arguments");
-    *out = nullptr;
-    if (int e = load_rccl()) return e;
-    RcclTransport *t = new (std::nothrow) RcclTransport();
-    if (!t) return fail(STMMQR_ERR_OUT_OF_MEMORY, "host allocation failed");
-    NcclId u;
-    memcpy(u.internal, id, 128);
-    const int rc = g_rccl.CommInitRank(&t->comm, world, u, rank);
-    if (rc) { delete t; return fail(STMMQR_ERR_DEVICE, std::string("ncclCommInitRank: ") + (g_rccl.GetErrorString ? g_rccl.GetErrorString(rc) : "error")); }
-    t->pub.ctx = t; t->pub.send = rccl_send; t->pub.recv = rccl_recv; t->pub.group_begin = rccl_gbegin; t->pub.group_end = rccl_gend;
-    t->pub.rank = rank; t->pub.size = world;
-    *out = &t->pub;
-    return 0;
-}
-
-void stmmqr_rccl_transport_destroy(stmmqr_transport *tr)
-{
-    if (!tr) return;
-    RcclTransport *t = (RcclTransport *)tr->ctx;
-    if (t && t->comm && g_rccl.CommDestroy) (void)g_rccl.CommDestroy(t->comm);
-    delete t;
-}
-
-/* a transport's own send / receive of one device buffer, ordered on `stream` (a hipStream_t): what the tests and the Python side
- * use to move a buffer with the same object the native loop uses */
-int stmmqr_transport_sendrecv(const stmmqr_transport *tr, const void *sendbuf, size_t sendbytes, int dst, void *recvbuf, size_t recvbytes,
-                              int src, void *stream)
-{
-    if (!tr) return fail(STMMQR_ERR_INVALID, "null transport");
-    int e = 0;
-    if (tr->group_begin) e |= tr->group_begin(tr->ctx);
-    if (sendbuf && sendbytes && dst >= 0) e |= tr->send(tr->ctx, sendbuf, sendbytes, dst, stream);
-    if (recvbuf && recvbytes && src >= 0) e |= tr->recv(tr->ctx, recvbuf, recvbytes, src, stream);
-    if (tr->group_end) e |= tr->group_end(tr->ctx);
-    return e ? fail(STMMQR_ERR_DEVICE, "transport: send / receive failed") : 0;
-}
-
-/* off[0..fn]: where each column of front f starts inside its packed R+H block (off[fn] = the block's size) */
-int stmmqr_plan_front_rhoff(stmmqr_plan *plan, stm_long f, stm_long *off)
-{
-    if (!plan || !plan->factored || f < 0 || f >= plan->nf || !off) return fail(STMMQR_ERR_INVALID, "bad front / no factorization held");
-    stmmqr_plan &P = *plan;
-    HIPCHK(hipSetDevice(P.device));
-    const FrontSym &s = P.fs[f];
-    std::vector<long long> h((size_t)std::max(1, s.fn));
-    if (s.fn > 0) HIPCHK(hipMemcpy(h.data(), P.d_Rhoff.p + s.rp, (size_t)s.fn * sizeof(long long), hipMemcpyDeviceToHost));
-    for (int k = 0; k < s.fn; k++) off[k] = (stm_long)h[(size_t)k];
-    off[s.fn] = (stm_long)P.h_fnum[(size_t)f].rsize;
-    return 0;
-}
-
-/* device memory held by the plan right now (bytes): arenas, factors, workspaces, index arrays */
-double stmmqr_plan_device_bytes(const stmmqr_plan *plan) { return plan ? plan->device_bytes() : 0.0; }
-
-/* out[0..1] = flops, flops of the trailing updates of front f (read from the device: valid once its panels are done) */
-int stmmqr_plan_front_flops(stmmqr_plan *plan, stm_long f, double *out)
-{
-    if (!plan || f < 0 || f >= plan->nf || !out) return fail(STMMQR_ERR_INVALID, "bad front");
-    stmmqr_plan &P = *plan;
-    HIPCHK(hipSetDevice(P.device));
-    HIPCHK(hipStreamSynchronize(P.stream));
-    FrontNum nm;
-    HIPCHK(hipMemcpy(&nm, P.d_fnum.p + f, sizeof nm, hipMemcpyDeviceToHost));
-    out[0] = nm.flops; out[1] = nm.flops_upd;
-    return 0;
-}
-
-int stmmqr_plan_result_sizes(const stmmqr_plan *plan, stm_long *rh_total, stm_long *rank)
-{
-    if (!plan || !plan->factored) return fail(STMMQR_ERR_INVALID, "no factorization held by the plan");
-    if (rh_total) *rh_total = (stm_long)plan->rh_total;
-    if (rank) *rank = plan->rank;
-    return 0;
-}
-
-// ---------------------------------------------------------------------------------------------
-// QR_qmult (SparseQR.c:1790-2020, methods QR_QTX / QR_QX) and QR_solve (RETX_EQUALS_B, :2024-2216)
-// on the factors that are still in HBM -- no download of the packed R+H.
-// ---------------------------------------------------------------------------------------------
-namespace {
-// host half of qr_hpinv for the device: Wmap[S-row id] = position in the permuted row order (same rule as in
-// stmmqr_plan_download); uploaded once per factorization together with the static maps
-int ensure_scratch(stmmqr_plan &P);
-int ensure_rowmap(stmmqr_plan &P)
-{
-    LCHK(ensure_scratch(P));
-    if (P.rowmap_ready) return 0;
-    hipStream_t st = P.stream;
-    const long nf = P.nf, m = P.m, n = P.n;
-    for (long f = 0; f < nf; f++)
-        if (P.group[f] < 0) return fail(STMMQR_ERR_INVALID, "Q-apply / solve need every front on this device");
-    std::vector<int> hii32((size_t)std::max(1L, P.hisize));
-    if (P.hisize > 0)
-        HIPCHK(hipMemcpyAsync(hii32.data(), P.d_Hii.p, (size_t)P.hisize * sizeof(int), hipMemcpyDeviceToHost, st));
-    if (P.h_fnum.size() != (size_t)nf) P.h_fnum.resize((size_t)nf);
-    if (nf > 0)
-        HIPCHK(hipMemcpyAsync(P.h_fnum.data(), P.d_fnum.p, (size_t)nf * sizeof(FrontNum), hipMemcpyDeviceToHost, st));
-    HIPCHK(hipStreamSynchronize(st));
-    std::vector<int> W((size_t)std::max(1L, m), 0);
-    long row1 = 0, row2 = m;
-    for (long i = P.Sleft[n]; i < m; i++) W[i] = (int)--row2;
-    for (long f = 0; f < nf; f++) {
-        const int *Hi = hii32.data() + P.Hip[f];
-        const FrontNum &nm = P.h_fnum[f];
-        const long rm = nm.rank, fm = nm.fm;
-        for (long i = 0; i < rm; i++) W[Hi[i]] = (int)row1++;
-        const long cn = P.fs[f].fn - P.fs[f].fp;
-        const long cm = std::min(fm - rm, cn);
-        for (long i = fm - 1; i >= rm + cm; i--) W[Hi[i]] = (int)--row2;
-    }
-    LCHK(P.d_Wmap.upload(W, st));
-    {
-        std::vector<int> rb((size_t)std::max(1L, nf), 0);
-        long run = 0;
-        for (long f = 0; f < nf; f++) { rb[f] = (int)run; run += P.h_fnum[f].rank; }
-        LCHK(P.d_rowbase.upload(rb, st));
-    }
-    HIPCHK(hipStreamSynchronize(st));
-    if (!P.d_Rj.p) {
-        std::vector<int> t((size_t)std::max(1L, P.rjsize));
-        for (long i = 0; i < P.rjsize; i++) t[i] = (int)P.Rj[i];
-        LCHK(P.d_Rj.upload(t, st));
-        HIPCHK(hipStreamSynchronize(st));
-        t.assign((size_t)std::max(1L, m), 0);
-        for (long i = 0; i < m; i++) t[i] = (int)P.PLinv[i];
-        LCHK(P.d_PLinv.upload(t, st));
-        HIPCHK(hipStreamSynchronize(st));
-        if (P.has_qfill) {
-            t.assign((size_t)std::max(1L, n), 0);
-            for (long j = 0; j < n; j++) t[j] = (int)P.Qfill[j];
-            LCHK(P.d_Qfill.upload(t, st));
-            HIPCHK(hipStreamSynchronize(st));
-        }
-        LCHK(P.d_W.alloc((size_t)std::max(1L, m)));
-        LCHK(P.d_Xs.alloc((size_t)std::max(1L, n)));
-        LCHK(P.d_Io.alloc((size_t)std::max(1L, std::max(m, n))));
-        LCHK(P.d_err.alloc(1));
-        // dynamic LDS per level: k_qapply holds fm doubles + fn ints, k_rsolve fp + (fn - fp) doubles
-        const auto &LV = P.glevels[0];
-        P.level_lds_qa.assign(LV.size(), 0);
-        P.level_lds_qa_all.assign(LV.size(), 0);
-        P.level_lds_rs.assign(LV.size(), 0);
-        P.level_lds_rt.assign(LV.size(), 0);
-        P.level_qbig.assign(LV.size(), stmmqr_plan::QbLevel());
-        P.t4items.clear(); P.t4fronts.clear(); P.t4dqo.clear(); P.qbt4off.clear();
-        P.t4_doubles = 0; P.dq4_ints = 0; P.t4_ok = false; P.t4_tried = false; P.t4_valid = false;
-        std::vector<QbDesc> qb;
-        long xf = 1, dq = 1, wq = 1;
-        for (size_t l = 0; l < LV.size(); l++) {
-            long xo = 0, dqo = 0, wo = 0;
-            P.level_qbig[l].off = (int)qb.size();
-            P.level_qbig[l].t4i_off = (int)P.t4items.size();
-            for (int q = 0; q < LV[l].n_all; q++) {
-                const int f = P.lists[LV[l].all_off + q];
-                const FrontSym &s = P.fs[f];
-                const int need = (int)(((s.fm_ub + 1) & ~1) * 8 + s.fn * 4 + 16);
-                P.level_lds_rt[l] = std::max(P.level_lds_rt[l], (int)((((s.fn + 1) & ~1) + ((std::min(s.fp, std::max(s.fm_ub, 1)) + 2) & ~1)) * 8 + s.fp * 4 + 32));
-                P.level_lds_qa_all[l] = std::max(P.level_lds_qa_all[l], need);
-                if (s.qbig) {
-                    QbDesc d;
-                    d.f = f; d.xoff = (int)xo; d.dqoff = (int)dqo; d.wqoff = (int)wo; d.nslab = (s.fm_ub + STM_QB_ROWS - 1) / STM_QB_ROWS; d.pad = 0;
-                    qb.push_back(d);
-                    {
-                        const int ngr = (s.npanels + 3) / 4;
-                        P.qbt4off.push_back(P.t4_doubles);
-                        P.t4fronts.push_back(f);
-                        P.t4dqo.push_back(P.dq4_ints);
-                        for (int g = 0; g < ngr; g++) {
-                            Qt4ItemHost it;
-                            it.f = f; it.g = g; it.off = P.t4_doubles + (long long)g * stm_qt4_doubles(); it.dqo = P.dq4_ints;
-                            P.t4items.push_back(it);
-                        }
-                        P.t4_doubles += (long long)ngr * stm_qt4_doubles();
-                        P.dq4_ints += s.fn;
-                    }
-                    xo += s.fm_ub; dqo += s.fn; wo += 2L * d.nslab * STM_NB;
-                    auto &Q = P.level_qbig[l];
-                    Q.n++; Q.max_np = std::max(Q.max_np, s.npanels); Q.max_nslab = std::max(Q.max_nslab, d.nslab);
-                    Q.max_fm = std::max(Q.max_fm, s.fm_ub);
-                    Q.max_rsteps = std::max(Q.max_rsteps, (std::min(s.fp, s.fm_ub) + 31) / 32);
-                } else {
-                    P.level_lds_qa[l] = std::max(P.level_lds_qa[l], need);
-                    P.level_lds_rs[l] = std::max(P.level_lds_rs[l], (int)((((s.fp + 1) & ~1) + (s.fn - s.fp) + 2) * 8 + s.fp * 4 + 16));
-                }
-            }
-            P.level_qbig[l].t4i_n = (int)P.t4items.size() - P.level_qbig[l].t4i_off;
-            xf = std::max(xf, xo); dq = std::max(dq, dqo); wq = std::max(wq, wo);
-        }
-        LCHK(P.d_Xf.alloc((size_t)xf));
-        LCHK(P.d_Dq.alloc((size_t)dq));
-        LCHK(P.d_Wq.alloc((size_t)wq));
-        P.wq4_doubles = 4 * wq;
-        P.xf_doubles = xf; P.wq_doubles = wq; P.rhs_cap = 1;
-        P.d_U.release(); P.d_Xr.release();
-        if (qb.empty()) qb.push_back(QbDesc());
-        LCHK(P.d_qb.alloc(qb.size()));
-        LCHK(P.d_Rm.alloc(qb.size()));
-        HIPCHK(hipMemcpy(P.d_qb.p, qb.data(), qb.size() * sizeof(QbDesc), hipMemcpyHostToDevice));
-    }
-    for (int b : P.level_lds_qa)
-        if (b > 131072) return fail(STMMQR_ERR_TOO_LARGE, "a front has more rows than the Q-apply kernel holds in LDS");
-    P.rowmap_ready = true;
-    return 0;
-}
-
-int check_device_err(stmmqr_plan &P, const char *what)
-{
-    int e = 0;
-    HIPCHK(hipMemcpyAsync(&e, P.d_err.p, sizeof(int), hipMemcpyDeviceToHost, P.stream));
-    HIPCHK(hipStreamSynchronize(P.stream));
-    if (e) return fail(STMMQR_ERR_INVALID, what);
-    return 0;
-}
-
-// Slab recycling: the resident-factor kernels read fronts in front form.  A front whose slab was recycled is put back into
-// that form, level by level, in a scratch that holds the widest tree level (res_ctx: the FrontSym array whose offsets point into
-// the scratch; level_to_front_form: zeros + the inverse of k_rh_copy for the level's fronts).  Kept fronts are read where they are
-// (their offset is taken relative to the scratch's base: one flat device address space).
-int ensure_scratch(stmmqr_plan &P)
-{
-    if (!P.recycle || (P.d_scr.p && P.d_fs_scr.p)) return 0;
-    // Two layouts.  Where HBM has room (all recycled slabs within a quarter of what is free; STMMQR_RESIDENT_CACHE=0 / 1 forces) the
-    // scratch holds EVERY front in front form, rebuilt once per factorization at the first Q-apply / solve and kept for the
-    // following ones: the memory comes back only while the factors are being used, never during the factorization.  Otherwise it
-    // holds the widest tree level and every level is rebuilt whenever a kernel walks it.
-    size_t freeb = 0, totalb = 0;
-    HIPCHK(hipMemGetInfo(&freeb, &totalb));
-    long long all = 0;
-    for (long f = 0; f < P.nf; f++) if (!P.kept[(size_t)f]) all += (long long)P.fs[f].ld * P.fs[f].fn;
-    const char *ev = getenv("STMMQR_RESIDENT_CACHE");
-    P.scr_all = ev ? atoi(ev) != 0 : (8.0 * (double)all <= 0.25 * (double)freeb);
-    if (P.scr_all) {
-        long long o = 0;
-        for (long f = 0; f < P.nf; f++)
-            if (!P.kept[(size_t)f]) { P.fs_scr[(size_t)f].foff = o; o += (long long)P.fs[f].ld * P.fs[f].fn; }
-    }
-    P.scr_valid = false;
-    P.t4_valid = false;
-    LCHK(P.d_scr.alloc((size_t)std::max(1LL, P.scr_all ? all : P.scr_doubles)));
-    std::vector<FrontSym> t = P.fs_scr;
-    for (long f = 0; f < P.nf; f++)
-        if (P.kept[(size_t)f]) t[(size_t)f].foff = (long long)((P.d_F.p + P.fs[f].foff) - P.d_scr.p);
-    LCHK(P.d_fs_scr.upload(t, P.stream));
-    HIPCHK(hipStreamSynchronize(P.stream));
-    return 0;
-}
-DevCtx res_ctx(stmmqr_plan &P)
-{
-    DevCtx c = P.ctx();
-    if (P.recycle) { c.fs = P.d_fs_scr.p; c.Farena = P.d_scr.p; }
-    return c;
-}
-int level_to_front_form(stmmqr_plan &P, size_t l)
-{
-    if (!P.recycle) return 0;
-    const auto &LV = P.glevels[0];
-    const DevCtx c = P.ctx();
-    if (P.scr_all) {
-        if (P.scr_valid) return 0;
-        // every front at once, kept until the next factorization (marked valid only once the launch was accepted)
-        const int e = stm_launch_rh_unpack(c, P.d_fs_scr.p, P.d_lists.p + P.own_off, P.n_own, 64, P.d_kept.p, P.d_RH.p, P.d_scr.p, P.stream);
-        P.scr_valid = (e == 0);
-        return e;
-    }
-    if (LV[l].n_all <= 0) return 0;
-    return stm_launch_rh_unpack(c, P.d_fs_scr.p, P.d_lists.p + LV[l].all_off, LV[l].n_all, 64, P.d_kept.p, P.d_RH.p, P.d_scr.p, P.stream);
-}
-
-// the per-vector buffers of the resident-factor operations for a batch of nb right-hand sides (grown on demand, never shrunk)
-int ensure_rhs_batch(stmmqr_plan &P, int nb)
-{
-    if (nb <= P.rhs_cap) return 0;
-    const size_t k = (size_t)nb;
-    LCHK(P.d_W.alloc(k * (size_t)std::max(1L, P.m)));
-    LCHK(P.d_Xs.alloc(k * (size_t)std::max(1L, P.n)));
-    LCHK(P.d_Xf.alloc(k * (size_t)P.xf_doubles));
-    LCHK(P.d_Wq.alloc(k * (size_t)P.wq_doubles));
-    if (P.d_Wq4.p) LCHK(P.d_Wq4.alloc(k * (size_t)std::max(1LL, P.wq4_doubles)));
-    if (P.d_U.p) { LCHK(P.d_U.alloc(k * (size_t)std::max(1L, P.rjsize))); LCHK(P.d_Xr.alloc(k * (size_t)std::max(1L, P.m))); }
-    P.rhs_cap = nb;
-    return 0;
-}
-RhsBatch rhs_strides(const stmmqr_plan &P)
-{
-    RhsBatch B;
-    B.w = P.m; B.x = P.n; B.xf = P.xf_doubles; B.wq = P.wq_doubles; B.wq4 = std::max(1LL, P.wq4_doubles); B.u = std::max(1L, P.rjsize);
-    return B;
-}
-// the largest batch the operations take in one pass (STMMQR_RHS_BATCH, default 32; 1: one vector after the other, as until round 4)
-int rhs_batch_max()
-{
-    static int v = -1;
-    if (v < 0) v = getenv("STMMQR_RHS_BATCH") ? std::max(1, atoi(getenv("STMMQR_RHS_BATCH"))) : 32;
-    return v;
-}
-
-// W (device, S-row order; nb vectors at stride m) <- Q' W or Q W
-int run_qapply(stmmqr_plan &P, int method, int nb = 1)
-{
-    const RhsBatch B = rhs_strides(P);
-    DevCtx c = res_ctx(P);
-    const int *L0 = P.d_lists.p;
-    const auto &LV = P.glevels[0];
-    // blocked form with the kept T factors; STMMQR_DBG bit 13 selects the reflector-by-reflector kernel (same result up
-    // to rounding: used by the tests to cross-check the two)
-    const bool blocked = c.Tall && !(c.dbg & 8192);
-    // grouped split Q-apply: its buffers at the first use (STMMQR_QT4=0: the per-panel launches)
-    const bool want_t4 = !(getenv("STMMQR_QT4") && atoi(getenv("STMMQR_QT4")) == 0);       // (read at every call: tests compare both)
-    if (blocked && want_t4 && !P.t4_tried && !P.t4items.empty()) {
-        P.t4_tried = true;
-        size_t freeb = 0, totalb = 0;
-        if (hipMemGetInfo(&freeb, &totalb) == hipSuccess &&
-            8.0 * ((double)P.t4_doubles + (double)P.wq4_doubles) + 4.0 * (double)P.dq4_ints < 0.25 * (double)freeb) {
-            LCHK(P.d_T4.alloc((size_t)P.t4_doubles));
-            LCHK(P.d_Wq4.alloc((size_t)P.rhs_cap * (size_t)std::max(1LL, P.wq4_doubles)));
-            LCHK(P.d_Dq4.alloc((size_t)std::max(1LL, P.dq4_ints)));
-            LCHK(P.d_t4items.upload(P.t4items, P.stream));
-            LCHK(P.d_t4fronts.upload(P.t4fronts, P.stream));
-            LCHK(P.d_t4dqo.upload(P.t4dqo, P.stream));
-            LCHK(P.d_qbt4off.upload(P.qbt4off, P.stream));
-            P.t4_ok = true;
-            P.t4_valid = false;
-        }
-    }
-    const bool use_t4 = blocked && want_t4 && P.t4_ok;
-    if (use_t4 && getenv("STMMQR_MEMDUMP") && !P.t4_valid)
-        fprintf(stderr, "[stmmqr_hip] grouped Q-apply: T4 of %zu groups of %zu split fronts, %.3f GB (+ %.3f GB of slab partials)\n", P.t4items.size(),
-                P.t4fronts.size(), 8e-9 * (double)P.t4_doubles, 8e-9 * (double)P.wq4_doubles);
-    auto launch = [&](size_t l, int m) -> int {
-        LCHK(level_to_front_form(P, l));
-        if (blocked) {
-            LCHK(stm_launch_qapply_t(c, L0 + LV[l].all_off, LV[l].n_all, m, P.d_W.p, P.level_lds_qa[l], P.stream, nb, B));
-            // the large fronts of the level (independent of the others): rows split over workgroups, a launch per group of four panels
-            // (k_qbig_step4, T4 built at the first use after a factorization) or per panel
-            const auto &Q = P.level_qbig[l];
-            if (Q.n > 0 && use_t4) {
-                if (!P.t4_valid) { P.t4_level_valid.assign(LV.size(), 0); P.t4_valid = true; }
-                if (!P.t4_level_valid[l]) {                          // (the level's fronts are in front form now: level_to_front_form)
-                    LCHK(stm_launch_qt4_build(c, P.d_t4fronts.p + Q.off, P.d_t4dqo.p + Q.off, Q.n, P.d_t4items.p + Q.t4i_off, Q.t4i_n, P.d_Dq4.p,
-                                              P.d_T4.p, P.stream));
-                    P.t4_level_valid[l] = 1;
-                }
-                LCHK(stm_launch_qapply_big4(c, P.d_qb.p + Q.off, P.d_qbt4off.p + Q.off, Q.n, Q.max_np, Q.max_nslab, Q.max_fm, m, P.d_W.p, P.d_Xf.p,
-                                            P.d_Dq.p, P.d_Wq4.p, P.d_T4.p, P.stream, nb, B));
-                return 0;
-            }
-            LCHK(stm_launch_qapply_big(c, P.d_qb.p + Q.off, Q.n, Q.max_np, Q.max_nslab, Q.max_fm, m, P.d_W.p, P.d_Xf.p, P.d_Dq.p,
-                                       P.d_Wq.p, P.stream, nb, B));
-            return 0;
-        }
-        if (P.level_lds_qa_all[l] > 131072) return fail(STMMQR_ERR_TOO_LARGE, "a front has more rows than the unblocked Q-apply kernel holds in LDS");
-        for (int j = 0; j < nb; j++)                                  // (the reflector-by-reflector cross-check kernel: one vector per launch)
-            LCHK(stm_launch_qapply(c, L0 + LV[l].all_off, LV[l].n_all, m, P.d_W.p + (size_t)j * (size_t)P.m, P.level_lds_qa_all[l], P.d_err.p, P.stream));
-        return 0;
-    };
-    if (method == 0) {
-        for (size_t l = 0; l < LV.size(); l++) LCHK(launch(l, 0));
-    } else {
-        for (size_t l = LV.size(); l-- > 0;) LCHK(launch(l, 1));
-    }
-    return 0;
-}
-}  // namespace
-
-namespace {
-// host matrix (rows x cols, leading dimension ld) <-> contiguous device matrix (rows x cols), one transfer each way
-int upload_cols(stmmqr_plan &P, DevBuf<double> &d, const double *H, long ld, long rows, long cols)
-{
-    if ((size_t)(rows * cols) > d.n) LCHK(d.alloc((size_t)std::max(1L, rows * cols)));
-    if (rows > 0 && cols > 0)
-        HIPCHK(hipMemcpy2DAsync(d.p, (size_t)rows * sizeof(double), H, (size_t)ld * sizeof(double), (size_t)rows * sizeof(double),
-                                (size_t)cols, hipMemcpyHostToDevice, P.stream));
-    return 0;
-}
-int download_cols(stmmqr_plan &P, const DevBuf<double> &d, double *H, long ld, long rows, long cols)
-{
-    if (rows > 0 && cols > 0)
-        HIPCHK(hipMemcpy2DAsync(H, (size_t)ld * sizeof(double), d.p, (size_t)rows * sizeof(double), (size_t)rows * sizeof(double),
-                                (size_t)cols, hipMemcpyDeviceToHost, P.stream));
-    HIPCHK(hipStreamSynchronize(P.stream));
-    return 0;
-}
-// nb vectors (stride m in `in` / `out`, device, the reference's row order) through Q' (method 0) or Q (method 1) in ONE pass over the tree
-int qapply_vectors(stmmqr_plan &P, int method, const double *in, double *out, int nb)
-{
-    hipStream_t st = P.stream;
-    const int m = (int)P.m;
-    LCHK(ensure_rhs_batch(P, nb));
-    if (method == 0) {
-        LCHK(stm_launch_perm(in, P.d_PLinv.p, P.d_W.p, m, 1, st, nb, m, m));            // W[PLinv[i]] = x[i]
-        LCHK(run_qapply(P, 0, nb));
-        LCHK(stm_launch_perm(P.d_W.p, P.d_Wmap.p, out, m, 1, st, nb, m, m));            // out[Wmap[r]] = W[r]
-    } else {
-        LCHK(stm_launch_perm(in, P.d_Wmap.p, P.d_W.p, m, 0, st, nb, m, m));             // W[r] = x[Wmap[r]]
-        LCHK(run_qapply(P, 1, nb));
-        LCHK(stm_launch_perm(P.d_W.p, P.d_PLinv.p, out, m, 0, st, nb, m, m));           // out[i] = W[PLinv[i]]
-    }
-    return 0;
-}
-// back substitution R x = y on the device work vectors W (internal row order; nb of them at stride m) -> d_Xs (R's column order, stride n)
-int rsolve_vector(stmmqr_plan &P, int nb = 1)
-{
-    const RhsBatch B = rhs_strides(P);
-    DevCtx c = res_ctx(P);
-    const int *L0 = P.d_lists.p;
-    const auto &LV = P.glevels[0];
-    hipStream_t st = P.stream;
-    for (size_t l = LV.size(); l-- > 0;) {
-        LCHK(level_to_front_form(P, l));
-        LCHK(stm_launch_rsolve(c, L0 + LV[l].all_off, LV[l].n_all, P.d_Rj.p, P.d_W.p, P.d_Xs.p, P.level_lds_rs[l], P.d_err.p, st, nb, B));
-        const auto &Q = P.level_qbig[l];         // the large fronts of the level: rows split over workgroups
-        LCHK(stm_launch_rsolve_big(c, P.d_qb.p + Q.off, Q.n, Q.max_rsteps, Q.max_nslab, P.d_Rj.p, P.d_W.p, P.d_Xs.p, P.d_Xf.p,
-                                   P.d_Dq.p, P.d_Rm.p + Q.off, P.d_err.p, st, nb, B));
-    }
-    return 0;
-}
-}  // namespace
-
-// QR_qmult (STMMQR/include/SparseQR.h:403-409, SparseQR.c:1815-2116) on the resident factors, in place:
-//   method 0 QR_QTX: X (m x k, ldx >= m) <- Q' X      method 1 QR_QX: X <- Q X
-//   method 2 QR_XQT: X (k x m, ldx >= k) <- X Q'      method 3 QR_XQ: X <- X Q
-// Row (methods 0, 1) / column (2, 3) order as in the reference: Q'X and X Q come out in the permuted order of the
-// factorization (HPinv), Q X and X Q' take it.  All vectors cross PCIe in ONE transfer each way.
-int stmmqr_plan_qmult(stmmqr_plan *plan, int method, double *X, stm_long ldx, stm_long k)
-{
-    if (!plan || !plan->factored) return fail(STMMQR_ERR_INVALID, "no factorization held by the plan");
-    if (!X || k < 0 || method < 0 || method > 3 || ldx < ((method <= 1) ? plan->m : k))
-        return fail(STMMQR_ERR_INVALID, "bad qmult arguments");
-    stmmqr_plan &P = *plan;
-    HIPCHK(hipSetDevice(P.device));
-    LCHK(ensure_rowmap(P));
-    const long m = P.m;
-    if (k == 0 || m == 0) return 0;
-    if (method <= 1) {
-        LCHK(upload_cols(P, P.d_Xall, X, ldx, m, k));
-        // (batches of right-hand sides: every launch of the pass over the tree carries all of them, RhsBatch)
-        for (stm_long j = 0; j < k; j += rhs_batch_max()) {
-            const int nb = (int)std::min<stm_long>(rhs_batch_max(), k - j);
-            LCHK(qapply_vectors(P, method, P.d_Xall.p + j * m, P.d_Xall.p + j * m, nb));
-        }
-        return download_cols(P, P.d_Xall, X, ldx, m, k);
-    }
-    // X Q' = (Q X')' and X Q = (Q' X')': the rows of X are the vectors (SparseQR.c:2040-2075: the same permutation pattern)
-    std::vector<double> T((size_t)m * (size_t)k);
-    for (stm_long r = 0; r < k; r++)
-        for (long i = 0; i < m; i++) T[(size_t)r * m + i] = X[r + (size_t)i * ldx];
-    LCHK(upload_cols(P, P.d_Xall, T.data(), m, m, k));
-    const int vm = (method == 2) ? 1 : 0;
-    for (stm_long r = 0; r < k; r += rhs_batch_max()) {
-        const int nb = (int)std::min<stm_long>(rhs_batch_max(), k - r);
-        LCHK(qapply_vectors(P, vm, P.d_Xall.p + r * m, P.d_Xall.p + r * m, nb));
-    }
-    LCHK(download_cols(P, P.d_Xall, T.data(), m, m, k));
-    for (stm_long r = 0; r < k; r++)
-        for (long i = 0; i < m; i++) X[r + (size_t)i * ldx] = T[(size_t)r * m + i];
-    return 0;
-}
-
-// QR_solve (STMMQR/include/SparseQR.h:411-417, SparseQR.c:2118-2216) on the resident factors:
-//   system 0 QR_RX_EQUALS_B   : X (n x nrhs) = R \ B            B (m x nrhs) in R's row order (what QR_QTX returns)
-//   system 1 QR_RETX_EQUALS_B : X = E (R \ B)
-//   system 2 QR_RTX_EQUALS_B  : X (m x nrhs) = R' \ B           B (n x nrhs), rows of X beyond the rank are zero
-//   system 3 QR_RTX_EQUALS_ETB: X = R' \ (E' B)
-// Dead pivot columns: x = 0 (systems 0, 1: the basic solution of qr_rsolve) / no equation (2, 3: the squeezed R).
-int stmmqr_plan_rsolve(stmmqr_plan *plan, int system, const double *B, stm_long ldb, double *X, stm_long ldx, stm_long nrhs)
-{
-    if (!plan || !plan->factored) return fail(STMMQR_ERR_INVALID, "no factorization held by the plan");
-    if (system < 0 || system > 3 || !B || !X || nrhs < 0) return fail(STMMQR_ERR_INVALID, "bad solve arguments");
-    stmmqr_plan &P = *plan;
-    const long m = P.m, n = P.n;
-    const long brows = (system <= 1) ? m : n, xrows = (system <= 1) ? n : m;
-    if (ldb < brows || ldx < xrows) return fail(STMMQR_ERR_INVALID, "bad leading dimension");
-    HIPCHK(hipSetDevice(P.device));
-    LCHK(ensure_rowmap(P));
-    hipStream_t st = P.stream;
-    if (nrhs == 0) return 0;
-    HIPCHK(hipMemsetAsync(P.d_err.p, 0, sizeof(int), st));
-    LCHK(upload_cols(P, P.d_Xall, B, ldb, brows, nrhs));
-    if ((size_t)(xrows * nrhs) > P.d_Yall.n) LCHK(P.d_Yall.alloc((size_t)std::max(1L, xrows * nrhs)));
-    const int nbmax = rhs_batch_max();
-    const RhsBatch RB = rhs_strides(P);
-    if (system <= 1) {
-        for (stm_long j = 0; j < nrhs; j += nbmax) {
-            const int nb = (int)std::min<stm_long>(nbmax, nrhs - j);
-            LCHK(ensure_rhs_batch(P, nb));
-            LCHK(stm_launch_perm(P.d_Xall.p + j * m, P.d_Wmap.p, P.d_W.p, (int)m, 0, st, nb, m, m));          // W[r] = b[Wmap[r]]
-            LCHK(rsolve_vector(P, nb));
-            LCHK(stm_launch_perm(P.d_Xs.p, (system == 1 && P.has_qfill) ? P.d_Qfill.p : nullptr, P.d_Yall.p + j * n, (int)n, 1, st, nb, n, n));
-        }
-    } else {
-        DevCtx c = res_ctx(P);
-        const int *L0 = P.d_lists.p;
-        const auto &LV = P.glevels[0];
-        if (!P.d_U.p) {
-            LCHK(P.d_U.alloc((size_t)P.rhs_cap * (size_t)std::max(1L, P.rjsize)));
-            LCHK(P.d_Xr.alloc((size_t)P.rhs_cap * (size_t)std::max(1L, m)));
-        }
-        for (int need : P.level_lds_rt)
-            if (need > 131072) return fail(STMMQR_ERR_TOO_LARGE, "a front is too wide for the one-workgroup R' solve");
-        for (stm_long j = 0; j < nrhs; j += nbmax) {
-            const int nb = (int)std::min<stm_long>(nbmax, nrhs - j);
-            LCHK(ensure_rhs_batch(P, nb));
-            // b in R's column order: E'B gathers through Qfill
-            LCHK(stm_launch_perm(P.d_Xall.p + j * n, (system == 3 && P.has_qfill) ? P.d_Qfill.p : nullptr, P.d_Xs.p, (int)n, 0, st, nb, n, n));
-            HIPCHK(hipMemsetAsync(P.d_Xr.p, 0, (size_t)nb * (size_t)std::max(1L, m) * sizeof(double), st));
-            for (size_t l = 0; l < LV.size(); l++) {
-                LCHK(level_to_front_form(P, l));
-                LCHK(stm_launch_rtsolve(c, L0 + LV[l].all_off, LV[l].n_all, P.d_Xs.p, P.d_U.p, P.d_Xr.p, P.d_rowbase.p,
-                                        P.level_lds_rt[l], st, nb, RB));
-            }
-            HIPCHK(hipMemcpyAsync(P.d_Yall.p + j * m, P.d_Xr.p, (size_t)nb * (size_t)m * sizeof(double), hipMemcpyDeviceToDevice, st));
-        }
-    }
-    LCHK(download_cols(P, P.d_Yall, X, ldx, xrows, nrhs));
-    return check_device_err(P, "internal: live pivot count of a front differs from its rank");
-}
-
-// X (n x nrhs, ldx >= n) = E * R^{-1} * (Q' B)(1:n)  for B (m x nrhs, ldb >= m): QR_qmult(QR_QTX) followed by
-// QR_solve(QR_RETX_EQUALS_B), the driver's least-squares solve (qrtest.c:11-53), without the trip to the host in between;
-// dead columns get x = 0 (basic solution).
-int stmmqr_plan_solve(stmmqr_plan *plan, const double *B, stm_long ldb, double *X, stm_long ldx, stm_long nrhs)
-{
-    if (!plan || !plan->factored) return fail(STMMQR_ERR_INVALID, "no factorization held by the plan");
-    if (!B || !X || ldb < plan->m || ldx < plan->n || nrhs < 0) return fail(STMMQR_ERR_INVALID, "bad solve arguments");
-    stmmqr_plan &P = *plan;
-    HIPCHK(hipSetDevice(P.device));
-    LCHK(ensure_rowmap(P));
-    hipStream_t st = P.stream;
-    const long m = P.m, n = P.n;
-    if (nrhs == 0) return 0;
-    HIPCHK(hipMemsetAsync(P.d_err.p, 0, sizeof(int), st));
-    LCHK(upload_cols(P, P.d_Xall, B, ldb, m, nrhs));
-    if ((size_t)(n * nrhs) > P.d_Yall.n) LCHK(P.d_Yall.alloc((size_t)std::max(1L, n * nrhs)));
-    for (stm_long j = 0; j < nrhs; j += rhs_batch_max()) {
-        const int nb = (int)std::min<stm_long>(rhs_batch_max(), nrhs - j);
-        LCHK(ensure_rhs_batch(P, nb));
-        LCHK(stm_launch_perm(P.d_Xall.p + j * m, P.d_PLinv.p, P.d_W.p, (int)m, 1, st, nb, m, m));
-        LCHK(run_qapply(P, 0, nb));
-        LCHK(rsolve_vector(P, nb));
-        LCHK(stm_launch_perm(P.d_Xs.p, P.has_qfill ? P.d_Qfill.p : nullptr, P.d_Yall.p + j * n, (int)n, 1, st, nb, n, n));   // X[Qfill[j]] = x[j]
-    }
-    LCHK(download_cols(P, P.d_Yall, X, ldx, n, nrhs));
-    return check_device_err(P, "internal: live pivot count of a front differs from its rank");
 }
 
 int stmmqr_plan_download(stmmqr_plan *plan, double *Stack, stm_long *Rblock_off, char *Rdead, stm_long *HStair,
@@ -3274,378 +2050,6 @@ int stmmqr_factorize_arrays(const stmmqr_symbolic_view *sym, const stm_long *Ap,
     if (!st) st = stmmqr_plan_download(P, Stack, Rblock_off, Rdead, HStair, HTau, Hii, HPinv, Hm, Hr, scalars, stats);
     stmmqr_plan_destroy(P);
     return st;
-}
-
-// -------------------------------------------------------------------------------------------------
-// drop-in seam: qr_factorize with the reference's structs
-// -------------------------------------------------------------------------------------------------
-static inline int &cc_int(stm_sparse_common *cc, size_t off) { return *(int *)((char *)cc + off); }
-static inline size_t &cc_size(stm_sparse_common *cc, size_t off) { return *(size_t *)((char *)cc + off); }
-static inline double &cc_dbl(stm_sparse_common *cc, size_t off) { return *(double *)((char *)cc + off); }
-
-// (stmmqr_internal.h: shared with stmmqr_seams.cpp / stmmqr_symbolic.cpp; local to the library)
-int stm_fail(int code, const char *msg) { return fail(code, msg ? msg : ""); }
-void stm_cc_set_status(stm_sparse_common *cc, int code) { if (cc) cc_int(cc, g_layout.status) = code; }
-static void *cc_malloc(size_t n, size_t size, stm_sparse_common *cc, bool zero = false);
-static void cc_free(size_t n, size_t size, void *p, stm_sparse_common *cc);
-void *stm_cc_malloc(size_t n, size_t size, stm_sparse_common *cc) { return cc_malloc(n, size, cc, false); }
-void stm_cc_free(size_t n, size_t size, void *p, stm_sparse_common *cc) { cc_free(n, size, p, cc); }
-// ... and exported for libstmmqr_hip_api.so (csrc/stmmqr_api.cpp): what it returns is released by the reference's own
-// SparseCore_free_dense / SparseCore_free and must be counted the same way
-void *stmmqr_cc_malloc(size_t n, size_t size, stm_sparse_common *cc) { return cc_malloc(n, size, cc, false); }
-void stmmqr_cc_free(size_t n, size_t size, void *p, stm_sparse_common *cc) { cc_free(n, size, p, cc); }
-void stmmqr_cc_set_status(stm_sparse_common *cc, int code) { stm_cc_set_status(cc, code); }
-
-// SparseCore_malloc semantics (src/core/SparseCore_common.c:603-655): malloc(max(1,n)*size) + counters
-static void *cc_malloc(size_t n, size_t size, stm_sparse_common *cc, bool zero)
-{
-    void *p = zero ? calloc(std::max<size_t>(1, n), size) : malloc(std::max<size_t>(1, n) * size);
-    if (!p) {
-        if (cc) cc_int(cc, g_layout.status) = STMMQR_ERR_OUT_OF_MEMORY;
-        return nullptr;
-    }
-    if (cc) {
-        cc_size(cc, g_layout.malloc_count)++;
-        cc_size(cc, g_layout.memory_inuse) += n * size;
-        cc_size(cc, g_layout.memory_usage) =
-            std::max(cc_size(cc, g_layout.memory_usage), cc_size(cc, g_layout.memory_inuse));
-    }
-    return p;
-}
-static void cc_free(size_t n, size_t size, void *p, stm_sparse_common *cc)
-{
-    if (!p) return;
-    free(p);
-    if (cc) {
-        cc_size(cc, g_layout.malloc_count)--;
-        cc_size(cc, g_layout.memory_inuse) -= n * size;
-    }
-}
-// SparseCore_free_sparse (src/core/SparseCore_matrix_type.c:146-180)
-static void cc_free_sparse(stm_sparse_csc **Ah, stm_sparse_common *cc)
-{
-    if (!Ah || !*Ah) return;
-    stm_sparse_csc *A = *Ah;
-    cc_free(A->ncol + 1, sizeof(stm_long), A->p, cc);
-    cc_free(A->nzmax, sizeof(stm_long), A->i, cc);
-    cc_free(A->ncol, sizeof(stm_long), A->nz, cc);
-    cc_free(A->nzmax, sizeof(double), A->x, cc);
-    cc_free(1, sizeof(stm_sparse_csc), A, cc);
-    *Ah = nullptr;
-}
-static void free_numeric(stm_qr_numeric *N, stm_sparse_common *cc)
-{
-    if (!N) return;
-    cc_free(N->nf, sizeof(double *), N->Rblock, cc);
-    cc_free(N->n, 1, N->Rdead, cc);
-    cc_free(N->rjsize, sizeof(stm_long), N->HStair, cc);
-    cc_free(N->rjsize, sizeof(double), N->HTau, cc);
-    cc_free(N->nf, sizeof(stm_long), N->Hm, cc);
-    cc_free(N->nf, sizeof(stm_long), N->Hr, cc);
-    cc_free(N->hisize, sizeof(stm_long), N->Hii, cc);
-    cc_free(N->m, sizeof(stm_long), N->HPinv, cc);
-    if (N->Stacks)
-        for (stm_long s = 0; s < N->ns; s++)
-            cc_free(N->Stack_size ? N->Stack_size[s] : N->maxstack, sizeof(double), N->Stacks[s], cc);
-    cc_free(N->ns, sizeof(double *), N->Stacks, cc);
-    cc_free(N->ns, sizeof(stm_long), N->Stack_size, cc);
-    cc_free(1, sizeof(stm_qr_numeric), N, cc);
-}
-
-// ---- plan cache of the drop-in seam ------------------------------------------------------------------------------------
-// The reference's driver calls qr_factorize once per SparseQR(); an application that refactorizes (new values, same pattern)
-// calls it again with an equal qr_symbolic.  Building the plan (symbolic upload, schedule, workspaces, arena allocation) costs
-// about as much as the factorization itself on the BASELINE matrices, so the seam keeps the last plans: the key is a hash of
-// everything the plan is derived from (the qr_symbolic's scalars and arrays, the options and the environment knobs read at plan
-// time), a second hash of A's pattern tells whether the value map (qr_stranspose2) is still valid.  A cached plan keeps its
-// device memory: STMMQR_PLAN_CACHE=0 turns the cache off, STMMQR_PLAN_CACHE=n keeps n plans (default 1),
-// stmmqr_plan_cache_clear() / stmmqr_shutdown() release them.
-namespace {
-inline unsigned long long hash_bytes(const void *p, size_t bytes, unsigned long long h)
-{
-    const unsigned long long *w = (const unsigned long long *)p;
-    const size_t nw = bytes / 8;
-    unsigned long long h0 = h, h1 = h ^ 0x9e3779b97f4a7c15ULL, h2 = h + 0x632be59bd9b4e019ULL, h3 = ~h;
-    size_t i = 0;
-    for (; i + 4 <= nw; i += 4) {                          // four independent lanes: ~8 GB/s on one host core
-        h0 = (h0 ^ w[i]) * 0x100000001b3ULL; h0 ^= h0 >> 29;
-        h1 = (h1 ^ w[i + 1]) * 0x100000001b3ULL; h1 ^= h1 >> 31;
-        h2 = (h2 ^ w[i + 2]) * 0x100000001b3ULL; h2 ^= h2 >> 27;
-        h3 = (h3 ^ w[i + 3]) * 0x100000001b3ULL; h3 ^= h3 >> 30;
-    }
-    for (; i < nw; i++) { h0 = (h0 ^ w[i]) * 0x100000001b3ULL; h0 ^= h0 >> 29; }
-    const unsigned char *c = (const unsigned char *)p + nw * 8;
-    for (size_t k = 0; k < bytes % 8; k++) h1 = (h1 ^ c[k]) * 0x100000001b3ULL;
-    return ((h0 * 31 + h1) * 31 + h2) * 31 + h3;
-}
-unsigned long long symbolic_key(const stm_qr_symbolic *S)
-{
-    unsigned long long h = 0xcbf29ce484222325ULL;
-    const stm_long sc[] = {S->m, S->n, S->anz, S->nf, S->maxfn, S->rjsize, S->hisize, S->do_rank_detection, S->keepH,
-                           (stm_long)(S->Qfill != nullptr), (stm_long)(S->Fm != nullptr), S->maxstack};   // (maxstack sizes the R+H arena)
-    h = hash_bytes(sc, sizeof sc, h);
-    auto add = [&](const stm_long *a, stm_long cnt) { if (a && cnt > 0) h = hash_bytes(a, (size_t)cnt * sizeof(stm_long), h); };
-    add(S->Sp, S->m + 1); add(S->Sj, S->anz); add(S->Qfill, S->n); add(S->PLinv, S->m); add(S->Sleft, S->n + 2);
-    add(S->Child, S->nf + 1); add(S->Childp, S->nf + 2); add(S->Super, S->nf + 1); add(S->Rp, S->nf + 1); add(S->Rj, S->rjsize);
-    add(S->Post, S->nf); add(S->Hip, S->nf + 1); add(S->Fm, S->nf);
-    h = hash_bytes(&g_opt, sizeof g_opt, h);
-    // (every knob of the environment that is read when the plan / its schedule / its arenas are built)
-    for (const char *k : {"STMMQR_CA_MIN", "STMMQR_PAIR_MIN", "STMMQR_SCHED", "STMMQR_RIDE", "STMMQR_QBIG_MIN", "STMMQR_RECYCLE", "STMMQR_TUNE",
-                          "STMMQR_RH_EST_SCALE"}) {
-        const char *v = getenv(k);
-        if (v) h = hash_bytes(v, strlen(v), h ^ 0x51ed);
-    }
-    return h;
-}
-struct CachedPlan { unsigned long long key = 0, pat = 0; stmmqr_plan *plan = nullptr; int device = -1; unsigned long tick = 0; };
-std::mutex g_cache_mu;
-std::vector<CachedPlan> g_cache;
-unsigned long g_cache_tick = 0;
-int cache_capacity()
-{
-    const char *v = getenv("STMMQR_PLAN_CACHE");
-    return v ? std::max(0, atoi(v)) : 1;
-}
-// take a plan for this key out of the cache (nullptr: none); the caller owns it until cache_put
-stmmqr_plan *cache_take(unsigned long long key, unsigned long long *pat)
-{
-    std::lock_guard<std::mutex> lock(g_cache_mu);
-    int dev = 0;
-    (void)hipGetDevice(&dev);
-    for (size_t i = 0; i < g_cache.size(); i++)
-        if (g_cache[i].plan && g_cache[i].key == key && g_cache[i].device == dev) {
-            stmmqr_plan *P = g_cache[i].plan;
-            *pat = g_cache[i].pat;
-            g_cache.erase(g_cache.begin() + (long)i);
-            return P;
-        }
-    return nullptr;
-}
-void cache_put(unsigned long long key, unsigned long long pat, stmmqr_plan *P)
-{
-    const int cap = cache_capacity();
-    std::vector<stmmqr_plan *> drop;
-    {
-        std::lock_guard<std::mutex> lock(g_cache_mu);
-        if (cap <= 0) drop.push_back(P);
-        else {
-            CachedPlan e; e.key = key; e.pat = pat; e.plan = P; e.device = P->device; e.tick = ++g_cache_tick;
-            g_cache.push_back(e);
-            while ((int)g_cache.size() > cap) {
-                size_t old = 0;
-                for (size_t i = 1; i < g_cache.size(); i++) if (g_cache[i].tick < g_cache[old].tick) old = i;
-                drop.push_back(g_cache[old].plan);
-                g_cache.erase(g_cache.begin() + (long)old);
-            }
-        }
-    }
-    for (stmmqr_plan *q : drop) stmmqr_plan_destroy(q);
-}
-}  // namespace
-
-void stmmqr_plan_cache_clear(void)
-{
-    std::vector<CachedPlan> old;
-    {
-        std::lock_guard<std::mutex> lock(g_cache_mu);
-        old.swap(g_cache);
-    }
-    for (auto &e : old) if (e.plan) stmmqr_plan_destroy(e.plan);
-}
-
-/* release a qr_numeric returned by qr_factorize (for hosts WITHOUT the reference's qr_freenum; same accounting) */
-void stmmqr_free_numeric(stm_qr_numeric **Nh, stm_sparse_common *cc);
-
-// a large result array of the seam: plain malloc (the reference's qr_freenum releases it with free()), but asked to come in
-// huge pages and populated NOW by the kernel in one call instead of page fault by page fault under the copy that fills it
-static void prefault(void *p, size_t bytes)
-{
-#ifdef __linux__
-    if (!p || bytes < (8u << 20)) return;
-    const uintptr_t a = ((uintptr_t)p + 4095) & ~(uintptr_t)4095, b = ((uintptr_t)p + bytes) & ~(uintptr_t)4095;
-    if (b <= a) return;
-#ifdef MADV_HUGEPAGE
-    (void)madvise((void *)a, b - a, MADV_HUGEPAGE);
-#endif
-#ifdef MADV_POPULATE_WRITE
-    // (in pieces: one call for a gigabyte holds the address-space lock long enough to stall the thread that launches kernels)
-    for (uintptr_t q = a; q < b; q += (uintptr_t)32 << 20)
-        (void)madvise((void *)q, std::min<uintptr_t>(b - q, (uintptr_t)32 << 20), MADV_POPULATE_WRITE);
-#endif
-#endif
-}
-
-stm_qr_numeric *qr_factorize(stm_sparse_csc **Ahandle, stm_long freeA, double tol, stm_long ntol,
-                             stm_qr_symbolic *S, stm_sparse_common *cc)
-{
-    const bool timing = getenv("STMMQR_SEAM_TIMING") != nullptr;
-    const double t_in = now_ms();
-    if (!S) {                                                  // SparseQR_factorize.c:247-254
-        if (freeA) cc_free_sparse(Ahandle, cc);
-        return nullptr;
-    }
-    auto set_status = [&](int st) { if (cc) cc_int(cc, g_layout.status) = st; };
-    stm_sparse_csc *A = Ahandle ? *Ahandle : nullptr;
-    if (!A) { set_status(STMMQR_ERR_INVALID); return nullptr; }
-    // A must be the matrix QRsym was made for BEFORE anything walks its arrays with QRsym's sizes (the cache key below hashes
-    // A->p over n + 1 and A->i over anz entries: a mismatched pair would be read past its end instead of being refused)
-    if ((stm_long)A->nrow != S->m || (stm_long)A->ncol != S->n || !A->p || (S->anz > 0 && (!A->i || !A->x)) ||
-        ((const stm_long *)A->p)[S->n] != S->anz || (stm_long)A->nzmax < S->anz) {
-        if (freeA) cc_free_sparse(Ahandle, cc);
-        set_status(STMMQR_ERR_INVALID);
-        return nullptr;
-    }
-
-    stmmqr_symbolic_view v;
-    v.m = S->m; v.n = S->n; v.anz = S->anz; v.nf = S->nf; v.maxfn = S->maxfn; v.rjsize = S->rjsize;
-    v.hisize = S->hisize; v.do_rank_detection = S->do_rank_detection;
-    v.Sp = S->Sp; v.Sj = S->Sj; v.Qfill = S->Qfill; v.PLinv = S->PLinv; v.Sleft = S->Sleft;
-    v.Child = S->Child; v.Childp = S->Childp; v.Super = S->Super; v.Rp = S->Rp; v.Rj = S->Rj; v.Post = S->Post;
-    v.Hip = S->Hip; v.Fm = S->Fm; v.maxstack = S->maxstack;
-
-    int st = 0;
-    // the plan: from the cache when an equal qr_symbolic was factorized before (same options), else built now
-    unsigned long long key = 0, pat = 0, pat_cached = 0;
-    const bool use_cache = cache_capacity() > 0;
-    stmmqr_plan *P = nullptr;
-    bool cached = false;
-    if (use_cache) {
-        st = ensure_device(-1);
-        if (!st) {
-            key = symbolic_key(S);
-            pat = hash_bytes(A->p, (size_t)(S->n + 1) * sizeof(stm_long), 0x1234567);
-            pat = hash_bytes(A->i, (size_t)std::max<stm_long>(0, S->anz) * sizeof(stm_long), pat);
-            P = cache_take(key, &pat_cached);
-            cached = P != nullptr;
-        }
-    }
-    if (!st && !P) P = stmmqr_plan_create(&v, -1, &st);
-    const double t_plan = now_ms();
-    stmmqr_stats stats;
-    const bool same_pattern = cached && pat_cached == pat && P->pattern_set;
-    // The returned stack (the packed R+H: 1.2 GB for the xenon1 stand-in) is malloc'ed -- the reference's qr_freenum free()s it --
-    // and populating its pages costs the host 40 ms per GB: that runs in a helper thread BESIDE the factorization.  Its exact size
-    // is only known at the end (it depends on the numerical rank), so the thread takes the size of the last factorization with
-    // this plan (+ 2 %) or, the first time, the reference's own first allocation QRsym->maxstack (SparseQR_factorize.c:405-422),
-    // and the block is shrunk to the exact size afterwards, as the reference shrinks its stack (:597-663).
-    double *early_stack = nullptr;
-    size_t early_doubles = 0;
-    std::thread early;
-    if (!st && !(getenv("STMMQR_SEAM_EARLY_ALLOC") && atoi(getenv("STMMQR_SEAM_EARLY_ALLOC")) == 0)) {
-        // (a first call has only QRsym->maxstack to go by -- about twice the packed factors on the BASELINE matrices -- and
-        //  populating that much beside the factorization costs more than it saves: the helper runs for cached plans only,
-        //  STMMQR_SEAM_EARLY_ALLOC=2 forces it for first calls too)
-        const bool force = getenv("STMMQR_SEAM_EARLY_ALLOC") && atoi(getenv("STMMQR_SEAM_EARLY_ALLOC")) == 2;
-        early_doubles = (cached && P->rh_total > 0) ? (size_t)((double)P->rh_total * 1.02) + 1024
-                                                    : (force ? (size_t)std::max<stm_long>(S->maxstack, 1) : 0);
-        if (early_doubles * sizeof(double) >= (64u << 20)) {
-            try {                                                  // (nothing may be thrown across the C ABI: no helper, plain allocation later)
-                early = std::thread([&early_stack, early_doubles]() {
-                    early_stack = (double *)malloc(early_doubles * sizeof(double));
-                    prefault(early_stack, early_doubles * sizeof(double));
-                });
-            } catch (...) {
-                early_doubles = 0;
-            }
-        } else early_doubles = 0;
-    }
-    if (!st) st = stmmqr_factorize_device(P, same_pattern ? nullptr : (const stm_long *)A->p, same_pattern ? nullptr : (const stm_long *)A->i,
-                                          (const double *)A->x, 0, tol, ntol, &stats);
-    if (st == STMMQR_ERR_OUT_OF_MEMORY && use_cache && !cached) {
-        // The cache keeps the device memory of the plans it holds (3 GB on the xenon1 stand-in, 25 GB on the configs[4] stand-in) after
-        // qr_factorize returns; the reference frees everything.  A new matrix that does not fit BESIDE a cached plan must not fail
-        // where the reference would succeed: the cache is emptied and the call tried once more.
-        bool any;
-        { std::lock_guard<std::mutex> lock(g_cache_mu); any = !g_cache.empty(); }
-        if (any) {
-            if (g_opt.verbose) fprintf(stderr, "[stmmqr_hip] out of device memory beside cached plans: cache emptied, trying again\n");
-            if (P) { stmmqr_plan_destroy(P); P = nullptr; }
-            stmmqr_plan_cache_clear();
-            st = 0;
-            P = stmmqr_plan_create(&v, -1, &st);
-            if (!st) st = stmmqr_factorize_device(P, (const stm_long *)A->p, (const stm_long *)A->i, (const double *)A->x, 0, tol, ntol, &stats);
-        }
-    }
-    const double t_fact = now_ms();
-    if (freeA) cc_free_sparse(Ahandle, cc);                    // :324-327
-    if (early.joinable()) early.join();
-    if (st) {
-        free(early_stack);
-        if (P) stmmqr_plan_destroy(P);
-        set_status(st);
-        return nullptr;
-    }
-    const stm_long nf = S->nf, n = S->n, m = S->m;
-    stm_qr_numeric *N = (stm_qr_numeric *)cc_malloc(1, sizeof(stm_qr_numeric), cc, true);
-    if (!N) { free(early_stack); stmmqr_plan_destroy(P); return nullptr; }
-    N->n = n; N->m = m; N->nf = nf; N->rjsize = S->rjsize; N->hisize = S->hisize; N->keepH = S->keepH;
-    N->maxstack = S->maxstack; N->ns = 1; N->ntasks = 1; N->maxfm = -1; N->norm_E_fro = 0;
-    N->Rblock = (double **)cc_malloc(nf, sizeof(double *), cc);
-    N->Rdead = (char *)cc_malloc(n, 1, cc, true);
-    N->Stacks = (double **)cc_malloc(1, sizeof(double *), cc, true);
-    N->Stack_size = (stm_long *)cc_malloc(1, sizeof(stm_long), cc, true);
-    N->HStair = (stm_long *)cc_malloc(S->rjsize, sizeof(stm_long), cc);
-    N->HTau = (double *)cc_malloc(S->rjsize, sizeof(double), cc);
-    N->Hii = (stm_long *)cc_malloc(S->hisize, sizeof(stm_long), cc);
-    N->Hm = (stm_long *)cc_malloc(nf, sizeof(stm_long), cc);
-    N->Hr = (stm_long *)cc_malloc(nf, sizeof(stm_long), cc);
-    N->HPinv = (stm_long *)cc_malloc(m, sizeof(stm_long), cc);
-    std::vector<stm_long> roff((size_t)std::max<stm_long>(1, nf));
-    stm_long scal[4] = {0, 0, 0, 0};
-    bool ok = N->Rblock && N->Rdead && N->Stacks && N->Stack_size && N->HStair && N->HTau && N->Hii && N->Hm &&
-              N->Hr && N->HPinv;
-    if (ok) {
-        // the reference shrinks its stack to exactly the packed R+H (:597-663): allocate that size directly
-        N->Stack_size[0] = (stm_long)P->rh_total;
-        if (early_stack && (size_t)P->rh_total <= early_doubles) {
-            // shrink to the exact size (an mmap'ed block shrinks in place); counted as ONE allocation of that size
-            double *q = (double *)realloc(early_stack, std::max<size_t>(1, (size_t)P->rh_total) * sizeof(double));
-            N->Stacks[0] = q ? q : early_stack;
-            early_stack = nullptr;
-            if (cc) {
-                cc_size(cc, g_layout.malloc_count)++;
-                cc_size(cc, g_layout.memory_inuse) += (size_t)P->rh_total * sizeof(double);
-                cc_size(cc, g_layout.memory_usage) = std::max(cc_size(cc, g_layout.memory_usage), cc_size(cc, g_layout.memory_inuse));
-            }
-        } else {
-            free(early_stack);                                  // (too small: more live rows than last time)
-            early_stack = nullptr;
-            N->Stacks[0] = (double *)cc_malloc((size_t)P->rh_total, sizeof(double), cc);
-            if (N->Stacks[0]) prefault(N->Stacks[0], (size_t)P->rh_total * sizeof(double));
-        }
-        ok = N->Stacks[0] != nullptr;
-    }
-    free(early_stack);
-    const double t_alloc = now_ms();
-    const double P_rh_bytes = 8.0 * (double)P->rh_total;
-    if (ok) {
-        st = stmmqr_plan_download(P, N->Stacks[0], roff.data(), N->Rdead, N->HStair, N->HTau, N->Hii, N->HPinv, N->Hm,
-                                  N->Hr, scal, &stats);
-        ok = st == 0;
-    }
-    const double t_down = now_ms();
-    if (use_cache && ok) cache_put(key, pat, P);               // (keeps its device memory for the next call with this qr_symbolic)
-    else stmmqr_plan_destroy(P);
-    if (!ok) {
-        free_numeric(N, cc);
-        set_status(st ? st : STMMQR_ERR_OUT_OF_MEMORY);
-        return nullptr;
-    }
-    for (stm_long f = 0; f < nf; f++) N->Rblock[f] = N->Stacks[0] + roff[f];
-    N->rank = scal[0]; N->rank1 = scal[1]; N->maxfrank = scal[2]; N->maxfm = scal[3];
-    if (cc) cc_dbl(cc, g_layout.SPQR_flopcount) = stats.flops;
-    if (timing)
-        fprintf(stderr, "[stmmqr_hip] qr_factorize seam: plan %s %.1f ms, factorization %.1f ms (device %.1f), host arrays %.1f ms, "
-                        "download of %.0f MB %.1f ms, total %.1f ms\n", cached ? (same_pattern ? "cached" : "cached (new pattern)") : "built",
-                t_plan - t_in, t_fact - t_plan, stats.ms_total, t_alloc - t_fact, (double)P_rh_bytes * 1e-6, t_down - t_alloc, now_ms() - t_in);
-    return N;
-}
-
-void stmmqr_free_numeric(stm_qr_numeric **Nh, stm_sparse_common *cc)
-{
-    if (!Nh || !*Nh) return;
-    free_numeric(*Nh, cc);
-    *Nh = nullptr;
 }
 
 }  // extern "C"

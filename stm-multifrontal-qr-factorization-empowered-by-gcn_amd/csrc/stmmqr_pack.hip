@@ -334,7 +334,7 @@ int stm_launch_rh_copy(const DevCtx &c, const int *flist, const int *nparts, int
     hipLaunchKernelGGL(k_rh_copy, dim3(maxparts, nfr), dim3(NT), 0, st, c, flist, nparts, RH);
     return (int)hipGetLastError();
 }
-// One panel message of a shared front (stmmqr_host.cpp: panel_msg) packed / unpacked on the device in ONE launch: six byte ranges
+// One panel message of a shared front (stmmqr_multi.cpp: panel_msg) packed / unpacked on the device in ONE launch: six byte ranges
 // (the panel's columns, T, the front's Tau / Stair / Rdead ranges, its FrontNum) between their homes and a contiguous buffer.
 // Six hipMemcpyAsync cost 6 x 5-8 us of device time per panel step; this is one kernel bound by the 2-13 MB of the columns.
 struct MsgSeg { char *home; long long off, bytes; };

@@ -371,7 +371,7 @@ def run_shared_front(plan, sp: ShardPlan, f, comm: Comm):
     nsteps = plan.group_steps(g)
     native = getattr(comm, "native", None) is not None and hasattr(plan, "shared_front_native")
     if native:
-        # the same loop in C++ (csrc/stmmqr_host.cpp): panels, updates and messages enqueued without a host round trip per step
+        # the same loop in C++ (csrc/stmmqr_multi.cpp): panels, updates and messages enqueued without a host round trip per step
         plan.shared_front_native(g, f, r0, R, comm.native)
     ring = None if native else sp.panel_ring(plan, f, comm)
     dev = _use_dev(plan, comm, "export_panel_dev")
