@@ -546,7 +546,8 @@ def _run(args, torch, rank, world, local, guard):
         if not rehearsal and os.environ.get("STMMQR_NATIVE_LOOP", "1") != "0":
             try:
                 native = pkg.RcclTransport(dist, dev)
-                native_note = "native loop (stmmqr_factorize_shared_front), RCCL ncclSend / ncclRecv on a comm stream"
+                native_note = ("native phase loop (stmmqr_factorize_phases: subtree exchange as device-packed messages, shared-front panel loop, "
+                               "gather), RCCL ncclSend / ncclRecv")
             except Exception as e:                      # noqa: BLE001 (every rank takes the same branch: the id broadcast is collective)
                 print(f"[bench] rank {rank}: RCCL transport not available ({e}); python loop", file=sys.stderr, flush=True)
         ok = torch.tensor([1 if native is not None else 0], dtype=torch.int64, device=dev if not rehearsal else "cpu")

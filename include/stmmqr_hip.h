@@ -271,6 +271,36 @@ typedef struct stmmqr_transport {
     int rank, size;
 } stmmqr_transport;
 int stmmqr_factorize_shared_front(stmmqr_plan *plan, int group, stm_long f, int first_rank, int nranks, const stmmqr_transport *tr);
+/* The subtree exchange, native (round 5): the contribution blocks that enter a phase from other ranks.  The unit of exchange is the
+ * reference's: the packed C block of a child front with its row ids (SparseQR_factorize.c:1228; between the reference's tasks it
+ * stays in shared memory).  Block q of the `out` list goes to rank out_peer[q], block q of the `in` list comes from in_peer[q]; for
+ * one pair of ranks the fronts appear in the same order on both sides.  A block is ONE message whose size the plan knows (8 doubles
+ * of header + the front's symbolic C slot + fn - fp row ids), packed by a kernel that reads the front's state on the device, sent
+ * and received on the plan's stream in one transport group, unpacked by a kernel that writes the state
+ * stmmqr_plan_import_front would: the host neither waits for the device nor learns (fm, rank, cm).  A message that does not fit the
+ * front's symbolic bounds makes the factorization fail (stats.failed at stmmqr_factorize_finish).
+ * stmmqr_shared_front_gather: after the panel loop of a shared front, the columns of its contribution block that the other ranks
+ * of the group own, collected on the group's first rank (the native form of stmmqr_plan_export/import_front_cols; nothing to do
+ * for a root).
+ * stmmqr_factorize_phases: everything between stmmqr_factorize_begin and stmmqr_factorize_finish of a sharded factorization as ONE
+ * call -- per phase k: the exchange (lists [out_ptr[k], out_ptr[k+1]) / [in_ptr[k], in_ptr[k+1])), then the shared front this rank
+ * takes part in (shared_front[k] >= 0: panel loop + gather, group [shared_first[k], + shared_span[k])) or its own fronts of the
+ * phase (has_group[k]: stmmqr_factorize_group(plan, k)).  The only host waits left are the four bytes stmmqr_factorize_group reads
+ * after a group. */
+int stmmqr_factorize_exchange(stmmqr_plan *plan, stm_long nout, const stm_long *out_front, const int *out_peer, stm_long nin,
+                              const stm_long *in_front, const int *in_peer, const stmmqr_transport *tr);
+int stmmqr_shared_front_gather(stmmqr_plan *plan, stm_long f, int first_rank, int nranks, const stmmqr_transport *tr);
+typedef struct stmmqr_shard_phases {
+    int nphase;
+    const stm_long *out_ptr, *out_front;    /* [nphase + 1], [out_ptr[nphase]] */
+    const int *out_peer;
+    const stm_long *in_ptr, *in_front;
+    const int *in_peer;
+    const stm_long *shared_front;           /* [nphase]: -1 = none */
+    const int *shared_first, *shared_span;  /* [nphase] */
+    const int *has_group;                   /* [nphase] */
+} stmmqr_shard_phases;
+int stmmqr_factorize_phases(stmmqr_plan *plan, const stmmqr_shard_phases *ph, const stmmqr_transport *tr);
 int stmmqr_device_copy(void *dst, const void *src, size_t bytes, void *hip_stream);   /* D2D, complete on return, after the stream's work */
 int stmmqr_rccl_unique_id(char id[128]);
 int stmmqr_rccl_transport_create(int world, int rank, const char id[128], stmmqr_transport **out);

@@ -156,6 +156,19 @@ class TransportC(C.Structure):
 
 
 lib.stmmqr_factorize_shared_front.argtypes = [C.c_void_p, C.c_int, C.c_long, C.c_int, C.c_int, C.POINTER(TransportC)]
+
+
+class ShardPhasesC(C.Structure):
+    """stmmqr_shard_phases (include/stmmqr_hip.h): what one rank does in each phase of a sharded factorization"""
+    _LP, _IP = C.POINTER(C.c_long), C.POINTER(C.c_int)
+    _fields_ = [("nphase", C.c_int), ("out_ptr", _LP), ("out_front", _LP), ("out_peer", _IP), ("in_ptr", _LP), ("in_front", _LP),
+                ("in_peer", _IP), ("shared_front", _LP), ("shared_first", _IP), ("shared_span", _IP), ("has_group", _IP)]
+
+
+lib.stmmqr_factorize_exchange.argtypes = [C.c_void_p, C.c_long, C.POINTER(C.c_long), C.POINTER(C.c_int), C.c_long, C.POINTER(C.c_long),
+                                          C.POINTER(C.c_int), C.POINTER(TransportC)]
+lib.stmmqr_shared_front_gather.argtypes = [C.c_void_p, C.c_long, C.c_int, C.c_int, C.POINTER(TransportC)]
+lib.stmmqr_factorize_phases.argtypes = [C.c_void_p, C.POINTER(ShardPhasesC), C.POINTER(TransportC)]
 lib.stmmqr_rccl_unique_id.argtypes = [C.c_char_p]
 lib.stmmqr_rccl_transport_create.argtypes = [C.c_int, C.c_int, C.c_char_p, C.POINTER(C.POINTER(TransportC))]
 lib.stmmqr_rccl_transport_destroy.restype = None
@@ -407,6 +420,21 @@ class HipQR:
         CallbackTransport"""
         _check(lib.stmmqr_factorize_shared_front(self._h, int(group), int(f), int(first_rank), int(nranks), transport.ptr),
                "stmmqr_factorize_shared_front")
+
+    def exchange_native(self, out, inn, transport):
+        """the contribution blocks entering a phase, [(front, peer)] each way, in ONE native call (stmmqr_factorize_exchange)"""
+        of, op = np.array([c for c, _ in out], I64), np.array([p for _, p in out], np.int32)
+        nf, npr = np.array([c for c, _ in inn], I64), np.array([p for _, p in inn], np.int32)
+        i32 = lambda a: a.ctypes.data_as(C.POINTER(C.c_int))       # noqa: E731
+        _check(lib.stmmqr_factorize_exchange(self._h, len(of), _ip(of), i32(op), len(nf), _ip(nf), i32(npr), transport.ptr),
+               "stmmqr_factorize_exchange")
+
+    def gather_native(self, f, first_rank, nranks, transport):
+        _check(lib.stmmqr_shared_front_gather(self._h, int(f), int(first_rank), int(nranks), transport.ptr), "stmmqr_shared_front_gather")
+
+    def phases_native(self, phases, transport):
+        """every phase of a sharded factorization in ONE native call (stmmqr_factorize_phases); phases: ShardPlan.c_phases()"""
+        _check(lib.stmmqr_factorize_phases(self._h, C.byref(phases[0]), transport.ptr), "stmmqr_factorize_phases")
 
     def panel_doubles(self, f) -> int:
         n = np.zeros(1, I64)

@@ -127,5 +127,10 @@ int stm_launch_rsolve(const DevCtx &c, const int *flist, int nfr, const int *Rj,
 int stm_launch_rtsolve(const DevCtx &c, const int *flist, int nfr, const double *Bp, double *U, double *Xr, const int *rowbase,
                        int lds_bytes, hipStream_t st, int nb, const RhsBatch &B);
 int stm_launch_panel_msg(void *const homes[6], const long long offs[6], const long long bytes[6], void *buf, int out, hipStream_t st);
+// subtree exchange: contribution blocks between plans as fixed-size messages, packed / unpacked on the device (stmmqr_pack.hip)
+struct StmFrontMsg { long long off, slot; int f, pad; };      // front f at buf + off: [8 | slot | fn - fp] doubles
+struct StmFrontMsgs { StmFrontMsg m[16]; };
+int stm_launch_front_msg(const DevCtx &c, const StmFrontMsgs &g, int nmsg, long long max_slot, double *buf, int out, hipStream_t st);
+int stm_launch_front_cols(const DevCtx &c, int f, int part, int nparts, int nown, long long max_run, double *buf, int out, hipStream_t st);
 int stm_launch_perm(const double *in, const int *perm, double *out, int n, int scatter, hipStream_t st, int nb = 1, long long sin = 0,
                     long long sout = 0);

@@ -1,6 +1,7 @@
 // stmmqr_multi.cpp -- multi-GPU support of the numeric phase: contribution blocks and panels in and out of a plan,
 // the step interface, the native panel loop of a front SHARED between plans, the RCCL point-to-point transport.
 #include "stmmqr_plan.h"
+#include <algorithm>
 
 extern "C" {
 
@@ -274,7 +275,7 @@ void stmmqr_plan_release_rings(stmmqr_plan *plan)
     }
 }
 
-int stmmqr_factorize_shared_front(stmmqr_plan *plan, int group, stm_long f, int first_rank, int nranks, const stmmqr_transport *tr)
+static int shared_front_loop(stmmqr_plan *plan, int group, stm_long f, int first_rank, int nranks, const stmmqr_transport *tr, bool host_sync)
 {
     if (!plan || !plan->begun) return fail(STMMQR_ERR_INVALID, "stmmqr_factorize_begin was not called");
     if (!tr || !tr->send || !tr->recv) return fail(STMMQR_ERR_INVALID, "null transport");
@@ -333,11 +334,232 @@ int stmmqr_factorize_shared_front(stmmqr_plan *plan, int group, stm_long f, int 
     }
     if (!e) e = step(nsteps - 1, STMMQR_STEP_UPDATE | STMMQR_STEP_GRAM, mod(i - nsteps), R, -1);
     if (!e) e = step(nsteps - 1, STMMQR_STEP_POST, 0, 1, -1);
+    if (!host_sync) {
+        // (stmmqr_factorize_phases: whatever follows on the plan's stream is ordered after the last send -- no host wait at all)
+        HIPCHK(hipEventRecord(ring->ev_exp, cs));
+        HIPCHK(hipStreamWaitEvent(st, ring->ev_exp, 0));
+        return e;
+    }
     // the caller gathers the contribution block (stmmqr_plan_export_front_cols) and goes on with the next phase: it needs the
     // device to have finished this one -- ONE synchronisation per shared front, not one per step
     HIPCHK(hipStreamSynchronize(cs));
     HIPCHK(hipStreamSynchronize(st));
     return e;
+}
+
+int stmmqr_factorize_shared_front(stmmqr_plan *plan, int group, stm_long f, int first_rank, int nranks, const stmmqr_transport *tr)
+{
+    return shared_front_loop(plan, group, f, first_rank, nranks, tr, true);
+}
+
+// ---- the subtree exchange, native (round 5; sharded.factorize_sharded's Python exchange stays the CPU-testable form).  Where
+// subtrees join, the contribution block of a front factorized on one rank is assembled by a front of another (the unit of
+// exchange of the reference's task tree: the child's packed C block, SparseQR_factorize.c:1228).  The Python form asks the device
+// for (fm, rank, cm, csize) of every block, trades these as a message of their own, allocates buffers of the sizes received and
+// then trades blocks and row ids: two host synchronisations, two rounds of messages and a dozen interpreter calls per block.
+// Here a block is ONE message of a size the plan knows (its symbolic slot: stm_launch_front_msg), packed on the device, sent and
+// received on the plan's stream, unpacked on the device: nothing waits on the host. ----
+static long long front_msg_doubles(const stmmqr_plan &P, stm_long f) { return 8 + P.c_slot[(size_t)f] + (P.fs[f].fn - P.fs[f].fp); }
+
+static int msg_arena(stmmqr_plan &P, long long doubles)
+{
+    if ((long long)P.d_msg.n >= doubles) return 0;
+    HIPCHK(hipStreamSynchronize(P.stream));                  // (growing: first exchange of a grouping only)
+    if (P.d_msg.alloc((size_t)doubles)) return fail(STMMQR_ERR_OUT_OF_MEMORY, "message buffers of the subtree exchange");
+    return 0;
+}
+
+int stmmqr_factorize_exchange(stmmqr_plan *plan, stm_long nout, const stm_long *out_front, const int *out_peer, stm_long nin,
+                              const stm_long *in_front, const int *in_peer, const stmmqr_transport *tr)
+{
+    if (!plan || !plan->begun) return fail(STMMQR_ERR_INVALID, "stmmqr_factorize_begin was not called");
+    if (!tr || !tr->send || !tr->recv) return fail(STMMQR_ERR_INVALID, "null transport");
+    if (nout < 0 || nin < 0 || (nout > 0 && (!out_front || !out_peer)) || (nin > 0 && (!in_front || !in_peer)))
+        return fail(STMMQR_ERR_INVALID, "stmmqr_factorize_exchange: null lists");
+    stmmqr_plan &P = *plan;
+    HIPCHK(hipSetDevice(P.device));
+    // every front packed once (it may go to several ranks: the ranks that share its parent), every incoming block its own buffer
+    std::vector<stm_long> uo;
+    std::vector<long long> off_o((size_t)nout, 0), off_i((size_t)nin, 0);
+    std::vector<long long> uoff;
+    long long top = 0;
+    for (stm_long q = 0; q < nout; q++) {
+        const stm_long f = out_front[q];
+        if (int e = stm_check_c_slot(P, f, 0, "stmmqr_factorize_exchange")) return e;
+        if (out_peer[q] < 0 || out_peer[q] >= tr->size || out_peer[q] == tr->rank) return fail(STMMQR_ERR_INVALID, "stmmqr_factorize_exchange: bad peer");
+        size_t u = 0;
+        while (u < uo.size() && uo[u] != f) u++;
+        if (u == uo.size()) { uo.push_back(f); uoff.push_back(top); top += front_msg_doubles(P, f); }
+        off_o[(size_t)q] = uoff[u];
+    }
+    for (stm_long q = 0; q < nin; q++) {
+        const stm_long f = in_front[q];
+        if (int e = stm_check_c_slot(P, f, 0, "stmmqr_factorize_exchange")) return e;
+        if (in_peer[q] < 0 || in_peer[q] >= tr->size || in_peer[q] == tr->rank) return fail(STMMQR_ERR_INVALID, "stmmqr_factorize_exchange: bad peer");
+        off_i[(size_t)q] = top;
+        top += front_msg_doubles(P, f);
+    }
+    if (top == 0) return 0;
+    if (int e = msg_arena(P, top)) return e;
+    const DevCtx c = P.ctx();
+    hipStream_t st = P.stream;
+    auto launch = [&](const std::vector<stm_long> &fr, const long long *off, int out) -> int {
+        for (size_t q0 = 0; q0 < fr.size(); q0 += 16) {
+            StmFrontMsgs g;
+            memset(&g, 0, sizeof g);
+            long long mx = 0;
+            const int n = (int)std::min<size_t>(16, fr.size() - q0);
+            for (int q = 0; q < n; q++) {
+                const stm_long f = fr[q0 + (size_t)q];
+                g.m[q].f = (int)f; g.m[q].off = off[q0 + (size_t)q]; g.m[q].slot = P.c_slot[(size_t)f];
+                mx = std::max(mx, P.c_slot[(size_t)f]);
+            }
+            LCHK(stm_launch_front_msg(c, g, n, mx, P.d_msg.p, out, st));
+            P.stats.nlaunch++;
+        }
+        return 0;
+    };
+    if (int e = launch(uo, uoff.data(), 1)) return e;
+    int e = 0;
+    if (tr->group_begin && tr->group_begin(tr->ctx)) return fail(STMMQR_ERR_DEVICE, "transport: group begin");
+    for (stm_long q = 0; q < nout && !e; q++)
+        if (tr->send(tr->ctx, P.d_msg.p + off_o[(size_t)q], (size_t)front_msg_doubles(P, out_front[q]) * sizeof(double), out_peer[q], (void *)st))
+            e = fail(STMMQR_ERR_DEVICE, "transport: send of a contribution block failed");
+    for (stm_long q = 0; q < nin && !e; q++)
+        if (tr->recv(tr->ctx, P.d_msg.p + off_i[(size_t)q], (size_t)front_msg_doubles(P, in_front[q]) * sizeof(double), in_peer[q], (void *)st))
+            e = fail(STMMQR_ERR_DEVICE, "transport: receive of a contribution block failed");
+    if (tr->group_end && tr->group_end(tr->ctx) && !e) e = fail(STMMQR_ERR_DEVICE, "transport: group end");
+    if (e) return e;
+    std::vector<stm_long> fin(in_front, in_front + nin);
+    return launch(fin, off_i.data(), 0);
+}
+
+// The contribution block of a shared front, complete on every rank of its group in the columns that rank owns, collected on the
+// group's first rank -- the native form of the tail of sharded.run_shared_front.  Message of place j: its runs of columns back to
+// back (k_front_cols), sized by the symbolic bound of cm so that nobody asks the device for cm.
+static long long front_cols_bound(const stmmqr_plan &P, stm_long f, int part, int nparts, int *nown, long long *max_run)
+{
+    const FrontSym &s = P.fs[f];
+    const long long cn = s.fn - s.fp, fm = s.fm_ub;
+    const long long cm = P.do_rank ? std::min(fm, cn) : std::min(std::max(fm - std::min(fm, (long long)s.fp), 0LL), cn);
+    auto coff = [&](long long j) -> long long { return j < cm ? j * (j + 1) / 2 : cm * (cm + 1) / 2 + (j - cm) * cm; };
+    long long tot = 0;
+    *nown = 0; *max_run = 0;
+    for (long long q = s.fp / STM_NB; q * STM_NB < s.fn; q++) {
+        if (q % nparts != part) continue;
+        const long long j0 = std::max(0LL, q * STM_NB - (long long)s.fp), j1 = std::min(cn, (q + 1) * STM_NB - (long long)s.fp);
+        if (j1 <= j0) continue;
+        (*nown)++;
+        *max_run = std::max(*max_run, coff(j1) - coff(j0));
+        tot += coff(j1) - coff(j0);
+    }
+    return tot;
+}
+
+int stmmqr_shared_front_gather(stmmqr_plan *plan, stm_long f, int first_rank, int nranks, const stmmqr_transport *tr)
+{
+    if (!plan || !plan->begun) return fail(STMMQR_ERR_INVALID, "stmmqr_factorize_begin was not called");
+    if (!tr || !tr->send || !tr->recv) return fail(STMMQR_ERR_INVALID, "null transport");
+    stmmqr_plan &P = *plan;
+    if (f < 0 || f >= P.nf || (size_t)f >= P.shared.size() || !P.shared[(size_t)f]) return fail(STMMQR_ERR_INVALID, "not a shared front");
+    const int R = nranks, i = tr->rank - first_rank;
+    if (R < 1 || i < 0 || i >= R) return fail(STMMQR_ERR_INVALID, "this rank is not in the front's group");
+    if (R == 1 || P.fs[f].parent < 0) return 0;              // (the root's contribution block is empty)
+    HIPCHK(hipSetDevice(P.device));
+    if (int e = stm_check_c_slot(P, f, 0, "stmmqr_shared_front_gather")) return e;
+    std::vector<long long> nd((size_t)R, 0), mr((size_t)R, 0), off((size_t)R, 0);
+    std::vector<int> nown((size_t)R, 0);
+    long long top = 0;
+    for (int j = (i == 0 ? 1 : i); j < (i == 0 ? R : i + 1); j++) {
+        nd[(size_t)j] = front_cols_bound(P, f, j, R, &nown[(size_t)j], &mr[(size_t)j]);
+        off[(size_t)j] = top;
+        top += nd[(size_t)j];
+    }
+    if (top == 0) return 0;
+    if (int e = msg_arena(P, top)) return e;
+    const DevCtx c = P.ctx();
+    hipStream_t st = P.stream;
+    int e = 0;
+    if (i != 0) {
+        LCHK(stm_launch_front_cols(c, (int)f, i, R, nown[(size_t)i], mr[(size_t)i], P.d_msg.p, 1, st));
+        P.stats.nlaunch++;
+    }
+    if (tr->group_begin && tr->group_begin(tr->ctx)) return fail(STMMQR_ERR_DEVICE, "transport: group begin");
+    if (i != 0) {
+        if (tr->send(tr->ctx, P.d_msg.p, (size_t)nd[(size_t)i] * sizeof(double), first_rank, (void *)st)) e = fail(STMMQR_ERR_DEVICE, "transport: send of a shared front's columns failed");
+    } else
+        for (int j = 1; j < R && !e; j++)
+            if (nd[(size_t)j] > 0 && tr->recv(tr->ctx, P.d_msg.p + off[(size_t)j], (size_t)nd[(size_t)j] * sizeof(double), first_rank + j, (void *)st))
+                e = fail(STMMQR_ERR_DEVICE, "transport: receive of a shared front's columns failed");
+    if (tr->group_end && tr->group_end(tr->ctx) && !e) e = fail(STMMQR_ERR_DEVICE, "transport: group end");
+    if (e) return e;
+    if (i == 0)
+        for (int j = 1; j < R; j++)
+            if (nd[(size_t)j] > 0) {
+                LCHK(stm_launch_front_cols(c, (int)f, j, R, nown[(size_t)j], mr[(size_t)j], P.d_msg.p + off[(size_t)j], 0, st));
+                P.stats.nlaunch++;
+            }
+    return 0;
+}
+
+// One sharded factorization between stmmqr_factorize_begin and stmmqr_factorize_finish as ONE call: per phase the exchange of the
+// blocks that enter it, the shared front this rank takes part in (panel loop + gather) or the rank's own fronts of the phase.
+// The only host waits left are the four bytes stmmqr_factorize_group reads after a group (did a bounded panel wait run out?).
+int stmmqr_factorize_phases(stmmqr_plan *plan, const stmmqr_shard_phases *ph, const stmmqr_transport *tr)
+{
+    if (!plan || !plan->begun) return fail(STMMQR_ERR_INVALID, "stmmqr_factorize_begin was not called");
+    if (!ph || ph->nphase < 1 || !ph->out_ptr || !ph->in_ptr || !ph->shared_front || !ph->has_group)
+        return fail(STMMQR_ERR_INVALID, "stmmqr_factorize_phases: null phase lists");
+    if (!tr) return fail(STMMQR_ERR_INVALID, "null transport");
+    {
+        // the message buffers of the largest phase, once, before anything is enqueued (growing them later would wait for the device)
+        stmmqr_plan &P = *plan;
+        long long need = 0;
+        for (int k = 0; k < ph->nphase; k++) {
+            long long t = 0;
+            std::vector<stm_long> seen;
+            for (stm_long q = ph->out_ptr[k]; k > 0 && q < ph->out_ptr[k + 1]; q++) {
+                const stm_long f = ph->out_front[q];
+                if (f < 0 || f >= P.nf) return fail(STMMQR_ERR_INVALID, "stmmqr_factorize_phases: no such front");
+                if (std::find(seen.begin(), seen.end(), f) == seen.end()) { seen.push_back(f); t += front_msg_doubles(P, f); }
+            }
+            for (stm_long q = ph->in_ptr[k]; k > 0 && q < ph->in_ptr[k + 1]; q++) {
+                const stm_long f = ph->in_front[q];
+                if (f < 0 || f >= P.nf) return fail(STMMQR_ERR_INVALID, "stmmqr_factorize_phases: no such front");
+                t += front_msg_doubles(P, f);
+            }
+            need = std::max(need, t);
+            const stm_long f = ph->shared_front[k];
+            if (f >= 0 && f < P.nf && ph->shared_span && ph->shared_first && P.fs[f].parent >= 0) {
+                const int R = ph->shared_span[k], i = tr->rank - ph->shared_first[k];
+                long long g = 0, mr;
+                int no;
+                for (int j = (i == 0 ? 1 : i); j < (i == 0 ? R : i + 1) && j < R && j >= 0; j++) g += front_cols_bound(P, f, j, R, &no, &mr);
+                need = std::max(need, g);
+            }
+        }
+        HIPCHK(hipSetDevice(P.device));
+        if (need > 0)
+            if (int e = msg_arena(P, need)) return e;
+    }
+    for (int k = 0; k < ph->nphase; k++) {
+        if (k > 0 && tr->size > 1) {
+            const stm_long o0 = ph->out_ptr[k], o1 = ph->out_ptr[k + 1], i0 = ph->in_ptr[k], i1 = ph->in_ptr[k + 1];
+            if (o1 > o0 || i1 > i0)
+                if (int e = stmmqr_factorize_exchange(plan, o1 - o0, ph->out_front + o0, ph->out_peer + o0, i1 - i0, ph->in_front + i0,
+                                                      ph->in_peer + i0, tr))
+                    return e;
+        }
+        const stm_long f = ph->shared_front[k];
+        if (f >= 0) {
+            if (!ph->shared_first || !ph->shared_span) return fail(STMMQR_ERR_INVALID, "stmmqr_factorize_phases: null phase lists");
+            if (int e = shared_front_loop(plan, k, f, ph->shared_first[k], ph->shared_span[k], tr, false)) return e;
+            if (int e = stmmqr_shared_front_gather(plan, f, ph->shared_first[k], ph->shared_span[k], tr)) return e;
+        }
+        if (ph->has_group[k])
+            if (int e = stmmqr_factorize_group(plan, k, 0)) return e;
+    }
+    return 0;
 }
 
 // ---- RCCL point-to-point transport (ncclSend / ncclRecv on the comm stream).  librccl is loaded at run time -- the library

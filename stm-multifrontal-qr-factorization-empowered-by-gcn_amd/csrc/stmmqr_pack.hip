@@ -358,3 +358,89 @@ int stm_launch_panel_msg(void *const homes[6], const long long offs[6], const lo
     hipLaunchKernelGGL(k_panel_msg, dim3(gx, 6), dim3(256), 0, st, g, (char *)buf, out);
     return (int)hipGetLastError();
 }
+
+// ---- subtree exchange (stmmqr_multi.cpp: stmmqr_factorize_exchange): the contribution block of a front travels between plans as
+// ONE message of a size known at plan time -- [8 doubles header: fm, rank, cm, csize | the front's C slot (its symbolic bound) |
+// fn - fp row ids as doubles] -- so neither side asks the device what was factorized before it posts the send / the receive:
+// the kernel that packs reads the front's FrontNum on the device, the kernel that unpacks writes it (stmmqr_plan_import_front's
+// state: fm, rank, cm, done = 1, g = rank), the block and the row ids.  One launch packs / unpacks up to 16 fronts. ----
+__global__ __launch_bounds__(256) void k_front_msg(DevCtx c, StmFrontMsgs g, double *__restrict__ buf, int out)
+{
+    const StmFrontMsg m = g.m[blockIdx.y];
+    const FrontSym s = c.fs[m.f];
+    double *b = buf + m.off;
+    FrontNum *num = &c.fnum[m.f];
+    const int cn = s.fn - s.fp;
+    const long long t0 = (long long)blockIdx.x * 256 + threadIdx.x, nt = (long long)gridDim.x * 256;
+    if (out) {
+        const int fm = num->fm, rank = num->rank, cm = num->cm;
+        const long long csize = (long long)cm * (cm + 1) / 2 + (long long)cm * (cn - cm);
+        if (t0 == 0) { b[0] = fm; b[1] = rank; b[2] = cm; b[3] = (double)csize; b[4] = b[5] = b[6] = b[7] = 0.0; }
+        if (cm < 0 || cm > cn || csize > m.slot) { if (t0 == 0 && c.abort) c.abort[1] = 1; return; }
+        const double *C = c.Carena + s.coff;
+        for (long long i = t0; i < csize; i += nt) b[8 + i] = C[i];
+        const int *rows = c.Hii + s.hip + rank;
+        for (long long i = t0; i < cm; i += nt) b[8 + m.slot + i] = (double)rows[i];
+        return;
+    }
+    const int fm = (int)b[0], rank = (int)b[1], cm = (int)b[2];
+    const long long csize = (long long)cm * (cm + 1) / 2 + (long long)cm * (cn - cm);
+    if (cm < 0 || cm > cn || rank < 0 || rank + cm > s.fm_ub || csize > m.slot || (long long)b[3] != csize) {
+        if (t0 == 0 && c.abort) c.abort[1] = 1;          // (a message that does not fit the symbolic bounds: the factorization fails)
+        return;
+    }
+    if (t0 == 0) {
+        int *w = reinterpret_cast<int *>(num);
+        for (int i = 0; i < (int)(sizeof(FrontNum) / sizeof(int)); i++) w[i] = 0;
+        num->fm = fm; num->rank = rank; num->cm = cm; num->done = 1; num->g = rank;
+    }
+    double *C = c.Carena + s.coff;
+    for (long long i = t0; i < csize; i += nt) C[i] = b[8 + i];
+    int *rows = c.Hii + s.hip + rank;
+    for (long long i = t0; i < cm; i += nt) rows[i] = (int)b[8 + m.slot + i];
+}
+int stm_launch_front_msg(const DevCtx &c, const StmFrontMsgs &g, int nmsg, long long max_slot, double *buf, int out, hipStream_t st)
+{
+    if (nmsg <= 0) return 0;
+    long long gx = (max_slot + 256 * 8 - 1) / (256 * 8);
+    gx = gx < 1 ? 1 : (gx > 1024 ? 1024 : gx);
+    hipLaunchKernelGGL(k_front_msg, dim3((unsigned)gx, nmsg), dim3(256), 0, st, c, g, buf, out);
+    return (int)hipGetLastError();
+}
+
+// The packed contribution block of a SHARED front is complete only in the columns of the panels a plan owns (panel q of the front
+// = columns [32 q, 32 q + 32), owned by place q mod nparts): those runs, back to back, are the message of place `part` to the
+// group's first rank.  Where a run starts depends on cm, which only the device knows: workgroup row y finds its run by walking the
+// panels (a few hundred at most).  The host sizes the message by the symbolic bound of cm (stm_front_cols_bound).
+__global__ __launch_bounds__(256) void k_front_cols(DevCtx c, int f, int part, int nparts, double *__restrict__ buf, int out)
+{
+    const FrontSym s = c.fs[f];
+    const long long cn = s.fn - s.fp, cm = c.fnum[f].cm;
+    if (cm <= 0 || cm > cn) return;
+    auto coff = [&](long long j) -> long long { return j < cm ? j * (j + 1) / 2 : cm * (cm + 1) / 2 + (j - cm) * cm; };
+    long long pos = 0, a = 0, e = 0;
+    int own = -1;
+    for (long long q = s.fp / STM_NB; q * STM_NB < s.fn; q++) {
+        if (q % nparts != part) continue;
+        long long j0 = q * STM_NB - s.fp, j1 = (q + 1) * STM_NB - s.fp;
+        j0 = j0 < 0 ? 0 : j0; j1 = j1 > cn ? cn : j1;
+        if (j1 <= j0) continue;
+        a = coff(j0); e = coff(j1);
+        if (++own == (int)blockIdx.y) break;
+        pos += e - a;
+    }
+    if (own != (int)blockIdx.y) return;
+    double *C = c.Carena + s.coff + a;
+    double *b = buf + pos;
+    const long long t0 = (long long)blockIdx.x * 256 + threadIdx.x, nt = (long long)gridDim.x * 256;
+    if (out) for (long long i = t0; i < e - a; i += nt) b[i] = C[i];
+    else for (long long i = t0; i < e - a; i += nt) C[i] = b[i];
+}
+int stm_launch_front_cols(const DevCtx &c, int f, int part, int nparts, int nown, long long max_run, double *buf, int out, hipStream_t st)
+{
+    if (nown <= 0) return 0;
+    long long gx = (max_run + 256 * 8 - 1) / (256 * 8);
+    gx = gx < 1 ? 1 : (gx > 256 ? 256 : gx);
+    hipLaunchKernelGGL(k_front_cols, dim3((unsigned)gx, nown), dim3(256), 0, st, c, f, part, nparts, buf, out);
+    return (int)hipGetLastError();
+}

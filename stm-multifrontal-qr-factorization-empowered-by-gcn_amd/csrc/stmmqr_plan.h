@@ -188,6 +188,7 @@ struct stmmqr_plan {
     DevBuf<long long> d_ypoff;                 // [nf] offsets into it (-1: not a pair-update front)
     std::vector<long long> ypoff;
     long long yp_doubles = 0;
+    DevBuf<double> d_msg;                // subtree exchange: message buffers (stmmqr_factorize_exchange, grown on demand)
     DevBuf<int> d_wcnt, d_wcnt2;         // per column block of the update workspaces: slab tickets (zero between launches)
     DevBuf<int> d_wflag, d_wflag2;       // ... fused update: step + 1 once W2 of the column block is in its slot
     DevBuf<int> d_abort;

@@ -33,6 +33,8 @@ the very same orchestration with a CPU stand-in plan.
 """
 from __future__ import annotations
 
+import os
+
 import numpy as np
 
 I64 = np.int64
@@ -342,6 +344,23 @@ class ShardPlan:
             self.shared_at[int(self.phase[f])] = int(f)
         self.shared = [int(f) for f in np.nonzero(mine & (self.span > 1))[0]]
 
+    def c_phases(self):
+        """the phase lists as the C structure of stmmqr_factorize_phases (built once; the arrays stay alive with it)"""
+        if getattr(self, "_c_phases", None) is None:
+            from .capi import ShardPhasesC
+            import ctypes as C
+            optr = np.cumsum([0] + [len(x) for x in self.out]).astype(I64)
+            iptr = np.cumsum([0] + [len(x) for x in self.inn]).astype(I64)
+            arrs = [optr, np.array([c for l in self.out for c, _ in l], I64), np.array([p for l in self.out for _, p in l], np.int32),
+                    iptr, np.array([c for l in self.inn for c, _ in l], I64), np.array([p for l in self.inn for _, p in l], np.int32),
+                    np.array([-1 if f is None else f for f in self.shared_at], I64),
+                    np.array([0 if f is None else int(self.owner[f]) for f in self.shared_at], np.int32),
+                    np.array([1 if f is None else int(self.span[f]) for f in self.shared_at], np.int32),
+                    np.array([int(h) for h in self.has], np.int32)]
+            ptr = lambda a: a.ctypes.data_as(C.POINTER(C.c_long if a.dtype == I64 else C.c_int))       # noqa: E731
+            self._c_phases = (ShardPhasesC(self.nphase, *[ptr(a) for a in arrs]), arrs)
+        return self._c_phases
+
     def panel_ring(self, plan, f, comm):
         """R message buffers of a shared front (slot q mod R: a rank receives R - 1 panels between two of its own exports,
         and an export waits for everything queued before it, so a slot is free again when its turn comes)"""
@@ -442,7 +461,13 @@ def factorize_sharded(plan, sym: dict, Ax, tol, ntol, comm: Comm, Ap=None, Ai=No
     sp = shard_plan
     owner, phase = sp.owner, sp.phase
     plan.begin(Ax, tol, ntol, Ap, Ai, device_ptr=device_ptr)
-    for k in range(sp.nphase):
+    native = getattr(comm, "native", None)
+    whole = native is not None and hasattr(plan, "phases_native") and os.environ.get("STMMQR_NATIVE_PHASES", "1") != "0"
+    if whole:
+        # every phase -- exchanges, shared fronts, this rank's groups -- enqueued by ONE native call (csrc/stmmqr_multi.cpp:
+        # stmmqr_factorize_phases): no interpreter and no host wait between two phases
+        plan.phases_native(sp.c_phases(), native)
+    for k in range(0 if whole else sp.nphase):
         if k > 0 and comm.size > 1:
             # contribution blocks move up the tree only where subtrees join: every block that enters phase k from another rank
             mine_out, mine_in = sp.out[k], sp.inn[k]

@@ -268,13 +268,19 @@ def test_shared_fronts_equal_unsharded(name, nranks, small, on_device):
     np.testing.assert_array_equal(G.Stack[:G.rh_total], ref.Stack[:ref.rh_total])
 
 
+@pytest.mark.parametrize("whole", [1, 0])
 @pytest.mark.parametrize("name,nranks,small", [("grid20_standin", 2, True), ("lns_3937", 4, True), ("epb1", 2, True),
                                                ("syn_rankdef_grid", 2, True), ("sme3dc_standin", 4, False), ("c5mini_standin", 8, False)])
-def test_native_shared_front_loop_equals_unsharded(name, nranks, small):
+def test_native_shared_front_loop_equals_unsharded(name, nranks, small, whole, monkeypatch):
     """round-3 verdict item 7: the panel loop of a shared front as ONE native call per rank (stmmqr_factorize_shared_front: panels,
     updates and messages enqueued on the plan's stream and a comm stream, ordered by events, no host round trip per step).  The
     ranks are threads on this GPU with a callback transport; on a multi-GPU node the transport is RCCL.  Merged result identical
-    to one plan's, exactly like the step-by-step Python loop."""
+    to one plan's, exactly like the step-by-step Python loop.
+    whole = 1 (round-4 verdict item 6): the whole sharded factorization as ONE native call per rank (stmmqr_factorize_phases):
+    per phase the subtree exchange as fixed-size messages packed / unpacked on the device, the shared front's panel loop and the
+    gather of its contribution block, the rank's own groups -- no Python between two phases.  whole = 0: the Python phase loop
+    with the native panel loop only."""
+    monkeypatch.setenv("STMMQR_NATIVE_PHASES", str(whole))
     pkg = importlib.import_module(PKG)
     sh = importlib.import_module(PKG + ".sharded")
     g = load_golden(name)
@@ -297,6 +303,53 @@ def test_native_shared_front_loop_equals_unsharded(name, nranks, small):
     for k in ("Hm", "Hr", "HStair", "HPinv", "Rdead", "Rblock_off", "Hii", "HTau"):
         np.testing.assert_array_equal(getattr(G, k), getattr(ref, k), err_msg=k)
     np.testing.assert_array_equal(G.Stack[:G.rh_total], ref.Stack[:ref.rh_total])
+
+
+@pytest.mark.parametrize("name,nranks", [("grid20_standin", 2), ("grid20_standin", 4), ("lns_3937", 8), ("syn_rankdef_grid", 2),
+                                         ("dwt_992", 4), ("epb1", 4), ("sme3dc_standin", 4)])
+def test_native_subtree_exchange_equals_unsharded(name, nranks):
+    """the subtree partition WITHOUT shared fronts (sharded.partition) through stmmqr_factorize_phases: what crosses ranks are the
+    contribution blocks where subtrees join, each as one fixed-size message (header, C slot, row ids) that the device packs and
+    unpacks.  Identical to one plan's result, rank detection included (syn_rankdef_grid: dead columns change fm / rank / cm of
+    the blocks that travel -- the sizes the host never sees)."""
+    pkg = importlib.import_module(PKG)
+    sh = importlib.import_module(PKG + ".sharded")
+    g = load_golden(name)
+    S = Symbolic(g)
+    sym = {**S.sc, **{k: v for k, v in S.arr.items() if v is not None}}
+    tol, ntol = scalar(g, "in_tol"), int(scalar(g, "in_ntol"))
+    ref = pkg.qr_factorize(sym, g["in_Ap"], g["in_Ai"], g["in_Ax"], tol, ntol)
+    owner, phase = sh.partition(sym, nranks)
+    out = _run_ranks(pkg, sh, sym, g, tol, ntol, nranks, owner, phase, None, True, native=True)
+    G = sh.merge_shards(sym, [o[1] for o in out], ntol)
+    assert sum(o[0]["flops"] for o in out) == ref.stats["flops"]
+    assert (G.rank, G.rank1, G.maxfrank, G.maxfm, G.rh_total) == (ref.rank, ref.rank1, ref.maxfrank, ref.maxfm, ref.rh_total)
+    for k in ("Hm", "Hr", "HStair", "HPinv", "Rdead", "Rblock_off", "Hii", "HTau"):
+        np.testing.assert_array_equal(getattr(G, k), getattr(ref, k), err_msg=k)
+    np.testing.assert_array_equal(G.Stack[:G.rh_total], ref.Stack[:ref.rh_total])
+
+
+def test_native_exchange_refuses_what_does_not_fit():
+    """stmmqr_factorize_exchange outside begin / finish, with a null transport, with a peer that is this rank or a front without
+    a contribution-block slot: refused with an error, nothing enqueued"""
+    pkg = importlib.import_module(PKG)
+    g = load_golden("grid20_standin")
+    S = Symbolic(g)
+    sym = {**S.sc, **{k: v for k, v in S.arr.items() if v is not None}}
+    plan = pkg.HipQR(sym)
+    tr = pkg.CallbackTransport(0, 2, lambda *a: 0, lambda *a: 0)
+    with pytest.raises(RuntimeError):
+        plan.exchange_native([(0, 1)], [], tr)                       # not begun
+    group = np.zeros(int(sym["nf"]), np.int32)
+    plan.set_groups(group)
+    plan.begin(g["in_Ax"], scalar(g, "in_tol"), int(scalar(g, "in_ntol")), g["in_Ap"], g["in_Ai"])
+    with pytest.raises(RuntimeError):
+        plan.exchange_native([(0, 0)], [], tr)                       # to myself
+    with pytest.raises(RuntimeError):
+        plan.exchange_native([(int(sym["nf"]), 1)], [], tr)          # no such front
+    plan.run_group(0)
+    plan.finish()
+    plan.close()
 
 
 def test_rccl_transport_single_rank_loopback():
