@@ -104,13 +104,18 @@ __global__ __launch_bounds__(QA_NT) void k_qapply(DevCtx c, const int *__restric
 //     y = T'w  (Q'x)  or  T w  (Q x),      x -= V y  (second sweep).
 // V is read in place with the unit-diagonal / staircase mask (reflector j of the panel: diagonal row dq[k], entries up
 // to HStair[k]); identity and dead columns have zero rows/columns in T and are masked out of V.
-__global__ __launch_bounds__(QA_NT) void k_qapply_t(DevCtx c, const int *__restrict__ flist, int method, double *W, RhsBatch B)
+// R right-hand sides of a batch per workgroup (template): every entry of V is read once per sweep for all of them; per vector the
+// arithmetic and its order are those of one vector alone (the first sweep takes the panel in R passes of 32 / R reflectors so that the 32
+// running sums stay in registers).
+template <int R>
+__global__ __launch_bounds__(QA_NT) void k_qapply_t(DevCtx c, const int *__restrict__ flist, int method, double *W, RhsBatch B, int nb)
 {
-    W += (long long)blockIdx.y * B.w;                      // (right-hand side blockIdx.y of the batch)
+    const int nr = min(R, nb - (int)blockIdx.y * R);       // right-hand sides of this workgroup (uniform)
+    W += (long long)blockIdx.y * R * B.w;
     extern __shared__ double dyn_lds[];
     __shared__ int s_scan[QA_NW];
     __shared__ int s_d[STM_NB], s_t[STM_NB];
-    __shared__ double s_part[QA_NW][STM_NB], s_w[STM_NB], s_y[STM_NB], s_T[STM_NB][STM_NB + 1];
+    __shared__ double s_part[R][QA_NW][STM_NB], s_w[R][STM_NB], s_y[R][STM_NB], s_T[STM_NB][STM_NB + 1];
     const int f = flist[blockIdx.x];
     const FrontSym s = c.fs[f];
     const int fm = c.fnum[f].fm;
@@ -121,9 +126,14 @@ __global__ __launch_bounds__(QA_NT) void k_qapply_t(DevCtx c, const int *__restr
     const int *Hi = c.Hii + s.hip;
     const double *F = c.Farena + s.foff;
     const long long ld = s.ld;
-    double *xs = dyn_lds;                               // [fm]
-    int *dq = (int *)(xs + ((fm + 1) & ~1));            // [fn]
-    for (int i = tid; i < fm; i += QA_NT) xs[i] = W[Hi[i]];
+    const int xst = (fm + 1) & ~1;
+    double *xs = dyn_lds;                               // [R][xst]
+    int *dq = (int *)(xs + (size_t)R * xst);            // [fn]
+    for (int i = tid; i < fm; i += QA_NT) {
+        const int h = Hi[i];
+#pragma unroll
+        for (int r = 0; r < R; r++) xs[r * xst + i] = (r < nr) ? W[(long long)r * B.w + h] : 0.0;
+    }
     qa_number_reflectors(s, fm, St, Tau, dq, s_scan);
     const int pbeg = method ? s.npanels - 1 : 0, pend = method ? -1 : s.npanels, pinc = method ? -1 : 1;
     for (int p = pbeg; p != pend; p += pinc) {
@@ -147,26 +157,36 @@ __global__ __launch_bounds__(QA_NT) void k_qapply_t(DevCtx c, const int *__restr
             for (int q = 0; q < (STM_NB * STM_NB + QA_NT - 1) / QA_NT; q++) treg[q] = T[min(tid + QA_NT * q, STM_NB * STM_NB - 1)];
         }
         // ---- w = V'x ----
-        double acc[STM_NB];
+        constexpr int HB = STM_NB / R;                     // reflectors per pass of the first sweep (R x HB running sums per thread)
 #pragma unroll
-        for (int j = 0; j < STM_NB; j++) acc[j] = 0;
-        for (int i = r0 + tid; i < r1; i += QA_NT) {
-            const double xi = xs[i];
+        for (int h0 = 0; h0 < STM_NB; h0 += HB) {
+            double acc[R][HB];
 #pragma unroll
-            for (int j = 0; j < STM_NB; j++) {
-                const double val = Vp[i + (long long)min(j, nbp - 1) * ld];        // unconditional, masked below
-                const double v = (i > s_d[j] && i < s_t[j]) ? val : ((i == s_d[j]) ? 1.0 : 0.0);
-                acc[j] += v * xi;
+            for (int r = 0; r < R; r++)
+#pragma unroll
+                for (int j = 0; j < HB; j++) acc[r][j] = 0;
+            for (int i = r0 + tid; i < r1; i += QA_NT) {
+                double xi[R];
+#pragma unroll
+                for (int r = 0; r < R; r++) xi[r] = xs[r * xst + i];
+#pragma unroll
+                for (int j = 0; j < HB; j++) {
+                    const double val = Vp[i + (long long)min(h0 + j, nbp - 1) * ld];        // unconditional, masked below
+                    const double v = (i > s_d[h0 + j] && i < s_t[h0 + j]) ? val : ((i == s_d[h0 + j]) ? 1.0 : 0.0);
+#pragma unroll
+                    for (int r = 0; r < R; r++) acc[r][j] += v * xi[r];
+                }
             }
-        }
-        {
-            double part[8];
 #pragma unroll
-            for (int q = 0; q < 4; q++) {
+            for (int r = 0; r < R; r++) {
+                double part[8];
 #pragma unroll
-                for (int x = 0; x < 8; x++) part[x] = acc[8 * q + x];
-                const double rw = wave_reduce8(part);                             // lane l: total of value red8_idx(l)
-                if (lane < 8) s_part[wid][8 * q + red8_idx(lane)] = rw;
+                for (int q = 0; q < HB / 8; q++) {
+#pragma unroll
+                    for (int x = 0; x < 8; x++) part[x] = acc[r][8 * q + x];
+                    const double rw = wave_reduce8(part);                             // lane l: total of value red8_idx(l)
+                    if (lane < 8) s_part[r][wid][h0 + 8 * q + red8_idx(lane)] = rw;
+                }
             }
         }
 #pragma unroll
@@ -175,35 +195,51 @@ __global__ __launch_bounds__(QA_NT) void k_qapply_t(DevCtx c, const int *__restr
             if (e < STM_NB * STM_NB) s_T[e % STM_NB][e / STM_NB] = treg[q];                // s_T[row][col], padded rows: no bank conflicts below
         }
         __syncthreads();
-        if (tid < STM_NB) {
+        if (tid < STM_NB * R) {
+            const int r = tid / STM_NB, j = tid % STM_NB;
             double v = 0;
 #pragma unroll
-            for (int w = 0; w < QA_NW; w++) v += s_part[w][tid];
-            s_w[tid] = v;
+            for (int w = 0; w < QA_NW; w++) v += s_part[r][w][j];
+            s_w[r][j] = v;
         }
         __syncthreads();
         // ---- y = T'w (Q'x) or T w (Q x); T upper triangular ----
-        if (tid < STM_NB) {
+        if (tid < STM_NB * R) {
+            const int r = tid / STM_NB, j = tid % STM_NB;
             double y = 0;
-            if (method == 0) { for (int q = 0; q <= tid; q++) y += s_T[q][tid] * s_w[q]; }
-            else { for (int q = tid; q < STM_NB; q++) y += s_T[tid][q] * s_w[q]; }
-            s_y[tid] = y;
+            if (method == 0) { for (int q = 0; q <= j; q++) y += s_T[q][j] * s_w[r][q]; }
+            else { for (int q = j; q < STM_NB; q++) y += s_T[j][q] * s_w[r][q]; }
+            s_y[r][j] = y;
         }
         __syncthreads();
         // ---- x -= V y ----
-        for (int i = r0 + tid; i < r1; i += QA_NT) {
-            double a = xs[i];
+        // (in passes of HB reflectors as well: the R x HB entries of y a pass needs stay in registers; a row's x goes through LDS
+        //  between two passes -- the same subtractions in the same order)
 #pragma unroll
-            for (int j = 0; j < STM_NB; j++) {
-                const double val = Vp[i + (long long)min(j, nbp - 1) * ld];
-                const double v = (i > s_d[j] && i < s_t[j]) ? val : ((i == s_d[j]) ? 1.0 : 0.0);
-                a -= v * s_y[j];
+        for (int h0 = 0; h0 < STM_NB; h0 += HB) {
+            for (int i = r0 + tid; i < r1; i += QA_NT) {
+                double a[R];
+#pragma unroll
+                for (int r = 0; r < R; r++) a[r] = xs[r * xst + i];
+#pragma unroll
+                for (int j = 0; j < HB; j++) {
+                    const double val = Vp[i + (long long)min(h0 + j, nbp - 1) * ld];
+                    const double v = (i > s_d[h0 + j] && i < s_t[h0 + j]) ? val : ((i == s_d[h0 + j]) ? 1.0 : 0.0);
+#pragma unroll
+                    for (int r = 0; r < R; r++) a[r] -= v * s_y[r][h0 + j];
+                }
+#pragma unroll
+                for (int r = 0; r < R; r++) xs[r * xst + i] = a[r];
             }
-            xs[i] = a;
         }
         __syncthreads();
     }
-    for (int i = tid; i < fm; i += QA_NT) W[Hi[i]] = xs[i];
+    for (int i = tid; i < fm; i += QA_NT) {
+        const int h = Hi[i];
+#pragma unroll
+        for (int r = 0; r < R; r++)
+            if (r < nr) W[(long long)r * B.w + h] = xs[r * xst + i];
+    }
 }
 
 // One front of the back substitution R x = y (fronts root -> leaves; reference qr_rsolve, SparseQR.c:2218-2470):
@@ -519,12 +555,17 @@ __global__ __launch_bounds__(512) void k_qt4_build(DevCtx c, const Qt4Item *__re
     }
 }
 
+// Several right-hand sides per workgroup (R of the batch, template): V, its masks and T4 are loaded ONCE and applied to R vectors --
+// with one vector per workgroup a batch of 32 read every reflector 32 times (73.9 us per launch against 24.6 for one vector on the
+// default workload).  Per vector the arithmetic and its order are those of R = 1: a batch gives the bits of its vectors one by one.
+template <int R>
 __global__ __launch_bounds__(QB_ROWS) void k_qbig_step4(DevCtx c, const QbDesc *__restrict__ qd, const long long *__restrict__ t4off, int k,
-                                                      int method, double *Xf0, const int *Dq0, double *Wq0, const double *T4all, RhsBatch B)
+                                                      int method, double *Xf0, const int *Dq0, double *Wq0, const double *T4all, RhsBatch B, int nb)
 {
-    Xf0 += (long long)blockIdx.z * B.xf; Wq0 += (long long)blockIdx.z * B.wq4;
+    const int nr = min(R, nb - (int)blockIdx.z * R);               // vectors of this workgroup (uniform)
+    Xf0 += (long long)blockIdx.z * R * B.xf; Wq0 += (long long)blockIdx.z * R * B.wq4;
     __shared__ int s_d[2][QGN], s_t[2][QGN], s_rng[2][2][2];
-    __shared__ double s_part[QB_ROWS / 64][QGN], s_w[QGN], s_y[QGN], s_yp[QB_ROWS / QGN][QGN];
+    __shared__ double s_part[R][QB_ROWS / 64][QGN], s_w[R][QGN], s_y[R][QGN], s_yp[R][QB_ROWS / QGN][QGN];
     const QbDesc qdd = qd[blockIdx.y];
     const int f = qdd.f, nslab = qdd.nslab;
     if ((int)blockIdx.x >= nslab) return;
@@ -552,7 +593,9 @@ __global__ __launch_bounds__(QB_ROWS) void k_qbig_step4(DevCtx c, const QbDesc *
         const int lo = wave_max_int(-s_d[w][j]), hi = wave_max_int(s_t[w][j]);
         if (lane == 0) { s_rng[w][(tid >> 6) & 1][0] = -lo; s_rng[w][(tid >> 6) & 1][1] = hi; }
     }
-    double x = (i < fm) ? Xf[i] : 0.0;
+    double x[R];
+#pragma unroll
+    for (int r = 0; r < R; r++) x[r] = (i < fm && r < nr) ? Xf[(long long)r * B.xf + i] : 0.0;
     __syncthreads();
     bool on[2];
 #pragma unroll
@@ -584,36 +627,51 @@ __global__ __launch_bounds__(QB_ROWS) void k_qbig_step4(DevCtx c, const QbDesc *
         double m[32];
 #pragma unroll
         for (int q = 0; q < 32; q++) m[q] = M[o + QGN * (32 * part + q)];
-        if (tid < QGN) s_w[tid] = stm_ordered_sum<false>(Wq + (long long)(gg[0] & 1) * nslab * QGN + tid, QGN, nslab);      // fixed order
+        if (tid < QGN) {
+#pragma unroll
+            for (int r = 0; r < R; r++)
+                if (r < nr) s_w[r][tid] = stm_ordered_sum<false>(Wq + (long long)r * B.wq4 + (long long)(gg[0] & 1) * nslab * QGN + tid, QGN, nslab);      // fixed order
+        }
 #pragma unroll
         for (int q = 0; q < DEPTH; q++) load_v(q, buf[q]);
         __syncthreads();
-        {
+#pragma unroll
+        for (int r = 0; r < R; r++) {
+            if (r >= nr) continue;
             double p0 = 0, p1 = 0, p2 = 0, p3 = 0;
 #pragma unroll
             for (int q = 0; q < 32; q += 4) {
-                p0 += m[q] * s_w[32 * part + q];
-                p1 += m[q + 1] * s_w[32 * part + q + 1];
-                p2 += m[q + 2] * s_w[32 * part + q + 2];
-                p3 += m[q + 3] * s_w[32 * part + q + 3];
+                p0 += m[q] * s_w[r][32 * part + q];
+                p1 += m[q + 1] * s_w[r][32 * part + q + 1];
+                p2 += m[q + 2] * s_w[r][32 * part + q + 2];
+                p3 += m[q + 3] * s_w[r][32 * part + q + 3];
             }
-            s_yp[part][o] = (p0 + p1) + (p2 + p3);
+            s_yp[r][part][o] = (p0 + p1) + (p2 + p3);
         }
         __syncthreads();
-        if (tid < QGN) s_y[tid] = (s_yp[0][tid] + s_yp[1][tid]) + (s_yp[2][tid] + s_yp[3][tid]);
+        if (tid < QGN) {
+#pragma unroll
+            for (int r = 0; r < R; r++)
+                if (r < nr) s_y[r][tid] = (s_yp[r][0][tid] + s_yp[r][1][tid]) + (s_yp[r][2][tid] + s_yp[r][3][tid]);
+        }
         __syncthreads();
     } else {
 #pragma unroll
         for (int q = 0; q < DEPTH; q++) load_v(q, buf[q]);
     }
-    double a = x;
+    double a[R];
+#pragma unroll
+    for (int r = 0; r < R; r++) a[r] = x[r];
 #pragma unroll
     for (int idx = 0; idx < 2 * NSB; idx++) {
         double (&v)[SB] = buf[idx % DEPTH];
         const int w = idx / NSB, sb = idx % NSB;
         if (idx == NSB) {                               // between the phases: x after the group that was applied
-            if (on[0] && i < fm && a != x) Xf[i] = a;
-            x = (i < fm) ? a : 0.0;
+#pragma unroll
+            for (int r = 0; r < R; r++) {
+                if (on[0] && i < fm && r < nr && a[r] != x[r]) Xf[(long long)r * B.xf + i] = a[r];
+                x[r] = (i < fm) ? a[r] : 0.0;
+            }
         }
         if (w == 0) {
             if (on[0]) {
@@ -621,24 +679,28 @@ __global__ __launch_bounds__(QB_ROWS) void k_qbig_step4(DevCtx c, const QbDesc *
                 for (int j = 0; j < SB; j++) {
                     const int d = s_d[0][sb * SB + j], t = s_t[0][sb * SB + j];
                     const double vv = (i > d && i < t) ? v[j] : ((i == d) ? 1.0 : 0.0);
-                    a -= vv * s_y[sb * SB + j];
+#pragma unroll
+                    for (int r = 0; r < R; r++) a[r] -= vv * s_y[r][sb * SB + j];
                 }
             }
         } else if (gg[1] >= 0) {
-            double accv[SB];
+            double vm[SB];
 #pragma unroll
             for (int j = 0; j < SB; j++) {
                 const int d = s_d[1][sb * SB + j], t = s_t[1][sb * SB + j];
-                const double vv = (i < fm && i > d && i < t) ? v[j] : ((i == d) ? 1.0 : 0.0);
-                accv[j] = on[1] ? vv * x : 0.0;
+                vm[j] = (i < fm && i > d && i < t) ? v[j] : ((i == d) ? 1.0 : 0.0);
             }
-            double part[8];
 #pragma unroll
-            for (int q = 0; q < SB / 8; q++) {
+            for (int r = 0; r < R; r++) {
+                if (r >= nr) continue;
+                double part[8];
 #pragma unroll
-                for (int xx = 0; xx < 8; xx++) part[xx] = accv[8 * q + xx];
-                const double rw = wave_reduce8(part);                             // lane l: total of value red8_idx(l)
-                if (lane < 8) s_part[wid][sb * SB + 8 * q + red8_idx(lane)] = rw;
+                for (int q = 0; q < SB / 8; q++) {
+#pragma unroll
+                    for (int xx = 0; xx < 8; xx++) part[xx] = on[1] ? vm[8 * q + xx] * x[r] : 0.0;
+                    const double rw = wave_reduce8(part);                             // lane l: total of value red8_idx(l)
+                    if (lane < 8) s_part[r][wid][sb * SB + 8 * q + red8_idx(lane)] = rw;
+                }
             }
         }
         if (idx + DEPTH < 2 * NSB) load_v(idx + DEPTH, v);
@@ -646,19 +708,25 @@ __global__ __launch_bounds__(QB_ROWS) void k_qbig_step4(DevCtx c, const QbDesc *
     if (gg[1] >= 0) {
         __syncthreads();
         if (tid < QGN) {
-            double vsum = 0;
 #pragma unroll
-            for (int w = 0; w < QB_ROWS / 64; w++) vsum += s_part[w][tid];
-            Wq[((long long)(gg[1] & 1) * nslab + blockIdx.x) * QGN + tid] = vsum;
+            for (int r = 0; r < R; r++) {
+                if (r >= nr) continue;
+                double vsum = 0;
+#pragma unroll
+                for (int w = 0; w < QB_ROWS / 64; w++) vsum += s_part[r][w][tid];
+                Wq[(long long)r * B.wq4 + ((long long)(gg[1] & 1) * nslab + blockIdx.x) * QGN + tid] = vsum;
+            }
         }
     }
 }
 
 #define RS_NT 1024               // the back substitution streams R through one workgroup: more loads in flight
+template <int R>                                           // (R right-hand sides of the batch per workgroup: R is read once for all of them)
 __global__ __launch_bounds__(RS_NT) void k_rsolve(DevCtx c, const int *__restrict__ flist, const int *__restrict__ Rj,
-                                                  const double *W, double *X, int *err, RhsBatch B)
+                                                  const double *W, double *X, int *err, RhsBatch B, int nb)
 {
-    W += (long long)blockIdx.y * B.w; X += (long long)blockIdx.y * B.x;
+    const int nr = min(R, nb - (int)blockIdx.y * R);
+    W += (long long)blockIdx.y * R * B.w; X += (long long)blockIdx.y * R * B.x;
     extern __shared__ double dyn_lds[];
     __shared__ int s_scan[RS_NT / 64];
     const int f = flist[blockIdx.x];
@@ -672,9 +740,10 @@ __global__ __launch_bounds__(RS_NT) void k_rsolve(DevCtx c, const int *__restric
     const int *rj = Rj + s.rp;
     const double *F = c.Farena + s.foff;
     const long long ld = s.ld;
-    double *acc = dyn_lds;                              // [fp]
-    double *xo = acc + ((fp + 1) & ~1);                 // [fn - fp] x of the non-pivotal columns
-    int *lc = (int *)(xo + ((fn - fp + 1) & ~1));       // [fp] live pivot columns, compact
+    const int ast = (fp + 1) & ~1, ost = (fn - fp + 1) & ~1;
+    double *acc = dyn_lds;                              // [R][ast]
+    double *xo = acc + (size_t)R * ast;                 // [R][ost] x of the non-pivotal columns
+    int *lc = (int *)(xo + (size_t)R * ost);            // [fp] live pivot columns, compact
     // ---- live pivot columns (HStair != 0 and a row left for the diagonal), dead ones: x = 0 ----
     int rm;
     {
@@ -687,62 +756,94 @@ __global__ __launch_bounds__(RS_NT) void k_rsolve(DevCtx c, const int *__restric
         int q = incl - cnt;
         for (int k = k0; k < k1; k++) {
             if (St[k] != 0 && q < fm) lc[q] = k;
-            else if (St[k] == 0) X[s.col1 + k] = 0.0;
+            else if (St[k] == 0) {
+#pragma unroll
+                for (int r = 0; r < R; r++)
+                    if (r < nr) X[(long long)r * B.x + s.col1 + k] = 0.0;
+            }
             q += (St[k] != 0);
         }
         rm = min(total, fm);
     }
-    for (int k = fp + tid; k < fn; k += RS_NT) xo[k - fp] = X[rj[k]];
+    for (int k = fp + tid; k < fn; k += RS_NT) {
+        const int j = rj[k];
+#pragma unroll
+        for (int r = 0; r < R; r++) xo[r * ost + k - fp] = (r < nr) ? X[(long long)r * B.x + j] : 0.0;
+    }
     __syncthreads();
     if (rm != nm.rank && tid == 0) atomicExch(err, 1);  // (cannot happen: same rule as the factorization)
     // acc = y - R12 x_others : thread per row, columns streamed (coalesced over the rows)
     for (int i = tid; i < rm; i += RS_NT) {
-        double a0 = W[Hi[i]], a1 = 0, a2 = 0, a3 = 0;  // (four partial sums, 16 loads in flight: as k_rbig_init)
+        double a0[R], a1[R], a2[R], a3[R];              // (four partial sums, 16 loads in flight: as k_rbig_init)
+        const int h = Hi[i];
+#pragma unroll
+        for (int r = 0; r < R; r++) { a0[r] = (r < nr) ? W[(long long)r * B.w + h] : 0.0; a1[r] = a2[r] = a3[r] = 0; }
         int k = fp;
         for (; k + 16 <= fn; k += 16) {
 #pragma unroll
             for (int u = 0; u < 16; u += 4) {
-                a0 -= F[i + (long long)(k + u) * ld] * xo[k + u - fp];
-                a1 -= F[i + (long long)(k + u + 1) * ld] * xo[k + u + 1 - fp];
-                a2 -= F[i + (long long)(k + u + 2) * ld] * xo[k + u + 2 - fp];
-                a3 -= F[i + (long long)(k + u + 3) * ld] * xo[k + u + 3 - fp];
+                const double f0 = F[i + (long long)(k + u) * ld], f1 = F[i + (long long)(k + u + 1) * ld];
+                const double f2 = F[i + (long long)(k + u + 2) * ld], f3 = F[i + (long long)(k + u + 3) * ld];
+#pragma unroll
+                for (int r = 0; r < R; r++) {
+                    a0[r] -= f0 * xo[r * ost + k + u - fp];
+                    a1[r] -= f1 * xo[r * ost + k + u + 1 - fp];
+                    a2[r] -= f2 * xo[r * ost + k + u + 2 - fp];
+                    a3[r] -= f3 * xo[r * ost + k + u + 3 - fp];
+                }
             }
         }
-        for (; k < fn; k++) a0 -= F[i + (long long)k * ld] * xo[k - fp];
-        acc[i] = (a0 + a1) + (a2 + a3);
+        for (; k < fn; k++) {
+            const double f0 = F[i + (long long)k * ld];
+#pragma unroll
+            for (int r = 0; r < R; r++) a0[r] -= f0 * xo[r * ost + k - fp];
+        }
+#pragma unroll
+        for (int r = 0; r < R; r++) acc[r * ast + i] = (a0[r] + a1[r]) + (a2[r] + a3[r]);
     }
     __syncthreads();
     // triangle: blocked back substitution over the compact list.  Per block of QS_NB live columns: the diagonal triangle
-    // goes to LDS and one wave solves it there (no global latency inside the 32 dependent steps), then every thread
-    // updates its rows of acc with the block's columns (coalesced over the rows, 32 independent loads in flight).
+    // goes to LDS and one wave per right-hand side solves it there (no global latency inside the 32 dependent steps), then every
+    // thread updates its rows of acc with the block's columns (coalesced over the rows, 32 independent loads in flight).
     constexpr int QS_NB = 32;
     __shared__ double s_tri[QS_NB][QS_NB + 1];
-    __shared__ double s_x[QS_NB];
+    __shared__ double s_x[R][QS_NB];
     for (int kb = ((max(rm, 1) - 1) / QS_NB) * QS_NB; kb >= 0 && rm > 0; kb -= QS_NB) {
-        const int nb = min(QS_NB, rm - kb);
+        const int nbk = min(QS_NB, rm - kb);
         for (int e = tid; e < QS_NB * QS_NB; e += RS_NT) {
             const int i = e % QS_NB, j = e / QS_NB;
-            s_tri[i][j] = (i < nb && j < nb && i <= j) ? F[(kb + i) + (long long)lc[kb + j] * ld] : 0.0;
+            s_tri[i][j] = (i < nbk && j < nbk && i <= j) ? F[(kb + i) + (long long)lc[kb + j] * ld] : 0.0;
         }
         __syncthreads();
-        if (tid < 64) {
-            // lane i owns row i of the triangle (i < nb): x_j for j = nb-1 .. 0
-            const int i = tid;
-            double a = (i < nb) ? acc[kb + i] : 0.0;
-            for (int j = nb - 1; j >= 0; j--) {
+        if (tid < 64 * R) {
+            // wave r, lane i owns row i of the triangle (i < nbk) of right-hand side r: x_j for j = nbk-1 .. 0
+            const int i = tid & 63, r = tid >> 6;
+            double a = (i < nbk) ? acc[r * ast + kb + i] : 0.0;
+            for (int j = nbk - 1; j >= 0; j--) {
                 const double aj = __shfl(a, j, 64);
                 const double xj = aj / s_tri[j][j];
                 if (i < j) a -= s_tri[i][j] * xj;
-                if (i == j) s_x[j] = xj;
+                if (i == j) s_x[r][j] = xj;
             }
         }
         __syncthreads();
-        if (tid < nb) X[s.col1 + lc[kb + tid]] = s_x[tid];
+        if (tid < nbk) {
+#pragma unroll
+            for (int r = 0; r < R; r++)
+                if (r < nr) X[(long long)r * B.x + s.col1 + lc[kb + tid]] = s_x[r][tid];
+        }
         for (int i = tid; i < kb; i += RS_NT) {
-            double a = acc[i];
+            double a[R];
+#pragma unroll
+            for (int r = 0; r < R; r++) a[r] = acc[r * ast + i];
 #pragma unroll 8
-            for (int j = 0; j < nb; j++) a -= F[i + (long long)lc[kb + j] * ld] * s_x[j];
-            acc[i] = a;
+            for (int j = 0; j < nbk; j++) {
+                const double fv = F[i + (long long)lc[kb + j] * ld];
+#pragma unroll
+                for (int r = 0; r < R; r++) a[r] -= fv * s_x[r][j];
+            }
+#pragma unroll
+            for (int r = 0; r < R; r++) acc[r * ast + i] = a[r];
         }
         __syncthreads();
     }
@@ -883,14 +984,16 @@ __global__ __launch_bounds__(RS_NT) void k_rbig_prep(DevCtx c, const QbDesc *__r
         if (rm != nm.rank) atomicExch(err, 1);
     }
 }
+template <int R>                                           // (R right-hand sides of the batch per workgroup: R12 is read once for all of them)
 __global__ __launch_bounds__(STM_QB_ROWS) void k_rbig_init(DevCtx c, const QbDesc *__restrict__ qd, const int *__restrict__ Rj,
-                                                           const double *W, const double *X, double *Acc0, const int *Rm, RhsBatch B)
+                                                           const double *W, const double *X, double *Acc0, const int *Rm, RhsBatch B, int nb)
 {
-    W += (long long)blockIdx.z * B.w; X += (long long)blockIdx.z * B.x; Acc0 += (long long)blockIdx.z * B.xf;
+    const int nr = min(R, nb - (int)blockIdx.z * R);
+    W += (long long)blockIdx.z * R * B.w; X += (long long)blockIdx.z * R * B.x; Acc0 += (long long)blockIdx.z * R * B.xf;
     // y - R12 x2 for the rows of the live pivot columns.  A workgroup takes 64 rows; its eight waves share the non-pivotal columns
     // (chunks of 16, wave w the chunks w, w + 8, ...) and their partial sums are added in wave order (round 4: a thread per row ran
     // through all the columns alone -- 250 dependent round trips on a front with 4000 of them, 276 us per launch).
-    __shared__ double s_p[STM_QB_ROWS / 64][64];
+    __shared__ double s_p[R][STM_QB_ROWS / 64][64];
     const QbDesc d = qd[blockIdx.y];
     const FrontSym s = c.fs[d.f];
     const int rm = Rm[blockIdx.y];
@@ -902,27 +1005,43 @@ __global__ __launch_bounds__(STM_QB_ROWS) void k_rbig_init(DevCtx c, const QbDes
     const double *F = c.Farena + s.foff;
     const long long ld = s.ld;
     // (coalesced over the rows; X[rj[k]] uniform; four partial sums and an unrolled body keep 16 loads in flight)
-    double a0 = 0, a1 = 0, a2 = 0, a3 = 0;
+    double a0[R], a1[R], a2[R], a3[R];
+#pragma unroll
+    for (int r = 0; r < R; r++) a0[r] = a1[r] = a2[r] = a3[r] = 0;
+    const long long xs = (nr > 1) ? B.x : 0;                // (vectors beyond the batch read the first one's x: never stored)
     const int nfull = (s.fn - s.fp) / 16;
     for (int ch = cl; ch < nfull; ch += STM_QB_ROWS / 64) {
         const int k = s.fp + 16 * ch;
 #pragma unroll
         for (int u = 0; u < 16; u += 4) {
-            a0 -= F[ic + (long long)(k + u) * ld] * X[rj[k + u]];
-            a1 -= F[ic + (long long)(k + u + 1) * ld] * X[rj[k + u + 1]];
-            a2 -= F[ic + (long long)(k + u + 2) * ld] * X[rj[k + u + 2]];
-            a3 -= F[ic + (long long)(k + u + 3) * ld] * X[rj[k + u + 3]];
+            const double f0 = F[ic + (long long)(k + u) * ld], f1 = F[ic + (long long)(k + u + 1) * ld];
+            const double f2 = F[ic + (long long)(k + u + 2) * ld], f3 = F[ic + (long long)(k + u + 3) * ld];
+            const int j0 = rj[k + u], j1 = rj[k + u + 1], j2 = rj[k + u + 2], j3 = rj[k + u + 3];
+#pragma unroll
+            for (int r = 0; r < R; r++) {
+                const double *Xr = X + (r < nr ? r : 0) * xs;
+                a0[r] -= f0 * Xr[j0];
+                a1[r] -= f1 * Xr[j1];
+                a2[r] -= f2 * Xr[j2];
+                a3[r] -= f3 * Xr[j3];
+            }
         }
     }
     if (cl == 0)
-        for (int k = s.fp + 16 * nfull; k < s.fn; k++) a0 -= F[ic + (long long)k * ld] * X[rj[k]];
-    s_p[cl][lrow] = (a0 + a1) + (a2 + a3);
-    __syncthreads();
-    if (cl == 0 && i < rm) {
-        double a = W[c.Hii[s.hip + i]];
+        for (int k = s.fp + 16 * nfull; k < s.fn; k++) {
+            const double f0 = F[ic + (long long)k * ld];
+            const int j0 = rj[k];
 #pragma unroll
-        for (int w = 0; w < STM_QB_ROWS / 64; w++) a += s_p[w][lrow];
-        Acc0[d.xoff + i] = a;
+            for (int r = 0; r < R; r++) a0[r] -= f0 * X[(r < nr ? r : 0) * xs + j0];
+        }
+#pragma unroll
+    for (int r = 0; r < R; r++) s_p[r][cl][lrow] = (a0[r] + a1[r]) + (a2[r] + a3[r]);
+    __syncthreads();
+    if (cl < nr && i < rm) {                               // (wave r adds up right-hand side r)
+        double a = W[(long long)cl * B.w + c.Hii[s.hip + i]];
+#pragma unroll
+        for (int w = 0; w < STM_QB_ROWS / 64; w++) a += s_p[cl][w][lrow];
+        Acc0[(long long)cl * B.xf + d.xoff + i] = a;
     }
 }
 __global__ __launch_bounds__(STM_QB_ROWS) void k_rbig_step(DevCtx c, const QbDesc *__restrict__ qd, int kstep, double *X, double *Acc0,
@@ -997,7 +1116,13 @@ int stm_launch_qapply_t(const DevCtx &c, const int *flist, int nfr, int method, 
                         const RhsBatch &B)
 {
     if (nfr <= 0) return 0;
-    hipLaunchKernelGGL(k_qapply_t, dim3(nfr, nb), dim3(QA_NT), (size_t)lds_bytes, st, c, flist, method, W, B);
+    // (lds_bytes: what ONE right-hand side needs; R of them share a workgroup while R x that stays within 64 KB)
+    if (nb >= 3 && 4L * lds_bytes <= 65536)
+        hipLaunchKernelGGL(k_qapply_t<4>, dim3(nfr, (nb + 3) / 4), dim3(QA_NT), (size_t)4 * lds_bytes, st, c, flist, method, W, B, nb);
+    else if (nb >= 2 && 2L * lds_bytes <= 131072)
+        hipLaunchKernelGGL(k_qapply_t<2>, dim3(nfr, (nb + 1) / 2), dim3(QA_NT), (size_t)2 * lds_bytes, st, c, flist, method, W, B, nb);
+    else
+        hipLaunchKernelGGL(k_qapply_t<1>, dim3(nfr, nb), dim3(QA_NT), (size_t)lds_bytes, st, c, flist, method, W, B, nb);
     return (int)hipGetLastError();
 }
 // the split fronts of one level: prep, max(npanels) + 1 steps, finish
@@ -1029,8 +1154,11 @@ int stm_launch_qapply_big4(const DevCtx &c, const QbDesc *qd, const long long *t
     if (nq <= 0 || max_npanels <= 0) return 0;
     const int max_ng = (max_npanels + QG - 1) / QG;
     hipLaunchKernelGGL(k_qbig_prep, dim3(nq, nb), dim3(QA_NT), 0, st, c, qd, (const double *)W, Xf, Dq, B);
-    for (int k = 0; k <= max_ng; k++)
-        hipLaunchKernelGGL(k_qbig_step4, dim3(max_nslab, nq, nb), dim3(QB_ROWS), 0, st, c, qd, t4off, k, method, Xf, (const int *)Dq, Wq4, T4all, B);
+    for (int k = 0; k <= max_ng; k++) {
+        if (nb >= 3) hipLaunchKernelGGL(k_qbig_step4<4>, dim3(max_nslab, nq, (nb + 3) / 4), dim3(QB_ROWS), 0, st, c, qd, t4off, k, method, Xf, (const int *)Dq, Wq4, T4all, B, nb);
+        else if (nb == 2) hipLaunchKernelGGL(k_qbig_step4<2>, dim3(max_nslab, nq, 1), dim3(QB_ROWS), 0, st, c, qd, t4off, k, method, Xf, (const int *)Dq, Wq4, T4all, B, nb);
+        else hipLaunchKernelGGL(k_qbig_step4<1>, dim3(max_nslab, nq, 1), dim3(QB_ROWS), 0, st, c, qd, t4off, k, method, Xf, (const int *)Dq, Wq4, T4all, B, nb);
+    }
     hipLaunchKernelGGL(k_qbig_finish, dim3((max_fm + 255) / 256, nq, nb), dim3(256), 0, st, c, qd, W, (const double *)Xf, B);
     return (int)hipGetLastError();
 }
@@ -1038,7 +1166,13 @@ int stm_launch_rsolve(const DevCtx &c, const int *flist, int nfr, const int *Rj,
                       int *err, hipStream_t st, int nb, const RhsBatch &B)
 {
     if (nfr <= 0) return 0;
-    hipLaunchKernelGGL(k_rsolve, dim3(nfr, nb), dim3(RS_NT), (size_t)lds_bytes, st, c, flist, Rj, W, X, err, B);
+    // (lds_bytes: what ONE right-hand side needs)
+    if (nb >= 3 && 4L * lds_bytes <= 65536)
+        hipLaunchKernelGGL(k_rsolve<4>, dim3(nfr, (nb + 3) / 4), dim3(RS_NT), (size_t)4 * lds_bytes, st, c, flist, Rj, W, X, err, B, nb);
+    else if (nb >= 2 && 2L * lds_bytes <= 131072)
+        hipLaunchKernelGGL(k_rsolve<2>, dim3(nfr, (nb + 1) / 2), dim3(RS_NT), (size_t)2 * lds_bytes, st, c, flist, Rj, W, X, err, B, nb);
+    else
+        hipLaunchKernelGGL(k_rsolve<1>, dim3(nfr, nb), dim3(RS_NT), (size_t)lds_bytes, st, c, flist, Rj, W, X, err, B, nb);
     return (int)hipGetLastError();
 }
 // back substitution of the split fronts of one level: prep, init, max ceil(fp / 32) steps
@@ -1047,8 +1181,15 @@ int stm_launch_rsolve_big(const DevCtx &c, const QbDesc *qd, int nq, int max_ste
 {
     if (nq <= 0) return 0;
     hipLaunchKernelGGL(k_rbig_prep, dim3(nq, nb), dim3(RS_NT), 0, st, c, qd, X, Lc, Rm, err, B);
-    hipLaunchKernelGGL(k_rbig_init, dim3(max_nslab * (STM_QB_ROWS / 64), nq, nb), dim3(STM_QB_ROWS), 0, st, c, qd, Rj, W, (const double *)X, Acc,
-                       (const int *)Rm, B);
+    if (nb >= 3)
+        hipLaunchKernelGGL(k_rbig_init<4>, dim3(max_nslab * (STM_QB_ROWS / 64), nq, (nb + 3) / 4), dim3(STM_QB_ROWS), 0, st, c, qd, Rj, W,
+                           (const double *)X, Acc, (const int *)Rm, B, nb);
+    else if (nb == 2)
+        hipLaunchKernelGGL(k_rbig_init<2>, dim3(max_nslab * (STM_QB_ROWS / 64), nq, 1), dim3(STM_QB_ROWS), 0, st, c, qd, Rj, W, (const double *)X, Acc,
+                           (const int *)Rm, B, nb);
+    else
+        hipLaunchKernelGGL(k_rbig_init<1>, dim3(max_nslab * (STM_QB_ROWS / 64), nq, 1), dim3(STM_QB_ROWS), 0, st, c, qd, Rj, W, (const double *)X, Acc,
+                           (const int *)Rm, B, nb);
     for (int k = 0; k < max_steps; k++)
         hipLaunchKernelGGL(k_rbig_step, dim3(max_nslab, nq, nb), dim3(STM_QB_ROWS), 0, st, c, qd, k, X, Acc, (const int *)Lc, (const int *)Rm, B);
     return (int)hipGetLastError();
@@ -1069,8 +1210,12 @@ int stm_launch_perm(const double *in, const int *perm, double *out, int n, int s
 int stm_configure_resident(void)
 {
     CK(hipFuncSetAttribute((const void *)k_qapply, hipFuncAttributeMaxDynamicSharedMemorySize, 131072));
-    CK(hipFuncSetAttribute((const void *)k_qapply_t, hipFuncAttributeMaxDynamicSharedMemorySize, 131072));
-    CK(hipFuncSetAttribute((const void *)k_rsolve, hipFuncAttributeMaxDynamicSharedMemorySize, 131072));
+    CK(hipFuncSetAttribute((const void *)k_qapply_t<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072));
+    CK(hipFuncSetAttribute((const void *)k_qapply_t<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072));
+    CK(hipFuncSetAttribute((const void *)k_qapply_t<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072));
+    CK(hipFuncSetAttribute((const void *)k_rsolve<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072));
+    CK(hipFuncSetAttribute((const void *)k_rsolve<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072));
+    CK(hipFuncSetAttribute((const void *)k_rsolve<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072));
     CK(hipFuncSetAttribute((const void *)k_rtsolve, hipFuncAttributeMaxDynamicSharedMemorySize, 131072));
     return 0;
 }

@@ -288,10 +288,10 @@ def test_batched_right_hand_sides(pkg, oracle, monkeypatch, name):
 
 
 def test_batch_of_32_costs_little_more_than_one(pkg):
-    """32 right-hand sides in one pass over the tree against one (default workload).  The round-4 verdict asked for <= 3 x; the batch
-    (the same kernels, one set of workgroups per vector in every launch) reaches 3.0-3.6 x -- one vector after the other was 32 x --
-    because every vector's workgroup still streams V for itself (from L2): the last factor needs V shared inside a workgroup (a
-    block of right-hand sides per tile), which k_qbig_step4's 221 registers do not hold.  Gate: 4.5 x."""
+    """32 right-hand sides in one pass over the tree against one (default workload).  The round-4 verdict asked for <= 3 x.  The batch
+    alone (one set of workgroups per vector in every launch) reached 3.0-3.6 x -- one vector after the other was 32 x -- because
+    every vector's workgroup streamed V for itself; with four vectors per workgroup (k_qbig_step4 / k_qapply_t / k_rbig_init /
+    k_rsolve templates: V, its masks and T read once for the four) it is 2.4 x (Q'b) and 2.2 x (solve).  Gate: 3 x."""
     import time
     g = load_golden("xenon1_colamd_standin")
     S, plan = factorized_plan(pkg, g)
@@ -307,6 +307,6 @@ def test_batch_of_32_costs_little_more_than_one(pkg):
         q1, q32 = best(lambda: plan.qmult(0, B1.copy())), best(lambda: plan.qmult(0, B32.copy()))
         s1, s32 = best(lambda: plan.solve(B1)), best(lambda: plan.solve(B32))
         print(f"[rhs batch] Q'b: 1 rhs {q1 * 1e3:.1f} ms, 32 rhs {q32 * 1e3:.1f} ms; solve: 1 rhs {s1 * 1e3:.1f} ms, 32 rhs {s32 * 1e3:.1f} ms")
-        assert q32 <= 4.5 * q1 and s32 <= 4.5 * s1
+        assert q32 <= 3.0 * q1 and s32 <= 3.0 * s1
     finally:
         plan.close()
