@@ -287,6 +287,32 @@ def test_batched_right_hand_sides(pkg, oracle, monkeypatch, name):
         plan.close()
 
 
+@pytest.mark.parametrize("split_all", [0, 1])
+@pytest.mark.parametrize("k", [2, 3, 6])
+def test_small_batches_take_the_shared_workgroups_too(pkg, monkeypatch, k, split_all):
+    """batches of 2 (two vectors per workgroup), 3 (four per workgroup, one of them idle) and 6 (a full group + a ragged one) through
+    Q'b, Q b and the least-squares solve; split_all: every front through the split kernels of the large fronts (STMMQR_QBIG_MIN = 1).
+    Column j of a batched call is bit for bit the one-vector call."""
+    if split_all:
+        monkeypatch.setenv("STMMQR_QBIG_MIN", "1")
+    g = load_golden("lns_3937")
+    S, plan = factorized_plan(pkg, g)
+    if split_all:
+        monkeypatch.delenv("STMMQR_QBIG_MIN")
+    try:
+        rng = np.random.default_rng(43 + k)
+        X = rng.standard_normal((S.m, k))
+        for method in (0, 1):
+            Y = plan.qmult(method, X)
+            for j in range(k):
+                assert np.array_equal(Y[:, j], plan.qmult(method, X[:, j].copy()).ravel()), (method, j)
+        Xs = plan.solve(X)
+        for j in range(k):
+            assert np.array_equal(Xs[:, j], plan.solve(X[:, j].copy()).ravel()), j
+    finally:
+        plan.close()
+
+
 def test_batch_of_32_costs_little_more_than_one(pkg):
     """32 right-hand sides in one pass over the tree against one (default workload).  The round-4 verdict asked for <= 3 x.  The batch
     alone (one set of workgroups per vector in every launch) reached 3.0-3.6 x -- one vector after the other was 32 x -- because
