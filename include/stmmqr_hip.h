@@ -176,6 +176,10 @@ typedef struct stmmqr_stats {
     stm_long retries;          /* times (part of) the factorization was run again with one-workgroup panels because a bounded
                                   inter-workgroup wait of a panel kernel ran out (0 in a healthy run: bench.py asserts it)  */
     double device_bytes;       /* device memory held by the plan when the factorization finished (arenas, factors, workspaces) */
+    stm_long reschedules;      /* times the factorization was run again on the FULL schedule because a front still had rows at the
+                                  last panel the plan had scheduled for it (the schedule of a whole-tree plan stops every front where
+                                  the full-rank row estimate says it runs out of rows; rank-deficient input: once per plan, which
+                                  then keeps the full schedule)                                                           */
 } stmmqr_stats;
 
 typedef struct stmmqr_plan stmmqr_plan;     /* device-resident symbolic plan + arenas; reusable across calls */

@@ -66,7 +66,7 @@ class Stats(C.Structure):
                                           "ms_host", "bytes_assemble", "bytes_pack", "flops_update", "ms_update"]] + \
                [("nlaunch", C.c_long), ("nlevels", C.c_long), ("ms_panel", C.c_double), ("ms_small", C.c_double),
                 ("npanel_launch", C.c_long), ("nupdate_launch", C.c_long), ("nsteps", C.c_long),
-                ("flops_update_pair", C.c_double), ("retries", C.c_long), ("device_bytes", C.c_double)]
+                ("flops_update_pair", C.c_double), ("retries", C.c_long), ("device_bytes", C.c_double), ("reschedules", C.c_long)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}

@@ -26,6 +26,7 @@ struct FrontSym {
     int parent;              // parent front or -1
     int fm_est;              // rows of F if no pivot column dies (exact for full-rank fronts): launch planning only
     int tpan;                // index of this front's first panel in the kept-T array (DevCtx::Tall), panel p at tpan + p
+    int nsched;              // panels of this front that get a step of the timeline (<= npanels: build_schedule, "how many panels")
     int qbig;                // Q-apply on the resident factors: the rows of this front are split over workgroups, one launch
                              // per panel (k_qbig_*), instead of one workgroup for the whole front (plan time)
 };

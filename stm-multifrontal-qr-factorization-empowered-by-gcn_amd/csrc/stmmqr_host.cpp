@@ -300,6 +300,27 @@ void build_schedule(stmmqr_plan &P, std::vector<int> &tslot)
     P.gp_slabs = 1;
     P.wp_doubles = 0;
     P.wp2_doubles = 0;
+    // ---- how many panels of a front get a step (FrontSym::nsched).  A front of fm rows and fn > fm columns runs out of rows at
+    // column fm: the panel that holds that column finalises every column behind it (dev_panel: "no rows left") and the panels after
+    // it have nothing to do -- yet each was a step of the timeline, and the parent could not start before the last of them: 446 of the
+    // 1249 steps on the critical path of the default workload (8000 of its 15 313 panels), 40 of epb1's 132.  fm is only known on
+    // the device, but fm_est -- the rows if no pivot column dies -- is exact for a full-rank matrix: a plan that holds the whole tree
+    // schedules floor(min(fm_est, fn) / 32) + 1 panels per front.  Should a front NOT be finished by its last scheduled panel
+    // (pivot columns died below it: more rows reach it than estimated), k_cpack's extra workgroup raises abort[2] and the
+    // factorization is run again on the full schedule, which the plan then keeps (P.full_schedule; stats.retries counts it).
+    // STMMQR_EARLY_END=0: every panel a step, as before. ----
+    {
+        bool whole = (ngroups == 1) && nf > 0;
+        for (long f = 0; f < nf && whole; f++) whole = (P.group[f] == 0) && !((size_t)f < P.shared.size() && P.shared[(size_t)f]);
+        const bool early = whole && !P.full_schedule && !(getenv("STMMQR_EARLY_END") && atoi(getenv("STMMQR_EARLY_END")) == 0);
+        const int slack = getenv("STMMQR_EARLY_SLACK") ? atoi(getenv("STMMQR_EARLY_SLACK")) : 0;
+        for (long f = 0; f < nf; f++) {
+            FrontSym &s = P.fs[f];
+            s.nsched = s.npanels;
+            if (early && is_big((int)f) && !is_pair((int)f)) s.nsched = std::min(s.npanels, std::min(s.fm_est, s.fn) / STM_NB + 1 + slack);
+        }
+        P.early_end = early;
+    }
     for (int grp = 0; grp < ngroups; grp++) {
         // ---- tree levels (leaves = 0, counted inside the group): the order of the solves and of Q ----
         std::vector<int> level(nf, -1), start(nf, 0), end(nf, 0);
@@ -317,7 +338,7 @@ void build_schedule(stmmqr_plan &P, std::vector<int> &tslot)
             level[f] = lv;
             nlev = std::max(nlev, lv + 1);
             start[f] = t0;
-            end[f] = t0 + (is_big((int)f) ? P.fs[f].npanels : 1);
+            end[f] = t0 + (is_big((int)f) ? P.fs[f].nsched : 1);
             nstep = std::max(nstep, end[f]);
         }
         // the level-synchronous schedule: every front of a tree level starts when the level below has finished
@@ -331,7 +352,7 @@ void build_schedule(stmmqr_plan &P, std::vector<int> &tslot)
                     const long f = P.Post[kf];
                     if (P.group[f] != grp || level[f] != lv) continue;
                     lstart[f] = lvl_end[lv];
-                    lend[f] = lstart[f] + (is_big((int)f) ? P.fs[f].npanels : 1);
+                    lend[f] = lstart[f] + (is_big((int)f) ? P.fs[f].nsched : 1);
                     e1 = std::max(e1, lend[f]);
                 }
                 lvl_end[lv + 1] = e1;
@@ -341,7 +362,11 @@ void build_schedule(stmmqr_plan &P, std::vector<int> &tslot)
         // Which order (STMMQR_SCHED unset): the envelope rule reaches the minimum number of steps (nstep here) but its steps
         // are ~10-15 % longer than those of the level-synchronous order (a launch lasts as long as its slowest front and
         // rows are only a proxy for that; measured) -- it is taken when it removes more than a fifth of the steps.
-        const bool use_level = sched_policy == 1 || (sched_policy == 0 && 5L * nstep > 4L * nstep_level);
+        // (Round 5: with the update beyond block 0 riding on the chain's launches and the fronts ending where they run out of rows, the
+        //  envelope order wins wherever it removes steps at all -- default workload 803 against 985 steps: 94.4 against 106.3 ms, sme3Dc
+        //  stand-in 541 / 637: 65.9 / 71.3, xenon1-METIS 406 / 436: 43.9 / 45.0, epb1 96 / 124: 6.3 / 7.6; a tie in steps goes to the
+        //  level-synchronous order: c5mini 250 / 250: 42.3 / 42.6.)
+        const bool use_level = sched_policy == 1 || (sched_policy == 0 && 100L * nstep > 97L * nstep_level);
         if (use_level) {
             start = lstart; end = lend;
             nstep = nstep_level;
@@ -376,7 +401,7 @@ void build_schedule(stmmqr_plan &P, std::vector<int> &tslot)
                 const int f = (int)P.Post[kf];
                 if (P.group[f] != grp) continue;
                 if (!is_big(f)) { small_at[start[f]].push_back(f); continue; }
-                for (int q = 0; q < P.fs[f].npanels; q++) panel_at[start[f] + q].push_back({f, q});
+                for (int q = 0; q < P.fs[f].nsched; q++) panel_at[start[f] + q].push_back({f, q});
             }
         } else {
             std::vector<int> parent_in(nf, -1), pend(nf, 0), tails(nf, 0);
@@ -388,7 +413,7 @@ void build_schedule(stmmqr_plan &P, std::vector<int> &tslot)
             for (long kf = nf; kf-- > 0;) {
                 const long f = P.Post[kf];
                 if (P.group[f] != grp) continue;
-                tails[f] = (is_big((int)f) ? P.fs[f].npanels : 1) + (parent_in[f] >= 0 ? tails[parent_in[f]] : 0);
+                tails[f] = (is_big((int)f) ? P.fs[f].nsched : 1) + (parent_in[f] >= 0 ? tails[parent_in[f]] : 0);
             }
             std::vector<int> ready;
             for (long kf = 0; kf < nf; kf++)
@@ -419,7 +444,7 @@ void build_schedule(stmmqr_plan &P, std::vector<int> &tslot)
                     for (Fly &e : fly) {
                         if (rem(e) == rl || rows(e) <= ride * env) {
                             panel_at.back().push_back({e.f, e.p});
-                            if (++e.p >= P.fs[e.f].npanels) { finish(e.f); continue; }
+                            if (++e.p >= P.fs[e.f].nsched) { finish(e.f); continue; }
                         }
                         keep.push_back(e);
                     }
@@ -436,7 +461,7 @@ void build_schedule(stmmqr_plan &P, std::vector<int> &tslot)
             for (int f : small_at[t]) starting[t].push_back(f);
             for (const auto &fp : panel_at[t]) {
                 if (fp.second == 0) starting[t].push_back(fp.first);
-                if (fp.second == P.fs[fp.first].npanels - 1) ending[t].push_back(fp.first);
+                if (fp.second == P.fs[fp.first].nsched - 1) ending[t].push_back(fp.first);
             }
         }
         // The packing of finished fronts is batched: k_cpack runs at the last step before some front STARTS (only an
@@ -844,7 +869,7 @@ int build_plan(stmmqr_plan &P, const stmmqr_symbolic_view &v)
     LCHK(P.d_wcnt.alloc(P.wcnt_n));
     LCHK(P.d_wcnt2.alloc(P.wcnt_n));
     LCHK(P.d_wflag.alloc(P.wcnt_n));
-    if (!P.d_abort.p) LCHK(P.d_abort.alloc(2));
+    if (!P.d_abort.p) LCHK(P.d_abort.alloc(4));
     LCHK(P.d_wflag2.alloc(P.wcnt_n));
     HIPCHK(hipMemset(P.d_wcnt.p, 0, P.wcnt_n * sizeof(int)));
     HIPCHK(hipMemset(P.d_wcnt2.p, 0, P.wcnt_n * sizeof(int)));
@@ -920,7 +945,7 @@ int reset_factorization(stmmqr_plan &P)
     HIPCHK(hipMemsetAsync(P.d_wcnt2.p, 0, P.wcnt_n * sizeof(int), st));
     HIPCHK(hipMemsetAsync(P.d_wflag.p, 0, P.wcnt_n * sizeof(int), st));
     HIPCHK(hipMemsetAsync(P.d_wflag2.p, 0, P.wcnt_n * sizeof(int), st));
-    HIPCHK(hipMemsetAsync(P.d_abort.p, 0, 2 * sizeof(int), st));
+    HIPCHK(hipMemsetAsync(P.d_abort.p, 0, 4 * sizeof(int), st));
     LCHK(stm_launch_sigma(P.d_Ax.p, (int)P.anz, P.d_amax.p, P.d_sig.p, st));
     LCHK(stm_launch_gather_sx(P.d_Ax.p, P.d_smap.p, P.d_Sx.p, (int)P.anz, st));
     P.stats.nlaunch += 6;
@@ -944,7 +969,7 @@ int reset_group(stmmqr_plan &P, int grp)
     HIPCHK(hipMemsetAsync(P.d_wcnt2.p, 0, P.wcnt_n * sizeof(int), st));
     HIPCHK(hipMemsetAsync(P.d_wflag.p, 0, P.wcnt_n * sizeof(int), st));
     HIPCHK(hipMemsetAsync(P.d_wflag2.p, 0, P.wcnt_n * sizeof(int), st));
-    HIPCHK(hipMemsetAsync(P.d_abort.p, 0, 2 * sizeof(int), st));
+    HIPCHK(hipMemsetAsync(P.d_abort.p, 0, 3 * sizeof(int), st));   // ([3], a refused message of the subtree exchange, stays)
     // slab recycling: a recycling plan holds the whole tree in this one group, and the aborted attempt has staged packed blocks behind
     // the arena's bump pointer; the rerun stages every block again, so the pointer (and the overflow word) go back to zero -- otherwise
     // the second set lands behind the first and overflows an arena that holds the estimate + 12.5 %
@@ -1270,6 +1295,8 @@ int run_schedule(stmmqr_plan &P, bool detail, int grp, const StepReq *req = null
                 } else if ((e = update(S, 0, S.maxcb, true, P.d_Wp.p, st)))
                     return e;
             }
+            // (a front that ends at a panel with trailing columns -- FrontSym::nsched -- is packed only after the riders of that update)
+            if (pend && P.early_end && (S.n_cpk > 0 || (P.recycle && S.n_rhp > 0)) && (e = flush_alone())) return e;
             if ((e = post(S, st))) return e;
         }
         int e = flush_alone();
@@ -1313,7 +1340,8 @@ int run_schedule(stmmqr_plan &P, bool detail, int grp, const StepReq *req = null
             }
             prep_on_side = false;
             if (S.n_act > 0 && (e = panels(S))) return e;
-            const bool offload = S.n_act > 0 && S.maxcb > 1 && worth_it(S);
+            // (early end: a front may end at a panel with trailing columns; its step is packed after the whole update)
+            const bool offload = S.n_act > 0 && S.maxcb > 1 && worth_it(S) && !(P.early_end && (S.n_cpk > 0 || (P.recycle && S.n_rhp > 0)));
             if (!offload) {
                 if (S.n_act > 0) {
                     if (side_ev >= 0) { HIPCHK(hipStreamWaitEvent(st, P.ev_side[side_ev], 0)); side_ev = -1; }
@@ -1534,6 +1562,16 @@ int stmmqr_factorize_begin(stmmqr_plan *plan, const stm_long *Ap, const stm_long
         if (e) return e;
     }
     if (!P.pattern_set) return fail(STMMQR_ERR_INVALID, "pattern of A was never given");
+    if ((P.early_end || P.early_end_failed) && !P.whole_call) {
+        // phased use (begin / group / finish by the caller): no retry loop around the factorization, so the plan schedules every
+        // panel of every front (the cut schedule needs stmmqr_factorize_device's rerun when a front outlives it)
+        P.early_end_failed = false;
+        P.full_schedule = true;
+        P.begun = false;
+        std::vector<int> grp(P.group.begin(), P.group.end());
+        int e = stmmqr_plan_set_groups(plan, grp.data());
+        if (e) return e;
+    }
     if (P.arena_overflow && P.recycle && !P.whole_call) {
         // phased use (begin / group / finish by the caller): the previous factorization of this plan did not fit the R+H arena
         // (finish returned OUT_OF_MEMORY and run_pack noted rh_grow / overflowed).  Those only take effect when the schedule is
@@ -1659,7 +1697,16 @@ int stmmqr_factorize_finish(stmmqr_plan *plan, stmmqr_stats *stats)
     int e = run_pack(P);
     if (e) return e;
     HIPCHK(hipEventRecord(P.ev[5], st));
+    int hard[2] = {0, 0};                                     // abort[2]: a front outlived its schedule; abort[3]: a refused message
+    HIPCHK(hipMemcpyAsync(hard, P.d_abort.p + 2, 2 * sizeof(int), hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
+    if (hard[1]) return fail(STMMQR_ERR_DEVICE, "a contribution block received from another rank does not fit its front's symbolic bounds");
+    if (hard[0]) {
+        // (rank-deficient fronts: more rows reached a front than the full-rank estimate its schedule was cut to)
+        P.early_end_failed = true;
+        P.evused = 0;
+        return fail(STMMQR_ERR_DEVICE, "a front was not finished by its last scheduled panel (the schedule is rebuilt with every panel)");
+    }
     float ms = 0;
     HIPCHK(hipEventElapsedTime(&ms, P.ev[0], P.ev[1])); P.stats.ms_h2d = ms;
     HIPCHK(hipEventElapsedTime(&ms, P.ev[1], P.ev[5])); P.stats.ms_total = ms;
@@ -1714,6 +1761,9 @@ int stmmqr_factorize_finish(stmmqr_plan *plan, stmmqr_stats *stats)
         const FrontSym &s = P.fs[f];
         flops += nm.flops;
         fl_upd += nm.flops_upd;
+        if (getenv("STMMQR_DBG_EARLY") && s.nsched < s.npanels && (!nm.done || nm.g < std::min(nm.fm, s.fn)))
+            fprintf(stderr, "[early] front %ld fn %d fp %d fm %d fm_est %d fm_ub %d g %d rank %d done %d nsched %d npanels %d\n", f, s.fn, s.fp, nm.fm, s.fm_est,
+                    s.fm_ub, nm.g, nm.rank, nm.done, s.nsched, s.npanels);
         if ((size_t)f < P.pair_front.size() && P.pair_front[f]) fl_upd_pair += nm.flops_upd;
         rank += nm.rank;
         if (nm.perr) {
@@ -1797,13 +1847,14 @@ int stmmqr_factorize_device(stmmqr_plan *plan, const stm_long *Ap, const stm_lon
     // (the workgroups of a launch are not guaranteed to run together: a GPU shared with another job), the factorization is
     // not lost: it is run once more with every panel factorized by ONE workgroup (dev_panel: no inter-workgroup wait
     // anywhere), slower but independent of co-residency.
-    int arena_retries = 0;
+    int arena_retries = 0, reschedules = 0;
     for (int attempt = 0; attempt < 2; attempt++) {
         plan->serial_panels = (attempt == 1);
         plan->panel_wait_failed = false;
         plan->whole_call = true;
         int e = stmmqr_factorize_begin(plan, Ap, Ai, Ax, ax_on_device, tol, ntol);
         if (!e) plan->stats.retries = (attempt == 1 ? 1 : 0) + arena_retries;   // (visible in stmmqr_stats: bench.py asserts 0)
+        if (!e) plan->stats.reschedules = reschedules;
         for (int g = 0; g < (int)plan->glevels.size() && !e; g++) e = stmmqr_factorize_group(plan, g, detail);
         if (!e) e = stmmqr_factorize_finish(plan, stats);
         plan->whole_call = false;
@@ -1820,6 +1871,20 @@ int stmmqr_factorize_device(stmmqr_plan *plan, const stm_long *Ap, const stm_lon
             if (e2) return e2;
             arena_retries++;
             attempt = -1;                                             // (both attempts again)
+            Ap = nullptr; Ai = nullptr;
+            continue;
+        }
+        if (e && plan->early_end_failed) {
+            // a front had rows left at its last scheduled panel: once more with every panel scheduled (and from now on)
+            plan->early_end_failed = false;
+            plan->full_schedule = true;
+            if (g_opt.verbose) fprintf(stderr, "[stmmqr_hip] a front outlived its schedule (rank-deficient fronts): factorizing again on the full schedule\n");
+            plan->begun = false;
+            std::vector<int> grp(plan->group.begin(), plan->group.end());
+            int e2 = stmmqr_plan_set_groups(plan, grp.data());
+            if (e2) return e2;
+            reschedules++;
+            attempt = -1;
             Ap = nullptr; Ai = nullptr;
             continue;
         }
@@ -1891,7 +1956,7 @@ int stmmqr_plan_set_groups(stmmqr_plan *plan, const int *group)
     LCHK(grow(P.d_wcnt, P.wcnt_n));
     LCHK(grow(P.d_wcnt2, P.wcnt_n));
     LCHK(grow(P.d_wflag, P.wcnt_n));
-    if (!P.d_abort.p) LCHK(P.d_abort.alloc(2));
+    if (!P.d_abort.p) LCHK(P.d_abort.alloc(4));
     LCHK(grow(P.d_wflag2, P.wcnt_n));
     HIPCHK(hipMemset(P.d_wcnt.p, 0, P.wcnt_n * sizeof(int)));
     HIPCHK(hipMemset(P.d_wcnt2.p, 0, P.wcnt_n * sizeof(int)));

@@ -10,6 +10,12 @@ __device__ void dev_tlast(const DevCtx &c, int f, const FrontSym &s, FrontNum *n
     __shared__ PanelShared ps;
     const int p = s.npanels - 1;
     if (p < 0) return;
+    // a front whose schedule stopped before its last panel (FrontSym::nsched) must have run out of rows by now; if it has not,
+    // the host runs the factorization again on the full schedule (abort[2]; stmmqr_host.cpp, "how many panels")
+    if (s.nsched < s.npanels) {
+        if (threadIdx.x == 0 && !num->done && c.abort) c.abort[2] = 1;
+        return;                                                // (the last panel never ran: nothing pending of it)
+    }
     const PanelDesc *pd = &num->pd[STM_PDI(p)];
     if (pd->t_deferred != 2 || pd->pnb <= 0) return;
     const int tid = threadIdx.x;
@@ -376,7 +382,7 @@ __global__ __launch_bounds__(256) void k_front_msg(DevCtx c, StmFrontMsgs g, dou
         const int fm = num->fm, rank = num->rank, cm = num->cm;
         const long long csize = (long long)cm * (cm + 1) / 2 + (long long)cm * (cn - cm);
         if (t0 == 0) { b[0] = fm; b[1] = rank; b[2] = cm; b[3] = (double)csize; b[4] = b[5] = b[6] = b[7] = 0.0; }
-        if (cm < 0 || cm > cn || csize > m.slot) { if (t0 == 0 && c.abort) c.abort[1] = 1; return; }
+        if (cm < 0 || cm > cn || csize > m.slot) { if (t0 == 0 && c.abort) c.abort[3] = 1; return; }
         const double *C = c.Carena + s.coff;
         for (long long i = t0; i < csize; i += nt) b[8 + i] = C[i];
         const int *rows = c.Hii + s.hip + rank;
@@ -386,7 +392,7 @@ __global__ __launch_bounds__(256) void k_front_msg(DevCtx c, StmFrontMsgs g, dou
     const int fm = (int)b[0], rank = (int)b[1], cm = (int)b[2];
     const long long csize = (long long)cm * (cm + 1) / 2 + (long long)cm * (cn - cm);
     if (cm < 0 || cm > cn || rank < 0 || rank + cm > s.fm_ub || csize > m.slot || (long long)b[3] != csize) {
-        if (t0 == 0 && c.abort) c.abort[1] = 1;          // (a message that does not fit the symbolic bounds: the factorization fails)
+        if (t0 == 0 && c.abort) c.abort[3] = 1;          // (a message that does not fit the symbolic bounds: the factorization fails)
         return;
     }
     if (t0 == 0) {

@@ -165,6 +165,9 @@ struct stmmqr_plan {
     std::vector<FrontSym> fs_scr;        // FrontSym with foff into that scratch (kept fronts: their own slab, relative to it)
     bool scr_all = false, scr_valid = false;   // the scratch holds every front (rebuilt once per factorization) / is up to date
     bool overflowed = false;             // a factorization did not fit the R+H arena at its hard bound: this plan does not recycle
+    bool early_end = false;              // the schedule of group 0 stops every front at the panel where it is expected to run out of rows
+    bool full_schedule = false;          // ... it did not hold once (rank-deficient fronts): this plan schedules every panel from now on
+    bool early_end_failed = false;       // ... the last factorization found a front unfinished at its last scheduled panel
     bool arena_overflow = false;         // the last factorization did not fit the arena (it is repeated with a larger one / without)
     std::vector<int> lists;              // host copy of d_lists
     int post_off = 0, rh_parts_off = 0, rh_maxparts = 1;

@@ -66,6 +66,7 @@ struct OneFront {
         s.ld = (int)std::max(2L, (m + 1) & ~1L);
         s.fn = (int)n; s.fp = (int)std::min(n, std::max(0L, npiv)); s.fm_ub = (int)m; s.fm_est = (int)m;
         s.npanels = (int)((n + STM_NB - 1) / STM_NB);
+        s.nsched = s.npanels;
         s.parent = -1;
         nm.fm = (int)m; nm.rank = (int)std::min(m, (long)s.fp);
         std::vector<double> Fd((size_t)s.ld * std::max(1L, n), 0.0);

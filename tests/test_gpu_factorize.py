@@ -136,6 +136,50 @@ def test_lookahead_schedule_same_bits(pkg, name, bfc, algo):
             assert np.array_equal(x, y, equal_nan=True)
 
 
+@pytest.mark.parametrize("name", NAMES)
+@pytest.mark.parametrize("la", [2, 1, 0])
+def test_early_end_schedule_same_bits_and_fallback(pkg, monkeypatch, name, la):
+    """A whole-tree plan schedules, per front, only the panels up to the one where the front is expected to run out of rows
+    (floor(min(fm_est, fn) / 32) + 1 of ceil(fn / 32): FrontSym::nsched; fm_est = the rows if no pivot column dies).  The steps that
+    are gone did nothing, so the factors are the same bits as on the full schedule (STMMQR_EARLY_END=0) under every look-ahead
+    form -- a front now ENDS at a panel with trailing columns, whose update must be complete before the front is packed.
+    Rank-deficient input: more rows reach a front than estimated, a front is not finished at its last scheduled panel, k_cpack's
+    extra workgroup says so and the factorization runs again on the full schedule (stats.reschedules = 1, once per plan: the second
+    factorization of the same plan does not reschedule)."""
+    g = load_golden(name)
+    tol, ntol = scalar(g, "in_tol"), int(scalar(g, "in_ntol"))
+    S = Symbolic(g)
+    sym = {**S.sc, **{k: v for k, v in S.arr.items() if v is not None}}
+    pkg.set_options(lookahead=la)
+    try:
+        monkeypatch.setenv("STMMQR_EARLY_END", "0")
+        full = pkg.HipQR(sym)
+        st0 = full.factorize(g["in_Ax"], tol, ntol, g["in_Ap"], g["in_Ai"])
+        A = full.download()
+        full.close()
+        monkeypatch.delenv("STMMQR_EARLY_END")
+        plan = pkg.HipQR(sym)
+        st1 = plan.factorize(g["in_Ax"], tol, ntol, g["in_Ap"], g["in_Ai"])
+        B = plan.download()
+        st2 = plan.factorize(g["in_Ax"], tol, ntol)
+        C2 = plan.download()
+        plan.close()
+    finally:
+        pkg.set_options(lookahead=2)
+    assert st0["reschedules"] == 0 and st0["retries"] == 0 and st1["retries"] == 0
+    assert st1["nsteps"] <= st0["nsteps"]
+    full_rank = not np.any(A.Rdead)
+    if full_rank:
+        assert st1["reschedules"] == 0           # (the estimate is exact when no pivot column dies)
+    assert st1["reschedules"] in (0, 1) and st2["reschedules"] == 0
+    assert st1["flops"] == st0["flops"] == scalar(g, "flopcount")
+    for X in (B, C2):
+        assert (X.rank, X.rh_total) == (A.rank, A.rh_total)
+        for k in ("Hm", "Hr", "HStair", "Rdead", "Rblock_off", "Hii", "HTau"):
+            assert np.array_equal(getattr(X, k), getattr(A, k)), k
+        assert np.array_equal(X.Stack[:X.rh_total], A.Stack[:A.rh_total], equal_nan=True)
+
+
 @pytest.mark.parametrize("name", ["c5mini_standin", "xenon1_standin"])
 def test_lookahead_events_without_system_fence_same_bits(pkg, monkeypatch, name):
     """The events that order the plan's stream and the side stream are created with hipEventDisableSystemFence (they order two queues
@@ -595,9 +639,11 @@ def test_recycling_plan_through_the_phased_interface(pkg, monkeypatch, name):
         # (b) arena overflow on the phased path
         monkeypatch.setenv("STMMQR_RH_EST_SCALE", "0.3")
         plan = pkg.HipQR(sym)
-        monkeypatch.delenv("STMMQR_RH_EST_SCALE")
         try:
+            # (the first phased begin of a whole-tree plan rebuilds its schedule with every panel -- the cut schedule of
+            #  stmmqr_factorize_device needs that call's retry loop -- and reads the plan-time knobs again)
             plan.begin(g["in_Ax"], tol, ntol, g["in_Ap"], g["in_Ai"])
+            monkeypatch.delenv("STMMQR_RH_EST_SCALE")
             plan.run_group(0)
             with pytest.raises(Exception):
                 plan.finish()                                           # the packed factors exceed the arena: reported, nothing written past it

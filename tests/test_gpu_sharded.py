@@ -460,10 +460,10 @@ def test_rank_arenas_hold_only_its_fronts():
     os.environ["STMMQR_RECYCLE"] = "0"        # (the yardstick: a whole-tree plan WITHOUT slab recycling, like the ranks' plans)
     try:
         one = pkg.HipQR(sym)
+        before = one.device_bytes()
+        one.begin(g["in_Ax"], tol, ntol, g["in_Ap"], g["in_Ai"])      # (a phased begin rebuilds a whole-tree plan's schedule: knobs read again)
     finally:
         del os.environ["STMMQR_RECYCLE"]
-    before = one.device_bytes()
-    one.begin(g["in_Ax"], tol, ntol, g["in_Ap"], g["in_Ai"])
     whole = one.device_bytes()
     one.close()
     assert whole > before                                         # the arenas arrive with the first factorization
