@@ -156,7 +156,8 @@ struct QbDesc {
     int f;                   // front
     int xoff, dqoff, wqoff;  // offsets of its slices of the level's x (doubles), reflector numbering (ints), slab partials
     int nslab;               // row slabs of QB_ROWS rows (from fm_ub)
-    int pad;
+    int np_live;             // panels that can hold a live reflector in THIS factorization (<= npanels; set per factorization from the
+                             // front's fm / rank: the panels behind the column where the rows ran out are not visited)
 };
 
 // numeric, written by the kernels

@@ -231,7 +231,9 @@ struct stmmqr_plan {
     DevBuf<long long> d_t4dqo, d_qbt4off;
     DevBuf<double> d_T4, d_Wq4;
     bool t4_valid = false, t4_ok = false, t4_tried = false;
-    struct QbLevel { int off = 0, n = 0, max_np = 0, max_nslab = 0, max_fm = 0, max_rsteps = 0, t4i_off = 0, t4i_n = 0; };
+    struct QbLevel { int off = 0, n = 0, max_np = 0, max_nslab = 0, max_fm = 0, max_rsteps = 0, t4i_off = 0, t4i_n = 0;
+                     int live_np = 0, live_rsteps = 0; };     // (live_*: of the current factorization, ensure_rowmap)
+    std::vector<QbDesc> h_qb;            // host copy of d_qb (np_live is refreshed per factorization)
     std::vector<char> t4_level_valid;          // T4 of the level's split fronts is built (per level: with per-level scratch only the
                                                //  level at hand is in front form)
     DevBuf<int> d_Rm;                               // rows of R (live pivots) of the split fronts of a level (k_rbig_*)

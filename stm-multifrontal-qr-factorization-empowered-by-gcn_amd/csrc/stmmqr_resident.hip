@@ -293,7 +293,7 @@ __global__ __launch_bounds__(QB_ROWS) void k_qbig_step(DevCtx c, const QbDesc *_
     const int fm = c.fnum[f].fm;
     if (fm <= 0 || s.fn <= 0) return;
     // launch k: apply the (k-1)-th panel of the order, form the partials of the k-th (Q'x: ascending, Q x: descending)
-    const int np = s.npanels;
+    const int np = min(s.npanels, qdd.np_live);
     if (k > np) return;
     const int pp[2] = {(k >= 1) ? (method ? np - k : k - 1) : -1, (k < np) ? (method ? np - 1 - k : k) : -1};
     double *Xf = Xf0 + qdd.xoff;
@@ -572,7 +572,7 @@ __global__ __launch_bounds__(QB_ROWS) void k_qbig_step4(DevCtx c, const QbDesc *
     const FrontSym s = c.fs[f];
     const int fm = c.fnum[f].fm;
     if (fm <= 0 || s.fn <= 0) return;
-    const int ng = (s.npanels + QG - 1) / QG;
+    const int ng = (min(s.npanels, qdd.np_live) + QG - 1) / QG;
     if (k > ng) return;
     // launch k: apply the (k-1)-th group of the order, form the partials of the k-th (Q'x: ascending, Q x: descending)
     const int gg[2] = {(k >= 1) ? (method ? ng - k : k - 1) : -1, (k < ng) ? (method ? ng - 1 - k : k) : -1};

@@ -88,7 +88,7 @@ int ensure_rowmap(stmmqr_plan &P)
                 P.level_lds_qa_all[l] = std::max(P.level_lds_qa_all[l], need);
                 if (s.qbig) {
                     QbDesc d;
-                    d.f = f; d.xoff = (int)xo; d.dqoff = (int)dqo; d.wqoff = (int)wo; d.nslab = (s.fm_ub + STM_QB_ROWS - 1) / STM_QB_ROWS; d.pad = 0;
+                    d.f = f; d.xoff = (int)xo; d.dqoff = (int)dqo; d.wqoff = (int)wo; d.nslab = (s.fm_ub + STM_QB_ROWS - 1) / STM_QB_ROWS; d.np_live = s.npanels;
                     qb.push_back(d);
                     {
                         const int ngr = (s.npanels + 3) / 4;
@@ -126,6 +126,34 @@ int ensure_rowmap(stmmqr_plan &P)
         LCHK(P.d_qb.alloc(qb.size()));
         LCHK(P.d_Rm.alloc(qb.size()));
         HIPCHK(hipMemcpy(P.d_qb.p, qb.data(), qb.size() * sizeof(QbDesc), hipMemcpyHostToDevice));
+        P.h_qb = qb;
+    }
+    {
+        // Of THIS factorization: the panels of a split front that can hold a live reflector and the blocks of live pivot columns.  A
+        // front of fm rows has fm live reflectors at most; they sit in its first fm + (dead pivot columns) columns, and a front has at
+        // most fp - rank dead pivot columns.  The panels behind that column were launches that did nothing: on the default workload
+        // 330 launches per Q'b, 177 of them for panels without a reflector (same finding as the factorization's own schedule,
+        // stmmqr_host.cpp "how many panels").  STMMQR_LIVE_PANELS=0: every panel.
+        const bool live = !(getenv("STMMQR_LIVE_PANELS") && atoi(getenv("STMMQR_LIVE_PANELS")) == 0);
+        bool changed = false;
+        for (size_t l = 0; l < P.level_qbig.size(); l++) {
+            auto &Q = P.level_qbig[l];
+            Q.live_np = 0; Q.live_rsteps = 0;
+            for (int q = 0; q < Q.n; q++) {
+                QbDesc &d = P.h_qb[(size_t)(Q.off + q)];
+                const FrontSym &s = P.fs[d.f];
+                const FrontNum &nm = P.h_fnum[d.f];
+                int npl = s.npanels;
+                if (live) {
+                    const long lastcol = std::min((long)s.fn, (long)nm.fm + std::max(0L, (long)s.fp - (long)nm.rank));
+                    npl = (nm.fm <= 0) ? 0 : (int)std::min((long)s.npanels, (lastcol - 1) / STM_NB + 1);
+                }
+                if (d.np_live != npl) { d.np_live = npl; changed = true; }
+                Q.live_np = std::max(Q.live_np, npl);
+                Q.live_rsteps = std::max(Q.live_rsteps, live ? (int)((nm.rank + 31) / 32) : Q.max_rsteps);
+            }
+        }
+        if (changed && !P.h_qb.empty()) HIPCHK(hipMemcpy(P.d_qb.p, P.h_qb.data(), P.h_qb.size() * sizeof(QbDesc), hipMemcpyHostToDevice));
     }
     for (int b : P.level_lds_qa)
         if (b > 131072) return fail(STMMQR_ERR_TOO_LARGE, "a front has more rows than the Q-apply kernel holds in LDS");
@@ -270,11 +298,11 @@ int run_qapply(stmmqr_plan &P, int method, int nb = 1)
                                               P.d_T4.p, P.stream));
                     P.t4_level_valid[l] = 1;
                 }
-                LCHK(stm_launch_qapply_big4(c, P.d_qb.p + Q.off, P.d_qbt4off.p + Q.off, Q.n, Q.max_np, Q.max_nslab, Q.max_fm, m, P.d_W.p, P.d_Xf.p,
+                LCHK(stm_launch_qapply_big4(c, P.d_qb.p + Q.off, P.d_qbt4off.p + Q.off, Q.n, Q.live_np, Q.max_nslab, Q.max_fm, m, P.d_W.p, P.d_Xf.p,
                                             P.d_Dq.p, P.d_Wq4.p, P.d_T4.p, P.stream, nb, B));
                 return 0;
             }
-            LCHK(stm_launch_qapply_big(c, P.d_qb.p + Q.off, Q.n, Q.max_np, Q.max_nslab, Q.max_fm, m, P.d_W.p, P.d_Xf.p, P.d_Dq.p,
+            LCHK(stm_launch_qapply_big(c, P.d_qb.p + Q.off, Q.n, Q.live_np, Q.max_nslab, Q.max_fm, m, P.d_W.p, P.d_Xf.p, P.d_Dq.p,
                                        P.d_Wq.p, P.stream, nb, B));
             return 0;
         }
@@ -339,7 +367,7 @@ int rsolve_vector(stmmqr_plan &P, int nb = 1)
         LCHK(level_to_front_form(P, l));
         LCHK(stm_launch_rsolve(c, L0 + LV[l].all_off, LV[l].n_all, P.d_Rj.p, P.d_W.p, P.d_Xs.p, P.level_lds_rs[l], P.d_err.p, st, nb, B));
         const auto &Q = P.level_qbig[l];         // the large fronts of the level: rows split over workgroups
-        LCHK(stm_launch_rsolve_big(c, P.d_qb.p + Q.off, Q.n, Q.max_rsteps, Q.max_nslab, P.d_Rj.p, P.d_W.p, P.d_Xs.p, P.d_Xf.p,
+        LCHK(stm_launch_rsolve_big(c, P.d_qb.p + Q.off, Q.n, Q.live_rsteps, Q.max_nslab, P.d_Rj.p, P.d_W.p, P.d_Xs.p, P.d_Xf.p,
                                    P.d_Dq.p, P.d_Rm.p + Q.off, P.d_err.p, st, nb, B));
     }
     return 0;
