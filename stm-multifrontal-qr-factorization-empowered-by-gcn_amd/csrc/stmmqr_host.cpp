@@ -502,6 +502,8 @@ void build_schedule(stmmqr_plan &P, std::vector<int> &tslot)
             // (rows padded as dev_panel pads them, so that a whole panel fits whenever the cap allows: the sub-panel width
             //  of a front -- and with it the rounding -- must not depend on which other fronts share its step)
             S.lds_small = (int)std::min((long)LDS_CAP_SMALL, (((maxfm_small + 63) & ~63L) | 1) * STM_NB + 64);
+            // (the wave-pipelined panels of k_front_wg: an image of 32 x 128 rows, and dev_gram_T's 4 x 768 doubles of scratch)
+            if (S.n_small > 0) S.lds_small = std::max(S.lds_small, STM_NB * 128 + 64);
             // T / Gram-partial slots: a slot is held from the step a front starts to the step it ends
             for (int f : big) {
                 if (!freeslots.empty()) { tslot[f] = freeslots.back(); freeslots.pop_back(); }

@@ -1023,37 +1023,6 @@ __device__ __forceinline__ void dev_tall_group(PanelShared &ps, const FrontSym &
 }
 
 // ------------------------------------------------------------------------------------------------
-// small fronts: one workgroup runs the whole front (all panels, all trailing updates, C pack)
-// ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(NT) void k_front_wg(DevCtx c, const int *__restrict__ flist, int lds_doubles)
-{
-    extern __shared__ double dyn_lds[];
-    __shared__ double s_Tw[STM_NB * STM_NB];
-    __shared__ PanelShared ps;
-    const int f = flist[blockIdx.x];
-    const FrontSym s = c.fs[f];
-    FrontNum *num = &c.fnum[f];
-    double *F = c.Farena + s.foff;
-    auto Tkeep = [&](int p) { return c.Tall ? c.Tall + (long long)(s.tpan + p) * STM_NB * STM_NB : (double *)nullptr; };
-    for (int p = 0; p < s.npanels; p++) {
-        if ((c.dbg & 64) || panel_rows(s, num, c.Stair + s.rp, p) > lds_doubles - 65)
-            dev_panel<NT, true>(ps, s, num, F, c.Stair + s.rp, c.Tau + s.rp, c.Rdead + s.col1, p, c.tol, c.ntol, s_Tw,
-                                dyn_lds, lds_doubles, c.dbg, nullptr, Tkeep(p), c.sig);
-        else
-            dev_panel<NT, false>(ps, s, num, F, c.Stair + s.rp, c.Tau + s.rp, c.Rdead + s.col1, p, c.tol, c.ntol, s_Tw,
-                                 dyn_lds, lds_doubles, c.dbg, nullptr, Tkeep(p), c.sig);
-        const int k2 = min(s.fn, (p + 1) * STM_NB);
-        const int ncb = (s.fn - k2 + BN - 1) / BN;
-        const PanelDesc *pd = &num->pd[STM_PDI(p)];
-        for (int cb = 0; cb < ncb; cb++)
-            dev_update_block(F, s.ld, pd->pg1, pd->pt - pd->pg1, pd->pk1, pd->pnb, pd->pdiag, s_Tw, k2 + cb * BN,
-                             min(BN, s.fn - (k2 + cb * BN)), dyn_lds);
-        __syncthreads();
-    }
-    dev_cpack(c, s, num, 0, 1);
-}
-
-// ------------------------------------------------------------------------------------------------
 // Wave-pipelined panel (short panels: at most STM_WP_ROWS rows).  ONE workgroup, one WAVE per group of WP_SW columns,
 // every wave holds all the rows of its columns in registers (lane l: rows rb + l + 64 r).  The column step of qr_front
 // (SparseQR_factorize.c:1434-1609: dlarfg, dlarf on the rest of the group) then needs no workgroup barrier and no LDS
@@ -1074,13 +1043,15 @@ struct WaveShared {
     long long iflops, ilen;
 };
 
-template <int RPT>
+// (SW: columns per wave -- 4 in k_panel's 512-thread workgroups, 8 in the 256-thread workgroups of k_front_wg)
+template <int RPT, int SW = WP_SW>
 __device__ __forceinline__ void dev_wave_panel(PanelShared &ps, WaveShared &wsh, const FrontSym &s, FrontNum *num, PanelDesc *pd,
                                                double *F, int *St, double *Tau, char *Rdead, int p, int g1, int tmax, double tol,
                                                int ntol_global, double *Tout, double *lds, double *Tkeep, int defer_ok,
                                                const double *sigp)
 {
-    constexpr int SW = WP_SW, NTH = 64 * (STM_NB / WP_SW), RS = 64 * RPT;
+    constexpr int NTH = 64 * (STM_NB / SW), RS = 64 * RPT;
+    static_assert(SW == 4 || SW == 8, "a wave takes 4 or 8 columns");
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int m = num->fm, n = s.fn, npiv = s.fp;
     const long long ld = s.ld;
@@ -1137,6 +1108,10 @@ __device__ __forceinline__ void dev_wave_panel(PanelShared &ps, WaveShared &wsh,
             double wv[SW];
             wv[0] = tau * lane_bcast<red8_lane(0)>(rw); wv[1] = tau * lane_bcast<red8_lane(1)>(rw);
             wv[2] = tau * lane_bcast<red8_lane(2)>(rw); wv[3] = tau * lane_bcast<red8_lane(3)>(rw);
+            if constexpr (SW == 8) {
+                wv[4] = tau * lane_bcast<red8_lane(4)>(rw); wv[5] = tau * lane_bcast<red8_lane(5)>(rw);
+                wv[6] = tau * lane_bcast<red8_lane(6)>(rw); wv[7] = tau * lane_bcast<red8_lane(7)>(rw);
+            }
 #pragma unroll
             for (int r = 0; r < RPT; r++) {
 #pragma unroll
@@ -1177,7 +1152,11 @@ __device__ __forceinline__ void dev_wave_panel(PanelShared &ps, WaveShared &wsh,
                 const double rw = wave_reduce8(part);
                 const double sum0 = lane_bcast<red8_lane(0)>(rw), sum1 = lane_bcast<red8_lane(1)>(rw);
                 const double sum2 = lane_bcast<red8_lane(2)>(rw), sum3 = lane_bcast<red8_lane(3)>(rw);
-                const double sum[4] = {sum0, sum1, sum2, sum3};
+                double sum[SW] = {sum0, sum1, sum2, sum3};
+                if constexpr (SW == 8) {
+                    sum[4] = lane_bcast<red8_lane(4)>(rw); sum[5] = lane_bcast<red8_lane(5)>(rw);
+                    sum[6] = lane_bcast<red8_lane(6)>(rw); sum[7] = lane_bcast<red8_lane(7)>(rw);
+                }
                 const int ol = g - rb;                            // lane that holds row g in a[0][.]  (g - rb < STM_NB)
                 double top[SW];
 #pragma unroll
@@ -1280,6 +1259,64 @@ __device__ __forceinline__ void dev_wave_panel(PanelShared &ps, WaveShared &wsh,
             const int ai = e % STM_NB, bi = e / STM_NB;
             Tkeep[e] = (ai < nbp && bi < nbp && ai <= bi) ? ps.T[ai][bi] : 0.0;
         }
+}
+
+// ------------------------------------------------------------------------------------------------
+// small fronts: one workgroup runs the whole front (all panels, all trailing updates, C pack)
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(NT) void k_front_wg(DevCtx c, const int *__restrict__ flist, int lds_doubles)
+{
+    extern __shared__ double dyn_lds[];
+    __shared__ double s_Tw[STM_NB * STM_NB];
+    __shared__ PanelShared ps;
+    __shared__ WaveShared wsh;
+    const int f = flist[blockIdx.x];
+    const FrontSym s = c.fs[f];
+    FrontNum *num = &c.fnum[f];
+    double *F = c.Farena + s.foff;
+    auto Tkeep = [&](int p) { return c.Tall ? c.Tall + (long long)(s.tpan + p) * STM_NB * STM_NB : (double *)nullptr; };
+    for (int p = 0; p < s.npanels; p++) {
+        // A panel of at most 128 rows -- every panel of the fronts of a sparse matrix's lower tree levels: epb1's 825 small fronts have at
+        // most 38 rows -- goes to the wave-pipelined panel (dev_wave_panel: a wave per 8 columns, the rows along the lanes, no workgroup
+        // barrier and no LDS round trip per column) instead of the sub-panel code: k_front_wg 138 -> ... us per tree level on epb1.  The
+        // condition is the front's own (its rows when the panel starts): results do not depend on the launch.
+        {
+            const int k2w = min(s.fn, (p + 1) * STM_NB), g1w = num->g;
+            const int tmaxw = min(num->fm, max((c.Stair + s.rp)[k2w - 1], g1w + (k2w - p * STM_NB)));
+            const int rowsw = tmaxw - g1w;
+            if (!num->done && rowsw <= 128 && !(c.dbg & (64 | 16384)) && max(STM_NB * (rowsw <= 64 ? 64 : 128), 3072) <= lds_doubles) {
+                PanelDesc *pdw = &num->pd[STM_PDI(p)];
+                __syncthreads();                                   // (everyone has read FrontNum / Stair before the panel writes them)
+                if (threadIdx.x == 0) { pdw->mode = 2; pdw->pg1 = g1w; pdw->tmax = tmaxw; }
+#define WAVE_ARGS ps, wsh, s, num, pdw, F, c.Stair + s.rp, c.Tau + s.rp, c.Rdead + s.col1, p, g1w, tmaxw, c.tol, c.ntol, s_Tw, dyn_lds, Tkeep(p), 0, c.sig
+                if (rowsw <= 64) dev_wave_panel<1, 8>(WAVE_ARGS);
+                else dev_wave_panel<2, 8>(WAVE_ARGS);
+#undef WAVE_ARGS
+                __syncthreads();
+                const int k2 = min(s.fn, (p + 1) * STM_NB);
+                const int ncb = (s.fn - k2 + BN - 1) / BN;
+                for (int cb = 0; cb < ncb; cb++)
+                    dev_update_block(F, s.ld, pdw->pg1, pdw->pt - pdw->pg1, pdw->pk1, pdw->pnb, pdw->pdiag, s_Tw, k2 + cb * BN,
+                                     min(BN, s.fn - (k2 + cb * BN)), dyn_lds);
+                __syncthreads();
+                continue;
+            }
+        }
+        if ((c.dbg & 64) || panel_rows(s, num, c.Stair + s.rp, p) > lds_doubles - 65)
+            dev_panel<NT, true>(ps, s, num, F, c.Stair + s.rp, c.Tau + s.rp, c.Rdead + s.col1, p, c.tol, c.ntol, s_Tw,
+                                dyn_lds, lds_doubles, c.dbg, nullptr, Tkeep(p), c.sig);
+        else
+            dev_panel<NT, false>(ps, s, num, F, c.Stair + s.rp, c.Tau + s.rp, c.Rdead + s.col1, p, c.tol, c.ntol, s_Tw,
+                                 dyn_lds, lds_doubles, c.dbg, nullptr, Tkeep(p), c.sig);
+        const int k2 = min(s.fn, (p + 1) * STM_NB);
+        const int ncb = (s.fn - k2 + BN - 1) / BN;
+        const PanelDesc *pd = &num->pd[STM_PDI(p)];
+        for (int cb = 0; cb < ncb; cb++)
+            dev_update_block(F, s.ld, pd->pg1, pd->pt - pd->pg1, pd->pk1, pd->pnb, pd->pdiag, s_Tw, k2 + cb * BN,
+                             min(BN, s.fn - (k2 + cb * BN)), dyn_lds);
+        __syncthreads();
+    }
+    dev_cpack(c, s, num, 0, 1);
 }
 
 #define NTP 512               // threads of the large-front panel kernel (8 waves, <= 256 VGPRs each)
