@@ -34,6 +34,7 @@
 #include "stmmqr_kernels.h"
 #include "stmmqr_wave.h"
 #include "stmmqr_devutil.h"
+#include "stmmqr_riders.h"
 
 #define CA_NT 512
 #define CA_LD (STM_CA_R + 2)      // column stride of the slab image (doubles): = 2 mod 32, MFMA operand reads conflict free
@@ -141,18 +142,20 @@ __device__ __forceinline__ void ca_publish_block(const double (*src)[STM_NB + 1]
     __syncthreads();
 }
 
-__global__ __launch_bounds__(CA_NT) void k_panel_ca(DevCtx c, const int *__restrict__ flist, const int *__restrict__ plist, int defer_ok)
+// the body of k_panel_ca: slab workgroup by of the bx-th front of the launch's lists
+__device__ __forceinline__ void dev_k_panel_ca(const DevCtx &c, const int *__restrict__ flist, const int *__restrict__ plist, int defer_ok,
+                                               int bx, int by)
 {
-    const int p = plist[blockIdx.x];                            // every front of a step is at its own panel
+    const int p = plist[bx];                                    // every front of a step is at its own panel
     __builtin_amdgcn_s_setprio(3);                              // (the panel chain is the critical path: ahead of the update waves
                                                                 //  of the side stream that share the CU)
     extern __shared__ double S[];                       // slab image [STM_NB][CA_LD]
     __shared__ CaShared cs;
     __shared__ int s_ok;
-    const int f = flist[blockIdx.x];
+    const int f = flist[bx];
     const FrontSym s = c.fs[f];
     if (p >= s.npanels || !stm_use_ca(s, p, c.panel_algo, c.ca_min_rows)) return;
-    const int w = blockIdx.y;
+    const int w = by;
     const int nwf = stm_ca_slabs(s);                    // symbolic: every workgroup of the launch agrees
     if (w >= nwf) return;
     if ((c.dbg & 2048) && w == ((c.dbg >> 20) & 7)) {   // tests: this slab workgroup starts ~1 ms late
@@ -515,11 +518,77 @@ __global__ __launch_bounds__(CA_NT) void k_panel_ca(DevCtx c, const int *__restr
 #undef TC
 }
 
+__global__ __launch_bounds__(CA_NT) void k_panel_ca(DevCtx c, const int *__restrict__ flist, const int *__restrict__ plist, int defer_ok)
+{
+    dev_k_panel_ca(c, flist, plist, defer_ok, blockIdx.x, blockIdx.y);
+}
+
+// A step whose panels are all Gram-based has no k_panel_pc launch for the k_upd_c riders of the step before it (passenger launches,
+// stmmqr_riders.h): they ride here instead.  (They ran as a launch of their own before: 77 x 26 us on the chain of the default
+// workload.)  A ONE-dimensional grid: the first npan * nw workgroups are the panel's slab workgroups in the order of k_panel_ca's own
+// grid (front fastest), the riders follow (column block fastest, then slab group, then front of the PREVIOUS step's lists).  The slab
+// workgroups wait for each other, one per CU: consecutive workgroup ids go round the XCDs, so they spread over the chip as in their own
+// launch -- as a sub-block of a 3-D grid their ids were a row length apart, all on one XCD, more than it has CUs (measured: the wait
+// ran out on c5mini).
+__global__ __launch_bounds__(CA_NT) void k_panel_ca_pc(DevCtx c, const int *__restrict__ flist, const int *__restrict__ plist, int npan, int nw,
+                                                     int defer_ok, const int *__restrict__ uflist, const int *__restrict__ uplist, int ucb0,
+                                                     int uncb, int uy, const double *Wp, const long long *__restrict__ uwpoff, int rspw)
+{
+    extern __shared__ double ca_dyn[];
+    __shared__ int s_pdr[STM_NB];
+    const int lin = blockIdx.x;
+    if (lin < npan * nw) {
+        dev_k_panel_ca(c, flist, plist, defer_ok, lin % npan, lin / npan);
+        return;
+    }
+    const int r = lin - npan * nw;
+    dev_upd_c_h2(c, uflist, uplist, ucb0, Wp, uwpoff, r / (uncb * uy), r % uncb, (r / uncb) % uy, rspw, ca_dyn, s_pdr);
+}
+
 int stm_ca_lds_bytes(void) { return (int)(STM_NB * CA_LD * sizeof(double)); }
+static size_t ca_pc_lds_bytes(void)
+{
+    const size_t a = (size_t)stm_ca_lds_bytes(), b = (size_t)STM_PC_LDS_DOUBLES * sizeof(double);
+    return a > b ? a : b;
+}
 
 int stm_configure_capanel(void)
 {
-    return (int)hipFuncSetAttribute((const void *)k_panel_ca, hipFuncAttributeMaxDynamicSharedMemorySize, stm_ca_lds_bytes());
+    hipError_t e = hipFuncSetAttribute((const void *)k_panel_ca, hipFuncAttributeMaxDynamicSharedMemorySize, stm_ca_lds_bytes());
+    if (e != hipSuccess) return (int)e;
+    return (int)hipFuncSetAttribute((const void *)k_panel_ca_pc, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ca_pc_lds_bytes());
+}
+
+// the Gram-based panels of a step + the k_upd_c riders of the step before it (one launch; more fronts than fit a launch: the rest alone)
+int stm_launch_panel_ca_pc(const DevCtx &c, const int *flist, const int *plist, int nfr, int nw, int defer_ok, const int *uflist,
+                           const int *uplist, int unfr, int ucb0, int uncb, int umaxsl, const double *Wp, const long long *uwpoff, hipStream_t st)
+{
+    if (nfr <= 0 || unfr <= 0 || uncb <= 0 || umaxsl <= 0) return -1;     // (the caller launches the two separately)
+    if (nw < 1) nw = 1;
+    int K = 240 / nw;
+    if (K < 1) K = 1;
+    const int n0 = nfr < K ? nfr : K;
+    int rspw = 1;
+    {
+        static int force = -1;
+        if (force < 0) force = getenv("STMMQR_RSPW") ? atoi(getenv("STMMQR_RSPW")) : 0;
+        double best = 1e30;
+        for (int k = 1; k <= 16; k *= 2) {
+            const long wgs = (long)unfr * uncb * ((umaxsl + k - 1) / k);
+            const double t = (double)((wgs + 239) / 240) * (5.0 + 1.0 * k);
+            if (t < best) { best = t; rspw = k; }
+        }
+        if (force > 0) rspw = force;
+    }
+    const int uy = (umaxsl + rspw - 1) / rspw;
+    const long total = (long)n0 * nw + (long)uncb * uy * unfr;
+    if (total > 0x7fffffffL) return -1;
+    hipLaunchKernelGGL(k_panel_ca_pc, dim3((unsigned)total), dim3(CA_NT), ca_pc_lds_bytes(), st, c, flist, plist, n0, nw, defer_ok, uflist, uplist,
+                       ucb0, uncb, uy, Wp, uwpoff, rspw);
+    for (int i = n0; i < nfr; i += K)
+        hipLaunchKernelGGL(k_panel_ca, dim3(nfr - i < K ? nfr - i : K, nw), dim3(CA_NT), (size_t)stm_ca_lds_bytes(), st, c, flist + i, plist + i,
+                           defer_ok);
+    return (int)hipGetLastError();
 }
 
 int stm_launch_panel_ca(const DevCtx &c, const int *flist, const int *plist, int nfr, int nw, int defer_ok, hipStream_t st)

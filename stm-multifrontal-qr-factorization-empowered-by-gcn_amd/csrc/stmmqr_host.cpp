@@ -1234,7 +1234,14 @@ int run_schedule(stmmqr_plan &P, bool detail, int grp, const StepReq *req = null
             if (e) return e;
             if (S.n_act > 0) {
                 const int *act = L0 + S.act_off, *pl = L0 + S.plist_off;
-                if (S.nca_use) { LCHK(stm_launch_panel_ca(c, act, pl, S.n_act, S.nca, 1, st)); nlaunch++; }
+                if (S.nca_use && !S.npipe_use && pend && !(abl & 6) && !(getenv("STMMQR_CA_RIDERS") && atoi(getenv("STMMQR_CA_RIDERS")) == 0)) {
+                    // (every panel of the step is Gram-based: the riders of the step before take THAT launch)
+                    const Step &Q = *pend;
+                    pend = nullptr;
+                    LCHK(stm_launch_panel_ca_pc(c, act, pl, S.n_act, S.nca, 1, L0 + Q.act_off, L0 + Q.plist_off, Q.n_norm, 1, Q.maxcb - 1, Q.maxsl,
+                                                P.d_Wp2.p, P.d_wlists.p + Q.wp_off, st));
+                    nlaunch++;
+                } else if (S.nca_use) { LCHK(stm_launch_panel_ca(c, act, pl, S.n_act, S.nca, 1, st)); nlaunch++; }
                 if (S.npipe_use) {
                     const int lds = (c.dbg & (64 | 256)) ? S.lds_big : S.lds_plan;
                     if (pend && (abl & 2)) pend = nullptr;

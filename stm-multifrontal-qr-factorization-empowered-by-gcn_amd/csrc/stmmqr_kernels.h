@@ -69,6 +69,8 @@ int stm_launch_front_wg(const DevCtx &c, const int *flist, int nfr, int lds_doub
 int stm_launch_panel(const DevCtx &c, const int *flist, const int *plist, int nfr, int nsub, int defer_ok, int lds_doubles, hipStream_t st);
 int stm_configure_capanel(void);
 int stm_launch_panel_ca(const DevCtx &c, const int *flist, const int *plist, int nfr, int nw, int defer_ok, hipStream_t st);
+int stm_launch_panel_ca_pc(const DevCtx &c, const int *flist, const int *plist, int nfr, int nw, int defer_ok, const int *uflist,
+                           const int *uplist, int unfr, int ucb0, int uncb, int umaxsl, const double *Wp, const long long *uwpoff, hipStream_t st);
 int stm_launch_update(const DevCtx &c, const int *flist, const int *plist, int nfr, int cb0, int ncb, hipStream_t st);
 int stm_launch_update_fused(const DevCtx &c, const int *flist, const int *plist, int nfr, int cb0, int ncb, int maxsl, double *Wp,
                             const long long *wpoff, int *wcnt, int *wflag, int epoch, int with_gram, hipStream_t st);
