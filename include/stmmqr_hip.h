@@ -35,6 +35,8 @@ typedef long stm_long;
 #define STMMQR_ERR_TOO_LARGE     (-3)   /* SPARSE_TOO_LARGE     */
 #define STMMQR_ERR_INVALID       (-4)   /* SPARSE_INVALID       */
 #define STMMQR_ERR_DEVICE        (-5)   /* SPARSE_GPU_PROBLEM: no gfx950 device / HIP runtime error */
+#define STMMQR_ERR_RESCHEDULE    (-6)   /* stmmqr_factorize_finish: a front still had rows at the last panel the plan scheduled for it
+                                           (stmmqr_plan_set_early_end); nothing is lost but this attempt -- factorize again */
 
 /* ================================================================================================
  * Layout-compatible mirrors of the structs that cross the seam
@@ -294,6 +296,15 @@ int stmmqr_factorize_shared_front(stmmqr_plan *plan, int group, stm_long f, int 
 int stmmqr_factorize_exchange(stmmqr_plan *plan, stm_long nout, const stm_long *out_front, const int *out_peer, stm_long nin,
                               const stm_long *in_front, const int *in_peer, const stmmqr_transport *tr);
 int stmmqr_shared_front_gather(stmmqr_plan *plan, stm_long f, int first_rank, int nranks, const stmmqr_transport *tr);
+/* How many panels of a front get a step ("How many panels"): a front of fm rows needs floor(fm / 32) + 1 of its
+ * ceil(fn / 32) panels, and fm -- known on the device only -- equals the plan-time estimate unless pivot columns die.
+ * stmmqr_factorize_device cuts the schedule of a whole-tree plan there by itself and runs a factorization that outlives it again on
+ * the full schedule.  A caller of the phased interface (begin / group / finish: sharded plans) has no such loop around it and gets the
+ * full schedule unless it asks: mode 1 = cut schedule, and the CALLER handles STMMQR_ERR_RESCHEDULE from stmmqr_factorize_finish --
+ * every rank of a sharded factorization must then factorize again (sharded.factorize_sharded agrees on that with one tiny exchange per
+ * factorization); the plan that failed schedules every panel from its next begin on, the others are told by mode 0.
+ * Rebuilds the schedule; not between begin and finish (except after that failure).  Shared fronts always keep every panel. */
+int stmmqr_plan_set_early_end(stmmqr_plan *plan, int mode);
 typedef struct stmmqr_shard_phases {
     int nphase;
     const stm_long *out_ptr, *out_front;    /* [nphase + 1], [out_ptr[nphase]] */

@@ -20,7 +20,10 @@ I64 = np.int64
 
 
 class StmmqrError(RuntimeError):
-    pass
+    code = 0
+
+
+ERR_RESCHEDULE = -6                        # STMMQR_ERR_RESCHEDULE (include/stmmqr_hip.h)
 
 
 if not lib_path.exists():
@@ -126,6 +129,7 @@ lib.stmmqr_factorize_begin.argtypes = [C.c_void_p, c_long_p, c_long_p, C.c_void_
 lib.stmmqr_factorize_group.argtypes = [C.c_void_p, C.c_int, C.c_int]
 lib.stmmqr_factorize_finish.argtypes = [C.c_void_p, C.POINTER(Stats)]
 lib.stmmqr_plan_set_groups.argtypes = [C.c_void_p, C.POINTER(C.c_int)]
+lib.stmmqr_plan_set_early_end.argtypes = [C.c_void_p, C.c_int]
 lib.stmmqr_plan_front_info.argtypes = [C.c_void_p, C.c_long, c_long_p]
 lib.stmmqr_plan_export_front.argtypes = [C.c_void_p, C.c_long, C.c_void_p, c_long_p, C.c_int]
 lib.stmmqr_plan_import_front.argtypes = [C.c_void_p, C.c_long, C.c_long, C.c_long, C.c_long, C.c_void_p, c_long_p, C.c_int]
@@ -271,7 +275,9 @@ def set_options(**kw):
 
 def _check(rc: int, what: str):
     if rc != 0:
-        raise StmmqrError(f"{what} failed ({rc}): {last_error()}")
+        e = StmmqrError(f"{what} failed ({rc}): {last_error()}")
+        e.code = int(rc)
+        raise e
 
 
 class QRNumeric:
@@ -351,6 +357,10 @@ class HipQR:
         g = np.ascontiguousarray(group, np.int32)
         assert g.size == self.sym["nf"]
         _check(lib.stmmqr_plan_set_groups(self._h, g.ctypes.data_as(C.POINTER(C.c_int))), "stmmqr_plan_set_groups")
+
+    def set_early_end(self, mode: int):
+        """1: the cut schedule under the phased interface (the caller handles ERR_RESCHEDULE at finish); 0: every panel a step"""
+        _check(lib.stmmqr_plan_set_early_end(self._h, int(mode)), "stmmqr_plan_set_early_end")
 
     def begin(self, Ax, tol, ntol, Ap=None, Ai=None, device_ptr=None):
         if Ap is not None:

@@ -312,12 +312,12 @@ void build_schedule(stmmqr_plan &P, std::vector<int> &tslot)
     {
         bool whole = (ngroups == 1) && nf > 0;
         for (long f = 0; f < nf && whole; f++) whole = (P.group[f] == 0) && !((size_t)f < P.shared.size() && P.shared[(size_t)f]);
-        const bool early = whole && !P.full_schedule && !(getenv("STMMQR_EARLY_END") && atoi(getenv("STMMQR_EARLY_END")) == 0);
+        const bool early = (whole || P.early_phased) && !P.full_schedule && !(getenv("STMMQR_EARLY_END") && atoi(getenv("STMMQR_EARLY_END")) == 0);
         const int slack = getenv("STMMQR_EARLY_SLACK") ? atoi(getenv("STMMQR_EARLY_SLACK")) : 0;
         for (long f = 0; f < nf; f++) {
             FrontSym &s = P.fs[f];
             s.nsched = s.npanels;
-            if (early && is_big((int)f) && !is_pair((int)f)) s.nsched = std::min(s.npanels, std::min(s.fm_est, s.fn) / STM_NB + 1 + slack);
+            if (early && is_big((int)f) && !is_pair((int)f) && P.group[f] >= 0 && !((size_t)f < P.shared.size() && P.shared[(size_t)f])) s.nsched = std::min(s.npanels, std::min(s.fm_est, s.fn) / STM_NB + 1 + slack);
         }
         P.early_end = early;
     }
@@ -1571,7 +1571,7 @@ int stmmqr_factorize_begin(stmmqr_plan *plan, const stm_long *Ap, const stm_long
         if (e) return e;
     }
     if (!P.pattern_set) return fail(STMMQR_ERR_INVALID, "pattern of A was never given");
-    if ((P.early_end || P.early_end_failed) && !P.whole_call) {
+    if (((P.early_end && !P.early_phased) || P.early_end_failed) && !P.whole_call) {
         // phased use (begin / group / finish by the caller): no retry loop around the factorization, so the plan schedules every
         // panel of every front (the cut schedule needs stmmqr_factorize_device's rerun when a front outlives it)
         P.early_end_failed = false;
@@ -1714,7 +1714,7 @@ int stmmqr_factorize_finish(stmmqr_plan *plan, stmmqr_stats *stats)
         // (rank-deficient fronts: more rows reached a front than the full-rank estimate its schedule was cut to)
         P.early_end_failed = true;
         P.evused = 0;
-        return fail(STMMQR_ERR_DEVICE, "a front was not finished by its last scheduled panel (the schedule is rebuilt with every panel)");
+        return fail(STMMQR_ERR_RESCHEDULE, "a front was not finished by its last scheduled panel (the schedule is rebuilt with every panel)");
     }
     float ms = 0;
     HIPCHK(hipEventElapsedTime(&ms, P.ev[0], P.ev[1])); P.stats.ms_h2d = ms;
@@ -1905,6 +1905,20 @@ int stmmqr_factorize_device(stmmqr_plan *plan, const stm_long *Ap, const stm_lon
         Ap = nullptr; Ai = nullptr;                  // (the pattern is set; begin uploads / copies the values again)
     }
     return fail(STMMQR_ERR_DEVICE, "panel kernels failed twice");
+}
+
+int stmmqr_plan_set_early_end(stmmqr_plan *plan, int mode)
+{
+    if (!plan) return fail(STMMQR_ERR_INVALID, "null plan");
+    stmmqr_plan &P = *plan;
+    if (P.begun && !P.early_end_failed) return fail(STMMQR_ERR_INVALID, "stmmqr_plan_set_early_end between factorize_begin and factorize_finish");
+    P.begun = false;
+    P.early_end_failed = false;
+    P.early_phased = (mode != 0);
+    P.full_schedule = (mode == 0);
+    std::vector<int> grp(P.group.begin(), P.group.end());
+    for (size_t f = 0; f < grp.size(); f++) if (f < P.shared.size() && P.shared[f]) grp[f] |= STMMQR_GROUP_SHARED;
+    return stmmqr_plan_set_groups(plan, grp.data());
 }
 
 // ---- multi-GPU support: regroup the fronts, move contribution blocks in and out of a plan --------------

@@ -167,6 +167,7 @@ struct stmmqr_plan {
     bool overflowed = false;             // a factorization did not fit the R+H arena at its hard bound: this plan does not recycle
     bool early_end = false;              // the schedule of group 0 stops every front at the panel where it is expected to run out of rows
     bool full_schedule = false;          // ... it did not hold once (rank-deficient fronts): this plan schedules every panel from now on
+    bool early_phased = false;           // ... the caller of the phased interface asked for the cut schedule (stmmqr_plan_set_early_end)
     bool early_end_failed = false;       // ... the last factorization found a front unfinished at its last scheduled panel
     bool arena_overflow = false;         // the last factorization did not fit the arena (it is repeated with a larger one / without)
     std::vector<int> lists;              // host copy of d_lists

@@ -319,7 +319,13 @@ class ShardPlan:
         mine = (lo <= r) & (r < hi)                           # fronts factorized (or shared) here
         self.mine = mine
         self.group = np.where(mine, self.phase + np.where(self.span > 1, SHARED, 0), -1).astype(np.int32)
+        # the cut schedule (a front gets the panels up to the one where it runs out of rows: include/stmmqr_hip.h,
+        # stmmqr_plan_set_early_end): a front that outlives it is reported at finish and EVERY rank factorizes again on the full
+        # schedule -- factorize_sharded agrees on that with one 8-byte exchange per factorization.  STMMQR_EARLY_END_SHARDED=0: off
+        self.early = hasattr(plan, "set_early_end") and os.environ.get("STMMQR_EARLY_END_SHARDED", "1") != "0"
         plan.set_groups(self.group)
+        if self.early:
+            plan.set_early_end(1)
         self.nphase = int(self.phase.max(initial=0)) + 1
         parent, _, _ = tree_arrays(sym)
         self.parent = parent
@@ -460,6 +466,41 @@ def factorize_sharded(plan, sym: dict, Ax, tol, ntol, comm: Comm, Ap=None, Ai=No
         shard_plan = ShardPlan(plan, sym, owner, phase, comm, span)
     sp = shard_plan
     owner, phase = sp.owner, sp.phase
+    if getattr(sp, "early", False):
+        from .capi import StmmqrError, ERR_RESCHEDULE
+        for attempt in (0, 1):
+            bad, stats = 0, None
+            try:
+                stats = _factorize_sharded_once(plan, sp, Ax, tol, ntol, comm, Ap, Ai, device_ptr)
+            except StmmqrError as e:
+                if e.code != ERR_RESCHEDULE:
+                    raise
+                bad = 1
+            if not _any_rank(comm, bad):
+                stats["reschedules"] = attempt
+                return stats, owner, phase
+            # some rank's front outlived the cut schedule (rank-deficient fronts): every rank runs again on the full schedule, and
+            # keeps it (the plan that failed has switched by itself and is told again: harmless)
+            sp.early = False
+            plan.set_early_end(0)
+            Ap = Ai = None                                    # (the pattern is set)
+    stats = _factorize_sharded_once(plan, sp, Ax, tol, ntol, comm, Ap, Ai, device_ptr)
+    return stats, owner, phase
+
+
+def _any_rank(comm, flag: int) -> int:
+    """max of an integer flag over the ranks: one 8-byte message to and from every other rank (point-to-point, like everything here)"""
+    if comm.size <= 1:
+        return int(flag)
+    mine = comm.tensor(np.array([int(flag)], I64))
+    others = [comm.empty(1, np.int64) for _ in range(comm.size - 1)]
+    peers = [r for r in range(comm.size) if r != comm.rank]
+    comm.exchange([(mine, r) for r in peers], list(zip(others, peers)))
+    return max([int(flag)] + [int(t.cpu().numpy()[0]) for t in others])
+
+
+def _factorize_sharded_once(plan, sp, Ax, tol, ntol, comm, Ap, Ai, device_ptr):
+    owner, phase = sp.owner, sp.phase
     plan.begin(Ax, tol, ntol, Ap, Ai, device_ptr=device_ptr)
     native = getattr(comm, "native", None)
     whole = native is not None and hasattr(plan, "phases_native") and os.environ.get("STMMQR_NATIVE_PHASES", "1") != "0"
@@ -502,7 +543,7 @@ def factorize_sharded(plan, sym: dict, Ax, tol, ntol, comm: Comm, Ap=None, Ai=No
         stats["flops"] = stats.get("flops", 0.0) - fl
         if "flops_update" in stats:
             stats["flops_update"] -= flu
-    return stats, owner, phase
+    return stats
 
 
 def shard_of(N, sym: dict, owned, plan=None, shard_plan: ShardPlan | None = None, rank=0):

@@ -6,7 +6,7 @@ import importlib
 import numpy as np
 import pytest
 
-from stmmqr_testlib import Symbolic, load_golden, scalar
+from stmmqr_testlib import golden_names, Symbolic, load_golden, scalar
 
 pytestmark = pytest.mark.gpu
 PKG = "stm-multifrontal-qr-factorization-empowered-by-gcn_amd"
@@ -321,6 +321,37 @@ def test_native_subtree_exchange_equals_unsharded(name, nranks):
     ref = pkg.qr_factorize(sym, g["in_Ap"], g["in_Ai"], g["in_Ax"], tol, ntol)
     owner, phase = sh.partition(sym, nranks)
     out = _run_ranks(pkg, sh, sym, g, tol, ntol, nranks, owner, phase, None, True, native=True)
+    G = sh.merge_shards(sym, [o[1] for o in out], ntol)
+    assert sum(o[0]["flops"] for o in out) == ref.stats["flops"]
+    assert (G.rank, G.rank1, G.maxfrank, G.maxfm, G.rh_total) == (ref.rank, ref.rank1, ref.maxfrank, ref.maxfm, ref.rh_total)
+    for k in ("Hm", "Hr", "HStair", "HPinv", "Rdead", "Rblock_off", "Hii", "HTau"):
+        np.testing.assert_array_equal(getattr(G, k), getattr(ref, k), err_msg=k)
+    np.testing.assert_array_equal(G.Stack[:G.rh_total], ref.Stack[:ref.rh_total])
+
+
+@pytest.mark.parametrize("native", [False, True])
+@pytest.mark.parametrize("name,nranks", [("bayer10", 2), ("syn_rankdef_grid", 2), ("lns_3937", 4), ("cvxqp3", 2), ("grid20_standin", 2)])
+def test_sharded_cut_schedule_and_its_fallback(name, nranks, native):
+    """Sharded plans take the cut schedule too (a front gets the panels up to the one where the full-rank row estimate says it runs
+    out of rows: stmmqr_plan_set_early_end(1) by ShardPlan).  On rank-deficient input a front outlives it on SOME rank: that rank's
+    finish says STMMQR_ERR_RESCHEDULE, the ranks agree (one 8-byte exchange per factorization) and ALL of them factorize again on the
+    full schedule -- stats["reschedules"] is the same on every rank, and the merged result is the unsharded plan's."""
+    if name not in golden_names():
+        pytest.skip("fixture not present")
+    pkg = importlib.import_module(PKG)
+    sh = importlib.import_module(PKG + ".sharded")
+    g = load_golden(name)
+    S = Symbolic(g)
+    sym = {**S.sc, **{k: v for k, v in S.arr.items() if v is not None}}
+    tol, ntol = scalar(g, "in_tol"), int(scalar(g, "in_ntol"))
+    ref = pkg.qr_factorize(sym, g["in_Ap"], g["in_Ai"], g["in_Ax"], tol, ntol)
+    owner, phase = sh.partition(sym, nranks)
+    out = _run_ranks(pkg, sh, sym, g, tol, ntol, nranks, owner, phase, None, True, native=native)
+    res = {int(o[0]["reschedules"]) for o in out}
+    assert len(res) == 1 and res <= {0, 1}
+    if not np.any(ref.Rdead):
+        assert res == {0}                                # (full rank: the estimate is exact)
+    print(f"[cut schedule] {name} on {nranks} ranks: reschedules {res}")
     G = sh.merge_shards(sym, [o[1] for o in out], ntol)
     assert sum(o[0]["flops"] for o in out) == ref.stats["flops"]
     assert (G.rank, G.rank1, G.maxfrank, G.maxfm, G.rh_total) == (ref.rank, ref.rank1, ref.maxfrank, ref.maxfm, ref.rh_total)
