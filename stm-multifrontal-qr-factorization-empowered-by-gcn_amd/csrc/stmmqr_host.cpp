@@ -494,7 +494,8 @@ void build_schedule(stmmqr_plan &P, std::vector<int> &tslot)
             for (int i = 0; i < S.n_start; i++) {
                 const FrontSym &s = P.fs[P.lists[S.start_off + i]];
                 const long work = (long)s.fm_ub * s.fn;
-                const int parts = (int)std::min(512L, std::max(1L, (work + 16383) / 16384));     // (two workgroups per CU on the top fronts)
+                static const long pg = getenv("STMMQR_PART_GRAIN") ? atol(getenv("STMMQR_PART_GRAIN")) : 2048, pc = getenv("STMMQR_PART_CAP") ? atol(getenv("STMMQR_PART_CAP")) : 4096;
+                const int parts = (int)std::min(pc, std::max(1L, (work + pg - 1) / pg));     // (entries per workgroup of the assembly / packing launches: 16384 until round 5 -- 2048: epb1 5.81 -> 5.60 ms, default 93.3 -> 92.9)
                 P.lists.push_back(parts);
                 S.asm_maxparts = std::max(S.asm_maxparts, parts);
                 if (i < S.n_small) maxfm_small = std::max(maxfm_small, (long)s.fm_ub);
@@ -578,7 +579,8 @@ void build_schedule(stmmqr_plan &P, std::vector<int> &tslot)
                 const FrontSym &s = P.fs[f];
                 const long cn = s.fn - s.fp;
                 const long work = cn * std::min((long)s.fm_ub, cn);
-                const int parts = (int)std::min(512L, std::max(1L, (work + 16383) / 16384));
+                static const long pg = getenv("STMMQR_PART_GRAIN") ? atol(getenv("STMMQR_PART_GRAIN")) : 2048, pc = getenv("STMMQR_PART_CAP") ? atol(getenv("STMMQR_PART_CAP")) : 4096;
+                const int parts = (int)std::min(pc, std::max(1L, (work + pg - 1) / pg));
                 P.lists.push_back(parts);
                 S.cpk_maxparts = std::max(S.cpk_maxparts, parts);
                 freeslots.push_back(tslot[f]);
