@@ -669,30 +669,37 @@ __device__ __forceinline__ void dev_tall_group(PanelShared &ps, const FrontSym &
 #endif
     // ---- apply the reflectors of the groups before mine, as they become available ----
     int prev_done = 0;
-    constexpr int HW = SWT / 2;                                // reflectors per published half group
+    // (8-column groups publish in QUARTERS since round 5: the part on the chain -- the last one of the group before mine -- is two
+    //  reflectors instead of four; halves: default workload 92.4 ms, quarters 91.3, single columns 93.8 -- every publish costs the
+    //  producer a wait for its stores and a barrier.  -DSTM_TALL_NPART=2 / 8 for the other two)
+#ifndef STM_TALL_NPART
+#define STM_TALL_NPART 4
+#endif
+    constexpr int NPART = (SWT == 8) ? STM_TALL_NPART : 2;      // a group publishes its columns in this many parts
+    constexpr int HW = SWT / NPART;                            // reflectors per published part
     constexpr int NPV = HW * SWT, NGP = (NPV + 7) / 8;         // V'C products, in exchange groups of eight
-    // (a group publishes twice: after the first half of its columns and at the end, so that the next group applies the
-    //  first half of the reflectors while the second half is still being factorized)
+    // (a group publishes in NPART parts -- after every HW of its columns -- so that the next group applies the earlier reflectors
+    //  while the later ones are still being factorized)
     int seen = -1;
     bool have_chain = false;
     int ch_g = 0, ch_rank = 0, ch_pt = 0, ch_nl = 0;
     double ch_ls = 0, ch_fl = 0;
     for (int sp = 0; sp < b && !prev_done; sp++)
-    for (int half = 0; half < 2; half++) {
-        if (!wait_progress(&num->prog, STM_PROG * p + 2 * sp + 1 + half, seen)) {
+    for (int half = 0; half < NPART; half++) {
+        if (!wait_progress(&num->prog, STM_PROG * p + NPART * sp + 1 + half, seen)) {
             if (tid == 0) { st_agent(&num->perr, 1); if (abortp) st_agent(abortp + 1, 1); }      // (= STM_SET_PERR)
             return;
         }
         TSTAMP(7);
 #ifdef STMMQR_STAMPS
-        tl_h = (sp == b - 1) ? half : 8;                       // (only the last two half applications: the ones on the chain)
+        tl_h = (sp == b - 1 && half >= NPART - 2) ? half - (NPART - 2) : 8;                       // (only the last two part applications: the ones on the chain)
 #endif
         TL(2 + 3 * tl_h);
-        const int pc0 = SWT * sp + half * (SWT / 2);
+        const int pc0 = SWT * sp + half * HW;
         // (group sp ran out of rows?  Not num->done: a group that starts late would see the flag of a LATER group and
         //  skip the reflectors of the groups in between)
-        if (half == 1) prev_done = (ld_agent(&pd->done_group) == sp);
-        if (half == 1 && sp == b - 1) {
+        if (half == NPART - 1) prev_done = (ld_agent(&pd->done_group) == sp);
+        if (half == NPART - 1 && sp == b - 1) {
             // the scalars that travel along the chain of groups were stored before this flag: load them now, the
             // round trip hides behind the block application below (after the loop it would delay my first column)
             ch_g = ld_agent(&num->g); ch_rank = ld_agent(&num->rank); ch_pt = ld_agent(&pd->pt);
@@ -865,9 +872,9 @@ __device__ __forceinline__ void dev_tall_group(PanelShared &ps, const FrontSym &
     for (int j = 0; j < SWT; j++) {
         if (j >= sw || prev_done) continue;
         const int jp = c0 + j, k = k1 + jp;
-        if (j == SWT / 2 && b + 1 < ns) {
-            flush_cols(0, min(j, jdone)); flushed = j;
-            publish_progress(&num->prog, STM_PROG * p + 2 * b + 1);   // first half is in F
+        if (j > 0 && j % HW == 0 && b + 1 < ns) {
+            flush_cols(min(flushed, jdone), min(j, jdone)); flushed = j;
+            publish_progress(&num->prog, STM_PROG * p + NPART * b + j / HW);   // the part before column j is in F
         }
         if (!done && g >= m) {
             // no rows left: remaining pivotal columns are dead, remaining columns are empty (:1444-1458)
@@ -972,7 +979,7 @@ __device__ __forceinline__ void dev_tall_group(PanelShared &ps, const FrontSym &
         if (done) st_agent(&pd->done_group, b);
     }
     if (!last) {
-        publish_progress(&num->prog, STM_PROG * p + 2 * b + 2);
+        publish_progress(&num->prog, STM_PROG * p + NPART * b + NPART);
         TL(30);
         return;
     }
@@ -993,7 +1000,7 @@ __device__ __forceinline__ void dev_tall_group(PanelShared &ps, const FrontSym &
         num->flops_upd += 4.0 * (double)(n - k2) * (prev_done ? ls_before : ls_before + lensum);
     }
     if (defer_t) {
-        publish_progress(&num->prog, STM_PROG * p + 2 * b + 2);
+        publish_progress(&num->prog, STM_PROG * p + NPART * b + NPART);
         return;
     }
     if (tid < STM_NB) {
@@ -1015,7 +1022,7 @@ __device__ __forceinline__ void dev_tall_group(PanelShared &ps, const FrontSym &
     TL(31);
     // (when an earlier group ran out of rows the groups after mine are still storing their columns: the kernel
     //  boundary orders those stores before the trailing update)
-    publish_progress(&num->prog, STM_PROG * p + 2 * b + 2);
+    publish_progress(&num->prog, STM_PROG * p + NPART * b + NPART);
 #undef TSTAMP
 #undef TL
 #undef TLW
