@@ -1216,7 +1216,7 @@ int run_schedule(stmmqr_plan &P, bool detail, int grp, const StepReq *req = null
     }
     if (pass) {
         const long fw_max = getenv("STMMQR_PASS_MAXWG") ? atol(getenv("STMMQR_PASS_MAXWG")) : 384;
-        const int pass_rows = getenv("STMMQR_PASS_ROWS") ? atoi(getenv("STMMQR_PASS_ROWS")) : 5120;
+        const int pass_rows = getenv("STMMQR_PASS_ROWS") ? atoi(getenv("STMMQR_PASS_ROWS")) : 16384;
         const double pass_k = getenv("STMMQR_PASS_K") ? atof(getenv("STMMQR_PASS_K")) : 1e30;
         const long pass_tiles = getenv("STMMQR_PASS_TILES") ? atol(getenv("STMMQR_PASS_TILES")) : (1L << 40);   // (measured: riding always wins -- 2000: 123 ms, 3000: 117, never: 109.9 on the default workload)
         const int abl = getenv("STMMQR_PASS_ABL") ? atoi(getenv("STMMQR_PASS_ABL")) : 0;   // timing-only ablations (WRONG results): 1 no k_upd_w riders, 2 no k_upd_c riders
@@ -1288,8 +1288,10 @@ int run_schedule(stmmqr_plan &P, bool detail, int grp, const StepReq *req = null
                     fwg += 2L * stm_upd_nsl(P.fs[P.lists[S.act_off + i]]);
                     rows_max = std::max(rows_max, stm_panel_rows_est(P.fs[P.lists[S.act_off + i]], P.lists[S.plist_off + i]));
                 }
-                // (beyond ~5000 rows -- 20+ slabs -- the one-launch block 0 is the slower form: its slab workgroups idle while the
-                //  partials are added; measured on the 7818-row fronts of c5mini)
+                // (pass_rows: 5120 until the riders of a step before Gram-based panels got a launch to ride on (k_panel_ca_pc) -- beyond
+                //  ~5000 rows the one-launch block 0 is the slower form of T + block 0, but the riders no longer cost a launch of their
+                //  own on the chain: c5mini 41.1 -> 37.0 ms, default 91.4 -> 90.9 at 8192 ... unlimited; 16384 = where the pair-update
+                //  fronts begin, which never ride)
                 const bool ride = S.split && S.n_sweep() == 0 && S.n_norm > 0 && S.maxcb > 1 && S.maxsl <= 256 && fwg <= fw_max &&
                                   rows_max <= pass_rows && !g_opt.fused_update;
                 if (ride) {
