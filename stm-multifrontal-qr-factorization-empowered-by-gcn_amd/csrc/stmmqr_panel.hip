@@ -675,7 +675,10 @@ __device__ __forceinline__ void dev_tall_group(PanelShared &ps, const FrontSym &
 #ifndef STM_TALL_NPART
 #define STM_TALL_NPART 4
 #endif
-    constexpr int NPART = (SWT == 8) ? STM_TALL_NPART : 2;      // a group publishes its columns in this many parts
+#ifndef STM_TALL_NPART4
+#define STM_TALL_NPART4 2
+#endif
+    constexpr int NPART = (SWT == 8) ? STM_TALL_NPART : (SWT == 4) ? STM_TALL_NPART4 : 2;      // a group publishes its columns in this many parts
     constexpr int HW = SWT / NPART;                            // reflectors per published part
     constexpr int NPV = HW * SWT, NGP = (NPV + 7) / 8;         // V'C products, in exchange groups of eight
     // (a group publishes in NPART parts -- after every HW of its columns -- so that the next group applies the earlier reflectors
