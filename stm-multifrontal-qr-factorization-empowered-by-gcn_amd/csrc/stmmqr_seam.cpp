@@ -119,7 +119,7 @@ unsigned long long symbolic_key(const stm_qr_symbolic *S)
     h = hash_bytes(&g_opt, sizeof g_opt, h);
     // (every knob of the environment that is read when the plan / its schedule / its arenas are built)
     for (const char *k : {"STMMQR_CA_MIN", "STMMQR_PAIR_MIN", "STMMQR_SCHED", "STMMQR_RIDE", "STMMQR_QBIG_MIN", "STMMQR_RECYCLE", "STMMQR_TUNE",
-                          "STMMQR_RH_EST_SCALE"}) {
+                          "STMMQR_RH_EST_SCALE", "STMMQR_EARLY_END", "STMMQR_EARLY_SLACK", "STMMQR_PART_GRAIN", "STMMQR_PART_CAP"}) {
         const char *v = getenv(k);
         if (v) h = hash_bytes(v, strlen(v), h ^ 0x51ed);
     }
