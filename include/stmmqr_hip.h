@@ -401,7 +401,15 @@ double stmmqr_last_seam_ms(void);
  * read per factorization), STMMQR_SIDE_RESERVE (compute units the side stream leaves alone; 32), STMMQR_DUMPSTEPS=file
  * (detail runs: one line per step with what ran and how long); STMMQR_DBG bits of general use: 16 diagnosis counters printed
  * by stmmqr_factorize_finish (panels by actual rows, launched / useful update workgroups, refresh rounds), 16384 no
- * wave-pipelined panels (every short panel through the multi-workgroup pipeline). */
+ * wave-pipelined panels (every short panel through the multi-workgroup pipeline).
+ * Round 5: STMMQR_EARLY_END=0 (every panel of every front a step of the timeline; default: a front is scheduled up to the panel
+ * where the full-rank row estimate says it runs out of rows) and STMMQR_EARLY_SLACK (extra panels per front, 0);
+ * STMMQR_PASSENGERS=0 / STMMQR_PASS_ROWS (16384) / STMMQR_PASS_MAXWG (384) / STMMQR_CA_RIDERS=0 (passenger launches: off, the rows
+ * up to which a step rides, the workgroups of its block-0 launch, riders on the Gram-based panel launch); STMMQR_PART_GRAIN / _CAP
+ * (entries per workgroup, 2048, and workgroups per front, 4096, of the assembly / packing launches); STMMQR_LIVE_PANELS=0 (Q-apply /
+ * back substitution visit every panel, not only those that can hold a reflector); STMMQR_RHS_BATCH (right-hand sides per pass of
+ * the resident-factor operations, 32); STMMQR_NATIVE_PHASES=0 and STMMQR_EARLY_END_SHARDED=0 (sharded.py: the Python phase loop;
+ * the full schedule on sharded plans). */
 typedef struct stmmqr_options {
     int panel_width;        /* Householder panel width on device (<= 32); reference FCHUNK = 32                    */
     int big_front_cols;     /* fronts with fn >= this use the multi-workgroup panel/update path                     */
@@ -413,9 +421,10 @@ typedef struct stmmqr_options {
                                panels of at most 512 actual rows are taken by ONE workgroup, a wave per 4 columns     */
     int split_update;       /* row-parallel (2-launch) trailing update for fronts of >= 3 row slabs (1)             */
     int tall_min_rows;      /* panels with more rows than this run as a pipeline of column groups (plan time; 0)    */
-    int lookahead;          /* 1 (default): the trailing update beyond the next panel's columns, the packing of finished
-                               fronts and the assembly of the next ones run on a second stream beside the panel chain;
-                               0: one stream, serial order.  Same bits either way.                                  */
+    int lookahead;          /* 2 (default since round 5): one stream, the trailing update beyond the next panel's columns rides
+                               on the chain's own launches as extra workgroups (passenger launches); 1: that update, the
+                               packing of finished fronts and the assembly of the next ones run on a second stream beside
+                               the panel chain; 0: one stream, serial order.  Same bits every way.                     */
     int fused_update;       /* 0 (default): the row-parallel trailing update is two launches (k_upd_w, k_upd_c);
                                1: ONE launch that keeps its tiles of C in registers between V'C and the application
                                (C read once, written once per panel).  Same bits either way; measured 1.1x - 2.5x slower
