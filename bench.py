@@ -792,6 +792,14 @@ def _run(args, torch, rank, world, local, guard):
                 res = float(np.linalg.norm(csc_matvec(S.m, Ap_, Ai_, Ax_, xs) - b) /
                             (np.linalg.norm(Ax_) * np.linalg.norm(xs) + np.linalg.norm(b)))
                 out["f1_resident_factors"] = {"qmult_qtx_ms": (t1 - t0) * 1e3, "solve_ms": (t2 - t1) * 1e3, "residual": res}
+                # a block of 32 right-hand sides through the same passes (batched: DESIGN.md 6b); column 0 is b
+                B32 = np.column_stack([b] + [np.roll(b, 7 * (j + 1)) for j in range(31)])
+                plan.qmult(0, B32.copy()); xs32 = plan.solve(B32)
+                t3 = time.perf_counter(); plan.qmult(0, B32.copy()); t4 = time.perf_counter()
+                xs32 = plan.solve(B32); t5 = time.perf_counter()
+                out["f1_resident_factors"].update({"qmult_qtx_32rhs_ms": (t4 - t3) * 1e3, "solve_32rhs_ms": (t5 - t4) * 1e3,
+                                                   "rhs32_over_rhs1": [(t4 - t3) / max(t1 - t0, 1e-9), (t5 - t4) / max(t2 - t1, 1e-9)],
+                                                   "rhs32_column0_equals_single": bool(np.array_equal(np.asarray(xs32)[:, 0], np.asarray(xs).ravel()))})
         except Exception as e:  # rank-deficient inputs: the device solve refuses them
             out["f1_resident_factors"] = {"error": str(e)}
         # Outside `value`: what the drop-in seam adds around the device time -- ONE call of the exported qr_factorize
